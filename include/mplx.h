@@ -1,0 +1,164 @@
+/*
+ * mplx.h -- C-ABI of the MI355X motion-primitive search back-end (libmplx.so).
+ *
+ * This is the drop-in boundary under the reference's C++ planner classes: a C++ shim with the MPL
+ * class names (include/mpl_shim/) or any FFI binds exactly these entry points.  Plain pointers and
+ * sizes only; no torch / Eigen types.  Each entry cites the reference interface it replaces
+ * (paths relative to the reference repo sikang/mpl_ros; the MPL classes themselves live in the
+ * un-vendored submodule motion_primitive_library, so the citations are the in-tree call sites).
+ *
+ * All functions return MPLX_OK (0) or a negative MPLX_ERR_* code; mplx_last_error() gives the
+ * message.  plan() outcomes (no path, start occupied, ...) are reported in mplx_result.status, not
+ * as errors, mirroring `bool PlannerBase::plan()` + printf diagnostics.
+ * Single-threaded use per context, like the reference (one planner object, one thread).
+ */
+#ifndef MPLX_H
+#define MPLX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* error codes */
+#define MPLX_OK 0
+#define MPLX_ERR_HIP (-1)       /* a HIP runtime call failed (no GPU, OOM, launch failure) */
+#define MPLX_ERR_ARG (-2)       /* invalid argument / call order */
+#define MPLX_ERR_CAPACITY (-3)  /* a device pool is too small for the request */
+
+/* plan status (mplx_result.status) */
+#define MPLX_PLAN_OK 0
+#define MPLX_PLAN_NO_PATH 1         /* OPEN ran empty */
+#define MPLX_PLAN_START_OCCUPIED 2  /* ENV_->is_free(start.pos) failed */
+#define MPLX_PLAN_MAX_EXPAND 3      /* max_expand reached */
+#define MPLX_PLAN_POOL_FULL 4       /* per-query device pool exhausted (raise mplx_set_capacity) */
+
+/* Control kinds = union of use_pos|use_vel|use_acc|use_jrk bits of a Waypoint
+ * (mpl_test_node/src/map_planner_node.cpp:155-171 sets the bits; Control::VEL..SNP). */
+#define MPLX_VEL 1
+#define MPLX_ACC 3
+#define MPLX_JRK 7
+#define MPLX_SNP 15
+
+/* Waypoint<3>: search-state record (fields used in-tree: map_planner_node.cpp:155-171,
+ * env_poly_map.h:63-64).  yaw is carried but not propagated by this back-end. */
+typedef struct {
+  double pos[3], vel[3], acc[3], jrk[3];
+  double yaw, t;
+  int32_t control;  /* MPLX_VEL / ACC / JRK / SNP */
+  int32_t enable_t; /* must be 0 for the voxel-map environment */
+} mplx_waypoint;
+
+/* Primitive<3>: 6 coefficients per axis, p(t) = c0/120 t^5 + ... + c5
+ * (planning_ros_msgs/msg/Primitive.msg:2-8, primitive_ros_utils.h:12-33). */
+typedef struct {
+  double c[3][6];
+  double t;
+  int32_t control;
+  int32_t pad;
+} mplx_primitive;
+
+/* Planner set-up = the setter calls of PlannerBase / MapPlanner
+ * (setVmax/setAmax/setJmax/setDt/setU/setTol/setEpsilon/setMaxNum/setW/setHeurIgnoreDynamics:
+ *  map_planner_node.cpp:176-183, map_replanner_node.cpp:415-437, ellipsoid_planner_node.cpp:67-74). */
+typedef struct {
+  int32_t control;  /* control kind of the search states (start.control) */
+  int32_t n_u;      /* number of control inputs */
+  const double *U;  /* n_u x 3, host pointer, copied */
+  double dt, v_max, a_max, j_max;
+  double w;         /* setW, default 10 */
+  double eps;       /* setEpsilon, default 1 */
+  double tol_pos, tol_vel, tol_acc; /* setTol; < 0 disables vel / acc */
+  double t_max;     /* +inf unless set */
+  int32_t max_expand; /* setMaxNum; <= 0 unlimited */
+  int32_t heur_ignore_dynamics;
+} mplx_config;
+
+/* One successor of env_map::get_succ (vec_E<Waypoint>& succ, succ_cost, action_idx:
+ * env_poly_map.h:45-47, env_cloud.h:50-52) plus what the parity tests look at. */
+typedef struct {
+  mplx_waypoint wp;    /* tn (t = curr.t + dt) */
+  double cost;         /* J + w dt, or +inf when the primitive is blocked */
+  int32_t action;      /* index into U */
+  int32_t valid;       /* 0: skipped (tn == curr or validate_primitive failed) */
+  int32_t key[12];     /* quantised Waypoint key of tn */
+  int32_t nkey;
+  int32_t voxel_reads; /* map look-ups of is_free(pr), early-out honoured */
+} mplx_succ;
+
+typedef struct {
+  int32_t status;      /* MPLX_PLAN_* */
+  int32_t traj_len;    /* number of primitives of the recovered trajectory */
+  double cost;         /* getTrajCost(); +inf when no trajectory */
+  uint64_t n_expanded; /* get_succ calls == expanded_nodes_.size() */
+  uint64_t n_closed;   /* getCloseSet().size() */
+  uint64_t n_nodes;    /* states created in the state space (hm_.size()) */
+  uint64_t n_edges;    /* predecessor records stored */
+  uint64_t n_primitives, n_succ, n_succ_finite;
+  uint64_t voxel_reads;
+  uint64_t n_push, n_reopen;
+  uint64_t n_refill, n_evict; /* OPEN-structure maintenance events (diagnostics) */
+  uint64_t expand_hash; /* order-dependent hash of the expanded node ids (== same search) */
+} mplx_result;
+
+typedef struct mplx_ctx mplx_ctx;
+
+/* ---- context ---- */
+int mplx_ctx_create(int device, mplx_ctx **out);
+void mplx_ctx_destroy(mplx_ctx *ctx);
+const char *mplx_last_error(const mplx_ctx *ctx); /* ctx may be NULL: last create error */
+/* run all work of this context on an existing HIP stream (hipStream_t); NULL = own stream */
+int mplx_set_stream(mplx_ctx *ctx, void *hip_stream);
+
+/* ---- MapUtil<3> (VoxelMapUtil): setMap(ori, dim, std::vector<signed char>, res)
+ *      map_planner_node.cpp:10-18; grid x-fastest idx = x + dx*y + dx*dy*z (voxel_grid.cpp:88),
+ *      free 0 / occupied 100 / unknown -1 (voxel_grid.h:43-45). ---- */
+int mplx_map_set(mplx_ctx *ctx, const int8_t *data, const int32_t dim[3], const double origin[3], double res);
+/* adopt a grid already resident in HBM (e.g. the RCCL-broadcast replica); not copied, not owned */
+int mplx_map_set_device(mplx_ctx *ctx, const void *device_ptr, const int32_t dim[3], const double origin[3], double res);
+int mplx_map_free_unknown(mplx_ctx *ctx);          /* MapUtil::freeUnknown, map_planner_node.cpp:71 */
+int mplx_map_get(mplx_ctx *ctx, int8_t *out);      /* MapUtil::getMap, map_planner_node.cpp:35 */
+int mplx_map_info(const mplx_ctx *ctx, int32_t dim[3], double origin[3], double *res);
+/* batched MapUtil::floatToInt + isFree/isOccupied/isOutside for n points (xyz interleaved);
+ * cells: n x 3 int32; state: 0 free, 1 occupied, 2 unknown, 3 outside */
+int mplx_map_query(mplx_ctx *ctx, int n, const double *pts, int32_t *cells, int8_t *state);
+
+/* ---- planner configuration ---- */
+int mplx_planner_config(mplx_ctx *ctx, const mplx_config *cfg);
+/* device pools: concurrent query slots and per-slot capacities (0 = keep current / default) */
+int mplx_set_capacity(mplx_ctx *ctx, int32_t n_slots, uint32_t max_nodes, uint32_t max_edges, uint32_t max_open_log);
+/* f-width of one far OPEN bucket (0 = default w*dt/8) */
+int mplx_set_bucket_width(mplx_ctx *ctx, double width);
+
+/* ---- env_map::get_succ for K nodes in one launch (unit-testable kernel entry).
+ *      out: K x n_u records, record [k*n_u + i] belongs to control input i. ---- */
+int mplx_expand_batch(mplx_ctx *ctx, int K, const mplx_waypoint *nodes, mplx_succ *out);
+/* env_base::get_heur / is_goal for n states against `goal` */
+int mplx_heuristic_batch(mplx_ctx *ctx, int n, const mplx_waypoint *states, const mplx_waypoint *goal, double *h, int32_t *is_goal);
+
+/* ---- PlannerBase::plan(start, goal) -> GraphSearch::Astar, entirely on the device
+ *      (map_planner_node.cpp:187).  Keeps the query's state space on the device for the getters. ---- */
+int mplx_plan(mplx_ctx *ctx, const mplx_waypoint *start, const mplx_waypoint *goal, mplx_result *out);
+/* nq independent queries on the shared map, one workgroup per in-flight query */
+int mplx_plan_batch(mplx_ctx *ctx, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals, mplx_result *out);
+
+/* ---- results of query q of the last plan / plan_batch ---- */
+/* getTraj(): prs[traj_len] primitives, wps[traj_len+1] waypoints, actions[traj_len]; NULLs allowed */
+int mplx_result_traj(mplx_ctx *ctx, int q, mplx_primitive *prs, mplx_waypoint *wps, int32_t *actions, int32_t *node_ids);
+/* getExpandedNodes(): expansion order; needs mplx_set_record(ctx, cap) before planning.
+ * ids: node ids, pos: n x 3.  Returns the number written via *n (<= cap). */
+int mplx_set_record(mplx_ctx *ctx, uint32_t cap_per_query);
+int mplx_result_expanded(mplx_ctx *ctx, int q, uint32_t cap, int32_t *ids, uint32_t *n);
+/* state-space dump of the LAST single mplx_plan(): node coords (getCloseSet / getOpenSet are
+ * filters on `closed` / `opened`), g, h.  Arrays sized n_nodes; NULLs allowed. */
+int mplx_result_nodes(mplx_ctx *ctx, mplx_waypoint *coords, double *g, double *h, int32_t *closed, int32_t *opened);
+
+/* ---- measurement ---- */
+/* duration (ms, HIP events on the context's stream) of the last search / expand kernel launch */
+int mplx_last_kernel_ms(const mplx_ctx *ctx, float *ms);
+const char *mplx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,104 @@
+"""ctypes declarations for libmplx.so (include/mplx.h).  No compute happens in Python.
+
+The library is built in-tree by `make -C mpl_ros_amd/csrc` (hipcc --offload-arch=gfx950) or by
+__graft_entry__.build().  Loading fails loudly if it is missing: there is no fallback path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmplx.so")
+
+VEL, ACC, JRK, SNP = 1, 3, 7, 15
+PLAN_OK, PLAN_NO_PATH, PLAN_START_OCCUPIED, PLAN_MAX_EXPAND, PLAN_POOL_FULL = 0, 1, 2, 3, 4
+OK, ERR_HIP, ERR_ARG, ERR_CAPACITY = 0, -1, -2, -3
+
+
+class Waypoint(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("vel", C.c_double * 3), ("acc", C.c_double * 3),
+                ("jrk", C.c_double * 3), ("yaw", C.c_double), ("t", C.c_double),
+                ("control", C.c_int32), ("enable_t", C.c_int32)]
+
+
+class Primitive(C.Structure):
+    _fields_ = [("c", (C.c_double * 6) * 3), ("t", C.c_double), ("control", C.c_int32), ("pad", C.c_int32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("control", C.c_int32), ("n_u", C.c_int32), ("U", C.POINTER(C.c_double)),
+                ("dt", C.c_double), ("v_max", C.c_double), ("a_max", C.c_double), ("j_max", C.c_double),
+                ("w", C.c_double), ("eps", C.c_double),
+                ("tol_pos", C.c_double), ("tol_vel", C.c_double), ("tol_acc", C.c_double),
+                ("t_max", C.c_double), ("max_expand", C.c_int32), ("heur_ignore_dynamics", C.c_int32)]
+
+
+class Succ(C.Structure):
+    _fields_ = [("wp", Waypoint), ("cost", C.c_double), ("action", C.c_int32), ("valid", C.c_int32),
+                ("key", C.c_int32 * 12), ("nkey", C.c_int32), ("voxel_reads", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("traj_len", C.c_int32), ("cost", C.c_double)] + \
+               [(n, C.c_uint64) for n in ("n_expanded", "n_closed", "n_nodes", "n_edges", "n_primitives", "n_succ",
+                                          "n_succ_finite", "voxel_reads", "n_push", "n_reopen", "n_refill", "n_evict",
+                                          "expand_hash")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = [
+    "mplx_ctx_create", "mplx_ctx_destroy", "mplx_last_error", "mplx_set_stream",
+    "mplx_map_set", "mplx_map_set_device", "mplx_map_free_unknown", "mplx_map_get", "mplx_map_info", "mplx_map_query",
+    "mplx_planner_config", "mplx_set_capacity", "mplx_set_bucket_width",
+    "mplx_expand_batch", "mplx_heuristic_batch", "mplx_plan", "mplx_plan_batch",
+    "mplx_result_traj", "mplx_set_record", "mplx_result_expanded", "mplx_result_nodes",
+    "mplx_last_kernel_ms", "mplx_version",
+]
+
+_lib = None
+
+
+class MplxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmplx.so; raises MplxError when the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MplxError(f"{LIB_PATH} is missing: build it with `make -C mpl_ros_amd/csrc` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    I3 = C.POINTER(C.c_int32)
+    D3 = C.POINTER(C.c_double)
+    L.mplx_ctx_create.argtypes = [C.c_int, C.POINTER(P)]
+    L.mplx_ctx_destroy.argtypes = [P]
+    L.mplx_ctx_destroy.restype = None
+    L.mplx_last_error.argtypes = [P]
+    L.mplx_last_error.restype = C.c_char_p
+    L.mplx_set_stream.argtypes = [P, C.c_void_p]
+    L.mplx_map_set.argtypes = [P, C.c_void_p, I3, D3, C.c_double]
+    L.mplx_map_set_device.argtypes = [P, C.c_void_p, I3, D3, C.c_double]
+    L.mplx_map_free_unknown.argtypes = [P]
+    L.mplx_map_get.argtypes = [P, C.c_void_p]
+    L.mplx_map_info.argtypes = [P, I3, D3, D3]
+    L.mplx_map_query.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mplx_planner_config.argtypes = [P, C.POINTER(Config)]
+    L.mplx_set_capacity.argtypes = [P, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.mplx_set_bucket_width.argtypes = [P, C.c_double]
+    L.mplx_expand_batch.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(Succ)]
+    L.mplx_heuristic_batch.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(Waypoint), C.c_void_p, C.c_void_p]
+    L.mplx_plan.argtypes = [P, C.POINTER(Waypoint), C.POINTER(Waypoint), C.POINTER(Result)]
+    L.mplx_plan_batch.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(Waypoint), C.POINTER(Result)]
+    L.mplx_result_traj.argtypes = [P, C.c_int, C.POINTER(Primitive), C.POINTER(Waypoint), I3, I3]
+    L.mplx_set_record.argtypes = [P, C.c_uint32]
+    L.mplx_result_expanded.argtypes = [P, C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+    L.mplx_result_nodes.argtypes = [P, C.POINTER(Waypoint), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mplx_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float)]
+    L.mplx_version.restype = C.c_char_p
+    _lib = L
+    return L

@@ -1,0 +1,642 @@
+// mplx_api.hip -- C-ABI (include/mplx.h) of the MI355X motion-primitive search back-end.
+// Host side: context, map replica, planner configuration, device pools, launches, result copy-out.
+// There is no CPU fallback: every compute entry point launches a gfx950 kernel or fails with
+// MPLX_ERR_HIP.
+#include "../../include/mplx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mplx_kernels.h"
+
+using namespace mplx;
+
+static_assert(sizeof(SuccOut) == sizeof(mplx_succ), "SuccOut must mirror mplx_succ");
+static_assert(sizeof(State) == 12 * sizeof(double), "State layout");
+
+static std::string g_create_error;
+
+struct mplx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  std::string err;
+  // map
+  int8_t *map = nullptr;
+  bool own_map = false;
+  int32_t dim[3] = {0, 0, 0};
+  double origin[3] = {0, 0, 0};
+  double res = 0;
+  // config
+  bool have_cfg = false;
+  mplx_config cfg{};
+  std::vector<double> U;
+  double *dU = nullptr, *dUcost = nullptr;
+  double bucket_width = 0;
+  // capacities
+  int32_t n_slots = 1;
+  uint32_t cap_nodes = 1u << 20, cap_edges = 1u << 22, cap_log = 1u << 21, cap_rec = 0;
+  // pools
+  bool pools_valid = false;
+  int32_t pool_slots = 0, pool_nk = 0;
+  uint32_t pool_nodes = 0, pool_edges = 0, pool_log = 0, pool_table = 0;
+  SearchParams pools{};  // only pool pointers are used
+  std::vector<void *> pool_allocs;
+  // last batch
+  int last_nq = 0;
+  bool last_single = false;
+  std::vector<QueryOut> last_out;
+  QueryOut *d_out = nullptr;
+  QueryIn *d_in = nullptr;
+  int32_t *d_traj_nodes = nullptr, *d_traj_actions = nullptr, *d_rec = nullptr, *d_next = nullptr;
+  double *d_traj_states = nullptr;
+  int batch_cap = 0;
+  uint32_t batch_rec = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0;
+};
+
+static int fail(mplx_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return code;
+}
+#define HIPCHK(c, call)                                                                         \
+  do {                                                                                          \
+    hipError_t e__ = (call);                                                                    \
+    if (e__ != hipSuccess) return fail((c), MPLX_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
+  } while (0)
+
+extern "C" const char *mplx_version(void) { return "mplx 0.1 (gfx950)"; }
+extern "C" const char *mplx_last_error(const mplx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int mplx_ctx_create(int device, mplx_ctx **out) {
+  if (!out) return fail(nullptr, MPLX_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(nullptr, MPLX_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(nullptr, MPLX_ERR_ARG, "device %d out of range (%d devices)", device, n);
+  mplx_ctx *c = new mplx_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return fail(nullptr, MPLX_ERR_HIP, "stream/event creation failed");
+  }
+  *out = c;
+  return MPLX_OK;
+}
+
+static void free_pools(mplx_ctx *c) {
+  for (void *p : c->pool_allocs) (void)hipFree(p);
+  c->pool_allocs.clear();
+  c->pools_valid = false;
+}
+static void free_batch(mplx_ctx *c) {
+  (void)hipFree(c->d_out); (void)hipFree(c->d_in); (void)hipFree(c->d_traj_nodes); (void)hipFree(c->d_traj_actions);
+  (void)hipFree(c->d_traj_states); (void)hipFree(c->d_rec); (void)hipFree(c->d_next);
+  c->d_out = nullptr; c->d_in = nullptr; c->d_traj_nodes = c->d_traj_actions = c->d_rec = c->d_next = nullptr;
+  c->d_traj_states = nullptr;
+  c->batch_cap = 0;
+}
+
+extern "C" void mplx_ctx_destroy(mplx_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_pools(c);
+  free_batch(c);
+  if (c->own_map) (void)hipFree(c->map);
+  (void)hipFree(c->dU);
+  (void)hipFree(c->dUcost);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int mplx_set_stream(mplx_ctx *c, void *s) {
+  if (!c) return MPLX_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  if (s) {
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
+  } else {
+    HIPCHK(c, hipStreamCreate(&c->stream));
+    c->own_stream = true;
+  }
+  return MPLX_OK;
+}
+
+// ------------------------------------------------------------------ map
+static int set_map_meta(mplx_ctx *c, const int32_t dim[3], const double origin[3], double res) {
+  if (!dim || !origin || dim[0] <= 0 || dim[1] <= 0 || dim[2] <= 0 || !(res > 0)) return fail(c, MPLX_ERR_ARG, "bad map geometry");
+  for (int i = 0; i < 3; i++) {
+    c->dim[i] = dim[i];
+    c->origin[i] = origin[i];
+  }
+  c->res = res;
+  return MPLX_OK;
+}
+extern "C" int mplx_map_set(mplx_ctx *c, const int8_t *data, const int32_t dim[3], const double origin[3], double res) {
+  if (!c || !data) return fail(c, MPLX_ERR_ARG, "null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  int r = set_map_meta(c, dim, origin, res);
+  if (r) return r;
+  size_t n = (size_t)dim[0] * dim[1] * dim[2];
+  if (c->own_map) (void)hipFree(c->map);
+  c->map = nullptr;
+  c->own_map = true;
+  HIPCHK(c, hipMalloc((void **)&c->map, n));
+  HIPCHK(c, hipMemcpyAsync(c->map, data, n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+extern "C" int mplx_map_set_device(mplx_ctx *c, const void *dptr, const int32_t dim[3], const double origin[3], double res) {
+  if (!c || !dptr) return fail(c, MPLX_ERR_ARG, "null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  int r = set_map_meta(c, dim, origin, res);
+  if (r) return r;
+  if (c->own_map) (void)hipFree(c->map);
+  c->map = (int8_t *)dptr;
+  c->own_map = false;
+  return MPLX_OK;
+}
+extern "C" int mplx_map_free_unknown(mplx_ctx *c) {
+  if (!c || !c->map) return fail(c, MPLX_ERR_ARG, "no map");
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t n = (size_t)c->dim[0] * c->dim[1] * c->dim[2];
+  hipLaunchKernelGGL(free_unknown_kernel, dim3(2048), dim3(256), 0, c->stream, c->map, n);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+extern "C" int mplx_map_get(mplx_ctx *c, int8_t *out) {
+  if (!c || !c->map || !out) return fail(c, MPLX_ERR_ARG, "no map");
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t n = (size_t)c->dim[0] * c->dim[1] * c->dim[2];
+  HIPCHK(c, hipMemcpyAsync(out, c->map, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+extern "C" int mplx_map_info(const mplx_ctx *c, int32_t dim[3], double origin[3], double *res) {
+  if (!c || !c->map) return MPLX_ERR_ARG;
+  for (int i = 0; i < 3; i++) {
+    if (dim) dim[i] = c->dim[i];
+    if (origin) origin[i] = c->origin[i];
+  }
+  if (res) *res = c->res;
+  return MPLX_OK;
+}
+static MapDev map_dev(const mplx_ctx *c) {
+  MapDev m;
+  m.data = c->map;
+  for (int i = 0; i < 3; i++) {
+    m.dim[i] = c->dim[i];
+    m.origin[i] = c->origin[i];
+  }
+  m.res = c->res;
+  return m;
+}
+extern "C" int mplx_map_query(mplx_ctx *c, int n, const double *pts, int32_t *cells, int8_t *state) {
+  if (!c || !c->map || n < 0 || !pts || !cells || !state) return fail(c, MPLX_ERR_ARG, "bad argument");
+  if (n == 0) return MPLX_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  double *dp = nullptr;
+  int32_t *dc = nullptr;
+  int8_t *ds = nullptr;
+  HIPCHK(c, hipMalloc((void **)&dp, sizeof(double) * 3 * n));
+  HIPCHK(c, hipMalloc((void **)&dc, sizeof(int32_t) * 3 * n));
+  HIPCHK(c, hipMalloc((void **)&ds, n));
+  HIPCHK(c, hipMemcpyAsync(dp, pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(map_query_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, map_dev(c), n, dp, dc, ds);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(cells, dc, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(state, ds, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(dp); (void)hipFree(dc); (void)hipFree(ds);
+  return MPLX_OK;
+}
+
+// ------------------------------------------------------------------ configuration
+static bool control_ok(int c) { return c == CTRL_VEL || c == CTRL_ACC || c == CTRL_JRK || c == CTRL_SNP; }
+
+extern "C" int mplx_planner_config(mplx_ctx *c, const mplx_config *cfg) {
+  if (!c || !cfg || !cfg->U) return fail(c, MPLX_ERR_ARG, "null argument");
+  if (!control_ok(cfg->control)) return fail(c, MPLX_ERR_ARG, "unsupported control %d", cfg->control);
+  if (cfg->n_u <= 0 || cfg->n_u > 256) return fail(c, MPLX_ERR_ARG, "n_u must be in [1,256], got %d", cfg->n_u);
+  if (!(cfg->dt > 0)) return fail(c, MPLX_ERR_ARG, "dt must be > 0");
+  HIPCHK(c, hipSetDevice(c->device));
+  c->cfg = *cfg;
+  c->U.assign(cfg->U, cfg->U + 3 * (size_t)cfg->n_u);
+  c->cfg.U = c->U.data();
+  // per-control edge cost J(control) + w dt: depends on the control input only
+  std::vector<double> ucost(cfg->n_u);
+  for (int i = 0; i < cfg->n_u; i++) {
+    double cc[3][6];
+    for (int ax = 0; ax < 3; ax++) prim_build_axis(cfg->control, 0.0, 0.0, 0.0, 0.0, c->U[3 * i + ax], cc[ax]);
+    ucost[i] = prim_J(cfg->control, cc, cfg->dt) + cfg->w * cfg->dt;
+  }
+  (void)hipFree(c->dU);
+  (void)hipFree(c->dUcost);
+  c->dU = c->dUcost = nullptr;
+  HIPCHK(c, hipMalloc((void **)&c->dU, sizeof(double) * 3 * cfg->n_u));
+  HIPCHK(c, hipMalloc((void **)&c->dUcost, sizeof(double) * cfg->n_u));
+  HIPCHK(c, hipMemcpyAsync(c->dU, c->U.data(), sizeof(double) * 3 * cfg->n_u, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->dUcost, ucost.data(), sizeof(double) * cfg->n_u, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_cfg = true;
+  return MPLX_OK;
+}
+
+extern "C" int mplx_set_capacity(mplx_ctx *c, int32_t n_slots, uint32_t max_nodes, uint32_t max_edges, uint32_t max_log) {
+  if (!c) return MPLX_ERR_ARG;
+  if (n_slots > 0) c->n_slots = n_slots;
+  if (max_nodes) {
+    if (max_nodes >= CLAIM_BASE / 2) return fail(c, MPLX_ERR_ARG, "max_nodes too large");
+    c->cap_nodes = max_nodes;
+  }
+  if (max_edges) c->cap_edges = max_edges;
+  if (max_log) c->cap_log = max_log;
+  return MPLX_OK;
+}
+extern "C" int mplx_set_bucket_width(mplx_ctx *c, double w) {
+  if (!c || w < 0) return MPLX_ERR_ARG;
+  c->bucket_width = w;
+  return MPLX_OK;
+}
+extern "C" int mplx_set_record(mplx_ctx *c, uint32_t cap) {
+  if (!c) return MPLX_ERR_ARG;
+  c->cap_rec = cap;
+  return MPLX_OK;
+}
+
+static void fill_params(const mplx_ctx *c, SearchParams &P) {
+  const mplx_config &g = c->cfg;
+  P.control = g.control;
+  P.n_u = g.n_u;
+  P.ns = P.nk = state_len(g.control);
+  P.dt = g.dt; P.v_max = g.v_max; P.a_max = g.a_max; P.j_max = g.j_max;
+  P.w = g.w; P.eps = g.eps;
+  P.tol_pos = g.tol_pos; P.tol_vel = g.tol_vel; P.tol_acc = g.tol_acc;
+  P.t_max = g.t_max;
+  P.max_expand = g.max_expand;
+  P.heur_ignore_dynamics = g.heur_ignore_dynamics;
+  P.U = c->dU;
+  P.ucost = c->dUcost;
+  P.map = map_dev(c);
+  P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt / 8.0 : 1.0);
+}
+
+template <typename T>
+static int pool_alloc(mplx_ctx *c, T **p, size_t count) {
+  void *v = nullptr;
+  hipError_t e = hipMalloc(&v, count * sizeof(T));
+  if (e != hipSuccess) return fail(c, MPLX_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+  c->pool_allocs.push_back(v);
+  *p = (T *)v;
+  return MPLX_OK;
+}
+
+static uint32_t next_pow2(uint64_t v) {
+  uint64_t p = 1;
+  while (p < v) p <<= 1;
+  return (uint32_t)p;
+}
+
+static int ensure_pools(mplx_ctx *c, int slots) {
+  const int nk = state_len(c->cfg.control);
+  if (c->pools_valid && c->pool_slots >= slots && c->pool_nk == nk && c->pool_nodes == c->cap_nodes &&
+      c->pool_edges == c->cap_edges && c->pool_log == c->cap_log)
+    return MPLX_OK;
+  free_pools(c);
+  SearchParams &P = c->pools;
+  const size_t S = (size_t)slots, N = c->cap_nodes, E = c->cap_edges, L = c->cap_log;
+  const uint32_t T = next_pow2(2ull * N);
+  int r;
+#define PA(ptr, cnt) if ((r = pool_alloc(c, &(ptr), (cnt))) != MPLX_OK) { free_pools(c); return r; }
+  PA(P.node_key, S * N * nk);
+  PA(P.node_state, S * N * (nk + 1));
+  PA(P.node_g, S * N);
+  PA(P.node_h, S * N);
+  PA(P.node_flags, S * N);
+  PA(P.node_pred, S * N);
+  PA(P.table, S * T);
+  PA(P.edge_parent, S * E);
+  PA(P.edge_next, S * E);
+  PA(P.edge_action, S * E);
+  PA(P.log_f, S * L);
+  PA(P.log_g, S * L);
+  PA(P.log_id, S * L);
+  PA(P.log_next, S * L);
+  PA(P.bkt_head, S * NB * NSUB);
+#undef PA
+  c->pool_slots = slots;
+  c->pool_nk = nk;
+  c->pool_nodes = c->cap_nodes;
+  c->pool_edges = c->cap_edges;
+  c->pool_log = c->cap_log;
+  c->pool_table = T;
+  c->pools_valid = true;
+  return MPLX_OK;
+}
+
+static int ensure_batch(mplx_ctx *c, int nq) {
+  if (c->batch_cap >= nq && c->batch_rec == c->cap_rec) return MPLX_OK;
+  free_batch(c);
+  HIPCHK(c, hipMalloc((void **)&c->d_out, sizeof(QueryOut) * nq));
+  HIPCHK(c, hipMalloc((void **)&c->d_in, sizeof(QueryIn) * nq));
+  HIPCHK(c, hipMalloc((void **)&c->d_traj_nodes, sizeof(int32_t) * (size_t)nq * (MAX_TRAJ + 1)));
+  HIPCHK(c, hipMalloc((void **)&c->d_traj_actions, sizeof(int32_t) * (size_t)nq * MAX_TRAJ));
+  HIPCHK(c, hipMalloc((void **)&c->d_traj_states, sizeof(double) * (size_t)nq * (MAX_TRAJ + 1) * 13));
+  HIPCHK(c, hipMalloc((void **)&c->d_next, sizeof(int32_t)));
+  if (c->cap_rec) HIPCHK(c, hipMalloc((void **)&c->d_rec, sizeof(int32_t) * (size_t)nq * c->cap_rec));
+  c->batch_cap = nq;
+  c->batch_rec = c->cap_rec;
+  return MPLX_OK;
+}
+
+static void wp_to_state(const mplx_waypoint &w, State &s) {
+  for (int i = 0; i < 3; i++) {
+    s.p[i] = w.pos[i];
+    s.v[i] = (w.control & 2) ? w.vel[i] : 0.0;
+    s.a[i] = (w.control & 4) ? w.acc[i] : 0.0;
+    s.j[i] = (w.control & 8) ? w.jrk[i] : 0.0;
+  }
+}
+
+static int pick_block(int n_u) { return n_u <= 64 ? 64 : (n_u <= 128 ? 128 : 256); }
+
+template <int BLOCK>
+static void launch_astar(int control, int grid, hipStream_t s, const SearchParams &P) {
+  switch (control) {
+    case CTRL_VEL: hipLaunchKernelGGL((astar_kernel<BLOCK, CTRL_VEL>), dim3(grid), dim3(BLOCK), 0, s, P); break;
+    case CTRL_ACC: hipLaunchKernelGGL((astar_kernel<BLOCK, CTRL_ACC>), dim3(grid), dim3(BLOCK), 0, s, P); break;
+    case CTRL_JRK: hipLaunchKernelGGL((astar_kernel<BLOCK, CTRL_JRK>), dim3(grid), dim3(BLOCK), 0, s, P); break;
+    default: hipLaunchKernelGGL((astar_kernel<BLOCK, CTRL_SNP>), dim3(grid), dim3(BLOCK), 0, s, P); break;
+  }
+}
+template <int BLOCK>
+static void launch_expand(int control, int grid, hipStream_t s, const SearchParams &P, const State *n, const double *t, int K, SuccOut *o) {
+  switch (control) {
+    case CTRL_VEL: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_VEL>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o); break;
+    case CTRL_ACC: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_ACC>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o); break;
+    case CTRL_JRK: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_JRK>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o); break;
+    default: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_SNP>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o); break;
+  }
+}
+
+static int check_ready(mplx_ctx *c) {
+  if (!c) return MPLX_ERR_ARG;
+  if (!c->map) return fail(c, MPLX_ERR_ARG, "no map set (mplx_map_set)");
+  if (!c->have_cfg) return fail(c, MPLX_ERR_ARG, "planner not configured (mplx_planner_config)");
+  return MPLX_OK;
+}
+
+// ------------------------------------------------------------------ expand_batch
+extern "C" int mplx_expand_batch(mplx_ctx *c, int K, const mplx_waypoint *nodes, mplx_succ *out) {
+  int r = check_ready(c);
+  if (r) return r;
+  if (K <= 0 || !nodes || !out) return fail(c, MPLX_ERR_ARG, "bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  SearchParams P{};
+  fill_params(c, P);
+  std::vector<State> hs(K);
+  std::vector<double> ht(K);
+  for (int i = 0; i < K; i++) {
+    mplx_waypoint w = nodes[i];
+    w.control = c->cfg.control;
+    wp_to_state(w, hs[i]);
+    ht[i] = nodes[i].t;
+  }
+  State *dn = nullptr;
+  double *dt = nullptr;
+  SuccOut *dout = nullptr;
+  const size_t no = (size_t)K * P.n_u;
+  HIPCHK(c, hipMalloc((void **)&dn, sizeof(State) * K));
+  HIPCHK(c, hipMalloc((void **)&dt, sizeof(double) * K));
+  HIPCHK(c, hipMalloc((void **)&dout, sizeof(SuccOut) * no));
+  HIPCHK(c, hipMemcpyAsync(dn, hs.data(), sizeof(State) * K, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dt, ht.data(), sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
+  const int grid = K < 4096 ? K : 4096;
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  switch (pick_block(P.n_u)) {
+    case 64: launch_expand<64>(P.control, grid, c->stream, P, dn, dt, K, dout); break;
+    case 128: launch_expand<128>(P.control, grid, c->stream, P, dn, dt, K, dout); break;
+    default: launch_expand<256>(P.control, grid, c->stream, P, dn, dt, K, dout); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipMemcpyAsync(out, dout, sizeof(SuccOut) * no, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+  (void)hipFree(dn); (void)hipFree(dt); (void)hipFree(dout);
+  return MPLX_OK;
+}
+
+extern "C" int mplx_heuristic_batch(mplx_ctx *c, int n, const mplx_waypoint *states, const mplx_waypoint *goal, double *h, int32_t *is_goal) {
+  int r = check_ready(c);
+  if (r) return r;
+  if (n <= 0 || !states || !goal || !h || !is_goal) return fail(c, MPLX_ERR_ARG, "bad argument");
+  if (!control_ok(goal->control)) return fail(c, MPLX_ERR_ARG, "bad goal control");
+  HIPCHK(c, hipSetDevice(c->device));
+  SearchParams P{};
+  fill_params(c, P);
+  HeurParams hp{};
+  hp.w = P.w; hp.v_max = P.v_max; hp.heur_ignore_dynamics = P.heur_ignore_dynamics;
+  hp.goal_control = goal->control;
+  wp_to_state(*goal, hp.goal);
+  hp.goal_nkey = state_key(goal->control, hp.goal, hp.goal_key);
+  std::vector<State> hs(n);
+  std::vector<double> ht(n);
+  for (int i = 0; i < n; i++) {
+    mplx_waypoint w = states[i];
+    w.control = c->cfg.control;
+    wp_to_state(w, hs[i]);
+    ht[i] = states[i].t;
+  }
+  State *ds = nullptr;
+  double *dt = nullptr, *dh = nullptr;
+  int32_t *dg = nullptr;
+  HIPCHK(c, hipMalloc((void **)&ds, sizeof(State) * n));
+  HIPCHK(c, hipMalloc((void **)&dt, sizeof(double) * n));
+  HIPCHK(c, hipMalloc((void **)&dh, sizeof(double) * n));
+  HIPCHK(c, hipMalloc((void **)&dg, sizeof(int32_t) * n));
+  HIPCHK(c, hipMemcpyAsync(ds, hs.data(), sizeof(State) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dt, ht.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(heuristic_kernel, dim3((n + 127) / 128), dim3(128), 0, c->stream, P, hp, n, ds, dt, dh, dg);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(h, dh, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(is_goal, dg, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(ds); (void)hipFree(dt); (void)hipFree(dh); (void)hipFree(dg);
+  return MPLX_OK;
+}
+
+// ------------------------------------------------------------------ plan
+static void fill_result(const QueryOut &o, mplx_result &r) {
+  r.status = o.status; r.traj_len = o.traj_len; r.cost = o.cost;
+  r.n_expanded = o.n_expanded; r.n_closed = o.n_closed; r.n_nodes = o.n_nodes; r.n_edges = o.n_edges;
+  r.n_primitives = o.n_primitives; r.n_succ = o.n_succ; r.n_succ_finite = o.n_succ_finite;
+  r.voxel_reads = o.voxel_reads; r.n_push = o.n_push; r.n_reopen = o.n_reopen;
+  r.n_refill = o.n_refill; r.n_evict = o.n_evict; r.expand_hash = o.expand_hash;
+}
+
+extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals, mplx_result *out) {
+  int r = check_ready(c);
+  if (r) return r;
+  if (nq <= 0 || !starts || !goals || !out) return fail(c, MPLX_ERR_ARG, "bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int slots = nq < c->n_slots ? nq : c->n_slots;
+  if ((r = ensure_pools(c, slots)) != MPLX_OK) return r;
+  if ((r = ensure_batch(c, nq)) != MPLX_OK) return r;
+  std::vector<QueryIn> in(nq);
+  for (int i = 0; i < nq; i++) {
+    if (starts[i].enable_t) return fail(c, MPLX_ERR_ARG, "enable_t is not supported by the voxel-map environment");
+    if (!control_ok(goals[i].control)) return fail(c, MPLX_ERR_ARG, "bad goal control");
+    mplx_waypoint s = starts[i];
+    s.control = c->cfg.control;
+    wp_to_state(s, in[i].start);
+    wp_to_state(goals[i], in[i].goal);
+    in[i].start_t = starts[i].t;
+    in[i].goal_control = goals[i].control;
+    in[i].pad = 0;
+  }
+  SearchParams P = c->pools;
+  fill_params(c, P);
+  P.cap_nodes = c->pool_nodes; P.cap_table = c->pool_table; P.cap_edges = c->pool_edges; P.cap_log = c->pool_log;
+  P.cap_rec = c->cap_rec;
+  P.nq = nq;
+  P.queries = c->d_in;
+  P.out = c->d_out;
+  P.traj_nodes = c->d_traj_nodes; P.traj_actions = c->d_traj_actions; P.traj_states = c->d_traj_states;
+  P.rec_ids = c->cap_rec ? c->d_rec : nullptr;
+  P.next_query = c->d_next;
+  HIPCHK(c, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * nq, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), c->stream));
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  switch (pick_block(P.n_u)) {
+    case 64: launch_astar<64>(P.control, slots, c->stream, P); break;
+    case 128: launch_astar<128>(P.control, slots, c->stream, P); break;
+    default: launch_astar<256>(P.control, slots, c->stream, P); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  c->last_out.resize(nq);
+  HIPCHK(c, hipMemcpyAsync(c->last_out.data(), c->d_out, sizeof(QueryOut) * nq, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+  for (int i = 0; i < nq; i++) fill_result(c->last_out[i], out[i]);
+  c->last_nq = nq;
+  c->last_single = (nq == 1);
+  return MPLX_OK;
+}
+
+extern "C" int mplx_plan(mplx_ctx *c, const mplx_waypoint *start, const mplx_waypoint *goal, mplx_result *out) {
+  return mplx_plan_batch(c, 1, start, goal, out);
+}
+
+extern "C" int mplx_result_traj(mplx_ctx *c, int q, mplx_primitive *prs, mplx_waypoint *wps, int32_t *actions, int32_t *node_ids) {
+  if (!c || q < 0 || q >= c->last_nq) return fail(c, MPLX_ERR_ARG, "no such query");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int len = c->last_out[q].traj_len;
+  if (c->last_out[q].status != MPLX_PLAN_OK || len <= 0) return MPLX_OK;
+  std::vector<int32_t> tn(len + 1), ta(len);
+  std::vector<double> ts((size_t)(len + 1) * 13);
+  HIPCHK(c, hipMemcpyAsync(tn.data(), c->d_traj_nodes + (size_t)q * (MAX_TRAJ + 1), sizeof(int32_t) * (len + 1), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(ta.data(), c->d_traj_actions + (size_t)q * MAX_TRAJ, sizeof(int32_t) * len, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(ts.data(), c->d_traj_states + (size_t)q * (MAX_TRAJ + 1) * 13, sizeof(double) * (len + 1) * 13, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // device order is goal -> start; emit start -> goal
+  const int control = c->cfg.control;
+  for (int i = 0; i <= len; i++) {
+    const double *s = &ts[(size_t)(len - i) * 13];
+    if (wps) {
+      mplx_waypoint &w = wps[i];
+      memset(&w, 0, sizeof(w));
+      for (int k = 0; k < 3; k++) {
+        w.pos[k] = s[k]; w.vel[k] = s[3 + k]; w.acc[k] = s[6 + k]; w.jrk[k] = s[9 + k];
+      }
+      w.t = s[12];
+      w.control = control;
+    }
+    if (node_ids) node_ids[i] = tn[len - i];
+  }
+  for (int i = 0; i < len; i++) {
+    const int a = ta[len - 1 - i];
+    if (actions) actions[i] = a;
+    if (prs) {  // forward_action(parent coord, action): primitive from the stored parent state
+      const double *s = &ts[(size_t)(len - i) * 13];
+      mplx_primitive &p = prs[i];
+      memset(&p, 0, sizeof(p));
+      for (int ax = 0; ax < 3; ax++) prim_build_axis(control, s[ax], s[3 + ax], s[6 + ax], s[9 + ax], c->U[3 * a + ax], p.c[ax]);
+      p.t = c->cfg.dt;
+      p.control = control;
+    }
+  }
+  return MPLX_OK;
+}
+
+extern "C" int mplx_result_expanded(mplx_ctx *c, int q, uint32_t cap, int32_t *ids, uint32_t *n) {
+  if (!c || q < 0 || q >= c->last_nq || !ids || !n) return fail(c, MPLX_ERR_ARG, "bad argument");
+  if (!c->batch_rec || !c->d_rec) return fail(c, MPLX_ERR_ARG, "recording disabled (mplx_set_record)");
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t cnt = c->last_out[q].n_recorded;
+  if (cnt > cap) cnt = cap;
+  if (cnt) HIPCHK(c, hipMemcpyAsync(ids, c->d_rec + (size_t)q * c->batch_rec, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n = cnt;
+  return MPLX_OK;
+}
+
+extern "C" int mplx_result_nodes(mplx_ctx *c, mplx_waypoint *coords, double *g, double *h, int32_t *closed, int32_t *opened) {
+  if (!c || !c->last_single || !c->pools_valid) return fail(c, MPLX_ERR_ARG, "state-space dump needs a preceding single mplx_plan()");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = c->last_out[0].n_nodes;
+  if (n == 0) return MPLX_OK;
+  const int nk = c->pool_nk;
+  std::vector<double> st(n * (nk + 1));
+  std::vector<uint32_t> fl(n);
+  std::vector<unsigned long long> gg(n);
+  HIPCHK(c, hipMemcpyAsync(st.data(), c->pools.node_state, sizeof(double) * n * (nk + 1), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(fl.data(), c->pools.node_flags, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(gg.data(), c->pools.node_g, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
+  if (h) HIPCHK(c, hipMemcpyAsync(h, c->pools.node_h, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < n; i++) {
+    if (coords) {
+      mplx_waypoint &w = coords[i];
+      memset(&w, 0, sizeof(w));
+      const double *s = &st[i * (nk + 1)];
+      for (int k = 0; k < nk; k++) {
+        double *dst = k < 3 ? w.pos : k < 6 ? w.vel : k < 9 ? w.acc : w.jrk;
+        dst[k % 3] = s[k];
+      }
+      w.t = s[nk];
+      w.control = c->cfg.control;
+    }
+    if (g) memcpy(&g[i], &gg[i], sizeof(double));
+    if (closed) closed[i] = (fl[i] & FLAG_CLOSED) ? 1 : 0;
+    if (opened) opened[i] = (fl[i] & FLAG_OPENED) ? 1 : 0;
+  }
+  return MPLX_OK;
+}
+
+extern "C" int mplx_last_kernel_ms(const mplx_ctx *c, float *ms) {
+  if (!c || !ms) return MPLX_ERR_ARG;
+  *ms = c->last_ms;
+  return MPLX_OK;
+}

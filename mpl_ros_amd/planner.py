@@ -1,0 +1,436 @@
+"""Host-side mirror of the reference's planner interface for the voxel-map path, over the C-ABI.
+
+Same names, argument meaning and error behaviour as the C++ classes the reference drivers use
+(mpl_test_node/src/map_planner_node.cpp:10-35,155-196):
+
+    map_util = VoxelMapUtil(); map_util.setMap(origin, dim, data, res); map_util.freeUnknown()
+    planner = VoxelMapPlanner(verbose); planner.setMapUtil(map_util); planner.setVmax(..) ...
+    ok = planner.plan(start, goal); traj = planner.getTraj(); planner.getCloseSet()
+
+Every call that computes goes through libmplx.so (HIP, gfx950).  Nothing here evaluates
+primitives, touches voxels or searches on the CPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi
+from ._capi import ACC, JRK, SNP, VEL, MplxError  # noqa: F401  (re-exported Control kinds)
+
+
+class Control:
+    VEL, ACC, JRK, SNP = VEL, ACC, JRK, SNP
+
+
+class Waypoint3D:
+    """Waypoint<3>: pos/vel/acc/jrk + use_* flags (control = union of the flags)."""
+
+    def __init__(self, control=0):
+        self.pos = np.zeros(3)
+        self.vel = np.zeros(3)
+        self.acc = np.zeros(3)
+        self.jrk = np.zeros(3)
+        self.yaw = 0.0
+        self.t = 0.0
+        self.enable_t = False
+        self.control = control
+
+    # use_pos .. use_jrk view the control bits, like the union in the reference's Waypoint
+    def _bit(self, b):
+        return bool(self.control & b)
+
+    def _set(self, b, v):
+        self.control = (self.control | b) if v else (self.control & ~b)
+
+    use_pos = property(lambda s: s._bit(1), lambda s, v: s._set(1, v))
+    use_vel = property(lambda s: s._bit(2), lambda s, v: s._set(2, v))
+    use_acc = property(lambda s: s._bit(4), lambda s, v: s._set(4, v))
+    use_jrk = property(lambda s: s._bit(8), lambda s, v: s._set(8, v))
+
+    def to_c(self):
+        w = _capi.Waypoint()
+        w.pos[:] = [float(x) for x in self.pos]
+        w.vel[:] = [float(x) for x in self.vel]
+        w.acc[:] = [float(x) for x in self.acc]
+        w.jrk[:] = [float(x) for x in self.jrk]
+        w.yaw, w.t = float(self.yaw), float(self.t)
+        w.control = int(self.control)
+        w.enable_t = int(bool(self.enable_t))
+        return w
+
+    @staticmethod
+    def from_c(w):
+        o = Waypoint3D(w.control)
+        o.pos, o.vel = np.array(w.pos[:]), np.array(w.vel[:])
+        o.acc, o.jrk = np.array(w.acc[:]), np.array(w.jrk[:])
+        o.yaw, o.t, o.enable_t = w.yaw, w.t, bool(w.enable_t)
+        return o
+
+    def state(self):
+        parts = [self.pos]
+        if self.control & 2:
+            parts.append(self.vel)
+        if self.control & 4:
+            parts.append(self.acc)
+        if self.control & 8:
+            parts.append(self.jrk)
+        return np.concatenate(parts)
+
+
+class Primitive3D:
+    """Primitive<3> as its coefficient table (pr(i).coeff(), t(), control())."""
+
+    def __init__(self, coeffs, t, control):
+        self._c = np.array(coeffs, dtype=np.float64).reshape(3, 6)
+        self._t = float(t)
+        self._control = control
+
+    def coeff(self, i):
+        return self._c[i]
+
+    def t(self):
+        return self._t
+
+    def control(self):
+        return self._control
+
+
+class Trajectory3D:
+    def __init__(self, prs, wps, actions, cost):
+        self.segs = prs
+        self._wps = wps
+        self.actions = actions
+        self.cost = cost
+
+    def getPrimitives(self):
+        return self.segs
+
+    def getWaypoints(self):
+        return self._wps
+
+    def getSegmentTimes(self):
+        return [p.t() for p in self.segs]
+
+    def getTotalTime(self):
+        return float(sum(p.t() for p in self.segs))
+
+
+def _check(ctx, code, lib):
+    if code != _capi.OK:
+        msg = lib.mplx_last_error(ctx)
+        raise MplxError(f"mplx error {code}: {msg.decode() if msg else ''}")
+
+
+class _Context:
+    """One device context (HIP stream + map replica + pools)."""
+
+    def __init__(self, device=0):
+        self.lib = _capi.load()
+        h = C.c_void_p()
+        code = self.lib.mplx_ctx_create(device, C.byref(h))
+        if code != _capi.OK:
+            msg = self.lib.mplx_last_error(None)
+            raise MplxError(f"mplx_ctx_create failed ({code}): {msg.decode() if msg else ''}")
+        self.h = h
+
+    def check(self, code):
+        _check(self.h, code, self.lib)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.mplx_ctx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class VoxelMapUtil:
+    """MapUtil<3>: the voxel grid lives in HBM; setMap copies it in (or adopts a device pointer)."""
+
+    def __init__(self, device=0):
+        self.ctx = _Context(device)
+        self._dim = None
+
+    def setMap(self, ori, dim, data, res):
+        """data: int8 sequence, x fastest (idx = x + dx*y + dx*dy*z); free 0, occupied >0, unknown -1."""
+        a = np.ascontiguousarray(data, dtype=np.int8).ravel()
+        if a.size != int(dim[0]) * int(dim[1]) * int(dim[2]):
+            raise ValueError("map size does not match dim")
+        d = (C.c_int32 * 3)(*[int(x) for x in dim])
+        o = (C.c_double * 3)(*[float(x) for x in ori])
+        self.ctx.check(self.ctx.lib.mplx_map_set(self.ctx.h, a.ctypes.data, d, o, float(res)))
+        self._dim = tuple(int(x) for x in dim)
+
+    def setMapDevice(self, device_ptr, ori, dim, res):
+        """Adopt a grid already in HBM (e.g. a torch uint8/int8 CUDA tensor's data_ptr())."""
+        d = (C.c_int32 * 3)(*[int(x) for x in dim])
+        o = (C.c_double * 3)(*[float(x) for x in ori])
+        self.ctx.check(self.ctx.lib.mplx_map_set_device(self.ctx.h, C.c_void_p(device_ptr), d, o, float(res)))
+        self._dim = tuple(int(x) for x in dim)
+
+    def _info(self):
+        d = (C.c_int32 * 3)()
+        o = (C.c_double * 3)()
+        r = C.c_double()
+        self.ctx.check(self.ctx.lib.mplx_map_info(self.ctx.h, d, o, C.byref(r)))
+        return np.array(d[:]), np.array(o[:]), r.value
+
+    def getDim(self):
+        return self._info()[0]
+
+    def getOrigin(self):
+        return self._info()[1]
+
+    def getRes(self):
+        return self._info()[2]
+
+    def getMap(self):
+        n = int(np.prod(self._dim))
+        out = np.empty(n, dtype=np.int8)
+        self.ctx.check(self.ctx.lib.mplx_map_get(self.ctx.h, out.ctypes.data))
+        return out
+
+    def freeUnknown(self):
+        self.ctx.check(self.ctx.lib.mplx_map_free_unknown(self.ctx.h))
+
+    def query(self, pts):
+        """Batched floatToInt + cell state for points (n,3): returns (cells int32 (n,3), state int8)
+        with state 0 free, 1 occupied, 2 unknown, 3 outside."""
+        p = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        cells = np.empty((p.shape[0], 3), dtype=np.int32)
+        st = np.empty(p.shape[0], dtype=np.int8)
+        self.ctx.check(self.ctx.lib.mplx_map_query(self.ctx.h, p.shape[0], p.ctypes.data, cells.ctypes.data, st.ctypes.data))
+        return cells, st
+
+    def floatToInt(self, pt):
+        return self.query([pt])[0][0]
+
+    def isFree(self, pt):
+        return int(self.query([pt])[1][0]) == 0
+
+    def isOccupied(self, pt):
+        return int(self.query([pt])[1][0]) == 1
+
+    def isOutside(self, pt):
+        return int(self.query([pt])[1][0]) == 3
+
+
+class VoxelMapPlanner:
+    """PlannerBase<3, Waypoint3D> + MapPlanner<3> over the device back-end."""
+
+    def __init__(self, verbose=False):
+        self.planner_verbose_ = verbose
+        self.map_util_ = None
+        self._U = None
+        self._v_max = self._a_max = self._j_max = -1.0
+        self._dt = 1.0
+        self._w = 10.0
+        self._eps = 1.0
+        self._tol = (0.5, -1.0, -1.0)
+        self._t_max = math.inf
+        self._max_num = -1
+        self._heur_ignore_dynamics = False
+        self._dirty = True
+        self._control = None
+        self._result = None
+        self._results = None
+        self.traj_cost_ = math.inf
+
+    # ---- setters (PlannerBase / MapPlanner)
+    def setMapUtil(self, map_util):
+        self.map_util_ = map_util
+        self._dirty = True
+
+    def setVmax(self, v):
+        self._v_max, self._dirty = float(v), True
+
+    def setAmax(self, a):
+        self._a_max, self._dirty = float(a), True
+
+    def setJmax(self, j):
+        self._j_max, self._dirty = float(j), True
+
+    def setDt(self, dt):
+        self._dt, self._dirty = float(dt), True
+
+    def setW(self, w):
+        self._w, self._dirty = float(w), True
+
+    def setEpsilon(self, eps):
+        self._eps, self._dirty = float(eps), True
+
+    def setMaxNum(self, n):
+        self._max_num, self._dirty = int(n), True
+
+    def setTmax(self, t):
+        self._t_max, self._dirty = float(t), True
+
+    def setHeurIgnoreDynamics(self, ignore):
+        self._heur_ignore_dynamics, self._dirty = bool(ignore), True
+
+    def setU(self, U):
+        self._U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, 3)
+        self._dirty = True
+
+    def setTol(self, tol_pos, tol_vel=-1.0, tol_acc=-1.0):
+        self._tol, self._dirty = (float(tol_pos), float(tol_vel), float(tol_acc)), True
+
+    # ---- device-side capacities (no reference counterpart: the reference grows std containers)
+    def setCapacity(self, n_slots=0, max_nodes=0, max_edges=0, max_open_log=0):
+        ctx = self._ctx()
+        ctx.check(ctx.lib.mplx_set_capacity(ctx.h, n_slots, max_nodes, max_edges, max_open_log))
+
+    def setBucketWidth(self, width):
+        ctx = self._ctx()
+        ctx.check(ctx.lib.mplx_set_bucket_width(ctx.h, float(width)))
+
+    def setRecord(self, cap):
+        ctx = self._ctx()
+        ctx.check(ctx.lib.mplx_set_record(ctx.h, int(cap)))
+
+    def _ctx(self):
+        if self.map_util_ is None:
+            raise MplxError("setMapUtil first")
+        return self.map_util_.ctx
+
+    def _configure(self, control):
+        if self._U is None:
+            raise MplxError("setU first")
+        if not self._dirty and control == self._control:
+            return
+        ctx = self._ctx()
+        cfg = _capi.Config()
+        cfg.control = control
+        cfg.n_u = self._U.shape[0]
+        cfg.U = self._U.ctypes.data_as(C.POINTER(C.c_double))
+        cfg.dt, cfg.v_max, cfg.a_max, cfg.j_max = self._dt, self._v_max, self._a_max, self._j_max
+        cfg.w, cfg.eps = self._w, self._eps
+        cfg.tol_pos, cfg.tol_vel, cfg.tol_acc = self._tol
+        cfg.t_max = self._t_max
+        cfg.max_expand = self._max_num
+        cfg.heur_ignore_dynamics = int(self._heur_ignore_dynamics)
+        ctx.check(ctx.lib.mplx_planner_config(ctx.h, C.byref(cfg)))
+        self._control = control
+        self._dirty = False
+
+    # ---- planning
+    def plan(self, start, goal):
+        """bool PlannerBase::plan(start, goal)."""
+        ctx = self._ctx()
+        self._configure(start.control)
+        res = _capi.Result()
+        s, g = start.to_c(), goal.to_c()
+        ctx.check(ctx.lib.mplx_plan(ctx.h, C.byref(s), C.byref(g), C.byref(res)))
+        self._result = res
+        self._results = [res]
+        self.traj_cost_ = res.cost
+        if res.status == _capi.PLAN_START_OCCUPIED:
+            if self.planner_verbose_:
+                print("[PlannerBase] start is not free!")
+            return False
+        if math.isinf(res.cost):
+            if self.planner_verbose_:
+                print("[MPPlanner] Cannot find a traj! status", res.status)
+            return False
+        return True
+
+    def planBatch(self, starts, goals):
+        """Independent queries on the shared map in one launch; returns the list of results."""
+        ctx = self._ctx()
+        self._configure(starts[0].control)
+        n = len(starts)
+        S = (_capi.Waypoint * n)(*[s.to_c() for s in starts])
+        G = (_capi.Waypoint * n)(*[g.to_c() for g in goals])
+        R = (_capi.Result * n)()
+        ctx.check(ctx.lib.mplx_plan_batch(ctx.h, n, S, G, R))
+        self._results = [R[i] for i in range(n)]
+        self._result = self._results[0]
+        return self._results
+
+    def lastKernelMs(self):
+        ctx = self._ctx()
+        ms = C.c_float()
+        ctx.check(ctx.lib.mplx_last_kernel_ms(ctx.h, C.byref(ms)))
+        return ms.value
+
+    # ---- results
+    def getTrajCost(self):
+        return self.traj_cost_
+
+    def getResult(self, q=0):
+        return self._results[q]
+
+    def getTraj(self, q=0):
+        ctx = self._ctx()
+        res = self._results[q]
+        n = res.traj_len if res.status == _capi.PLAN_OK else 0
+        if n <= 0:
+            return Trajectory3D([], [], np.zeros(0, dtype=np.int32), res.cost)
+        prs = (_capi.Primitive * n)()
+        wps = (_capi.Waypoint * (n + 1))()
+        act = (C.c_int32 * n)()
+        ids = (C.c_int32 * (n + 1))()
+        ctx.check(ctx.lib.mplx_result_traj(ctx.h, q, prs, wps, act, ids))
+        P = [Primitive3D([list(prs[i].c[k]) for k in range(3)], prs[i].t, prs[i].control) for i in range(n)]
+        W = [Waypoint3D.from_c(wps[i]) for i in range(n + 1)]
+        tr = Trajectory3D(P, W, np.array(act[:], dtype=np.int32), res.cost)
+        tr.node_ids = np.array(ids[:], dtype=np.int32)
+        return tr
+
+    def getExpandedIds(self, q=0):
+        ctx = self._ctx()
+        cap = int(self._results[q].n_expanded)
+        ids = np.zeros(max(cap, 1), dtype=np.int32)
+        n = C.c_uint32()
+        ctx.check(ctx.lib.mplx_result_expanded(ctx.h, q, cap, ids.ctypes.data, C.byref(n)))
+        return ids[:n.value]
+
+    def _nodes(self):
+        ctx = self._ctx()
+        n = int(self._result.n_nodes)
+        coords = (_capi.Waypoint * max(n, 1))()
+        g = np.zeros(n)
+        h = np.zeros(n)
+        closed = np.zeros(n, dtype=np.int32)
+        opened = np.zeros(n, dtype=np.int32)
+        if n:
+            ctx.check(ctx.lib.mplx_result_nodes(ctx.h, coords, g.ctypes.data, h.ctypes.data, closed.ctypes.data, opened.ctypes.data))
+        pos = np.array([coords[i].pos[:] for i in range(n)]).reshape(n, 3)
+        return coords, pos, g, h, closed, opened
+
+    def getCloseSet(self):
+        _, pos, _, _, closed, _ = self._nodes()
+        return pos[closed == 1]
+
+    def getOpenSet(self):
+        _, pos, _, _, closed, opened = self._nodes()
+        return pos[(opened == 1) & (closed == 0)]
+
+    def getExpandedNodes(self):
+        """Positions in expansion order (env_base::expanded_nodes_); needs setRecord()."""
+        ids = self.getExpandedIds(0)
+        _, pos, _, _, _, _ = self._nodes()
+        return pos[ids]
+
+    # ---- unit entry: env_map::get_succ for many nodes
+    def getSuccBatch(self, nodes):
+        ctx = self._ctx()
+        self._configure(nodes[0].control)
+        K = len(nodes)
+        N = (_capi.Waypoint * K)(*[n.to_c() for n in nodes])
+        out = (_capi.Succ * (K * self._U.shape[0]))()
+        ctx.check(ctx.lib.mplx_expand_batch(ctx.h, K, N, out))
+        return out
+
+    def heuristicBatch(self, states, goal):
+        ctx = self._ctx()
+        self._configure(states[0].control)
+        n = len(states)
+        S = (_capi.Waypoint * n)(*[s.to_c() for s in states])
+        g = goal.to_c()
+        h = np.zeros(n)
+        isg = np.zeros(n, dtype=np.int32)
+        ctx.check(ctx.lib.mplx_heuristic_batch(ctx.h, n, S, C.byref(g), h.ctypes.data, isg.ctypes.data))
+        return h, isg

@@ -1,0 +1,125 @@
+/*
+ * mpl_oracle.h -- CPU restatement of the motion_primitive_library v1.2 voxel-map search path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and there only as the
+ * checker / the reported CPU baseline.  The product path (mpl_ros_amd/csrc) shares no code with
+ * this directory.
+ *
+ * PARITY UNPINNED.  The reference tree (/root/reference) does not contain the algorithm: it lives
+ * in the un-vendored git submodule `motion_primitive_library` ("v1.2", reference README.md:4,
+ * .gitmodules:1-3; exact commit unrecoverable).  The reference also holds no tests, golden vectors
+ * or known answers for this path.  This file therefore restates the
+ * published algorithm, anchored on what IS citable in-tree:
+ *   - polynomial convention p(t)=c0/120 t^5+c1/24 t^4+c2/6 t^3+c3/2 t^2+c4 t+c5
+ *       mpl_external_planner/include/mpl_external_planner/poly_map_planner/primitive_geometry_utils.h:12-26,135-146
+ *   - get_succ control flow (clear; push expanded; for i in U: build, evaluate, filter, cost)
+ *       .../poly_map_planner/env_poly_map.h:45-69 and .../ellipsoid_planner/env_cloud.h:50-70
+ *   - sampling density n = ceil(max_v * t / res)            .../ellipsoid_planner/ellipsoid_util.h:67-70
+ *   - grid layout idx = x + dx*y + dx*dy*z, free 0 / occ 100 / unknown -1
+ *       planning_ros_utils/src/mapping_utils/voxel_grid.cpp:88, include/planning_ros_utils/voxel_grid.h:43-45
+ *   - node record pred_coord / pred_action_id / pred_action_cost   .../poly_map_planner/poly_map_planner.h:70-86
+ *   - control-set generation and start/goal construction      mpl_test_node/src/map_planner_node.cpp:108-171
+ * Everything else (hash resolutions, floatToInt rounding, validate_primitive, heuristic, A* loop
+ * order, heap comparator, defaults) is a recollection of upstream MPL and is tagged UNVERIFIED in
+ * mpl_oracle.c.  It is pinned only by analytic known answers (tests/test_oracle_kat.py).
+ */
+#ifndef MPL_ORACLE_H
+#define MPL_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Control bit flags (UNVERIFIED recollection of mpl_basis/control.h): a Waypoint's control is the
+ * union of its use_pos/use_vel/use_acc/use_jrk/use_yaw bits. */
+enum { ORC_VEL = 1, ORC_ACC = 3, ORC_JRK = 7, ORC_SNP = 15 };
+
+typedef struct {
+  double pos[3], vel[3], acc[3], jrk[3];
+  double yaw, t;
+  int32_t control;  /* ORC_VEL / ORC_ACC / ORC_JRK / ORC_SNP */
+  int32_t enable_t; /* time is part of the key (false for env_map) */
+} orc_waypoint;
+
+typedef struct {
+  double c[3][6]; /* per-axis coefficients, convention above */
+  double t;
+  int32_t control;
+  int32_t pad;
+} orc_primitive;
+
+typedef struct {
+  int32_t control;   /* control kind of the search states */
+  int32_t n_u;       /* number of control inputs */
+  const double *U;   /* n_u x 3 */
+  double dt, v_max, a_max, j_max;
+  double w;          /* time weight, default 10 */
+  double eps;        /* heuristic weight, default 1 */
+  double tol_pos, tol_vel, tol_acc; /* <0 disables vel/acc */
+  double t_max;      /* +inf unless set */
+  int32_t max_expand; /* <=0: unlimited */
+  int32_t heur_ignore_dynamics;
+} orc_config;
+
+typedef struct {
+  uint64_t n_expansions;  /* get_succ calls */
+  uint64_t n_voxel_reads; /* map_[idx] loads inside is_free(pr), early-out honoured */
+  uint64_t n_primitives;  /* primitives built */
+  uint64_t n_succ;        /* successors emitted (finite or inf cost) */
+  uint64_t n_succ_finite; /* successors with finite cost */
+  uint64_t n_new_nodes;   /* nodes created in the state space */
+  uint64_t n_heap_push, n_heap_decrease, n_reopen;
+} orc_counters;
+
+typedef struct orc_planner orc_planner;
+
+/* ---- basis (a3,a4,a5,a6,a9 of SURVEY 8a) ---- */
+void orc_primitive_build(const orc_waypoint *p, const double *u, double dt, orc_primitive *out);
+void orc_primitive_evaluate(const orc_primitive *pr, double t, orc_waypoint *out);
+double orc_primitive_max_vel(const orc_primitive *pr, int k);
+double orc_primitive_max_acc(const orc_primitive *pr, int k);
+double orc_primitive_max_jrk(const orc_primitive *pr, int k);
+double orc_primitive_J(const orc_primitive *pr, int control);
+int orc_validate_primitive(const orc_primitive *pr, double mv, double ma, double mj);
+/* quantised key of a waypoint: writes up to 13 ints, returns how many */
+int orc_waypoint_key(const orc_waypoint *w, int32_t *key);
+/* real roots in (lo, +inf) of sum a[i] x^i, i=0..n, ascending; returns count (<= n) */
+int orc_poly_roots_above(const double *a, int n, double lo, double *roots);
+
+/* ---- planner ---- */
+orc_planner *orc_create(void);
+void orc_destroy(orc_planner *);
+/* copy-in map; values: free 0, occupied >0, unknown -1 */
+void orc_set_map(orc_planner *, const int8_t *data, const int32_t dim[3], const double origin[3], double res);
+void orc_free_unknown(orc_planner *);
+void orc_set_config(orc_planner *, const orc_config *cfg);
+void orc_set_goal(orc_planner *, const orc_waypoint *goal);
+void orc_float_to_int(const orc_planner *, const double pt[3], int32_t pn[3]);
+int orc_is_free_point(const orc_planner *, const double pt[3]);
+int orc_is_free_primitive(orc_planner *, const orc_primitive *pr);
+double orc_heuristic(const orc_planner *, const orc_waypoint *state);
+int orc_is_goal(const orc_planner *, const orc_waypoint *state);
+/* env_map::get_succ; arrays sized n_u; returns number of successors emitted */
+int orc_get_succ(orc_planner *, const orc_waypoint *curr, orc_waypoint *succ, double *succ_cost, int32_t *action_idx);
+
+/* status codes shared with the product C-ABI */
+enum { ORC_OK = 0, ORC_NO_PATH = 1, ORC_START_OCCUPIED = 2, ORC_MAX_EXPAND = 3 };
+int orc_plan(orc_planner *, const orc_waypoint *start, const orc_waypoint *goal);
+double orc_traj_cost(const orc_planner *);
+/* results of the last plan(): sizes then copy-out */
+int orc_num_expanded(const orc_planner *);                 /* expansion sequence length */
+void orc_get_expanded(const orc_planner *, int32_t *node_ids, double *pos /* n x 3 */);
+int orc_num_nodes(const orc_planner *);
+void orc_get_node(const orc_planner *, int id, orc_waypoint *coord, double *g, double *h, int32_t *closed);
+int orc_num_closed(const orc_planner *);
+int orc_traj_len(const orc_planner *);                      /* number of primitives */
+void orc_get_traj(const orc_planner *, orc_primitive *prs, orc_waypoint *wps /* len+1 */, int32_t *actions, int32_t *node_ids /* len+1 */);
+void orc_get_counters(const orc_planner *, orc_counters *);
+void orc_reset_counters(orc_planner *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,240 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg, never by the product package (mpl_ros_amd).  See oracle/mpl_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liborc.so")
+
+VEL, ACC, JRK, SNP = 1, 3, 7, 15
+OK, NO_PATH, START_OCCUPIED, MAX_EXPAND = 0, 1, 2, 3
+
+
+class Waypoint(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("vel", C.c_double * 3), ("acc", C.c_double * 3),
+                ("jrk", C.c_double * 3), ("yaw", C.c_double), ("t", C.c_double),
+                ("control", C.c_int32), ("enable_t", C.c_int32)]
+
+
+class Primitive(C.Structure):
+    _fields_ = [("c", (C.c_double * 6) * 3), ("t", C.c_double), ("control", C.c_int32), ("pad", C.c_int32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("control", C.c_int32), ("n_u", C.c_int32), ("U", C.POINTER(C.c_double)),
+                ("dt", C.c_double), ("v_max", C.c_double), ("a_max", C.c_double), ("j_max", C.c_double),
+                ("w", C.c_double), ("eps", C.c_double),
+                ("tol_pos", C.c_double), ("tol_vel", C.c_double), ("tol_acc", C.c_double),
+                ("t_max", C.c_double), ("max_expand", C.c_int32), ("heur_ignore_dynamics", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_expansions", "n_voxel_reads", "n_primitives", "n_succ",
+                                          "n_succ_finite", "n_new_nodes", "n_heap_push", "n_heap_decrease",
+                                          "n_reopen")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def build(force=False):
+    """Compile liborc.so with oracle/Makefile (gcc only)."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "mpl_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        P = C.c_void_p
+        L.orc_create.restype = P
+        L.orc_destroy.argtypes = [P]
+        L.orc_set_map.argtypes = [P, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_double]
+        L.orc_free_unknown.argtypes = [P]
+        L.orc_set_config.argtypes = [P, C.POINTER(Config)]
+        L.orc_set_goal.argtypes = [P, C.POINTER(Waypoint)]
+        L.orc_float_to_int.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        L.orc_is_free_point.argtypes = [P, C.POINTER(C.c_double)]
+        L.orc_is_free_primitive.argtypes = [P, C.POINTER(Primitive)]
+        L.orc_heuristic.argtypes = [P, C.POINTER(Waypoint)]
+        L.orc_heuristic.restype = C.c_double
+        L.orc_is_goal.argtypes = [P, C.POINTER(Waypoint)]
+        L.orc_get_succ.argtypes = [P, C.POINTER(Waypoint), C.POINTER(Waypoint), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int32)]
+        L.orc_plan.argtypes = [P, C.POINTER(Waypoint), C.POINTER(Waypoint)]
+        L.orc_traj_cost.argtypes = [P]
+        L.orc_traj_cost.restype = C.c_double
+        for f in ("orc_num_expanded", "orc_num_nodes", "orc_num_closed", "orc_traj_len"):
+            getattr(L, f).argtypes = [P]
+        L.orc_get_expanded.argtypes = [P, C.c_void_p, C.c_void_p]
+        L.orc_get_node.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_int32)]
+        L.orc_get_traj.argtypes = [P, C.POINTER(Primitive), C.POINTER(Waypoint), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_int32)]
+        L.orc_get_counters.argtypes = [P, C.POINTER(Counters)]
+        L.orc_reset_counters.argtypes = [P]
+        L.orc_primitive_build.argtypes = [C.POINTER(Waypoint), C.POINTER(C.c_double), C.c_double, C.POINTER(Primitive)]
+        L.orc_primitive_evaluate.argtypes = [C.POINTER(Primitive), C.c_double, C.POINTER(Waypoint)]
+        for f in ("orc_primitive_max_vel", "orc_primitive_max_acc", "orc_primitive_max_jrk"):
+            getattr(L, f).argtypes = [C.POINTER(Primitive), C.c_int]
+            getattr(L, f).restype = C.c_double
+        L.orc_primitive_J.argtypes = [C.POINTER(Primitive), C.c_int]
+        L.orc_primitive_J.restype = C.c_double
+        L.orc_validate_primitive.argtypes = [C.POINTER(Primitive), C.c_double, C.c_double, C.c_double]
+        L.orc_waypoint_key.argtypes = [C.POINTER(Waypoint), C.POINTER(C.c_int32)]
+        L.orc_poly_roots_above.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+def waypoint(pos, vel=(0, 0, 0), acc=(0, 0, 0), jrk=(0, 0, 0), control=ACC, t=0.0):
+    w = Waypoint()
+    w.pos[:] = [float(x) for x in pos]
+    w.vel[:] = [float(x) for x in vel]
+    w.acc[:] = [float(x) for x in acc]
+    w.jrk[:] = [float(x) for x in jrk]
+    w.control = control
+    w.t = t
+    return w
+
+
+def wp_state(w, control=None):
+    """Key-relevant state of a waypoint as a flat float64 array (pos, vel, acc, jrk by control)."""
+    control = w.control if control is None else control
+    out = list(w.pos)
+    if control & 2:
+        out += list(w.vel)
+    if control & 4:
+        out += list(w.acc)
+    if control & 8:
+        out += list(w.jrk)
+    return np.array(out, dtype=np.float64)
+
+
+class Planner:
+    """Thin object wrapper over the orc_* functions."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = self.L.orc_create()
+        self._U = None
+        self.cfg = None
+
+    def __del__(self):
+        try:
+            self.L.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_map(self, grid, origin, res):
+        """grid: int8 array indexed [z][y][x] (x fastest in memory), i.e. shape (dz, dy, dx)."""
+        g = np.ascontiguousarray(grid, dtype=np.int8)
+        dim = (C.c_int32 * 3)(g.shape[2], g.shape[1], g.shape[0])
+        ori = (C.c_double * 3)(*[float(o) for o in origin])
+        self.L.orc_set_map(self.h, g.ctypes.data, dim, ori, float(res))
+
+    def free_unknown(self):
+        self.L.orc_free_unknown(self.h)
+
+    def set_config(self, control, U, dt=1.0, v_max=-1.0, a_max=-1.0, j_max=-1.0, w=10.0, eps=1.0,
+                   tol_pos=0.5, tol_vel=-1.0, tol_acc=-1.0, t_max=float("inf"), max_expand=-1,
+                   heur_ignore_dynamics=False):
+        self._U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, 3)
+        cfg = Config()
+        cfg.control = control
+        cfg.n_u = self._U.shape[0]
+        cfg.U = self._U.ctypes.data_as(C.POINTER(C.c_double))
+        cfg.dt, cfg.v_max, cfg.a_max, cfg.j_max = dt, v_max, a_max, j_max
+        cfg.w, cfg.eps = w, eps
+        cfg.tol_pos, cfg.tol_vel, cfg.tol_acc = tol_pos, tol_vel, tol_acc
+        cfg.t_max = t_max
+        cfg.max_expand = max_expand
+        cfg.heur_ignore_dynamics = int(heur_ignore_dynamics)
+        self.cfg = cfg
+        self.L.orc_set_config(self.h, C.byref(cfg))
+
+    def set_goal(self, goal):
+        self.L.orc_set_goal(self.h, C.byref(goal))
+
+    def heuristic(self, state):
+        return self.L.orc_heuristic(self.h, C.byref(state))
+
+    def is_goal(self, state):
+        return bool(self.L.orc_is_goal(self.h, C.byref(state)))
+
+    def float_to_int(self, pt):
+        p = (C.c_double * 3)(*pt)
+        o = (C.c_int32 * 3)()
+        self.L.orc_float_to_int(self.h, p, o)
+        return tuple(o)
+
+    def is_free_point(self, pt):
+        return bool(self.L.orc_is_free_point(self.h, (C.c_double * 3)(*pt)))
+
+    def get_succ(self, curr):
+        n = self.cfg.n_u
+        succ = (Waypoint * n)()
+        cost = (C.c_double * n)()
+        act = (C.c_int32 * n)()
+        k = self.L.orc_get_succ(self.h, C.byref(curr), succ, cost, act)
+        return [succ[i] for i in range(k)], np.array(cost[:k]), np.array(act[:k], dtype=np.int32)
+
+    def plan(self, start, goal):
+        return self.L.orc_plan(self.h, C.byref(start), C.byref(goal))
+
+    @property
+    def traj_cost(self):
+        return self.L.orc_traj_cost(self.h)
+
+    def expanded(self):
+        n = self.L.orc_num_expanded(self.h)
+        ids = np.zeros(n, dtype=np.int32)
+        pos = np.zeros((n, 3), dtype=np.float64)
+        if n:
+            self.L.orc_get_expanded(self.h, ids.ctypes.data, pos.ctypes.data)
+        return ids, pos
+
+    def num_nodes(self):
+        return self.L.orc_num_nodes(self.h)
+
+    def num_closed(self):
+        return self.L.orc_num_closed(self.h)
+
+    def node(self, i):
+        w = Waypoint()
+        g, h, c = C.c_double(), C.c_double(), C.c_int32()
+        self.L.orc_get_node(self.h, i, C.byref(w), C.byref(g), C.byref(h), C.byref(c))
+        return w, g.value, h.value, bool(c.value)
+
+    def traj(self):
+        n = self.L.orc_traj_len(self.h)
+        prs = (Primitive * max(n, 1))()
+        wps = (Waypoint * (n + 1))()
+        act = (C.c_int32 * max(n, 1))()
+        ids = (C.c_int32 * (n + 1))()
+        if n:
+            self.L.orc_get_traj(self.h, prs, wps, act, ids)
+        return {"n": n, "prs": [prs[i] for i in range(n)], "wps": [wps[i] for i in range(n + 1)] if n else [],
+                "actions": np.array(act[:n], dtype=np.int32), "node_ids": np.array(ids[:n + 1] if n else [], dtype=np.int32)}
+
+    def counters(self):
+        c = Counters()
+        self.L.orc_get_counters(self.h, C.byref(c))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self.L.orc_reset_counters(self.h)

@@ -1,0 +1,19 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver)")
+
+
+@pytest.fixture(scope="session")
+def skir():
+    import numpy as np
+    d = np.load(os.path.join(ROOT, "tests", "golden", "skir_map.npz"))
+    return d["grid"], d["origin"], float(d["res"])

@@ -1,0 +1,199 @@
+"""-m gpu: HIP path (through the C-ABI) vs the CPU oracle on the same seeded inputs. Bit-exact."""
+import numpy as np
+import pytest
+
+from mpl_ros_amd import mapgen
+from oracle import orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+CFG = {
+    orc.ACC: dict(num=1, kw=dict(v_max=2.0, a_max=1.0)),
+    orc.JRK: dict(num=2, kw=dict(v_max=2.0, a_max=1.0, j_max=1.0)),
+}
+
+
+@pytest.mark.parametrize("control", [orc.ACC, orc.JRK])
+def test_expand_batch_matches_get_succ(control):
+    grid, origin, res = util.small_map(64)
+    U = mapgen.control_lattice(1.0, CFG[control]["num"], True)
+    kw = CFG[control]["kw"]
+    P = util.make_oracle(grid, origin, res, control, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    rng = np.random.default_rng(1234 + control)
+    states = util.random_states(rng, 200, control, 0.3, 6.1)
+    nodes = [util.gpu_wp(p, v, a, j, control, t=0.5 * i) for i, (p, v, a, j) in enumerate(states)]
+    out = pl.getSuccBatch(nodes)
+    nU = U.shape[0]
+    total_reads = 0
+    P.reset_counters()
+    for k, (p, v, a, j) in enumerate(states):
+        cur = orc.waypoint(p, v, a, j, control, t=0.5 * k)
+        succ, cost, act = P.get_succ(cur)
+        got = [out[k * nU + i] for i in range(nU)]
+        got_valid = [g for g in got if g.valid]
+        assert [g.action for g in got_valid] == list(act)
+        for g, so, co in zip(got_valid, succ, cost):
+            assert g.cost == co or (np.isinf(g.cost) and np.isinf(co))
+            assert np.array_equal(np.array(g.wp.pos[:]), np.array(so.pos[:]))
+            assert np.array_equal(np.array(g.wp.vel[:]), np.array(so.vel[:]))
+            assert np.array_equal(np.array(g.wp.acc[:]), np.array(so.acc[:]))
+            assert np.array_equal(np.array(g.wp.jrk[:]), np.array(so.jrk[:]))
+            assert g.wp.t == so.t
+            key = (orc.C.c_int32 * 13)()
+            so.control = control
+            nk = orc.lib().orc_waypoint_key(orc.C.byref(so), key)
+            assert g.nkey == nk and list(g.key[:nk]) == list(key[:nk])
+        total_reads += sum(g.voxel_reads for g in got_valid)
+    assert total_reads == P.counters()["n_voxel_reads"]
+
+
+@pytest.mark.parametrize("control", [orc.ACC, orc.JRK])
+def test_heuristic_and_goal(control):
+    grid, origin, res = util.small_map(64)
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = CFG[control]["kw"]
+    P = util.make_oracle(grid, origin, res, control, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    rng = np.random.default_rng(99)
+    states = util.random_states(rng, 500, control, 0.0, 6.4)
+    goal_o = orc.waypoint((5.05, 4.05, 3.05), control=control)
+    P.set_goal(goal_o)
+    h, isg = pl.heuristicBatch([util.gpu_wp(p, v, a, j, control) for (p, v, a, j) in states], util.gpu_wp((5.05, 4.05, 3.05), control=control))
+    for i, (p, v, a, j) in enumerate(states):
+        so = orc.waypoint(p, v, a, j, control)
+        assert h[i] == P.heuristic(so)
+        assert bool(isg[i]) == P.is_goal(so)
+
+
+def test_map_query_matches_float_to_int(skir):
+    grid, origin, res = skir
+    P = util.make_oracle(grid, origin, res, orc.ACC, mapgen.control_lattice())
+    mu, pl = util.make_gpu(grid, origin, res, mapgen.control_lattice())
+    rng = np.random.default_rng(5)
+    pts = rng.uniform(-0.5, 10.5, (2000, 3))
+    pts[:100] = np.round(pts[:100], 1)  # cell-boundary cases
+    cells, st = mu.query(pts)
+    for i in range(len(pts)):
+        assert tuple(cells[i]) == P.float_to_int(pts[i])
+        assert (st[i] == 0) == P.is_free_point(pts[i])
+    assert np.array_equal(mu.getMap().reshape(grid.shape), grid)
+
+
+def test_plan_skir_reference_query(skir):
+    """The one runnable reference scenario: maps/skir/skir.bag + launch/map_planner_node/test.launch.skir."""
+    grid, origin, res = skir
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5)
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, record=1 << 16, **kw)
+    r, c = util.compare_plan(P, pl, ((5.5, 5.5, 0.5), (1, 0, 0)), ((1.5, 1.5, 5.5),), orc.ACC)
+    ids_o, pos_o = P.expanded()
+    assert np.array_equal(pl.getExpandedIds(), ids_o)
+    assert np.array_equal(pl.getExpandedNodes(), pos_o)
+    assert len(pl.getCloseSet()) == P.num_closed()
+    assert r.status == 0 and r.cost == 59.0 and r.n_expanded == 333
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_plan_acc_synthetic(seed):
+    grid, origin, res = util.small_map(96, seed=seed, occupancy=0.10)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    mapgen.carve_bubble(grid, (8.55, 8.55, 8.55), origin, res, 3)
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5)
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0)), ((8.55, 8.55, 8.55),), orc.ACC)
+
+
+def test_plan_jrk_capped():
+    grid, origin, res = util.small_map(96, seed=4, occupancy=0.10)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    U = mapgen.control_lattice(1.0, 2, True)
+    kw = dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=3000)
+    P = util.make_oracle(grid, origin, res, orc.JRK, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=1 << 19, max_edges=1 << 21, max_log=1 << 20, **kw)
+    r, c = util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0), (0, 0, 0)), ((8.55, 8.55, 8.55),), orc.JRK)
+
+
+def test_plan_jrk_reaches_goal():
+    grid, origin, res = util.small_map(64, seed=5, occupancy=0.05)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    mapgen.carve_bubble(grid, (4.55, 4.55, 3.05), origin, res, 3)
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=50000)
+    P = util.make_oracle(grid, origin, res, orc.JRK, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=1 << 19, max_edges=1 << 21, max_log=1 << 20, **kw)
+    util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0), (0, 0, 0)), ((4.55, 4.55, 3.05),), orc.JRK)
+
+
+def test_start_occupied_and_unreachable():
+    grid, origin, res = util.small_map(32, seed=9, occupancy=0.05)
+    grid[:, :, :] = np.where(grid > 0, grid, 0)
+    occ = np.argwhere(grid > 0)[0]
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = dict(v_max=2.0, a_max=1.0)
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    p_occ = ((occ[2] + 0.5) * res, (occ[1] + 0.5) * res, (occ[0] + 0.5) * res)
+    util.compare_plan(P, pl, (p_occ, (0, 0, 0)), ((1.0, 1.0, 1.0),), orc.ACC)
+    # goal walled in: OPEN runs empty (velocity-bounded lattice in a closed box is finite)
+    g2 = np.zeros((24, 24, 24), dtype=np.int8)
+    g2[8:16, 8:16, 8] = 100; g2[8:16, 8:16, 15] = 100
+    g2[8:16, 8, 8:16] = 100; g2[8:16, 15, 8:16] = 100
+    g2[8, 8:16, 8:16] = 100; g2[15, 8:16, 8:16] = 100
+    P = util.make_oracle(g2, origin, res, orc.ACC, U, **kw)
+    mu, pl = util.make_gpu(g2, origin, res, U, **kw)
+    r, c = util.compare_plan(P, pl, ((1.15, 1.15, 1.15), (0, 0, 0)), ((0.25, 0.25, 0.25),), orc.ACC)
+    assert r.status == 1
+
+
+def test_duplicate_controls_take_the_ordered_path():
+    """Two identical control inputs give two successors with one key: the commit must serialise."""
+    grid, origin, res = util.small_map(48, seed=11, occupancy=0.05)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    U = mapgen.control_lattice(1.0, 1, True)
+    U = np.vstack([U, U[5:9], U[20:22] + 1e-4])  # exact and near duplicates
+    kw = dict(v_max=2.0, a_max=1.0, max_expand=400)
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0)), ((3.55, 3.55, 3.05),), orc.ACC)
+
+
+def test_plan_batch_matches_single_queries():
+    grid, origin, res = util.small_map(96, seed=21, occupancy=0.10)
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = dict(v_max=2.0, a_max=1.0)
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
+    rng = mapgen.SplitMix64(77)
+    queries = mapgen.random_queries(grid, origin, res, 24, rng, min_dist=4.0)
+    mu, pl = util.make_gpu(grid, origin, res, U, n_slots=8, record=1 << 15, **kw)
+    starts = [util.gpu_wp(s) for s, g in queries]
+    goals = [util.gpu_wp(g) for s, g in queries]
+    res_b = pl.planBatch(starts, goals)
+    for q, (s, g) in enumerate(queries):
+        st = P.plan(orc.waypoint(s), orc.waypoint(g))
+        ids_o, _ = P.expanded()
+        r = res_b[q]
+        assert r.status == st
+        assert r.n_expanded == len(ids_o) and r.expand_hash == util.expand_hash(ids_o)
+        assert np.array_equal(pl.getExpandedIds(q), ids_o[: 1 << 15])
+        if st == 0:
+            assert r.cost == P.traj_cost
+            to, tg = P.traj(), pl.getTraj(q)
+            assert np.array_equal(tg.actions, to["actions"]) and np.array_equal(tg.node_ids, to["node_ids"])
+
+
+def test_near_far_open_structure_under_pressure():
+    """Tiny bucket width / eps=0 (Dijkstra: massive f ties) stress refill, eviction and tie-breaking."""
+    grid, origin, res = util.small_map(64, seed=31, occupancy=0.08)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    U = mapgen.control_lattice(1.0, 1, True)
+    for eps, width, me in ((0.0, 0.0, 4000), (1.0, 1e-3, 6000), (1.0, 500.0, 6000), (3.0, 0.0, 6000)):
+        kw = dict(v_max=2.0, a_max=1.0, eps=eps, max_expand=me)
+        P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
+        mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+        pl.setBucketWidth(width)
+        util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0)), ((5.55, 5.55, 5.05),), orc.ACC)

@@ -1,0 +1,105 @@
+"""Shared helpers of the parity tests: build the oracle and the HIP planner on the same inputs."""
+import numpy as np
+
+from mpl_ros_amd import mapgen
+from oracle import orc
+
+
+def small_map(n=64, seed=7, occupancy=0.08):
+    grid, _ = mapgen.random_box_map((n, n, n), seed=seed, occupancy=occupancy, edge=(2, 8))
+    return grid, (0.0, 0.0, 0.0), 0.1
+
+
+def make_oracle(grid, origin, res, control, U, **kw):
+    P = orc.Planner()
+    P.set_map(grid, origin, res)
+    P.free_unknown()
+    P.set_config(control, U, **kw)
+    return P
+
+
+def make_gpu(grid, origin, res, U, v_max=-1.0, a_max=-1.0, j_max=-1.0, dt=1.0, w=10.0, eps=1.0, tol_pos=0.5,
+             tol_vel=-1.0, tol_acc=-1.0, max_expand=-1, heur_ignore_dynamics=False, t_max=float("inf"),
+             n_slots=1, max_nodes=1 << 18, max_edges=1 << 20, max_log=1 << 19, record=0):
+    from mpl_ros_amd.planner import VoxelMapPlanner, VoxelMapUtil
+    mu = VoxelMapUtil()
+    dz, dy, dx = grid.shape
+    mu.setMap(origin, (dx, dy, dz), grid.ravel(), res)
+    mu.freeUnknown()
+    pl = VoxelMapPlanner(False)
+    pl.setMapUtil(mu)
+    pl.setVmax(v_max); pl.setAmax(a_max); pl.setJmax(j_max); pl.setDt(dt); pl.setW(w); pl.setEpsilon(eps)
+    pl.setTol(tol_pos, tol_vel, tol_acc); pl.setMaxNum(max_expand); pl.setHeurIgnoreDynamics(heur_ignore_dynamics)
+    pl.setTmax(t_max)
+    pl.setU(U)
+    pl.setCapacity(n_slots, max_nodes, max_edges, max_log)
+    if record:
+        pl.setRecord(record)
+    return mu, pl
+
+
+def gpu_wp(pos, vel=(0, 0, 0), acc=(0, 0, 0), jrk=(0, 0, 0), control=orc.ACC, t=0.0):
+    from mpl_ros_amd.planner import Waypoint3D
+    w = Waypoint3D(control)
+    w.pos, w.vel, w.acc, w.jrk = np.array(pos, float), np.array(vel, float), np.array(acc, float), np.array(jrk, float)
+    w.t = t
+    return w
+
+
+def expand_hash(ids):
+    h = 0
+    for i in ids:
+        h = (h * 0x100000001B3 + (int(i) + 1)) & ((1 << 64) - 1)
+    return h
+
+
+def random_states(rng, n, control, lo, hi, v_max=2.0, a_max=1.0):
+    """n random states (pos uniform in [lo,hi]^3, vel/acc on the 0.1 lattice like search states)."""
+    out = []
+    for _ in range(n):
+        pos = np.round(rng.uniform(lo, hi, 3), 2)
+        vel = np.round(rng.uniform(-v_max, v_max, 3), 1)
+        acc = np.round(rng.uniform(-a_max, a_max, 3), 1) if control & 4 else np.zeros(3)
+        jrk = np.round(rng.uniform(-1, 1, 3), 1) if control & 8 else np.zeros(3)
+        out.append((pos, vel, acc, jrk))
+    return out
+
+
+def compare_plan(P, pl, start, goal, control, check_traj=True):
+    """Run the same query on the oracle (P) and on the HIP planner (pl); assert bit-exact agreement."""
+    so = orc.waypoint(start[0], vel=start[1], acc=start[2] if len(start) > 2 else (0, 0, 0), control=control)
+    go = orc.waypoint(goal[0], vel=goal[1] if len(goal) > 1 else (0, 0, 0), control=control)
+    P.reset_counters()
+    st_o = P.plan(so, go)
+    sg = gpu_wp(start[0], vel=start[1], acc=start[2] if len(start) > 2 else (0, 0, 0), control=control)
+    gg = gpu_wp(goal[0], vel=goal[1] if len(goal) > 1 else (0, 0, 0), control=control)
+    ok = pl.plan(sg, gg)
+    r = pl.getResult()
+    assert r.status == st_o, (r.status, st_o)
+    assert ok == (st_o == orc.OK)
+    c = P.counters()
+    ids_o, _ = P.expanded()
+    assert r.n_expanded == c["n_expansions"] == len(ids_o)
+    assert r.expand_hash == expand_hash(ids_o)
+    assert r.n_nodes == P.num_nodes()
+    assert r.n_closed == P.num_closed()
+    assert r.voxel_reads == c["n_voxel_reads"]
+    assert r.n_succ == c["n_succ"] and r.n_succ_finite == c["n_succ_finite"]
+    assert r.n_primitives == c["n_primitives"]
+    assert r.n_reopen == c["n_reopen"]
+    if st_o == orc.OK:
+        assert r.cost == P.traj_cost  # bit-exact f64
+    else:
+        assert np.isinf(r.cost)
+    if check_traj and st_o == orc.OK:
+        to = P.traj()
+        tg = pl.getTraj()
+        assert len(tg.segs) == to["n"]
+        assert np.array_equal(tg.actions, to["actions"])
+        assert np.array_equal(tg.node_ids, to["node_ids"])
+        for wg, wo in zip(tg.getWaypoints(), to["wps"]):
+            assert np.array_equal(wg.state(), orc.wp_state(wo, control))  # bit-exact (<= 1e-6 required)
+        for pg, po in zip(tg.segs, to["prs"]):
+            for k in range(3):
+                assert np.array_equal(pg.coeff(k), np.array(po.c[k][:]))
+    return r, c
