@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- node-expansions/s of the device-resident A* on the BASELINE.json C4 workload.
+
+One "step" = one pass of the hot path over one batch of queries: `mplx_plan_batch` of Q independent
+start/goal queries on the shared 512^3 random-box voxel map (map generator of C3).
+Inputs (map replica, control set) are resident in HBM before the timed region; queries are a few
+hundred bytes each.  Weak scaling: every rank plans its own Q queries (rank-specific PRNG stream) on
+its own replica of the map, which rank 0 generates and RCCL-broadcasts over xGMI; no collective on
+the data path.
+
+    python bench.py                       # 1 GPU, defaults
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is the astar kernel: algorithmic bytes (SURVEY.md 8d
+B_exp, from the kernel's own counters) / its HIP-event duration; `cpu_baseline` is the CPU oracle
+(oracle/, "port") timed on a bounded sample of the same queries on one host core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured)
+
+
+def algorithmic_bytes(control, n_expanded, voxel_reads, n_succ_finite):
+    """B_exp = S_in + R_vox + N_succ (S_out + S_probe), summed over the run."""
+    ns = {3: 6, 7: 9}[control]
+    s_state = 8 * ns
+    s_in = s_state + 16
+    s_out = s_state + 8 + 4 + 4
+    s_probe = 2 * ns * 4 + 8
+    return n_expanded * s_in + voxel_reads + n_succ_finite * (s_out + s_probe)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--queries", type=int, default=1024, help="queries per GPU per step")
+    ap.add_argument("--map", type=int, default=512, help="voxel map edge length")
+    ap.add_argument("--lattice", choices=["acc", "jrk"], default="acc")
+    ap.add_argument("--max-expand", type=int, default=0, help="per-query expansion cap (default: none for acc, 20000 for jrk)")
+    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--max-nodes", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 disables)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mpl_ros_amd import mapgen
+    from mpl_ros_amd.planner import ACC, JRK, VoxelMapPlanner, VoxelMapUtil, Waypoint3D
+
+    control = ACC if args.lattice == "acc" else JRK
+    n = args.map
+    res = 0.1
+    origin = (0.0, 0.0, 0.0)
+
+    # ---- map: rank 0 generates, RCCL broadcast puts one replica in every GPU's HBM
+    t0 = time.time()
+    if rank == 0:
+        grid, _, _, _, _, _ = mapgen.benchmark_map(n)
+        map_t = torch.from_numpy(grid.reshape(-1)).to(dev)
+    else:
+        grid = None
+        map_t = torch.empty(n * n * n, dtype=torch.int8, device=dev)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    if world > 1:
+        dist.broadcast(map_t, src=0)
+        if grid is None:
+            grid = map_t.cpu().numpy().reshape(n, n, n)  # host copy only to draw free query cells
+    torch.cuda.synchronize()
+    t_bcast = time.time() - t0
+
+    mu = VoxelMapUtil(local_rank)
+    mu.setMapDevice(map_t.data_ptr(), origin, (n, n, n), res)
+
+    # ---- planner: C4 parameters
+    if control == ACC:
+        U = mapgen.control_lattice(1.0, 1, True)
+        max_expand = args.max_expand if args.max_expand > 0 else -1
+        caps = dict(nodes=args.max_nodes or (3 << 19), edges=(args.max_nodes or (3 << 19)) * 6, log=(args.max_nodes or (3 << 19)) * 3 // 2)
+        slots = args.slots or 384
+    else:
+        U = mapgen.control_lattice(1.0, 2, True)
+        max_expand = args.max_expand if args.max_expand > 0 else 20000
+        nn = args.max_nodes or max(1 << 16, max_expand * 16)
+        caps = dict(nodes=nn, edges=nn * 3, log=nn * 3 // 2)
+        slots = args.slots or 256
+    pl = VoxelMapPlanner(False)
+    pl.setMapUtil(mu)
+    pl.setVmax(2.0)
+    pl.setAmax(1.0)
+    if control == JRK:
+        pl.setJmax(1.0)
+    pl.setDt(1.0)
+    pl.setU(U)
+    pl.setTol(0.5)
+    pl.setMaxNum(max_expand)
+    pl.setCapacity(min(slots, args.queries), caps["nodes"], caps["edges"], caps["log"])
+
+    # ---- queries: rank-specific stream, free cell centres >= 10 m apart
+    qrng = mapgen.SplitMix64(20250620 + 7919 * (rank + 1))
+    queries = mapgen.random_queries(grid, origin, res, args.queries, qrng, min_dist=10.0)
+
+    def wp(p):
+        w = Waypoint3D(control)
+        w.pos = np.array(p, dtype=np.float64)
+        return w
+
+    starts = [wp(s) for s, g in queries]
+    goals = [wp(g) for s, g in queries]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pl.planBatch(starts, goals)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    results = None
+    for _ in range(args.steps):
+        results = pl.planBatch(starts, goals)
+        kernel_ms += pl.lastKernelMs()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    n_exp = sum(r.n_expanded for r in results)
+    reads = sum(r.voxel_reads for r in results)
+    nsf = sum(r.n_succ_finite for r in results)
+    status = np.bincount([r.status for r in results], minlength=5)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([n_exp, reads, nsf] + status.tolist(), dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        tot_exp = int(c[0].item())
+        tot_status = c[3:].tolist()
+    else:
+        tot_exp = n_exp
+        tot_status = status.tolist()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = tot_exp * args.steps / elapsed
+        k_ms = kernel_ms / args.steps  # rank 0's astar kernel, HIP events on its launch stream
+        alg = algorithmic_bytes(control, n_exp, reads, nsf)
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "node_expansions_per_s",
+            "value": value,
+            "unit": "expansions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C4-{args.lattice.upper()}: {args.queries} independent start/goal queries per GPU on one shared "
+                            f"{n}^3 random-box voxel map (10% occupied, seed 20250620), {U.shape[0]}-primitive {args.lattice} lattice, "
+                            f"dt 1 v_max 2 a_max 1 tol 0.5" + (f", max_expand {max_expand}" if max_expand > 0 else ""),
+                "queries_per_gpu": args.queries,
+                "map_dim": [n, n, n],
+                "n_primitives": int(U.shape[0]),
+                "slots_per_gpu": min(slots, args.queries),
+                "parallelism": f"queries sharded, {world} map replica(s), RCCL broadcast",
+            },
+            "expansions_per_step": tot_exp,
+            "plan_status_counts": {"ok": tot_status[0], "no_path": tot_status[1], "start_occupied": tot_status[2],
+                                   "max_expand": tot_status[3], "pool_full": tot_status[4]},
+            "plan_ms_mean_per_query": ms_per_step / args.queries,
+            "map_setup_s": {"generate": round(t_gen, 3), "broadcast": round(t_bcast, 3)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "astar_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
+                         "bytes_per_expansion": alg / max(n_exp, 1)},
+        }
+        if args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(grid, origin, res, control, U, max_expand, queries, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(grid, origin, res, control, U, max_expand, queries, budget_s):
+    """The CPU oracle (oracle/, a restatement -- kind "port") on a bounded sample of the same
+    queries, one host core, steady clock around plan() only."""
+    from oracle import orc
+    P = orc.Planner()
+    P.set_map(grid, origin, res)
+    kw = dict(dt=1.0, v_max=2.0, a_max=1.0, tol_pos=0.5, max_expand=max_expand)
+    if control == orc.JRK:
+        kw["j_max"] = 1.0
+    P.set_config(control, U, **kw)
+    n_exp, t_plan, nq = 0, 0.0, 0
+    for s, g in queries:
+        P.reset_counters()
+        t0 = time.perf_counter()
+        P.plan(orc.waypoint(s, control=control), orc.waypoint(g, control=control))
+        t_plan += time.perf_counter() - t0
+        n_exp += P.counters()["n_expansions"]
+        nq += 1
+        if t_plan >= budget_s:
+            break
+    return {"value": n_exp / t_plan, "unit": "expansions/s", "cores": 1, "kind": "port",
+            "sample": f"first {nq} of the {len(queries)} queries of rank 0 ({n_exp} expansions, {t_plan:.1f} s of plan())",
+            "plan_ms_mean_per_query": 1e3 * t_plan / nq}
+
+
+if __name__ == "__main__":
+    main()
