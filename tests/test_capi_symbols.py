@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library loads and exports every symbol include/mplx.h declares; without a GPU
+every compute path fails loudly (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from mpl_ros_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mplx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mplx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_list_agree():
+    assert declared_symbols() == sorted(_capi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load()
+    for name in declared_symbols():
+        assert getattr(lib, name) is not None
+    assert lib.mplx_version().startswith(b"mplx")
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(_capi.Waypoint) == 14 * 8 + 8
+    assert C.sizeof(_capi.Primitive) == 18 * 8 + 8 + 8
+    assert C.sizeof(_capi.Succ) == C.sizeof(_capi.Waypoint) + 8 + 8 + 48 + 8
+    assert C.sizeof(_capi.Result) == 16 + 13 * 8
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _capi.load()
+    h = C.c_void_p()
+    assert lib.mplx_ctx_create(0, C.byref(h)) == _capi.ERR_HIP
+    assert b"HIP device" in lib.mplx_last_error(None)
+    from mpl_ros_amd.planner import VoxelMapUtil
+    with pytest.raises(_capi.MplxError):
+        VoxelMapUtil()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "mpl_ros_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("no CPU fallback", ""), f

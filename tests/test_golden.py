@@ -1,0 +1,80 @@
+"""Committed fixtures: the skir map (extracted from the reference's skir.bag) and the plan results
+of tests/golden/plans.json.  CPU: the oracle reproduces them; GPU: the HIP path reproduces them."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mpl_ros_amd import mapgen
+from oracle import orc
+from tests import util
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PLANS = json.load(open(os.path.join(HERE, "golden", "plans.json")))
+
+
+def scenario_inputs(name, skir):
+    if name == "skir_launch_query":
+        grid, origin, res = skir
+        return grid, origin, res, orc.ACC, 1, ((5.5, 5.5, 0.5), (1, 0, 0)), (1.5, 1.5, 5.5), dict(v_max=2.0, a_max=1.0, tol_pos=0.5)
+    if name.startswith("acc96_seed"):
+        seed = int(name[-1])
+        grid, origin, res = util.small_map(96, seed=seed, occupancy=0.10)
+        mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+        mapgen.carve_bubble(grid, (8.55, 8.55, 8.55), origin, res, 3)
+        return grid, origin, res, orc.ACC, 1, ((1.05, 1.05, 1.05), (0, 0, 0)), (8.55, 8.55, 8.55), dict(v_max=2.0, a_max=1.0, tol_pos=0.5)
+    grid, origin, res = util.small_map(96, seed=4, occupancy=0.10)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    return grid, origin, res, orc.JRK, 2, ((1.05, 1.05, 1.05), (0, 0, 0)), (8.55, 8.55, 8.55), dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=3000)
+
+
+def test_skir_fixture_is_the_reference_grid(skir):
+    # sha256 of the int8 grid inside mpl_test_node/maps/skir/skir.bag
+    grid, origin, res = skir
+    assert grid.shape == (54, 99, 99)
+    assert hashlib.sha256(grid.tobytes()).hexdigest() == "28e42b1a1c4d492a9f7517bb1fb3249991f6834f99cad63d3ef3bbaa250a3642"
+    assert res == float(np.float32(0.1)) and origin[2] == float(np.float32(0.2))
+    assert int((grid == 100).sum()) == 50409 and int((grid == 0).sum()) == 478845
+
+
+def test_benchmark_map_generator_is_pinned():
+    grid, origin, res, start, goal, rng = mapgen.benchmark_map(64)
+    assert hashlib.sha256(grid.tobytes()).hexdigest() == "82ddb3378a01d381bfb3d9c5f66a7a450eaa6105058cc42399d985e804432c9c"
+    assert abs((grid > 0).mean() - 0.10) < 0.01
+    r = mapgen.SplitMix64(20250620)
+    assert [r.next() for _ in range(2)] == [18070495504912055082, 16367535455934044849]
+    assert mapgen.control_lattice(1, 1, True).shape == (27, 3) and mapgen.control_lattice(1, 2, True).shape == (125, 3)
+    assert mapgen.control_lattice(1, 1, False).shape == (9, 3)
+
+
+@pytest.mark.parametrize("plan", PLANS, ids=[p["name"] for p in PLANS])
+def test_oracle_reproduces_golden_plans(plan, skir):
+    grid, origin, res, control, num, start, goal, kw = scenario_inputs(plan["name"], skir)
+    P = util.make_oracle(grid, origin, res, control, mapgen.control_lattice(1.0, num, True), **kw)
+    st = P.plan(orc.waypoint(start[0], vel=start[1], control=control), orc.waypoint(goal, control=control))
+    ids, _ = P.expanded()
+    assert st == plan["status"] and len(ids) == plan["n_expanded"]
+    assert str(util.expand_hash(ids)) == plan["expand_hash"]
+    assert P.traj_cost == plan["cost"]
+    tr = P.traj()
+    assert tr["actions"].tolist() == plan["actions"] and tr["node_ids"].tolist() == plan["node_ids"]
+    assert [orc.wp_state(w, control).tolist() for w in tr["wps"]] == plan["waypoints"]
+    assert P.counters() == plan["counters"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("plan", PLANS, ids=[p["name"] for p in PLANS])
+def test_hip_reproduces_golden_plans(plan, skir):
+    grid, origin, res, control, num, start, goal, kw = scenario_inputs(plan["name"], skir)
+    mu, pl = util.make_gpu(grid, origin, res, mapgen.control_lattice(1.0, num, True), max_nodes=1 << 19, max_edges=1 << 21, max_log=1 << 20, **kw)
+    ok = pl.plan(util.gpu_wp(start[0], start[1], control=control), util.gpu_wp(goal, control=control))
+    r = pl.getResult()
+    assert ok and r.status == plan["status"] and r.n_expanded == plan["n_expanded"]
+    assert str(r.expand_hash) == plan["expand_hash"] and r.cost == plan["cost"]
+    tr = pl.getTraj()
+    assert tr.actions.tolist() == plan["actions"] and tr.node_ids.tolist() == plan["node_ids"]
+    assert [w.state().tolist() for w in tr.getWaypoints()] == plan["waypoints"]
+    c = plan["counters"]
+    assert (r.voxel_reads, r.n_succ, r.n_succ_finite, r.n_nodes) == (c["n_voxel_reads"], c["n_succ"], c["n_succ_finite"], c["n_new_nodes"])
