@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--lattice", choices=["acc", "jrk"], default="acc")
     ap.add_argument("--max-expand", type=int, default=0, help="per-query expansion cap (default: none for acc, 20000 for jrk)")
     ap.add_argument("--slots", type=int, default=0)
-    ap.add_argument("--max-nodes", type=int, default=0)
+    ap.add_argument("--max-nodes", type=int, default=0, help="mean states per query used to size the shared pools")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 disables)")
     args = ap.parse_args()
 
@@ -101,14 +101,15 @@ def main():
     if control == ACC:
         U = mapgen.control_lattice(1.0, 1, True)
         max_expand = args.max_expand if args.max_expand > 0 else -1
-        caps = dict(nodes=args.max_nodes or (3 << 19), edges=(args.max_nodes or (3 << 19)) * 6, log=(args.max_nodes or (3 << 19)) * 3 // 2)
-        slots = args.slots or 384
+        per_q = args.max_nodes or 450_000  # mean states per query (tail up to ~2 M; the pools are shared)
+        caps = dict(nodes=per_q * args.queries, edges=per_q * args.queries * 5 // 2, log=per_q * args.queries * 5 // 4)
+        slots = args.slots or 1024
     else:
         U = mapgen.control_lattice(1.0, 2, True)
         max_expand = args.max_expand if args.max_expand > 0 else 20000
-        nn = args.max_nodes or max(1 << 16, max_expand * 16)
-        caps = dict(nodes=nn, edges=nn * 3, log=nn * 3 // 2)
-        slots = args.slots or 256
+        per_q = args.max_nodes or max(1 << 16, max_expand * 16)
+        caps = dict(nodes=per_q * args.queries, edges=per_q * args.queries * 2, log=per_q * args.queries * 5 // 4)
+        slots = args.slots or 768
     pl = VoxelMapPlanner(False)
     pl.setMapUtil(mu)
     pl.setVmax(2.0)

@@ -125,8 +125,9 @@ int mplx_map_query(mplx_ctx *ctx, int n, const double *pts, int32_t *cells, int8
 
 /* ---- planner configuration ---- */
 int mplx_planner_config(mplx_ctx *ctx, const mplx_config *cfg);
-/* device pools: concurrent query slots and per-slot capacities (0 = keep current / default) */
-int mplx_set_capacity(mplx_ctx *ctx, int32_t n_slots, uint32_t max_nodes, uint32_t max_edges, uint32_t max_open_log);
+/* device pools: number of queries in flight (workgroups) and the TOTAL capacities shared by all
+ * queries of one batch -- states, predecessor records, OPEN-log entries (0 = keep current) */
+int mplx_set_capacity(mplx_ctx *ctx, int32_t n_slots, uint64_t total_nodes, uint64_t total_edges, uint64_t total_open_log);
 /* f-width of one far OPEN bucket (0 = default w*dt/8) */
 int mplx_set_bucket_width(mplx_ctx *ctx, double width);
 
@@ -154,6 +155,8 @@ int mplx_result_expanded(mplx_ctx *ctx, int q, uint32_t cap, int32_t *ids, uint3
 int mplx_result_nodes(mplx_ctx *ctx, mplx_waypoint *coords, double *g, double *h, int32_t *closed, int32_t *opened);
 
 /* ---- measurement ---- */
+/* device-clock begin / end (seconds since the first query of the batch started) and workgroup of query q */
+int mplx_result_timing(mplx_ctx *ctx, int q, double *t_begin_s, double *t_end_s, int32_t *slot);
 /* duration (ms, HIP events on the context's stream) of the last search / expand kernel launch */
 int mplx_last_kernel_ms(const mplx_ctx *ctx, float *ms);
 const char *mplx_version(void);

@@ -52,7 +52,7 @@ EXPORTS = [
     "mplx_map_set", "mplx_map_set_device", "mplx_map_free_unknown", "mplx_map_get", "mplx_map_info", "mplx_map_query",
     "mplx_planner_config", "mplx_set_capacity", "mplx_set_bucket_width",
     "mplx_expand_batch", "mplx_heuristic_batch", "mplx_plan", "mplx_plan_batch",
-    "mplx_result_traj", "mplx_set_record", "mplx_result_expanded", "mplx_result_nodes",
+    "mplx_result_traj", "mplx_set_record", "mplx_result_expanded", "mplx_result_nodes", "mplx_result_timing",
     "mplx_last_kernel_ms", "mplx_version",
 ]
 
@@ -88,7 +88,7 @@ def load():
     L.mplx_map_info.argtypes = [P, I3, D3, D3]
     L.mplx_map_query.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mplx_planner_config.argtypes = [P, C.POINTER(Config)]
-    L.mplx_set_capacity.argtypes = [P, C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.mplx_set_capacity.argtypes = [P, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]
     L.mplx_set_bucket_width.argtypes = [P, C.c_double]
     L.mplx_expand_batch.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(Succ)]
     L.mplx_heuristic_batch.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(Waypoint), C.c_void_p, C.c_void_p]
@@ -98,6 +98,7 @@ def load():
     L.mplx_set_record.argtypes = [P, C.c_uint32]
     L.mplx_result_expanded.argtypes = [P, C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
     L.mplx_result_nodes.argtypes = [P, C.POINTER(Waypoint), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mplx_result_timing.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), I3]
     L.mplx_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float)]
     L.mplx_version.restype = C.c_char_p
     _lib = L

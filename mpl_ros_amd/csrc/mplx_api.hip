@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -39,22 +40,25 @@ struct mplx_ctx {
   std::vector<double> U;
   double *dU = nullptr, *dUcost = nullptr;
   double bucket_width = 0;
-  // capacities
+  // capacities (shared by all queries of a batch)
   int32_t n_slots = 1;
-  uint32_t cap_nodes = 1u << 20, cap_edges = 1u << 22, cap_log = 1u << 21, cap_rec = 0;
+  uint64_t cap_nodes = 1u << 20, cap_edges = 1u << 22, cap_log = 1u << 21;
+  uint32_t cap_rec = 0;
   // pools
   bool pools_valid = false;
-  int32_t pool_slots = 0, pool_nk = 0;
-  uint32_t pool_nodes = 0, pool_edges = 0, pool_log = 0, pool_table = 0;
-  SearchParams pools{};  // only pool pointers are used
+  int32_t pool_slots = 0, pool_control = 0;
+  uint64_t pool_nodes = 0, pool_edges = 0, pool_log = 0;
+  SearchParams pools{};  // only pool pointers / sizes are used
   std::vector<void *> pool_allocs;
+  std::vector<uint32_t> last_node_table;
   // last batch
   int last_nq = 0;
   bool last_single = false;
   std::vector<QueryOut> last_out;
   QueryOut *d_out = nullptr;
   QueryIn *d_in = nullptr;
-  int32_t *d_traj_nodes = nullptr, *d_traj_actions = nullptr, *d_rec = nullptr, *d_next = nullptr;
+  int32_t *d_traj_nodes = nullptr, *d_traj_actions = nullptr, *d_rec = nullptr, *d_next = nullptr, *d_order = nullptr;
+  uint32_t *d_node_tables = nullptr;
   double *d_traj_states = nullptr;
   int batch_cap = 0;
   uint32_t batch_rec = 0;
@@ -105,8 +109,10 @@ static void free_pools(mplx_ctx *c) {
 }
 static void free_batch(mplx_ctx *c) {
   (void)hipFree(c->d_out); (void)hipFree(c->d_in); (void)hipFree(c->d_traj_nodes); (void)hipFree(c->d_traj_actions);
-  (void)hipFree(c->d_traj_states); (void)hipFree(c->d_rec); (void)hipFree(c->d_next);
-  c->d_out = nullptr; c->d_in = nullptr; c->d_traj_nodes = c->d_traj_actions = c->d_rec = c->d_next = nullptr;
+  (void)hipFree(c->d_traj_states); (void)hipFree(c->d_rec); (void)hipFree(c->d_next); (void)hipFree(c->d_order);
+  (void)hipFree(c->d_node_tables);
+  c->d_out = nullptr; c->d_in = nullptr; c->d_traj_nodes = c->d_traj_actions = c->d_rec = c->d_next = c->d_order = nullptr;
+  c->d_node_tables = nullptr;
   c->d_traj_states = nullptr;
   c->batch_cap = 0;
 }
@@ -262,13 +268,10 @@ extern "C" int mplx_planner_config(mplx_ctx *c, const mplx_config *cfg) {
   return MPLX_OK;
 }
 
-extern "C" int mplx_set_capacity(mplx_ctx *c, int32_t n_slots, uint32_t max_nodes, uint32_t max_edges, uint32_t max_log) {
+extern "C" int mplx_set_capacity(mplx_ctx *c, int32_t n_slots, uint64_t max_nodes, uint64_t max_edges, uint64_t max_log) {
   if (!c) return MPLX_ERR_ARG;
   if (n_slots > 0) c->n_slots = n_slots;
-  if (max_nodes) {
-    if (max_nodes >= CLAIM_BASE / 2) return fail(c, MPLX_ERR_ARG, "max_nodes too large");
-    c->cap_nodes = max_nodes;
-  }
+  if (max_nodes) c->cap_nodes = max_nodes;
   if (max_edges) c->cap_edges = max_edges;
   if (max_log) c->cap_log = max_log;
   return MPLX_OK;
@@ -311,45 +314,46 @@ static int pool_alloc(mplx_ctx *c, T **p, size_t count) {
   return MPLX_OK;
 }
 
-static uint32_t next_pow2(uint64_t v) {
+static uint64_t next_pow2(uint64_t v) {
   uint64_t p = 1;
   while (p < v) p <<= 1;
-  return (uint32_t)p;
+  return p;
 }
 
 static int ensure_pools(mplx_ctx *c, int slots) {
-  const int nk = state_len(c->cfg.control);
-  if (c->pools_valid && c->pool_slots >= slots && c->pool_nk == nk && c->pool_nodes == c->cap_nodes &&
+  const int control = c->cfg.control;
+  if (c->pools_valid && c->pool_slots >= slots && c->pool_control == control && c->pool_nodes == c->cap_nodes &&
       c->pool_edges == c->cap_edges && c->pool_log == c->cap_log)
     return MPLX_OK;
   free_pools(c);
   SearchParams &P = c->pools;
-  const size_t S = (size_t)slots, N = c->cap_nodes, E = c->cap_edges, L = c->cap_log;
-  const uint32_t T = next_pow2(2ull * N);
+  // every in-flight query needs at least one chunk of each pool
+  uint64_t nch = (c->cap_nodes + (1u << NODE_CH_LOG) - 1) >> NODE_CH_LOG;
+  uint64_t ech = (c->cap_edges + (1u << EDGE_CH_LOG) - 1) >> EDGE_CH_LOG;
+  uint64_t och = (c->cap_log + (1u << OPEN_CH_LOG) - 1) >> OPEN_CH_LOG;
+  if (nch < 1) nch = 1;
+  if (ech < 1) ech = 1;
+  if (och < 1) och = 1;
+  if (nch > 0x7FFFFFFFull || ech > 0x7FFFFFFFull || och > 0x7FFFFFFFull) return fail(c, MPLX_ERR_ARG, "capacity too large");
+  const uint64_t T = next_pow2(2ull * (nch << NODE_CH_LOG));
   int r;
 #define PA(ptr, cnt) if ((r = pool_alloc(c, &(ptr), (cnt))) != MPLX_OK) { free_pools(c); return r; }
-  PA(P.node_key, S * N * nk);
-  PA(P.node_state, S * N * (nk + 1));
-  PA(P.node_g, S * N);
-  PA(P.node_h, S * N);
-  PA(P.node_flags, S * N);
-  PA(P.node_pred, S * N);
-  PA(P.table, S * T);
-  PA(P.edge_parent, S * E);
-  PA(P.edge_next, S * E);
-  PA(P.edge_action, S * E);
-  PA(P.log_f, S * L);
-  PA(P.log_g, S * L);
-  PA(P.log_id, S * L);
-  PA(P.log_next, S * L);
-  PA(P.bkt_head, S * NB * NSUB);
+  PA(P.node_pool, (size_t)(nch << NODE_CH_LOG) * rec_bytes(control));
+  PA(P.edge_pool, (size_t)(ech << EDGE_CH_LOG) * EDGE_BYTES);
+  PA(P.open_pool, (size_t)(och << OPEN_CH_LOG) * OPEN_BYTES);
+  PA(P.table, (size_t)T);
+  PA(P.bkt_head, (size_t)slots * NB * NSUB);
+  PA(P.chunk_next, 4);
 #undef PA
+  P.node_chunks = (uint32_t)nch;
+  P.edge_chunks = (uint32_t)ech;
+  P.open_chunks = (uint32_t)och;
+  P.table_mask = T - 1;
   c->pool_slots = slots;
-  c->pool_nk = nk;
+  c->pool_control = control;
   c->pool_nodes = c->cap_nodes;
   c->pool_edges = c->cap_edges;
   c->pool_log = c->cap_log;
-  c->pool_table = T;
   c->pools_valid = true;
   return MPLX_OK;
 }
@@ -363,6 +367,8 @@ static int ensure_batch(mplx_ctx *c, int nq) {
   HIPCHK(c, hipMalloc((void **)&c->d_traj_actions, sizeof(int32_t) * (size_t)nq * MAX_TRAJ));
   HIPCHK(c, hipMalloc((void **)&c->d_traj_states, sizeof(double) * (size_t)nq * (MAX_TRAJ + 1) * 13));
   HIPCHK(c, hipMalloc((void **)&c->d_next, sizeof(int32_t)));
+  HIPCHK(c, hipMalloc((void **)&c->d_order, sizeof(int32_t) * nq));
+  HIPCHK(c, hipMalloc((void **)&c->d_node_tables, sizeof(uint32_t) * (size_t)nq * MAX_NODE_CH));
   if (c->cap_rec) HIPCHK(c, hipMalloc((void **)&c->d_rec, sizeof(int32_t) * (size_t)nq * c->cap_rec));
   c->batch_cap = nq;
   c->batch_rec = c->cap_rec;
@@ -515,16 +521,34 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
     in[i].goal_control = goals[i].control;
     in[i].pad = 0;
   }
+  if (nq >= 0xFFFF) return fail(c, MPLX_ERR_ARG, "at most 65534 queries per batch");
+  // launch order: longest expected search first (straight-line distance), so the tail of the batch
+  // is made of short queries
+  std::vector<int32_t> order(nq);
+  {
+    std::vector<std::pair<double, int32_t>> key(nq);
+    for (int i = 0; i < nq; i++) {
+      double d = 0;
+      for (int k = 0; k < 3; k++) d += (starts[i].pos[k] - goals[i].pos[k]) * (starts[i].pos[k] - goals[i].pos[k]);
+      key[i] = {-d, i};
+    }
+    std::stable_sort(key.begin(), key.end());
+    for (int i = 0; i < nq; i++) order[i] = key[i].second;
+  }
   SearchParams P = c->pools;
   fill_params(c, P);
-  P.cap_nodes = c->pool_nodes; P.cap_table = c->pool_table; P.cap_edges = c->pool_edges; P.cap_log = c->pool_log;
   P.cap_rec = c->cap_rec;
   P.nq = nq;
   P.queries = c->d_in;
+  P.order = c->d_order;
   P.out = c->d_out;
   P.traj_nodes = c->d_traj_nodes; P.traj_actions = c->d_traj_actions; P.traj_states = c->d_traj_states;
   P.rec_ids = c->cap_rec ? c->d_rec : nullptr;
+  P.node_tables = c->d_node_tables;
   P.next_query = c->d_next;
+  HIPCHK(c, hipMemcpyAsync(c->d_order, order.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(P.table, 0xFF, (size_t)(P.table_mask + 1) * sizeof(unsigned long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(P.chunk_next, 0, 4 * sizeof(uint32_t), c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), c->stream));
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -607,31 +631,52 @@ extern "C" int mplx_result_nodes(mplx_ctx *c, mplx_waypoint *coords, double *g, 
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = c->last_out[0].n_nodes;
   if (n == 0) return MPLX_OK;
-  const int nk = c->pool_nk;
-  std::vector<double> st(n * (nk + 1));
-  std::vector<uint32_t> fl(n);
-  std::vector<unsigned long long> gg(n);
-  HIPCHK(c, hipMemcpyAsync(st.data(), c->pools.node_state, sizeof(double) * n * (nk + 1), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(fl.data(), c->pools.node_flags, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(gg.data(), c->pools.node_g, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, c->stream));
-  if (h) HIPCHK(c, hipMemcpyAsync(h, c->pools.node_h, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  const int control = c->pool_control, nk = state_len(control), rb = rec_bytes(control), hot = rec_hot_bytes(control);
+  std::vector<uint32_t> tbl(MAX_NODE_CH);
+  HIPCHK(c, hipMemcpyAsync(tbl.data(), c->d_node_tables, sizeof(uint32_t) * MAX_NODE_CH, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  for (size_t i = 0; i < n; i++) {
-    if (coords) {
-      mplx_waypoint &w = coords[i];
-      memset(&w, 0, sizeof(w));
-      const double *s = &st[i * (nk + 1)];
-      for (int k = 0; k < nk; k++) {
-        double *dst = k < 3 ? w.pos : k < 6 ? w.vel : k < 9 ? w.acc : w.jrk;
-        dst[k % 3] = s[k];
+  const size_t per = (size_t)1 << NODE_CH_LOG;
+  std::vector<char> buf(per * rb);
+  for (size_t base = 0; base < n; base += per) {
+    const size_t cnt = n - base < per ? n - base : per;
+    const uint32_t ch = tbl[base >> NODE_CH_LOG];
+    if (ch == NIL) return fail(c, MPLX_ERR_ARG, "inconsistent chunk table");
+    HIPCHK(c, hipMemcpyAsync(buf.data(), c->pools.node_pool + ((size_t)ch << NODE_CH_LOG) * rb, cnt * rb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < cnt; k++) {
+      const char *r = buf.data() + k * rb;
+      const size_t i = base + k;
+      uint32_t fl;
+      memcpy(&fl, r + 16, 4);
+      if (g) memcpy(&g[i], r, 8);
+      if (h) memcpy(&h[i], r + 8, 8);
+      if (closed) closed[i] = (fl & FLAG_CLOSED) ? 1 : 0;
+      if (opened) opened[i] = (fl & FLAG_OPENED) ? 1 : 0;
+      if (coords) {
+        mplx_waypoint &w = coords[i];
+        memset(&w, 0, sizeof(w));
+        const double *st = (const double *)(r + hot);
+        for (int d = 0; d < nk; d++) {
+          double *dst = d < 3 ? w.pos : d < 6 ? w.vel : d < 9 ? w.acc : w.jrk;
+          dst[d % 3] = st[d];
+        }
+        w.t = st[nk];
+        w.control = control;
       }
-      w.t = s[nk];
-      w.control = c->cfg.control;
     }
-    if (g) memcpy(&g[i], &gg[i], sizeof(double));
-    if (closed) closed[i] = (fl[i] & FLAG_CLOSED) ? 1 : 0;
-    if (opened) opened[i] = (fl[i] & FLAG_OPENED) ? 1 : 0;
   }
+  return MPLX_OK;
+}
+
+extern "C" int mplx_result_timing(mplx_ctx *c, int q, double *t_begin_s, double *t_end_s, int32_t *slot) {
+  if (!c || q < 0 || q >= c->last_nq) return fail(c, MPLX_ERR_ARG, "no such query");
+  // wall_clock64() ticks at 100 MHz on gfx950; times are relative to the first query start of the batch
+  unsigned long long t0 = ~0ull;
+  for (int i = 0; i < c->last_nq; i++)
+    if (c->last_out[i].t_begin && c->last_out[i].t_begin < t0) t0 = c->last_out[i].t_begin;
+  if (t_begin_s) *t_begin_s = (double)(c->last_out[q].t_begin - t0) * 1e-8;
+  if (t_end_s) *t_end_s = (double)(c->last_out[q].t_end - t0) * 1e-8;
+  if (slot) *slot = (int32_t)c->last_out[q].slot;
   return MPLX_OK;
 }
 

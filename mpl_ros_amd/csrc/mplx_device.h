@@ -1,17 +1,35 @@
 // mplx_device.h -- shared POD layouts between the host API (mplx_api.hip) and the kernels.
+//
+// HBM layout of the search state (all queries of a batch share three chunked pools and one hash table):
+//   node pool  : records of rec_bytes(control) bytes, 8192 per chunk.  Record = hot part
+//                {g f64, h f64, flags u32, pred u32, key int32[nk]} in the first 64/80 B, then the
+//                first-arrival state (ns doubles) and t.  One 64 B load answers "same key? g? h?".
+//   edge pool  : predecessor records {parent u32, next u32, action u32}, 32768 per chunk.
+//   open pool  : OPEN-log records {f f64, g f64, id u32, next u32}, 16384 per chunk.
+//   hash table : 64-bit slots {tag16 | query16 | node id32}, open addressing, shared by all queries
+//                of the batch (the query index is part of the slot), cleared once per batch.
+// A query owns chunks through three small chunk tables that live in LDS while it runs; chunks are
+// bump-allocated from the pools and never returned within a batch.
 #pragma once
 #include "mplx_math.h"
 
 namespace mplx {
 
-constexpr int NB = 2048;          // far OPEN buckets per query
+constexpr int NB = 1024;          // far OPEN buckets per query
 constexpr int NSUB = 32;          // sub-lists per bucket (parallel pull)
-constexpr int NC = 1024;          // near OPEN capacity (LDS)
+constexpr int NC = 512;           // near OPEN capacity (LDS)
 constexpr uint32_t NIL = 0xFFFFFFFFu;
 constexpr uint64_t TBL_EMPTY = 0xFFFFFFFFFFFFFFFFull;
 constexpr uint32_t CLAIM_BASE = 0xFFFF0000u;  // table id field >= CLAIM_BASE: claimed in this expansion
 constexpr uint32_t FLAG_CLOSED = 1u, FLAG_OPENED = 2u;
 constexpr int MAX_TRAJ = 1024;
+
+constexpr int NODE_CH_LOG = 13, EDGE_CH_LOG = 15, OPEN_CH_LOG = 14;
+constexpr int MAX_NODE_CH = 512, MAX_EDGE_CH = 512, MAX_OPEN_CH = 512;  // per query: 4M nodes, 16M edges, 8M log
+constexpr int EDGE_BYTES = 12, OPEN_BYTES = 24;
+
+constexpr int rec_hot_bytes(int control) { return control == CTRL_SNP ? 80 : 64; }
+constexpr int rec_bytes(int control) { return control == CTRL_SNP ? 192 : control == CTRL_JRK ? 160 : 128; }
 
 struct MapDev {
   const int8_t *data;
@@ -27,13 +45,14 @@ struct QueryIn {
   int32_t pad;
 };
 
-// device copy of mplx_result + trajectory header (host reads it back)
+// device copy of mplx_result + diagnostics (host reads it back)
 struct QueryOut {
   int32_t status, traj_len;
   double cost;
   unsigned long long n_expanded, n_closed, n_nodes, n_edges, n_primitives, n_succ, n_succ_finite, voxel_reads, n_push,
       n_reopen, n_refill, n_evict, expand_hash;
-  uint32_t n_recorded, pad;
+  unsigned long long t_begin, t_end;  // wall_clock64() ticks (100 MHz)
+  uint32_t n_recorded, slot;
 };
 
 struct SearchParams {
@@ -45,29 +64,24 @@ struct SearchParams {
   const double *ucost;  // n_u: J(control) + w dt
   MapDev map;
   double bucket_width;
-  // per-slot capacities
-  uint32_t cap_nodes, cap_table, cap_edges, cap_log, cap_rec;
-  // per-slot pools (slot s uses [s*cap, (s+1)*cap))
-  int32_t *node_key;              // cap_nodes x nk
-  double *node_state;             // cap_nodes x (ns+1)   (last: t)
-  unsigned long long *node_g;     // f64 bits
-  double *node_h;
-  uint32_t *node_flags;
-  uint32_t *node_pred;            // newest predecessor edge, NIL if none
-  unsigned long long *table;      // cap_table: (tag << 32) | id
-  uint32_t *edge_parent, *edge_next;
-  uint8_t *edge_action;
-  double *log_f, *log_g;
-  uint32_t *log_id, *log_next;
-  uint32_t *bkt_head;             // NB x NSUB
+  // shared pools
+  char *node_pool, *edge_pool, *open_pool;
+  uint32_t node_chunks, edge_chunks, open_chunks;  // pool sizes in chunks
+  uint32_t *chunk_next;                            // [3] bump counters: node, edge, open
+  unsigned long long *table;
+  unsigned long long table_mask;                   // slots - 1
+  uint32_t *bkt_head;                              // per workgroup slot: NB x NSUB
+  uint32_t cap_rec;
   // queries
   int32_t nq;
   const QueryIn *queries;
+  const int32_t *order;           // launch order of the queries (longest expected first)
   QueryOut *out;
   int32_t *traj_nodes;            // nq x (MAX_TRAJ+1)
   int32_t *traj_actions;          // nq x MAX_TRAJ
   double *traj_states;            // nq x (MAX_TRAJ+1) x 13
   int32_t *rec_ids;               // nq x cap_rec (optional)
+  uint32_t *node_tables;          // nq x MAX_NODE_CH: chunk table of each query (state-space dump)
   int32_t *next_query;            // dynamic query counter
 };
 

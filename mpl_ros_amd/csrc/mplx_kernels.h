@@ -26,14 +26,20 @@ __device__ __forceinline__ unsigned long long ld_u64(const unsigned long long *p
 __device__ __forceinline__ void st_u64(unsigned long long *p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ uint32_t ld_u32(const uint32_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ bool entry_less(double f1, double g1, uint32_t i1, double f2, double g2, uint32_t i2) {
   if (f1 != f2) return f1 < f2;
   if (g1 != g2) return g1 < g2;
   return i1 < i2;
 }
+
+struct alignas(8) OpenRec {  // OPEN-log record (OPEN_BYTES)
+  double f, g;
+  uint32_t id, next;
+};
+struct EdgeRec {  // predecessor record (EDGE_BYTES)
+  uint32_t parent, next, action;
+};
+static_assert(sizeof(OpenRec) == OPEN_BYTES && sizeof(EdgeRec) == EDGE_BYTES, "record sizes");
 
 template <int BLOCK>
 struct Smem {
@@ -41,6 +47,8 @@ struct Smem {
   double near_f[NC], near_g[NC];
   uint32_t near_id[NC], near_idx[NC];
   uint32_t bkt_count[NB];
+  // chunk tables of the running query
+  uint32_t node_tbl[MAX_NODE_CH], edge_tbl[MAX_EDGE_CH], open_tbl[MAX_OPEN_CH];
   // expansion scratch
   double q[18][BLOCK];  // pre-divided polynomial coefficients per primitive
   double dts[BLOCK];
@@ -58,6 +66,7 @@ struct Smem {
   uint32_t hist[64];
   // scalars
   uint32_t n_near, n_nodes, n_edges, n_log;
+  uint32_t node_chunks, edge_chunks, open_chunks;  // chunks owned
   int32_t bcur;
   double ts_f, ts_g;
   uint32_t ts_id;  // split threshold inside bucket bcur
@@ -65,8 +74,8 @@ struct Smem {
   uint32_t cur_id;
   double cur_g;
   int32_t status, flag, q_index;
-  uint32_t tmp_u, best_pos;
-  double tmp_d0, tmp_d1;
+  uint32_t tmp_u;
+  double tmp_d0;
   unsigned long long c_expanded, c_closed, c_prims, c_succ, c_succ_finite, c_reads, c_push, c_reopen, c_refill, c_evict, c_hash;
 };
 
@@ -79,30 +88,39 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, Smem<BLOCK> &S, 
     uint32_t y = __shfl_up(x, d, 64);
     if (lane >= d) x += y;
   }
-  if (lane == 63) S.wsum[wave] = x;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
+  if constexpr (BLOCK == 64) {
+    total = __shfl(x, 63, 64);
+    return x - v;
+  } else {
+    if (lane == 63) S.wsum[wave] = x;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < BLOCK / 64; w++) {
-    uint32_t s = S.wsum[w];
-    if (w < wave) base += s;
-    tot += s;
+    for (int w = 0; w < BLOCK / 64; w++) {
+      uint32_t s = S.wsum[w];
+      if (w < wave) base += s;
+      tot += s;
+    }
+    total = tot;
+    __syncthreads();
+    return base + x - v;
   }
-  total = tot;
-  __syncthreads();
-  return base + x - v;
 }
 
 template <int BLOCK>
 __device__ __forceinline__ bool block_any(bool p, Smem<BLOCK> &S, int tid) {
   unsigned long long b = __ballot(p);
-  if ((tid & 63) == 0) S.wsum[tid >> 6] = b != 0ull;
-  __syncthreads();
-  bool r = false;
+  if constexpr (BLOCK == 64) {
+    return b != 0ull;
+  } else {
+    if ((tid & 63) == 0) S.wsum[tid >> 6] = b != 0ull;
+    __syncthreads();
+    bool r = false;
 #pragma unroll
-  for (int w = 0; w < BLOCK / 64; w++) r = r || (S.wsum[w] != 0);
-  __syncthreads();
-  return r;
+    for (int w = 0; w < BLOCK / 64; w++) r = r || (S.wsum[w] != 0);
+    __syncthreads();
+    return r;
+  }
 }
 
 __device__ __forceinline__ int bucket_of(double f, double f_base, double width) {
@@ -170,34 +188,55 @@ __device__ __forceinline__ void expand_phases(const SearchParams &P, Smem<BLOCK>
   S.offs[tid] = off;
   if (tid == BLOCK - 1) S.offs[BLOCK] = total;
   __syncthreads();
-  // phase 2: flattened (primitive, sample) pairs
+  // phase 2: flattened (primitive, sample) pairs, UNR voxel loads in flight per lane
   const int8_t *__restrict__ map = P.map.data;
   const int dx = P.map.dim[0], dy = P.map.dim[1], dz = P.map.dim[2];
-  for (uint32_t e = tid; e < total; e += BLOCK) {
-    int lo = 0, hi = BLOCK;  // largest p with offs[p] <= e
-    while (hi - lo > 1) {
-      int mid = (lo + hi) >> 1;
-      if (S.offs[mid] <= e) lo = mid; else hi = mid;
-    }
-    const int p = lo;
-    const uint32_t i = e - S.offs[p];
-    const double t = (double)i * S.dts[p];
-    double qq[6];
-    int32_t cell[3];
+  constexpr int UNR = 4;
+  for (uint32_t e0 = tid; e0 < total; e0 += BLOCK * UNR) {
+    int pp[UNR];
+    uint32_t ii[UNR];
+    int8_t vv[UNR];
+    bool inside[UNR], live[UNR];
 #pragma unroll
-    for (int ax = 0; ax < 3; ax++) {
+    for (int r = 0; r < UNR; r++) {
+      const uint32_t e = e0 + r * BLOCK;
+      live[r] = e < total;
+      inside[r] = false;
+      vv[r] = 0;
+      pp[r] = 0;
+      ii[r] = 0;
+      if (live[r]) {
+        int lo = 0, hi = BLOCK;  // largest p with offs[p] <= e
+        while (hi - lo > 1) {
+          int mid = (lo + hi) >> 1;
+          if (S.offs[mid] <= e) lo = mid; else hi = mid;
+        }
+        const int p = lo;
+        const uint32_t i = e - S.offs[p];
+        const double t = (double)i * S.dts[p];
+        double qq[6];
+        int32_t cell[3];
 #pragma unroll
-      for (int k = 0; k < 6; k++) qq[k] = S.q[ax * 6 + k][p];
-      cell[ax] = float_to_cell(pos_at_q(qq, t), P.map.origin[ax], P.map.res);
+        for (int ax = 0; ax < 3; ax++) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) qq[k] = S.q[ax * 6 + k][p];
+          cell[ax] = float_to_cell(pos_at_q(qq, t), P.map.origin[ax], P.map.res);
+        }
+        pp[r] = p;
+        ii[r] = i;
+        inside[r] = !(cell[0] < 0 || cell[0] >= dx || cell[1] < 0 || cell[1] >= dy || cell[2] < 0 || cell[2] >= dz);
+        if (inside[r]) vv[r] = map[(size_t)cell[0] + (size_t)dx * cell[1] + (size_t)dx * dy * cell[2]];
+      }
     }
-    uint32_t code = 0xFFFFFFFFu;
-    if (cell[0] < 0 || cell[0] >= dx || cell[1] < 0 || cell[1] >= dy || cell[2] < 0 || cell[2] >= dz) {
-      code = i << 1;
-    } else {
-      size_t idx = (size_t)cell[0] + (size_t)dx * cell[1] + (size_t)dx * dy * cell[2];
-      if (map[idx] > 0) code = (i << 1) | 1u;
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      if (live[r]) {
+        if (!inside[r])
+          atomicMin(&S.blk[pp[r]], ii[r] << 1);
+        else if (vv[r] > 0)
+          atomicMin(&S.blk[pp[r]], (ii[r] << 1) | 1u);
+      }
     }
-    if (code != 0xFFFFFFFFu) atomicMin(&S.blk[p], code);
   }
   __syncthreads();
   if (L.valid) {
@@ -248,39 +287,40 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const Sta
   }
 }
 
-// ------------------------------------------------------------------ per-query view of the slot pools
-struct Slot {
-  int32_t *node_key;
-  double *node_state;
-  unsigned long long *node_g;
-  double *node_h;
-  uint32_t *node_flags, *node_pred;
-  unsigned long long *table;
-  uint32_t *edge_parent, *edge_next;
-  uint8_t *edge_action;
-  double *log_f, *log_g;
-  uint32_t *log_id, *log_next;
+// ------------------------------------------------------------------ chunked pool access
+template <int BLOCK, int CONTROL>
+struct QView {
+  const SearchParams &P;
+  Smem<BLOCK> &S;
   uint32_t *bkt_head;
+  __device__ __forceinline__ char *node(uint32_t i) const {
+    return P.node_pool + (((size_t)S.node_tbl[i >> NODE_CH_LOG] << NODE_CH_LOG) + (i & ((1u << NODE_CH_LOG) - 1))) * rec_bytes(CONTROL);
+  }
+  __device__ __forceinline__ EdgeRec *edge(uint32_t i) const {
+    return (EdgeRec *)(P.edge_pool + (((size_t)S.edge_tbl[i >> EDGE_CH_LOG] << EDGE_CH_LOG) + (i & ((1u << EDGE_CH_LOG) - 1))) * EDGE_BYTES);
+  }
+  __device__ __forceinline__ OpenRec *open(uint32_t i) const {
+    return (OpenRec *)(P.open_pool + (((size_t)S.open_tbl[i >> OPEN_CH_LOG] << OPEN_CH_LOG) + (i & ((1u << OPEN_CH_LOG) - 1))) * OPEN_BYTES);
+  }
+  // record field accessors
+  static __device__ __forceinline__ double &g(char *r) { return *(double *)r; }
+  static __device__ __forceinline__ double &h(char *r) { return *(double *)(r + 8); }
+  static __device__ __forceinline__ uint32_t &flags(char *r) { return *(uint32_t *)(r + 16); }
+  static __device__ __forceinline__ uint32_t &pred(char *r) { return *(uint32_t *)(r + 20); }
+  static __device__ __forceinline__ int32_t *key(char *r) { return (int32_t *)(r + 24); }
+  static __device__ __forceinline__ double *state(char *r) { return (double *)(r + rec_hot_bytes(CONTROL)); }
 };
-__device__ __forceinline__ Slot make_slot(const SearchParams &P, int s) {
-  Slot L;
-  size_t n = (size_t)s * P.cap_nodes, e = (size_t)s * P.cap_edges, l = (size_t)s * P.cap_log;
-  L.node_key = P.node_key + n * P.nk;
-  L.node_state = P.node_state + n * (P.ns + 1);
-  L.node_g = P.node_g + n;
-  L.node_h = P.node_h + n;
-  L.node_flags = P.node_flags + n;
-  L.node_pred = P.node_pred + n;
-  L.table = P.table + (size_t)s * P.cap_table;
-  L.edge_parent = P.edge_parent + e;
-  L.edge_next = P.edge_next + e;
-  L.edge_action = P.edge_action + e;
-  L.log_f = P.log_f + l;
-  L.log_g = P.log_g + l;
-  L.log_id = P.log_id + l;
-  L.log_next = P.log_next + l;
-  L.bkt_head = P.bkt_head + (size_t)s * NB * NSUB;
-  return L;
+
+// thread 0: make sure the query owns chunks for `need` items of a pool; false when the pool is exhausted
+__device__ __forceinline__ bool ensure_chunks(uint32_t *tbl, uint32_t &owned, uint32_t need, int ch_log, int max_ch, uint32_t *next, uint32_t pool_chunks) {
+  const uint32_t want = (need + (1u << ch_log) - 1) >> ch_log;
+  while (owned < want) {
+    if (owned >= (uint32_t)max_ch) return false;
+    uint32_t c = atomicAdd(next, 1u);
+    if (c >= pool_chunks) return false;
+    tbl[owned++] = c;
+  }
+  return true;
 }
 
 // is entry (f,g,id) in the near region?
@@ -292,23 +332,23 @@ __device__ __forceinline__ bool is_near(const Smem<BLOCK> &S, double width, doub
 }
 
 // link log entry idx into its far bucket
-template <int BLOCK>
-__device__ __forceinline__ void far_link(Smem<BLOCK> &S, const Slot &Q, double width, double f, uint32_t idx) {
-  int b = bucket_of(f, S.f_base, width);
-  atomicAdd(&S.bkt_count[b], 1u);
+template <int BLOCK, int CONTROL>
+__device__ __forceinline__ void far_link(const QView<BLOCK, CONTROL> &Q, double f, uint32_t idx) {
+  int b = bucket_of(f, Q.S.f_base, Q.P.bucket_width);
+  atomicAdd(&Q.S.bkt_count[b], 1u);
   uint32_t old = atomicExch(&Q.bkt_head[b * NSUB + (idx & (NSUB - 1))], idx);
-  Q.log_next[idx] = old;
+  Q.open(idx)->next = old;
 }
 
 // ------------------------------------------------------------------ near-set eviction (split)
 // Moves roughly the upper half of the near set (under the total order) back to the far buckets and
 // lowers the near/far boundary accordingly.  Any split point keeps the structure exact.
-template <int BLOCK>
-__device__ void evict_half(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q, int tid) {
+template <int BLOCK, int CONTROL>
+__device__ void evict_half(const QView<BLOCK, CONTROL> &Q, int tid) {
+  Smem<BLOCK> &S = Q.S;
   const uint32_t n = S.n_near;
   if (n < 2) return;
-  // choose the split level: f, then g, then id
-  for (int level = 0; level < 3; level++) {
+  for (int level = 0; level < 3; level++) {  // split on f, else on g, else on id
     double lo = INFINITY, hi = -INFINITY;
     for (uint32_t i = tid; i < n; i += BLOCK) {
       double v = level == 0 ? S.near_f[i] : level == 1 ? S.near_g[i] : (double)S.near_id[i];
@@ -320,21 +360,22 @@ __device__ void evict_half(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q,
       lo = fmin(lo, __shfl_xor(lo, d, 64));
       hi = fmax(hi, __shfl_xor(hi, d, 64));
     }
-    if ((tid & 63) == 0) {
-      S.red_f[tid >> 6] = lo;
-      S.red_g[tid >> 6] = hi;
-    }
-    __syncthreads();
-    lo = S.red_f[0];
-    hi = S.red_g[0];
+    if constexpr (BLOCK > 64) {
+      if ((tid & 63) == 0) {
+        S.red_f[tid >> 6] = lo;
+        S.red_g[tid >> 6] = hi;
+      }
+      __syncthreads();
+      lo = S.red_f[0];
+      hi = S.red_g[0];
 #pragma unroll
-    for (int w = 1; w < BLOCK / 64; w++) {
-      lo = fmin(lo, S.red_f[w]);
-      hi = fmax(hi, S.red_g[w]);
+      for (int w = 1; w < BLOCK / 64; w++) {
+        lo = fmin(lo, S.red_f[w]);
+        hi = fmax(hi, S.red_g[w]);
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    if (!(lo < hi)) continue;  // all equal at this level (an infinite range also lands here via the bins below)
-    // 64-bin histogram; bin() is monotone in v
+    if (!(lo < hi)) continue;  // all equal at this level
     if (tid < 64) S.hist[tid] = 0;
     __syncthreads();
     const double scale = 64.0 / (hi - lo);
@@ -352,7 +393,7 @@ __device__ void evict_half(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q,
     if (tid == 0) {
       uint32_t cum = 0;
       int k = 1;
-      for (int b = 0; b < 63; b++) {  // keep bins [0,k): choose first k with cum >= n/2, 1 <= k <= 63
+      for (int b = 0; b < 63; b++) {  // keep bins [0,k): first k with cum >= n/2, 1 <= k <= 63
         cum += S.hist[b];
         k = b + 1;
         if (cum >= n / 2) break;
@@ -390,7 +431,7 @@ __device__ void evict_half(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q,
       S.ts_f = tf;
       S.ts_g = tg;
       S.ts_id = ti;
-      S.bcur = bucket_of(tf, S.f_base, P.bucket_width);
+      S.bcur = bucket_of(tf, S.f_base, Q.P.bucket_width);
       S.c_evict++;
     }
     __syncthreads();
@@ -408,10 +449,11 @@ __device__ void evict_half(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q,
           keepmask |= 1u << r;
           nkeep++;
         } else {
-          far_link<BLOCK>(S, Q, P.bucket_width, ef[r], eix[r]);
+          far_link(Q, ef[r], eix[r]);
         }
       }
     }
+    __syncthreads();
     uint32_t total;
     uint32_t base = block_excl_scan<BLOCK>(nkeep, S, tid, total);
 #pragma unroll
@@ -428,19 +470,22 @@ __device__ void evict_half(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q,
 }
 
 // ------------------------------------------------------------------ refill the near set from the lowest far bucket
-template <int BLOCK>
-__device__ bool refill(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q, int tid) {
+template <int BLOCK, int CONTROL>
+__device__ bool refill(const QView<BLOCK, CONTROL> &Q, int tid) {
+  Smem<BLOCK> &S = Q.S;
   int b = NB;
   for (int i = tid; i < NB; i += BLOCK)
     if (S.bkt_count[i] > 0) { b = i; break; }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) b = min(b, __shfl_xor(b, d, 64));
-  if ((tid & 63) == 0) S.red_id[tid >> 6] = (uint32_t)b;
-  __syncthreads();
-  b = (int)S.red_id[0];
+  if constexpr (BLOCK > 64) {
+    if ((tid & 63) == 0) S.red_id[tid >> 6] = (uint32_t)b;
+    __syncthreads();
+    b = (int)S.red_id[0];
 #pragma unroll
-  for (int w = 1; w < BLOCK / 64; w++) b = min(b, (int)S.red_id[w]);
-  __syncthreads();
+    for (int w = 1; w < BLOCK / 64; w++) b = min(b, (int)S.red_id[w]);
+    __syncthreads();
+  }
   if (b >= NB) return false;
   if (tid == 0) {
     S.bcur = b;
@@ -456,23 +501,22 @@ __device__ bool refill(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q, int
   for (;;) {
     if (!block_any<BLOCK>(cur != NIL, S, tid)) break;
     while (S.n_near > (uint32_t)(NC - BLOCK)) {
-      evict_half<BLOCK>(P, S, Q, tid);
+      evict_half(Q, tid);
       __syncthreads();
     }
     if (cur != NIL) {
-      double f = Q.log_f[cur], g = Q.log_g[cur];
-      uint32_t id = Q.log_id[cur], nxt = Q.log_next[cur];
+      const OpenRec r = *Q.open(cur);
       // entries evicted during this refill may have lowered the boundary below this entry
-      if (is_near<BLOCK>(S, P.bucket_width, f, g, id)) {
+      if (is_near<BLOCK>(S, Q.P.bucket_width, r.f, r.g, r.id)) {
         uint32_t pos = atomicAdd(&S.n_near, 1u);
-        S.near_f[pos] = f; S.near_g[pos] = g; S.near_id[pos] = id; S.near_idx[pos] = cur;
+        S.near_f[pos] = r.f; S.near_g[pos] = r.g; S.near_id[pos] = r.id; S.near_idx[pos] = cur;
         pulled++;
       } else {
         // stays far: relink (bucket count already includes it)
         uint32_t old = atomicExch(&Q.bkt_head[b * NSUB + (cur & (NSUB - 1))], cur);
-        Q.log_next[cur] = old;
+        Q.open(cur)->next = old;
       }
-      cur = nxt;
+      cur = r.next;
     }
     __syncthreads();
   }
@@ -484,17 +528,19 @@ __device__ bool refill(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q, int
 }
 
 // ------------------------------------------------------------------ push one OPEN entry (log append + near/far)
-template <int BLOCK>
-__device__ __forceinline__ void open_push(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q, uint32_t idx, double f, double g, uint32_t id) {
+template <int BLOCK, int CONTROL>
+__device__ __forceinline__ void open_push(const QView<BLOCK, CONTROL> &Q, uint32_t idx, double f, double g, uint32_t id) {
+  Smem<BLOCK> &S = Q.S;
   if (f != f) f = INFINITY;  // never let a NaN into the order
-  Q.log_f[idx] = f;
-  Q.log_g[idx] = g;
-  Q.log_id[idx] = id;
-  if (is_near<BLOCK>(S, P.bucket_width, f, g, id)) {
+  OpenRec *r = Q.open(idx);
+  r->f = f;
+  r->g = g;
+  r->id = id;
+  if (is_near<BLOCK>(S, Q.P.bucket_width, f, g, id)) {
     uint32_t pos = atomicAdd(&S.n_near, 1u);
     S.near_f[pos] = f; S.near_g[pos] = g; S.near_id[pos] = id; S.near_idx[pos] = idx;
   } else {
-    far_link<BLOCK>(S, Q, P.bucket_width, f, idx);
+    far_link(Q, f, idx);
   }
 }
 
@@ -503,30 +549,44 @@ __device__ __forceinline__ void open_push(const SearchParams &P, Smem<BLOCK> &S,
 // parallel; node / edge / log ids come from prefix sums in lane order, so they equal the ids a
 // sequential loop over the control inputs would assign.
 template <int BLOCK, int CONTROL>
-__device__ void commit_parallel(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q, int tid, bool act, const LaneSucc &L, unsigned long long h64) {
+__device__ void commit_parallel(const QView<BLOCK, CONTROL> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64) {
+  using V = QView<BLOCK, CONTROL>;
+  const SearchParams &P = Q.P;
+  Smem<BLOCK> &S = Q.S;
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   int role = 0;  // 1 found, 2 creator
   uint32_t id = NIL;
   size_t tslot = 0;
-  const uint32_t tag = (uint32_t)(h64 >> 32);
+  const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
+  double old_g = INFINITY, hval = 0.0;
+  uint32_t fl = 0, old_pred = NIL;
+  char *rec = nullptr;
   if (act) {
-    const size_t mask = (size_t)P.cap_table - 1;
-    size_t pos = (size_t)h64 & mask;
-    const unsigned long long claim = ((unsigned long long)tag << 32) | (unsigned long long)(CLAIM_BASE + (uint32_t)tid);
+    const size_t mask = (size_t)P.table_mask;
+    size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & mask;
+    const unsigned long long claim = tagq | (unsigned long long)(CLAIM_BASE + (uint32_t)tid);
     for (;;) {
-      unsigned long long v = ld_u64(&Q.table[pos]);
+      unsigned long long v = ld_u64(&P.table[pos]);
       if (v == TBL_EMPTY) {
-        unsigned long long old = atomicCAS(&Q.table[pos], TBL_EMPTY, claim);
+        unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, claim);
         if (old == TBL_EMPTY) { role = 2; tslot = pos; break; }
         v = old;
       }
-      uint32_t vid = (uint32_t)v;
-      if (vid < CLAIM_BASE && (uint32_t)(v >> 32) == tag) {
-        const int32_t *kk = Q.node_key + (size_t)vid * nk;
+      const uint32_t vid = (uint32_t)v;
+      if (vid < CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
+        // one 64 B load answers: same key?  and if so g, h, flags, newest predecessor
+        char *r = Q.node(vid);
+        const double rg = V::g(r), rh = V::h(r);
+        const uint32_t rfl = V::flags(r), rpred = V::pred(r);
+        const int32_t *kk = V::key(r);
         bool eq = true;
 #pragma unroll
         for (int i = 0; i < nk; i++) eq = eq && (kk[i] == L.key[i]);
-        if (eq) { role = 1; id = vid; break; }
+        if (eq) {
+          role = 1; id = vid; rec = r;
+          old_g = rg; hval = rh; fl = rfl; old_pred = rpred;
+          break;
+        }
       }
       pos = (pos + 1) & mask;
     }
@@ -535,39 +595,36 @@ __device__ void commit_parallel(const SearchParams &P, Smem<BLOCK> &S, const Slo
   uint32_t sc = block_excl_scan<BLOCK>((role == 2 ? 1u : 0u) | (act ? 1u << 12 : 0u), S, tid, total);
   const uint32_t n_new = total & 0xFFFu, n_fin = total >> 12;
   const uint32_t base_nodes = S.n_nodes, base_edges = S.n_edges;
-  const bool full = (base_nodes + n_new > P.cap_nodes) || (base_edges + n_fin > P.cap_edges);
-  if (full) {
-    if (tid == 0) S.status = 4;  // MPLX_PLAN_POOL_FULL
-    __syncthreads();
-    return;
+  if (tid == 0) {
+    bool ok = ensure_chunks(S.node_tbl, S.node_chunks, base_nodes + n_new, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks) &&
+              ensure_chunks(S.edge_tbl, S.edge_chunks, base_edges + n_fin, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks) &&
+              ensure_chunks(S.open_tbl, S.open_chunks, S.n_log + n_fin, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
+    if (!ok) S.status = 4;  // MPLX_PLAN_POOL_FULL
   }
-  double old_g = INFINITY, hval = 0.0;
-  uint32_t fl = 0;
+  __syncthreads();
+  if (S.status >= 0) return;
   if (role == 2) {
     id = base_nodes + (sc & 0xFFFu);
-    int32_t *kk = Q.node_key + (size_t)id * nk;
+    rec = Q.node(id);
+    int32_t *kk = V::key(rec);
 #pragma unroll
     for (int i = 0; i < nk; i++) kk[i] = L.key[i];
-    double *st = Q.node_state + (size_t)id * (ns + 1);
+    double *st = V::state(rec);
 #pragma unroll
     for (int i = 0; i < ns; i++) st[i] = i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3];
     st[ns] = S.cur[12] + P.dt;
     hval = P.eps == 0.0 ? 0.0 : get_heur(S.hp, CONTROL, L.tn, L.key, nk);
-    Q.node_h[id] = hval;
-    st_u64(&Q.table[tslot], ((unsigned long long)tag << 32) | id);
-  } else if (role == 1) {
-    old_g = __longlong_as_double((long long)ld_u64(&Q.node_g[id]));
-    fl = Q.node_flags[id];
-    hval = Q.node_h[id];
+    V::h(rec) = hval;
+    st_u64(&P.table[tslot], tagq | id);
   }
   bool improved = false;
   double tg = 0.0;
   if (act) {
-    const uint32_t e = base_edges + (sc >> 12);
-    Q.edge_parent[e] = S.cur_id;
-    Q.edge_action[e] = (uint8_t)tid;
-    Q.edge_next[e] = role == 2 ? NIL : Q.node_pred[id];
-    Q.node_pred[id] = e;
+    EdgeRec *e = Q.edge(base_edges + (sc >> 12));
+    e->parent = S.cur_id;
+    e->next = old_pred;
+    e->action = (uint32_t)tid;
+    V::pred(rec) = base_edges + (sc >> 12);
     tg = S.cur_g + P.ucost[tid];
     improved = tg < old_g;
     if (improved) {
@@ -579,19 +636,14 @@ __device__ void commit_parallel(const SearchParams &P, Smem<BLOCK> &S, const Slo
       fl |= FLAG_OPENED;
     }
     if (improved || role == 2) {
-      st_u64(&Q.node_g[id], (unsigned long long)__double_as_longlong(improved ? tg : old_g));
-      Q.node_flags[id] = fl;
+      V::g(rec) = improved ? tg : old_g;
+      V::flags(rec) = fl;
     }
   }
   uint32_t total_p;
   uint32_t sp = block_excl_scan<BLOCK>(improved ? 1u : 0u, S, tid, total_p);
   const uint32_t base_log = S.n_log;
-  if (base_log + total_p > P.cap_log) {
-    if (tid == 0) S.status = 4;
-    __syncthreads();
-    return;
-  }
-  if (improved) open_push<BLOCK>(P, S, Q, base_log + sp, tg + P.eps * hval, tg, id);
+  if (improved) open_push(Q, base_log + sp, tg + P.eps * hval, tg, id);
   if (tid == 0) {
     S.n_nodes = base_nodes + n_new;
     S.n_edges = base_edges + n_fin;
@@ -602,13 +654,17 @@ __device__ void commit_parallel(const SearchParams &P, Smem<BLOCK> &S, const Slo
 }
 
 // ------------------------------------------------------------------ pop the minimum valid OPEN entry
-template <int BLOCK>
-__device__ bool pop_min(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q, int tid) {
+// On success S.cur_id / S.cur_g / S.cur / S.cur_key describe the node to expand and it is closed.
+template <int BLOCK, int CONTROL>
+__device__ bool pop_min(const QView<BLOCK, CONTROL> &Q, int tid) {
+  using V = QView<BLOCK, CONTROL>;
+  Smem<BLOCK> &S = Q.S;
+  constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   for (;;) {
     if (S.n_near == 0) {
       __syncthreads();
-      if (!refill<BLOCK>(P, S, Q, tid)) return false;
-      if (S.n_near == 0) continue;  // the pulled bucket only held entries that were relinked
+      if (!refill(Q, tid)) return false;
+      if (S.n_near == 0) continue;
     }
     const uint32_t n = S.n_near;
     double bf = INFINITY, bg = INFINITY;
@@ -624,35 +680,49 @@ __device__ bool pop_min(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q, in
       uint32_t oi = __shfl_xor(bi, d, 64), op = __shfl_xor(bp, d, 64);
       if (op != NIL && (bp == NIL || entry_less(of, og, oi, bf, bg, bi))) { bf = of; bg = og; bi = oi; bp = op; }
     }
-    if ((tid & 63) == 0) {
-      S.red_f[tid >> 6] = bf; S.red_g[tid >> 6] = bg; S.red_id[tid >> 6] = bi; S.red_pos[tid >> 6] = bp;
-    }
-    __syncthreads();
-    if (tid == 0) {
+    if constexpr (BLOCK > 64) {
+      if ((tid & 63) == 0) {
+        S.red_f[tid >> 6] = bf; S.red_g[tid >> 6] = bg; S.red_id[tid >> 6] = bi; S.red_pos[tid >> 6] = bp;
+      }
+      __syncthreads();
+      bf = S.red_f[0]; bg = S.red_g[0]; bi = S.red_id[0]; bp = S.red_pos[0];
+#pragma unroll
       for (int w = 1; w < BLOCK / 64; w++) {
         uint32_t op = S.red_pos[w];
         if (op != NIL && (bp == NIL || entry_less(S.red_f[w], S.red_g[w], S.red_id[w], bf, bg, bi))) {
           bf = S.red_f[w]; bg = S.red_g[w]; bi = S.red_id[w]; bp = op;
         }
       }
-      // remove from the near set
+      __syncthreads();
+    }
+    // every lane knows the winner: fetch its record (hot part + state) in one round trip
+    char *rec = Q.node(bi);
+    const double rg = V::g(rec);
+    const uint32_t fl = V::flags(rec);
+    double sval = 0.0;
+    int32_t kval = 0;
+    if (tid <= ns) sval = V::state(rec)[tid];
+    if (tid < nk) kval = V::key(rec)[tid];
+    if (tid == 0) {  // remove from the near set
       const uint32_t last = n - 1;
       S.near_f[bp] = S.near_f[last]; S.near_g[bp] = S.near_g[last];
       S.near_id[bp] = S.near_id[last]; S.near_idx[bp] = S.near_idx[last];
       S.n_near = last;
-      // stale?  (node improved since this entry was pushed, or already closed)
-      unsigned long long gb = ld_u64(&Q.node_g[bi]);
-      uint32_t fl = Q.node_flags[bi];
-      bool ok = gb == (unsigned long long)__double_as_longlong(bg) && !(fl & FLAG_CLOSED);
-      S.flag = ok ? 1 : 0;
-      if (ok) {
+    }
+    // stale?  (node improved since this entry was pushed, or already closed)
+    const bool ok = __double_as_longlong(rg) == __double_as_longlong(bg) && !(fl & FLAG_CLOSED);
+    if (ok) {
+      if (tid <= ns) S.cur[tid < ns ? tid : 12] = sval;
+      if (tid >= ns && tid < 12) S.cur[tid] = 0.0;
+      if (tid < nk) S.cur_key[tid] = kval;
+      if (tid == 0) {
         S.cur_id = bi;
         S.cur_g = bg;
-        Q.node_flags[bi] = fl | FLAG_CLOSED;
+        V::flags(rec) = fl | FLAG_CLOSED;
       }
     }
     __syncthreads();
-    if (S.flag) return true;
+    if (ok) return true;
   }
 }
 
@@ -660,21 +730,24 @@ __device__ bool pop_min(const SearchParams &P, Smem<BLOCK> &S, const Slot &Q, in
 template <int BLOCK, int CONTROL>
 __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
   __shared__ Smem<BLOCK> S;
+  using V = QView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
-  const Slot Q = make_slot(P, blockIdx.x);
+  const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * NB * NSUB};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   for (;;) {
     if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
     __syncthreads();
-    const int q = S.q_index;
-    if (q >= P.nq) break;
+    const int qi = S.q_index;
+    if (qi >= P.nq) break;
+    const int q = P.order[qi];
     const QueryIn &in = P.queries[q];
-    // ---- reset the slot
-    for (size_t i = tid; i < (size_t)P.cap_table; i += BLOCK) Q.table[i] = TBL_EMPTY;
+    const unsigned long long t_begin = wall_clock64();
+    // ---- reset the workgroup's OPEN structure
     for (int i = tid; i < NB * NSUB; i += BLOCK) Q.bkt_head[i] = NIL;
     for (int i = tid; i < NB; i += BLOCK) S.bkt_count[i] = 0;
     if (tid == 0) {
       S.n_near = 0; S.n_nodes = 0; S.n_edges = 0; S.n_log = 0;
+      S.node_chunks = S.edge_chunks = S.open_chunks = 0;
       S.bcur = 0; S.ts_f = INFINITY; S.ts_g = INFINITY; S.ts_id = 0xFFFFFFFFu;
       S.status = -1;
       S.c_expanded = S.c_closed = S.c_prims = S.c_succ = S.c_succ_finite = S.c_reads = 0;
@@ -700,6 +773,11 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         cost0 = 0.0;
       }
       S.tmp_d0 = cost0;
+      if (S.status < 0) {
+        bool ok = ensure_chunks(S.node_tbl, S.node_chunks, 1, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks) &&
+                  ensure_chunks(S.open_tbl, S.open_chunks, 1, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
+        if (!ok) S.status = 4;
+      }
     }
     __syncthreads();
     uint32_t goal_id = NIL;
@@ -708,40 +786,44 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
       if (tid == 0) {
         int32_t key[MAX_KEY];
         state_key_c<CONTROL>(in.start, key);
-        for (int i = 0; i < nk; i++) Q.node_key[i] = key[i];
+        char *rec = Q.node(0);
+        for (int i = 0; i < nk; i++) V::key(rec)[i] = key[i];
         const double *src = (const double *)&in.start;
-        for (int i = 0; i < ns; i++) Q.node_state[i] = src[i];
-        Q.node_state[ns] = in.start_t;
+        for (int i = 0; i < ns; i++) V::state(rec)[i] = src[i];
+        V::state(rec)[ns] = in.start_t;
         double h = P.eps == 0.0 ? 0.0 : get_heur(S.hp, CONTROL, in.start, key, nk);
-        Q.node_h[0] = h;
-        st_u64(&Q.node_g[0], (unsigned long long)__double_as_longlong(0.0));
-        Q.node_flags[0] = FLAG_OPENED;
-        Q.node_pred[0] = NIL;
-        unsigned long long h64 = key_hash64(key, nk);
-        st_u64(&Q.table[(size_t)h64 & ((size_t)P.cap_table - 1)], (h64 & 0xFFFFFFFF00000000ull) | 0ull);
+        V::h(rec) = h;
+        V::g(rec) = 0.0;
+        V::flags(rec) = FLAG_OPENED;
+        V::pred(rec) = NIL;
+        const unsigned long long h64 = key_hash64(key, nk);
+        const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
+        size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
+        for (;;) {  // shared table: the home slot may belong to another query
+          unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, tagq | 0ull);
+          if (old == TBL_EMPTY) break;
+          pos = (pos + 1) & (size_t)P.table_mask;
+        }
         S.n_nodes = 1;
         S.f_base = 0.0 + P.eps * h;
         S.n_log = 1;
         S.c_push = 1;
       }
       __syncthreads();
-      if (tid == 0) open_push<BLOCK>(P, S, Q, 0u, S.f_base, 0.0, 0u);
+      if (tid == 0) open_push(Q, 0u, S.f_base, 0.0, 0u);
       __syncthreads();
       // ---- main loop
       for (;;) {
         while (S.n_near > (uint32_t)(NC - BLOCK)) {
-          evict_half<BLOCK>(P, S, Q, tid);
+          evict_half(Q, tid);
           __syncthreads();
         }
-        if (!pop_min<BLOCK>(P, S, Q, tid)) {
+        if (!pop_min(Q, tid)) {
           if (tid == 0) S.status = 1;  // OPEN empty
           __syncthreads();
           break;
         }
         const uint32_t cur = S.cur_id;
-        if (tid <= ns) S.cur[tid < ns ? tid : 12] = Q.node_state[(size_t)cur * (ns + 1) + tid];
-        if (tid >= ns && tid < 12) S.cur[tid] = 0.0;
-        if (tid < nk) S.cur_key[tid] = Q.node_key[(size_t)cur * nk + tid];
         if (tid == 0) {
           S.c_expanded++;
           S.c_closed++;
@@ -749,12 +831,10 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
           if (P.rec_ids && S.c_expanded <= P.cap_rec) P.rec_ids[(size_t)q * P.cap_rec + (S.c_expanded - 1)] = (int32_t)cur;
           S.flag = 0;
         }
-        __syncthreads();
         LaneSucc L;
         expand_phases<BLOCK, CONTROL>(P, S, tid, L);
         const bool act = L.valid && !L.blocked;
-        // counters
-        {
+        {  // counters
           uint32_t tot;
           block_excl_scan<BLOCK>((L.valid ? 1u : 0u) | (act ? 1u << 10 : 0u), S, tid, tot);
           uint32_t treads;
@@ -784,10 +864,10 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         }
         __syncthreads();
         if (!S.flag) {
-          commit_parallel<BLOCK, CONTROL>(P, S, Q, tid, act, L, h64);
+          commit_parallel(Q, tid, q, act, L, h64);
         } else {
           // rare: two control inputs reach the same key -> commit one successor at a time, in order
-          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel<BLOCK, CONTROL>(P, S, Q, tid, act && tid == i, L, h64);
+          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel(Q, tid, q, act && tid == i, L, h64);
         }
         __syncthreads();
         if (S.status >= 0) break;  // pool full
@@ -823,25 +903,26 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         uint32_t node = goal_id;
         tn[0] = (int32_t)node;
         bool ok = true;
-        while (Q.node_pred[node] != NIL) {
+        while (V::pred(Q.node(node)) != NIL) {
           uint32_t best = NIL;
           double min_rhs = INFINITY, min_g = INFINITY;
-          for (uint32_t e = Q.node_pred[node]; e != NIL; e = Q.edge_next[e]) {
-            double gp = __longlong_as_double((long long)ld_u64(&Q.node_g[Q.edge_parent[e]]));
-            double rhs = gp + P.ucost[Q.edge_action[e]];
+          for (uint32_t e = V::pred(Q.node(node)); e != NIL; e = Q.edge(e)->next) {
+            const EdgeRec er = *Q.edge(e);
+            double gp = V::g(Q.node(er.parent));
+            double rhs = gp + P.ucost[er.action];
             if (rhs < min_rhs || (rhs == min_rhs && gp >= min_g)) { min_rhs = rhs; min_g = gp; best = e; }
           }
           if (best == NIL || len >= MAX_TRAJ) { ok = false; break; }
-          ta[len] = (int32_t)Q.edge_action[best];
-          node = Q.edge_parent[best];
+          ta[len] = (int32_t)Q.edge(best)->action;
+          node = Q.edge(best)->parent;
           len++;
           tn[len] = (int32_t)node;
           if (node == 0u) break;
         }
         if (ok) {
-          cost = __longlong_as_double((long long)ld_u64(&Q.node_g[goal_id]));
+          cost = V::g(Q.node(goal_id));
           for (int i = 0; i <= len; i++) {
-            const double *st = Q.node_state + (size_t)(uint32_t)tn[i] * (ns + 1);
+            const double *st = V::state(Q.node((uint32_t)tn[i]));
             for (int k = 0; k < 12; k++) ts[i * 13 + k] = k < ns ? st[k] : 0.0;
             ts[i * 13 + 12] = st[ns];
           }
@@ -858,7 +939,12 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
       o.n_push = S.c_push; o.n_reopen = S.c_reopen; o.n_refill = S.c_refill; o.n_evict = S.c_evict;
       o.expand_hash = S.c_hash;
       o.n_recorded = (uint32_t)(S.c_expanded < P.cap_rec ? S.c_expanded : P.cap_rec);
+      o.slot = blockIdx.x;
+      o.t_begin = t_begin;
+      o.t_end = wall_clock64();
     }
+    for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)
+      P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? S.node_tbl[i] : NIL;
     __syncthreads();
   }
 }

@@ -196,27 +196,35 @@ MPLX_HD int32_t float_to_cell(double p, double origin, double res) { return (int
 
 // ------------------------------------------------------------------ polynomial real roots
 // Derivative-chain isolation + safeguarded Newton/bisection, basic arithmetic only (deterministic
-// on host and device).  Coefficients ascending: a[0] + a[1] x + ... + a[n] x^n.
-MPLX_HD double poly_eval(const double *a, int n, double x) {
-  double r = a[n];
-  for (int i = n - 1; i >= 0; i--) r = r * x + a[i];
+// on host and device).  Coefficients ascending: a[0] + a[1] x + ... + a[N] x^N.
+// Degrees are compile-time so every array is indexed statically and stays in registers; a zero
+// leading coefficient drops to the next lower instantiation (the derivative of a polynomial with a
+// non-zero leading coefficient keeps a non-zero leading coefficient, so no other trimming exists).
+template <int N>
+MPLX_HD double poly_eval(const double *a, double x) {
+  double r = a[N];
+#pragma unroll
+  for (int i = N - 1; i >= 0; i--) r = r * x + a[i];
   return r;
 }
-MPLX_HD void poly_eval2(const double *a, int n, double x, double &f, double &df) {
-  double r = a[n], d = 0.0;
-  for (int i = n - 1; i >= 0; i--) {
+template <int N>
+MPLX_HD void poly_eval2(const double *a, double x, double &f, double &df) {
+  double r = a[N], d = 0.0;
+#pragma unroll
+  for (int i = N - 1; i >= 0; i--) {
     d = d * x + r;
     r = r * x + a[i];
   }
   f = r;
   df = d;
 }
-MPLX_HD double poly_refine(const double *a, int n, double x1, double f1, double x2) {
+template <int N>
+MPLX_HD double poly_refine(const double *a, double x1, double f1, double x2) {
   double xl, xh;
   if (f1 < 0.0) { xl = x1; xh = x2; } else { xl = x2; xh = x1; }
   double x = 0.5 * (x1 + x2);
   double dxold = fabs(x2 - x1), dx = dxold, f, df;
-  poly_eval2(a, n, x, f, df);
+  poly_eval2<N>(a, x, f, df);
   for (int it = 0; it < 200; it++) {
     if ((((x - xh) * df - f) * ((x - xl) * df - f) > 0.0) || (fabs(2.0 * f) > fabs(dxold * df))) {
       dxold = dx;
@@ -231,79 +239,75 @@ MPLX_HD double poly_refine(const double *a, int n, double x1, double f1, double 
       if (tmp == x) return x;
     }
     if (fabs(dx) <= 4.0e-16 * fabs(x)) return x;
-    poly_eval2(a, n, x, f, df);
+    poly_eval2<N>(a, x, f, df);
     if (f == 0.0) return x;
     if (f < 0.0) xl = x; else xh = x;
   }
   return x;
 }
-// Roots of a degree-N polynomial inside (lo, hi), ascending.  Iterative over the derivative chain
-// (no recursion on device): level k holds the (N-k)-th ... derivative.
+// roots of a degree-N polynomial (a[N] != 0) inside (lo, hi), ascending; roots has room for N
 template <int N>
-MPLX_HD int poly_roots_in(const double *a_in, int n, double lo, double hi, double *roots) {
-  // derivative table: d[k] = k-th derivative's coefficients, degree n-k
-  double d[N + 1][N + 1];
-  int deg[N + 1];
-  for (int i = 0; i <= n; i++) d[0][i] = a_in[i];
-  deg[0] = n;
-  int levels = 0;
-  // build chain down to degree 1, trimming zero leading coefficients like the recursive form does
-  while (deg[levels] > 1) {
-    int dg = deg[levels];
-    for (int i = 1; i <= dg; i++) d[levels + 1][i - 1] = d[levels][i] * (double)i;
-    int nd = dg - 1;
-    while (nd > 0 && d[levels + 1][nd] == 0.0) nd--;
-    deg[levels + 1] = nd;
-    levels++;
-  }
-  double crit[N + 1], cur[N + 1];
-  int nc = 0;
-  // lowest level: degree 1 (or 0)
-  {
-    const double *a = d[levels];
-    if (deg[levels] == 1) {
-      double r = -a[0] / a[1];
-      if (r > lo && r < hi) crit[nc++] = r;
+MPLX_HD int poly_roots_in(const double *a, double lo, double hi, double *roots) {
+  if constexpr (N == 1) {
+    double r = -a[0] / a[1];
+    if (r > lo && r < hi) {
+      roots[0] = r;
+      return 1;
     }
-  }
-  for (int lv = levels - 1; lv >= 0; lv--) {
-    const double *a = d[lv];
-    int dg = deg[lv];
+    return 0;
+  } else {
+    double d[N], crit[N - 1 > 0 ? N - 1 : 1];
+#pragma unroll
+    for (int i = 1; i <= N; i++) d[i - 1] = a[i] * (double)i;
+    const int nc = poly_roots_in<N - 1>(d, lo, hi, crit);
     int nr = 0;
-    double x0 = lo, f0 = poly_eval(a, dg, lo);
-    for (int k = 0; k <= nc; k++) {
-      double x1 = (k < nc) ? crit[k] : hi;
-      double f1 = poly_eval(a, dg, x1);
-      if (f1 == 0.0) {
-        if (k < nc) cur[nr++] = x1;
-      } else if (f0 != 0.0 && ((f0 < 0.0) != (f1 < 0.0))) {
-        cur[nr++] = poly_refine(a, dg, x0, f0, x1);
+    double x0 = lo, f0 = poly_eval<N>(a, lo);
+#pragma unroll
+    for (int k = 0; k <= N - 1; k++) {
+      if (k <= nc) {
+        double x1 = hi;
+#pragma unroll
+        for (int m = 0; m < N - 1; m++)
+          if (m == k && k < nc) x1 = crit[m];
+        double f1 = poly_eval<N>(a, x1);
+        double r = 0.0;
+        bool have = false;
+        if (f1 == 0.0) {
+          if (k < nc) { r = x1; have = true; }
+        } else if (f0 != 0.0 && ((f0 < 0.0) != (f1 < 0.0))) {
+          r = poly_refine<N>(a, x0, f0, x1);
+          have = true;
+        }
+        if (have) {
+#pragma unroll
+          for (int m = 0; m < N; m++)
+            if (m == nr) roots[m] = r;
+          nr++;
+        }
+        x0 = x1;
+        f0 = f1;
       }
-      x0 = x1;
-      f0 = f1;
     }
-    nc = nr;
-    for (int k = 0; k < nr; k++) crit[k] = cur[k];
+    return nr;
   }
-  for (int k = 0; k < nc; k++) roots[k] = crit[k];
-  return nc;
 }
-// real roots in (lo, +inf), ascending
+// real roots in (lo, +inf), ascending, of a polynomial of degree <= N
 template <int N>
-MPLX_HD int poly_roots_above(const double *a_in, double lo, double *roots) {
-  double a[N + 1];
-  int n = N;
-  for (int i = 0; i <= N; i++) a[i] = a_in[i];
-  while (n > 0 && a[n] == 0.0) n--;
-  if (n == 0) return 0;
-  double m = 0.0;
-  for (int i = 0; i < n; i++) {
-    double q = fabs(a[i] / a[n]);
-    if (q > m) m = q;
+MPLX_HD int poly_roots_above(const double *a, double lo, double *roots) {
+  if constexpr (N == 0) {
+    return 0;
+  } else {
+    if (a[N] == 0.0) return poly_roots_above<N - 1>(a, lo, roots);
+    double m = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      double q = fabs(a[i] / a[N]);
+      if (q > m) m = q;
+    }
+    double hi = 1.0 + m;
+    if (!(hi > lo)) return 0;
+    return poly_roots_in<N>(a, lo, hi, roots);
   }
-  double hi = 1.0 + m;
-  if (!(hi > lo)) return 0;
-  return poly_roots_in<N>(a, n, lo, hi, roots);
 }
 
 // ------------------------------------------------------------------ heuristic (env_base::cal_heur)
@@ -317,28 +321,34 @@ MPLX_HD double linf3(const double *a, const double *b) {
   return m;
 }
 MPLX_HD double heur_min6(double a, double c, double d, double e, double f, double g, double t_bar) {
-  double co[7] = {g, f, e, d, c, 0.0, a}, ts[8];
-  int n = poly_roots_above<6>(co, t_bar > 0 ? t_bar : 0.0, ts);
-  ts[n++] = t_bar;
+  double co[7] = {g, f, e, d, c, 0.0, a}, ts[6];
+  const int n = poly_roots_above<6>(co, t_bar > 0 ? t_bar : 0.0, ts);
   double best = INFINITY;
-  for (int i = 0; i < n; i++) {
-    double t = ts[i];
-    if (t < t_bar) continue;
-    double cost = a * t - c / t - d / 2 / t / t - e / 3 / t / t / t - f / 4 / t / t / t / t - g / 5 / t / t / t / t / t;
-    if (cost < best) best = cost;
+#pragma unroll
+  for (int i = 0; i <= 6; i++) {  // the roots in ascending order, then t_bar itself
+    if (i < n || i == 6) {
+      double t = i == 6 ? t_bar : ts[i < 6 ? i : 0];
+      if (!(t < t_bar)) {
+        double cost = a * t - c / t - d / 2 / t / t - e / 3 / t / t / t - f / 4 / t / t / t / t - g / 5 / t / t / t / t / t;
+        if (cost < best) best = cost;
+      }
+    }
   }
   return best;
 }
 MPLX_HD double heur_min4(double c5, double c3, double c2, double c1, double w, double t_bar) {
-  double co[5] = {c1, c2, c3, 0.0, c5}, ts[6];
-  int n = poly_roots_above<4>(co, t_bar > 0 ? t_bar : 0.0, ts);
-  ts[n++] = t_bar;
+  double co[5] = {c1, c2, c3, 0.0, c5}, ts[4];
+  const int n = poly_roots_above<4>(co, t_bar > 0 ? t_bar : 0.0, ts);
   double best = INFINITY;
-  for (int i = 0; i < n; i++) {
-    double t = ts[i];
-    if (t < t_bar) continue;
-    double c = -c1 / 3 / t / t / t - c2 / 2 / t / t - c3 / t + w * t;
-    if (c < best) best = c;
+#pragma unroll
+  for (int i = 0; i <= 4; i++) {  // the roots in ascending order, then t_bar itself
+    if (i < n || i == 4) {
+      double t = i == 4 ? t_bar : ts[i < 4 ? i : 0];
+      if (!(t < t_bar)) {
+        double c = -c1 / 3 / t / t / t - c2 / 2 / t / t - c3 / t + w * t;
+        if (c < best) best = c;
+      }
+    }
   }
   return best;
 }

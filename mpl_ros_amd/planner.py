@@ -355,6 +355,13 @@ class VoxelMapPlanner:
         ctx.check(ctx.lib.mplx_last_kernel_ms(ctx.h, C.byref(ms)))
         return ms.value
 
+    def queryTiming(self, q=0):
+        """(begin_s, end_s, workgroup) of query q on the device clock, relative to the batch start."""
+        ctx = self._ctx()
+        b, e, s = C.c_double(), C.c_double(), C.c_int32()
+        ctx.check(ctx.lib.mplx_result_timing(ctx.h, q, C.byref(b), C.byref(e), C.byref(s)))
+        return b.value, e.value, s.value
+
     # ---- results
     def getTrajCost(self):
         return self.traj_cost_

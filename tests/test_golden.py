@@ -68,7 +68,7 @@ def test_oracle_reproduces_golden_plans(plan, skir):
 @pytest.mark.parametrize("plan", PLANS, ids=[p["name"] for p in PLANS])
 def test_hip_reproduces_golden_plans(plan, skir):
     grid, origin, res, control, num, start, goal, kw = scenario_inputs(plan["name"], skir)
-    mu, pl = util.make_gpu(grid, origin, res, mapgen.control_lattice(1.0, num, True), max_nodes=1 << 19, max_edges=1 << 21, max_log=1 << 20, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, mapgen.control_lattice(1.0, num, True), **kw)
     ok = pl.plan(util.gpu_wp(start[0], start[1], control=control), util.gpu_wp(goal, control=control))
     r = pl.getResult()
     assert ok and r.status == plan["status"] and r.n_expanded == plan["n_expanded"]

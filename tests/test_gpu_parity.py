@@ -114,7 +114,7 @@ def test_plan_jrk_capped():
     U = mapgen.control_lattice(1.0, 2, True)
     kw = dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=3000)
     P = util.make_oracle(grid, origin, res, orc.JRK, U, **kw)
-    mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=1 << 19, max_edges=1 << 21, max_log=1 << 20, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
     r, c = util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0), (0, 0, 0)), ((8.55, 8.55, 8.55),), orc.JRK)
 
 
@@ -125,7 +125,7 @@ def test_plan_jrk_reaches_goal():
     U = mapgen.control_lattice(1.0, 1, True)
     kw = dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=50000)
     P = util.make_oracle(grid, origin, res, orc.JRK, U, **kw)
-    mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=1 << 19, max_edges=1 << 21, max_log=1 << 20, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
     util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0), (0, 0, 0)), ((4.55, 4.55, 3.05),), orc.JRK)
 
 
