@@ -102,7 +102,7 @@ def main():
         U = mapgen.control_lattice(1.0, 1, True)
         max_expand = args.max_expand if args.max_expand > 0 else -1
         per_q = args.max_nodes or 450_000  # mean states per query (tail up to ~2 M; the pools are shared)
-        caps = dict(nodes=per_q * args.queries, edges=per_q * args.queries * 5 // 2, log=per_q * args.queries * 5 // 4)
+        caps = dict(nodes=per_q * args.queries, edges=per_q * args.queries * 9 // 2, log=per_q * args.queries * 5 // 4)
         slots = args.slots or 1024
     else:
         U = mapgen.control_lattice(1.0, 2, True)

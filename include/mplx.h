@@ -128,7 +128,7 @@ int mplx_planner_config(mplx_ctx *ctx, const mplx_config *cfg);
 /* device pools: number of queries in flight (workgroups) and the TOTAL capacities shared by all
  * queries of one batch -- states, predecessor records, OPEN-log entries (0 = keep current) */
 int mplx_set_capacity(mplx_ctx *ctx, int32_t n_slots, uint64_t total_nodes, uint64_t total_edges, uint64_t total_open_log);
-/* f-width of one far OPEN bucket (0 = default w*dt/8) */
+/* f-width of one coarse OPEN bucket (0 = default w*dt/2); the fine level divides it by 1024 */
 int mplx_set_bucket_width(mplx_ctx *ctx, double width);
 
 /* ---- env_map::get_succ for K nodes in one launch (unit-testable kernel entry).
@@ -157,6 +157,9 @@ int mplx_result_nodes(mplx_ctx *ctx, mplx_waypoint *coords, double *g, double *h
 /* ---- measurement ---- */
 /* device-clock begin / end (seconds since the first query of the batch started) and workgroup of query q */
 int mplx_result_timing(mplx_ctx *ctx, int q, double *t_begin_s, double *t_end_s, int32_t *slot);
+/* shader-clock cycles query q spent in: [0] pop (incl. refill), [1] expand (primitives + voxels),
+ * [2] commit (dedup, relax, push), [3] near-set eviction, [4] refill, [5] coarse-bucket activation */
+int mplx_result_cycles(mplx_ctx *ctx, int q, uint64_t cyc[8]);
 /* duration (ms, HIP events on the context's stream) of the last search / expand kernel launch */
 int mplx_last_kernel_ms(const mplx_ctx *ctx, float *ms);
 const char *mplx_version(void);

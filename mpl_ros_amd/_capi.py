@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmplx.so")
+LIB_PATH = os.environ.get("MPLX_LIB") or os.path.join(_HERE, "csrc", "libmplx.so")
 
 VEL, ACC, JRK, SNP = 1, 3, 7, 15
 PLAN_OK, PLAN_NO_PATH, PLAN_START_OCCUPIED, PLAN_MAX_EXPAND, PLAN_POOL_FULL = 0, 1, 2, 3, 4
@@ -52,7 +52,7 @@ EXPORTS = [
     "mplx_map_set", "mplx_map_set_device", "mplx_map_free_unknown", "mplx_map_get", "mplx_map_info", "mplx_map_query",
     "mplx_planner_config", "mplx_set_capacity", "mplx_set_bucket_width",
     "mplx_expand_batch", "mplx_heuristic_batch", "mplx_plan", "mplx_plan_batch",
-    "mplx_result_traj", "mplx_set_record", "mplx_result_expanded", "mplx_result_nodes", "mplx_result_timing",
+    "mplx_result_traj", "mplx_set_record", "mplx_result_expanded", "mplx_result_nodes", "mplx_result_timing", "mplx_result_cycles",
     "mplx_last_kernel_ms", "mplx_version",
 ]
 
@@ -99,6 +99,7 @@ def load():
     L.mplx_result_expanded.argtypes = [P, C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
     L.mplx_result_nodes.argtypes = [P, C.POINTER(Waypoint), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mplx_result_timing.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), I3]
+    L.mplx_result_cycles.argtypes = [P, C.c_int, C.POINTER(C.c_uint64)]
     L.mplx_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float)]
     L.mplx_version.restype = C.c_char_p
     _lib = L

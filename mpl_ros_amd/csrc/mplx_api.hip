@@ -301,7 +301,7 @@ static void fill_params(const mplx_ctx *c, SearchParams &P) {
   P.U = c->dU;
   P.ucost = c->dUcost;
   P.map = map_dev(c);
-  P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt / 8.0 : 1.0);
+  P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt / 2.0 : 1.0);
 }
 
 template <typename T>
@@ -342,7 +342,7 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   PA(P.edge_pool, (size_t)(ech << EDGE_CH_LOG) * EDGE_BYTES);
   PA(P.open_pool, (size_t)(och << OPEN_CH_LOG) * OPEN_BYTES);
   PA(P.table, (size_t)T);
-  PA(P.bkt_head, (size_t)slots * NB * NSUB);
+  PA(P.bkt_head, (size_t)slots * 2 * NB * NSUB);
   PA(P.chunk_next, 4);
 #undef PA
   P.node_chunks = (uint32_t)nch;
@@ -677,6 +677,12 @@ extern "C" int mplx_result_timing(mplx_ctx *c, int q, double *t_begin_s, double 
   if (t_begin_s) *t_begin_s = (double)(c->last_out[q].t_begin - t0) * 1e-8;
   if (t_end_s) *t_end_s = (double)(c->last_out[q].t_end - t0) * 1e-8;
   if (slot) *slot = (int32_t)c->last_out[q].slot;
+  return MPLX_OK;
+}
+
+extern "C" int mplx_result_cycles(mplx_ctx *c, int q, uint64_t cyc[8]) {
+  if (!c || q < 0 || q >= c->last_nq || !cyc) return fail(c, MPLX_ERR_ARG, "no such query");
+  for (int i = 0; i < 8; i++) cyc[i] = c->last_out[q].cyc[i];
   return MPLX_OK;
 }
 

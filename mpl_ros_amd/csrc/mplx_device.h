@@ -15,9 +15,10 @@
 
 namespace mplx {
 
-constexpr int NB = 1024;          // far OPEN buckets per query
-constexpr int NSUB = 32;          // sub-lists per bucket (parallel pull)
+constexpr int NB = 1024;          // OPEN buckets per level (coarse level 1, fine level 0)
+constexpr int NSUB = 64;          // sub-lists per bucket (parallel pull, one per lane of a wave)
 constexpr int NC = 512;           // near OPEN capacity (LDS)
+constexpr int OWN = 2048;         // LDS (primitive, sample) owner map; larger expansions fall back to a search
 constexpr uint32_t NIL = 0xFFFFFFFFu;
 constexpr uint64_t TBL_EMPTY = 0xFFFFFFFFFFFFFFFFull;
 constexpr uint32_t CLAIM_BASE = 0xFFFF0000u;  // table id field >= CLAIM_BASE: claimed in this expansion
@@ -52,6 +53,7 @@ struct QueryOut {
   unsigned long long n_expanded, n_closed, n_nodes, n_edges, n_primitives, n_succ, n_succ_finite, voxel_reads, n_push,
       n_reopen, n_refill, n_evict, expand_hash;
   unsigned long long t_begin, t_end;  // wall_clock64() ticks (100 MHz)
+  unsigned long long cyc[8];          // s_memtime cycles: pop, expand, commit, evict, refill, activate, -, -
   uint32_t n_recorded, slot;
 };
 
@@ -70,7 +72,7 @@ struct SearchParams {
   uint32_t *chunk_next;                            // [3] bump counters: node, edge, open
   unsigned long long *table;
   unsigned long long table_mask;                   // slots - 1
-  uint32_t *bkt_head;                              // per workgroup slot: NB x NSUB
+  uint32_t *bkt_head;                              // per workgroup slot: 2 levels x NB x NSUB
   uint32_t cap_rec;
   // queries
   int32_t nq;

@@ -46,13 +46,14 @@ struct Smem {
   // OPEN near set
   double near_f[NC], near_g[NC];
   uint32_t near_id[NC], near_idx[NC];
-  uint32_t bkt_count[NB];
+  uint32_t cnt[2][NB];  // entries per bucket: [0] fine level (inside coarse bucket cur1), [1] coarse level
   // chunk tables of the running query
   uint32_t node_tbl[MAX_NODE_CH], edge_tbl[MAX_EDGE_CH], open_tbl[MAX_OPEN_CH];
   // expansion scratch
-  double q[18][BLOCK];  // pre-divided polynomial coefficients per primitive
+  double q[15][BLOCK];  // pre-divided non-zero polynomial coefficients per primitive (3 axes x nq_c)
   double dts[BLOCK];
-  uint32_t cnt[BLOCK];  // samples per primitive (n+1), 0 if skipped
+  uint8_t owner[OWN];   // primitive that owns flattened sample e
+  uint32_t cnt_s[BLOCK];  // samples per primitive (n+1), 0 if skipped
   uint32_t offs[BLOCK + 1];
   uint32_t blk[BLOCK];  // first blocked sample: (i << 1) | inside
   unsigned long long dupset[2 * BLOCK];
@@ -67,9 +68,10 @@ struct Smem {
   // scalars
   uint32_t n_near, n_nodes, n_edges, n_log;
   uint32_t node_chunks, edge_chunks, open_chunks;  // chunks owned
-  int32_t bcur;
+  int32_t cur1, cur0;  // active coarse bucket, active fine bucket inside it
+  double lo1;          // f of the lower edge of coarse bucket cur1
   double ts_f, ts_g;
-  uint32_t ts_id;  // split threshold inside bucket bcur
+  uint32_t ts_id;      // split threshold inside fine bucket cur0
   double f_base;
   uint32_t cur_id;
   double cur_g;
@@ -77,7 +79,11 @@ struct Smem {
   uint32_t tmp_u;
   double tmp_d0;
   unsigned long long c_expanded, c_closed, c_prims, c_succ, c_succ_finite, c_reads, c_push, c_reopen, c_refill, c_evict, c_hash;
+  unsigned long long cyc[8];
 };
+
+#define MPLX_TIC(var) const unsigned long long var = __builtin_readcyclecounter()
+#define MPLX_TOC(S, k, var) do { if (threadIdx.x == 0) (S).cyc[k] += __builtin_readcyclecounter() - (var); } while (0)
 
 template <int BLOCK>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, Smem<BLOCK> &S, int tid, uint32_t &total) {
@@ -123,8 +129,8 @@ __device__ __forceinline__ bool block_any(bool p, Smem<BLOCK> &S, int tid) {
   }
 }
 
-__device__ __forceinline__ int bucket_of(double f, double f_base, double width) {
-  double b = floor((f - f_base) / width);
+__device__ __forceinline__ int bucket_idx(double f, double lo, double width) {
+  double b = floor((f - lo) / width);
   if (!(b > 0.0)) return 0;  // also NaN
   if (b >= (double)(NB - 1)) return NB - 1;
   return (int)b;
@@ -141,7 +147,7 @@ struct LaneSucc {
 
 template <int BLOCK, int CONTROL>
 __device__ __forceinline__ void expand_phases(const SearchParams &P, Smem<BLOCK> &S, int tid, LaneSucc &L) {
-  constexpr int control = CONTROL;
+  constexpr int NQ = nq_c(CONTROL);
   const double T = P.dt;
   L.valid = false;
   L.blocked = false;
@@ -151,47 +157,51 @@ __device__ __forceinline__ void expand_phases(const SearchParams &P, Smem<BLOCK>
     double c[3][6];
     const double *u = P.U + 3 * tid;
 #pragma unroll
-    for (int ax = 0; ax < 3; ax++) prim_build_axis(control, S.cur[ax], S.cur[3 + ax], S.cur[6 + ax], S.cur[9 + ax], u[ax], c[ax]);
+    for (int ax = 0; ax < 3; ax++) prim_build_axis(CONTROL, S.cur[ax], S.cur[3 + ax], S.cur[6 + ax], S.cur[9 + ax], u[ax], c[ax]);
 #pragma unroll
     for (int ax = 0; ax < 3; ax++) {
-      L.tn.p[ax] = pos_at(c[ax], T);
-      L.tn.v[ax] = vel_at(c[ax], T);
-      L.tn.a[ax] = acc_at(c[ax], T);
-      L.tn.j[ax] = jrk_at(c[ax], T);
+      L.tn.p[ax] = pos_at_c<CONTROL>(c[ax], T);
+      L.tn.v[ax] = vel_at_c<CONTROL>(c[ax], T);
+      L.tn.a[ax] = acc_at_c<CONTROL>(c[ax], T);
+      L.tn.j[ax] = jrk_at_c<CONTROL>(c[ax], T);
     }
     state_key_c<CONTROL>(L.tn, L.key);
     bool same = true;
 #pragma unroll
     for (int i = 0; i < key_len_c(CONTROL); i++) same = same && (L.key[i] == S.cur_key[i]);
     double max_v;
-    bool ok = !same && validate_and_maxv(control, c, T, P.v_max, P.a_max, P.j_max, &max_v);
+#ifdef MPLX_GENERIC_VALIDATE
+    bool ok = !same && validate_and_maxv(CONTROL, c, T, P.v_max, P.a_max, P.j_max, &max_v);
+#else
+    bool ok = !same && validate_and_maxv_c<CONTROL>(c, T, P.v_max, P.a_max, P.j_max, &max_v);
+#endif
     if (ok) {
       int n = (int)ceil(max_v * T / P.map.res);
       my_cnt = (uint32_t)(n + 1);
       S.dts[tid] = n > 0 ? T / n : 0.0;
 #pragma unroll
       for (int ax = 0; ax < 3; ax++) {
-        S.q[ax * 6 + 0][tid] = c[ax][0] / 120;
-        S.q[ax * 6 + 1][tid] = c[ax][1] / 24;
-        S.q[ax * 6 + 2][tid] = c[ax][2] / 6;
-        S.q[ax * 6 + 3][tid] = c[ax][3] / 2;
-        S.q[ax * 6 + 4][tid] = c[ax][4];
-        S.q[ax * 6 + 5][tid] = c[ax][5];
+        double qc[NQ];
+        pack_q_c<CONTROL>(c[ax], qc);
+#pragma unroll
+        for (int k = 0; k < NQ; k++) S.q[ax * NQ + k][tid] = qc[k];
       }
       L.valid = true;
     }
   }
-  S.cnt[tid] = my_cnt;
+  S.cnt_s[tid] = my_cnt;
   S.blk[tid] = 0xFFFFFFFFu;
   uint32_t total;
   uint32_t off = block_excl_scan<BLOCK>(my_cnt, S, tid, total);
   S.offs[tid] = off;
   if (tid == BLOCK - 1) S.offs[BLOCK] = total;
+  // owner map: flattened sample e -> primitive
+  for (uint32_t i = 0; i < my_cnt && off + i < (uint32_t)OWN; i++) S.owner[off + i] = (uint8_t)tid;
   __syncthreads();
   // phase 2: flattened (primitive, sample) pairs, UNR voxel loads in flight per lane
   const int8_t *__restrict__ map = P.map.data;
   const int dx = P.map.dim[0], dy = P.map.dim[1], dz = P.map.dim[2];
-  constexpr int UNR = 4;
+  constexpr int UNR = 6;
   for (uint32_t e0 = tid; e0 < total; e0 += BLOCK * UNR) {
     int pp[UNR];
     uint32_t ii[UNR];
@@ -206,21 +216,26 @@ __device__ __forceinline__ void expand_phases(const SearchParams &P, Smem<BLOCK>
       pp[r] = 0;
       ii[r] = 0;
       if (live[r]) {
-        int lo = 0, hi = BLOCK;  // largest p with offs[p] <= e
-        while (hi - lo > 1) {
-          int mid = (lo + hi) >> 1;
-          if (S.offs[mid] <= e) lo = mid; else hi = mid;
+        int p;
+        if (e < (uint32_t)OWN) {
+          p = S.owner[e];
+        } else {
+          int lo = 0, hi = BLOCK;  // largest p with offs[p] <= e
+          while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (S.offs[mid] <= e) lo = mid; else hi = mid;
+          }
+          p = lo;
         }
-        const int p = lo;
         const uint32_t i = e - S.offs[p];
         const double t = (double)i * S.dts[p];
-        double qq[6];
         int32_t cell[3];
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) {
+          double qq[NQ];
 #pragma unroll
-          for (int k = 0; k < 6; k++) qq[k] = S.q[ax * 6 + k][p];
-          cell[ax] = float_to_cell(pos_at_q(qq, t), P.map.origin[ax], P.map.res);
+          for (int k = 0; k < NQ; k++) qq[k] = S.q[ax * NQ + k][p];
+          cell[ax] = float_to_cell(pos_at_qc<CONTROL>(qq, t), P.map.origin[ax], P.map.res);
         }
         pp[r] = p;
         ii[r] = i;
@@ -323,29 +338,55 @@ __device__ __forceinline__ bool ensure_chunks(uint32_t *tbl, uint32_t &owned, ui
   return true;
 }
 
-// is entry (f,g,id) in the near region?
+// where does entry (f,g,id) belong?  -1: near set; [0,NB): fine bucket; [NB,2NB): coarse bucket
 template <int BLOCK>
-__device__ __forceinline__ bool is_near(const Smem<BLOCK> &S, double width, double f, double g, uint32_t id) {
-  int b = bucket_of(f, S.f_base, width);
-  if (b != S.bcur) return b < S.bcur;
-  return entry_less(f, g, id, S.ts_f, S.ts_g, S.ts_id);
+__device__ __forceinline__ int classify(const Smem<BLOCK> &S, double w1, double f, double g, uint32_t id) {
+  const int b1 = bucket_idx(f, S.f_base, w1);
+  if (b1 != S.cur1) return b1 < S.cur1 ? -1 : NB + b1;
+  const int b0 = bucket_idx(f, S.lo1, w1 * (1.0 / NB));
+  if (b0 != S.cur0) return b0 < S.cur0 ? -1 : b0;
+  return entry_less(f, g, id, S.ts_f, S.ts_g, S.ts_id) ? -1 : b0;
 }
 
-// link log entry idx into its far bucket
+// link log entry idx into far bucket `code` (fine or coarse)
 template <int BLOCK, int CONTROL>
-__device__ __forceinline__ void far_link(const QView<BLOCK, CONTROL> &Q, double f, uint32_t idx) {
-  int b = bucket_of(f, Q.S.f_base, Q.P.bucket_width);
-  atomicAdd(&Q.S.bkt_count[b], 1u);
-  uint32_t old = atomicExch(&Q.bkt_head[b * NSUB + (idx & (NSUB - 1))], idx);
+__device__ __forceinline__ void far_link(const QView<BLOCK, CONTROL> &Q, int code, uint32_t idx) {
+  atomicAdd(&Q.S.cnt[0][code], 1u);  // cnt is [2][NB]: code indexes it flat
+  uint32_t old = atomicExch(&Q.bkt_head[(size_t)code * NSUB + (idx & (NSUB - 1))], idx);
   Q.open(idx)->next = old;
+}
+
+// rare: the near/far boundary must drop below the active coarse bucket -> hand every fine bucket
+// back to the coarse level so that the fine level can be re-bound to a lower coarse bucket
+template <int BLOCK, int CONTROL>
+__device__ __forceinline__ void demote_fine(const QView<BLOCK, CONTROL> &Q, int tid) {
+  Smem<BLOCK> &S = Q.S;
+  const int c1 = NB + S.cur1;
+  for (int b = 0; b < NB; b++) {
+    if (S.cnt[0][b] == 0) continue;  // uniform
+    uint32_t cur = NIL, moved = 0;
+    if (tid < NSUB) cur = atomicExch(&Q.bkt_head[(size_t)b * NSUB + tid], NIL);
+    while (cur != NIL) {
+      const uint32_t nxt = Q.open(cur)->next;
+      uint32_t old = atomicExch(&Q.bkt_head[(size_t)c1 * NSUB + (cur & (NSUB - 1))], cur);
+      Q.open(cur)->next = old;
+      moved++;
+      cur = nxt;
+    }
+    if (moved) atomicAdd(&S.cnt[1][S.cur1], moved);
+    __syncthreads();
+    if (tid == 0) S.cnt[0][b] = 0;
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------ near-set eviction (split)
 // Moves roughly the upper half of the near set (under the total order) back to the far buckets and
 // lowers the near/far boundary accordingly.  Any split point keeps the structure exact.
 template <int BLOCK, int CONTROL>
-__device__ void evict_half(const QView<BLOCK, CONTROL> &Q, int tid) {
+__device__ __forceinline__ void evict_half(const QView<BLOCK, CONTROL> &Q, int tid) {
   Smem<BLOCK> &S = Q.S;
+  const double w1 = Q.P.bucket_width;
   const uint32_t n = S.n_near;
   if (n < 2) return;
   for (int level = 0; level < 3; level++) {  // split on f, else on g, else on id
@@ -425,13 +466,24 @@ __device__ void evict_half(const QView<BLOCK, CONTROL> &Q, int tid) {
       S.red_id[tid >> 6] = ti;
     }
     __syncthreads();
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++)
+      if (w == 0 || entry_less(S.red_f[w], S.red_g[w], S.red_id[w], tf, tg, ti)) { tf = S.red_f[w]; tg = S.red_g[w]; ti = S.red_id[w]; }
+    const int b1t = bucket_idx(tf, S.f_base, w1);
+    __syncthreads();
+    if (b1t < S.cur1) {  // uniform; rare (needs an inconsistent heuristic)
+      demote_fine(Q, tid);
+      if (tid == 0) {
+        S.cur1 = b1t;
+        S.lo1 = S.f_base + (double)b1t * w1;
+      }
+      __syncthreads();
+    }
     if (tid == 0) {
-      for (int w = 1; w < BLOCK / 64; w++)
-        if (entry_less(S.red_f[w], S.red_g[w], S.red_id[w], tf, tg, ti)) { tf = S.red_f[w]; tg = S.red_g[w]; ti = S.red_id[w]; }
+      S.cur0 = bucket_idx(tf, S.lo1, w1 * (1.0 / NB));
       S.ts_f = tf;
       S.ts_g = tg;
       S.ts_id = ti;
-      S.bcur = bucket_of(tf, S.f_base, Q.P.bucket_width);
       S.c_evict++;
     }
     __syncthreads();
@@ -445,11 +497,12 @@ __device__ void evict_half(const QView<BLOCK, CONTROL> &Q, int tid) {
       uint32_t i = tid + r * BLOCK;
       if (i < n) {
         ef[r] = S.near_f[i]; eg[r] = S.near_g[i]; eid[r] = S.near_id[i]; eix[r] = S.near_idx[i];
-        if (entry_less(ef[r], eg[r], eid[r], S.ts_f, S.ts_g, S.ts_id)) {
+        const int code = classify<BLOCK>(S, w1, ef[r], eg[r], eid[r]);
+        if (code < 0) {
           keepmask |= 1u << r;
           nkeep++;
         } else {
-          far_link(Q, ef[r], eix[r]);
+          far_link(Q, code, eix[r]);
         }
       }
     }
@@ -469,13 +522,12 @@ __device__ void evict_half(const QView<BLOCK, CONTROL> &Q, int tid) {
   }
 }
 
-// ------------------------------------------------------------------ refill the near set from the lowest far bucket
-template <int BLOCK, int CONTROL>
-__device__ bool refill(const QView<BLOCK, CONTROL> &Q, int tid) {
-  Smem<BLOCK> &S = Q.S;
+// lowest non-empty bucket of a level (NB if none)
+template <int BLOCK>
+__device__ __forceinline__ int lowest_bucket(Smem<BLOCK> &S, int level, int tid) {
   int b = NB;
   for (int i = tid; i < NB; i += BLOCK)
-    if (S.bkt_count[i] > 0) { b = i; break; }
+    if (S.cnt[level][i] > 0) { b = i; break; }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) b = min(b, __shfl_xor(b, d, 64));
   if constexpr (BLOCK > 64) {
@@ -486,45 +538,84 @@ __device__ bool refill(const QView<BLOCK, CONTROL> &Q, int tid) {
     for (int w = 1; w < BLOCK / 64; w++) b = min(b, (int)S.red_id[w]);
     __syncthreads();
   }
-  if (b >= NB) return false;
-  if (tid == 0) {
-    S.bcur = b;
-    S.ts_f = INFINITY;
-    S.ts_g = INFINITY;
-    S.ts_id = 0xFFFFFFFFu;
-    S.c_refill++;
-  }
+  return b;
+}
+
+// pull every entry of far bucket `code`; entries that classify as near go to the near set, the
+// rest are re-linked where they belong.  `to_near` false: activation of a coarse bucket (nothing
+// is near because cur0 == -1).
+template <int BLOCK, int CONTROL>
+__device__ __forceinline__ void pull_bucket(const QView<BLOCK, CONTROL> &Q, int code, int tid) {
+  Smem<BLOCK> &S = Q.S;
+  const double w1 = Q.P.bucket_width;
   uint32_t cur = NIL;
-  if (tid < NSUB) cur = atomicExch(&Q.bkt_head[b * NSUB + tid], NIL);
+  if (tid < NSUB) cur = atomicExch(&Q.bkt_head[(size_t)code * NSUB + tid], NIL);
   uint32_t pulled = 0;
   __syncthreads();
   for (;;) {
     if (!block_any<BLOCK>(cur != NIL, S, tid)) break;
     while (S.n_near > (uint32_t)(NC - BLOCK)) {
+      MPLX_TIC(te);
       evict_half(Q, tid);
       __syncthreads();
+      MPLX_TOC(S, 3, te);
     }
     if (cur != NIL) {
       const OpenRec r = *Q.open(cur);
-      // entries evicted during this refill may have lowered the boundary below this entry
-      if (is_near<BLOCK>(S, Q.P.bucket_width, r.f, r.g, r.id)) {
+      const int c = classify<BLOCK>(S, w1, r.f, r.g, r.id);
+      if (c < 0) {
         uint32_t pos = atomicAdd(&S.n_near, 1u);
         S.near_f[pos] = r.f; S.near_g[pos] = r.g; S.near_id[pos] = r.id; S.near_idx[pos] = cur;
-        pulled++;
       } else {
-        // stays far: relink (bucket count already includes it)
-        uint32_t old = atomicExch(&Q.bkt_head[b * NSUB + (cur & (NSUB - 1))], cur);
-        Q.open(cur)->next = old;
+        far_link(Q, c, cur);
       }
+      pulled++;
       cur = r.next;
     }
     __syncthreads();
   }
-  if (pulled) atomicSub(&S.bkt_count[b], pulled);
-  const bool any_pulled = block_any<BLOCK>(pulled != 0, S, tid);
-  if (!any_pulled && tid == 0 && S.ts_f == INFINITY) S.bkt_count[b] = 0;  // defensive: empty lists, stale count
+  if (pulled) atomicSub(&S.cnt[0][code], pulled);
   __syncthreads();
-  return true;
+}
+
+// near set empty: bring in the lowest far entries.  false when OPEN is empty.
+template <int BLOCK, int CONTROL>
+__device__ __forceinline__ bool refill(const QView<BLOCK, CONTROL> &Q, int tid) {
+  Smem<BLOCK> &S = Q.S;
+  for (int guard = 0; guard < 4 * NB; guard++) {
+    const int b0 = lowest_bucket<BLOCK>(S, 0, tid);
+    if (b0 < NB) {
+      MPLX_TIC(t0);
+      if (tid == 0) {
+        S.cur0 = b0;
+        S.ts_f = INFINITY;
+        S.ts_g = INFINITY;
+        S.ts_id = 0xFFFFFFFFu;
+        S.c_refill++;
+      }
+      __syncthreads();
+      pull_bucket(Q, b0, tid);
+      MPLX_TOC(S, 4, t0);
+      if (S.n_near > 0) return true;
+      __syncthreads();
+      continue;
+    }
+    const int b1 = lowest_bucket<BLOCK>(S, 1, tid);
+    if (b1 >= NB) return false;
+    MPLX_TIC(t1);
+    if (tid == 0) {  // activate coarse bucket b1: spread it over the fine level
+      S.cur1 = b1;
+      S.lo1 = S.f_base + (double)b1 * Q.P.bucket_width;
+      S.cur0 = -1;
+      S.ts_f = INFINITY;
+      S.ts_g = INFINITY;
+      S.ts_id = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    pull_bucket(Q, NB + b1, tid);
+    MPLX_TOC(S, 5, t1);
+  }
+  return false;
 }
 
 // ------------------------------------------------------------------ push one OPEN entry (log append + near/far)
@@ -536,11 +627,12 @@ __device__ __forceinline__ void open_push(const QView<BLOCK, CONTROL> &Q, uint32
   r->f = f;
   r->g = g;
   r->id = id;
-  if (is_near<BLOCK>(S, Q.P.bucket_width, f, g, id)) {
+  const int code = classify<BLOCK>(S, Q.P.bucket_width, f, g, id);
+  if (code < 0) {
     uint32_t pos = atomicAdd(&S.n_near, 1u);
     S.near_f[pos] = f; S.near_g[pos] = g; S.near_id[pos] = id; S.near_idx[pos] = idx;
   } else {
-    far_link(Q, f, idx);
+    far_link(Q, code, idx);
   }
 }
 
@@ -549,7 +641,7 @@ __device__ __forceinline__ void open_push(const QView<BLOCK, CONTROL> &Q, uint32
 // parallel; node / edge / log ids come from prefix sums in lane order, so they equal the ids a
 // sequential loop over the control inputs would assign.
 template <int BLOCK, int CONTROL>
-__device__ void commit_parallel(const QView<BLOCK, CONTROL> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64) {
+__device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64) {
   using V = QView<BLOCK, CONTROL>;
   const SearchParams &P = Q.P;
   Smem<BLOCK> &S = Q.S;
@@ -561,12 +653,22 @@ __device__ void commit_parallel(const QView<BLOCK, CONTROL> &Q, int tid, int q, 
   double old_g = INFINITY, hval = 0.0;
   uint32_t fl = 0, old_pred = NIL;
   char *rec = nullptr;
+  // the heuristic of a new state is needed only if the probe ends in "create", but computing it
+  // for every live lane while the first table load is in flight hides ~2-3k cycles of f64 ALU
+  const size_t mask = (size_t)P.table_mask;
+  size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & mask;
+  unsigned long long v0 = TBL_EMPTY;
+  if (act) v0 = ld_u64(&P.table[pos]);
+  double hspec = 0.0;
+#ifndef MPLX_NO_HSPEC
+  if (act && P.eps != 0.0) hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
+#endif
   if (act) {
-    const size_t mask = (size_t)P.table_mask;
-    size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & mask;
     const unsigned long long claim = tagq | (unsigned long long)(CLAIM_BASE + (uint32_t)tid);
+    bool first = true;
     for (;;) {
-      unsigned long long v = ld_u64(&P.table[pos]);
+      unsigned long long v = first ? v0 : ld_u64(&P.table[pos]);
+      first = false;
       if (v == TBL_EMPTY) {
         unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, claim);
         if (old == TBL_EMPTY) { role = 2; tslot = pos; break; }
@@ -613,7 +715,10 @@ __device__ void commit_parallel(const QView<BLOCK, CONTROL> &Q, int tid, int q, 
 #pragma unroll
     for (int i = 0; i < ns; i++) st[i] = i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3];
     st[ns] = S.cur[12] + P.dt;
-    hval = P.eps == 0.0 ? 0.0 : get_heur(S.hp, CONTROL, L.tn, L.key, nk);
+#ifdef MPLX_NO_HSPEC
+    hspec = P.eps == 0.0 ? 0.0 : get_heur(S.hp, CONTROL, L.tn, L.key, nk);
+#endif
+    hval = hspec;
     V::h(rec) = hval;
     st_u64(&P.table[tslot], tagq | id);
   }
@@ -656,7 +761,7 @@ __device__ void commit_parallel(const QView<BLOCK, CONTROL> &Q, int tid, int q, 
 // ------------------------------------------------------------------ pop the minimum valid OPEN entry
 // On success S.cur_id / S.cur_g / S.cur / S.cur_key describe the node to expand and it is closed.
 template <int BLOCK, int CONTROL>
-__device__ bool pop_min(const QView<BLOCK, CONTROL> &Q, int tid) {
+__device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL> &Q, int tid) {
   using V = QView<BLOCK, CONTROL>;
   Smem<BLOCK> &S = Q.S;
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
@@ -732,7 +837,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
   __shared__ Smem<BLOCK> S;
   using V = QView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
-  const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * NB * NSUB};
+  const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   for (;;) {
     if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
@@ -743,13 +848,14 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
     const QueryIn &in = P.queries[q];
     const unsigned long long t_begin = wall_clock64();
     // ---- reset the workgroup's OPEN structure
-    for (int i = tid; i < NB * NSUB; i += BLOCK) Q.bkt_head[i] = NIL;
-    for (int i = tid; i < NB; i += BLOCK) S.bkt_count[i] = 0;
+    for (int i = tid; i < 2 * NB * NSUB; i += BLOCK) Q.bkt_head[i] = NIL;
+    for (int i = tid; i < 2 * NB; i += BLOCK) S.cnt[0][i] = 0;
     if (tid == 0) {
       S.n_near = 0; S.n_nodes = 0; S.n_edges = 0; S.n_log = 0;
       S.node_chunks = S.edge_chunks = S.open_chunks = 0;
-      S.bcur = 0; S.ts_f = INFINITY; S.ts_g = INFINITY; S.ts_id = 0xFFFFFFFFu;
+      S.cur1 = 0; S.cur0 = 0; S.lo1 = 0.0; S.ts_f = INFINITY; S.ts_g = INFINITY; S.ts_id = 0xFFFFFFFFu;
       S.status = -1;
+      for (int i = 0; i < 8; i++) S.cyc[i] = 0;
       S.c_expanded = S.c_closed = S.c_prims = S.c_succ = S.c_succ_finite = S.c_reads = 0;
       S.c_push = S.c_reopen = S.c_refill = S.c_evict = 0;
       S.c_hash = 0;
@@ -806,6 +912,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         }
         S.n_nodes = 1;
         S.f_base = 0.0 + P.eps * h;
+        S.lo1 = S.f_base;
         S.n_log = 1;
         S.c_push = 1;
       }
@@ -815,10 +922,15 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
       // ---- main loop
       for (;;) {
         while (S.n_near > (uint32_t)(NC - BLOCK)) {
+          MPLX_TIC(te);
           evict_half(Q, tid);
           __syncthreads();
+          MPLX_TOC(S, 3, te);
         }
-        if (!pop_min(Q, tid)) {
+        MPLX_TIC(tp);
+        const bool popped = pop_min(Q, tid);
+        MPLX_TOC(S, 0, tp);
+        if (!popped) {
           if (tid == 0) S.status = 1;  // OPEN empty
           __syncthreads();
           break;
@@ -832,7 +944,10 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
           S.flag = 0;
         }
         LaneSucc L;
+        MPLX_TIC(tx);
         expand_phases<BLOCK, CONTROL>(P, S, tid, L);
+        MPLX_TOC(S, 1, tx);
+        MPLX_TIC(tc);
         const bool act = L.valid && !L.blocked;
         {  // counters
           uint32_t tot;
@@ -870,6 +985,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
           for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel(Q, tid, q, act && tid == i, L, h64);
         }
         __syncthreads();
+        MPLX_TOC(S, 2, tc);
         if (S.status >= 0) break;  // pool full
         // ---- termination tests, in the order of the reference loop: goal, max_expand (empty OPEN: next pop)
         if (tid == 0) {
@@ -942,6 +1058,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
       o.slot = blockIdx.x;
       o.t_begin = t_begin;
       o.t_end = wall_clock64();
+      for (int i = 0; i < 8; i++) o.cyc[i] = S.cyc[i];
     }
     for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)
       P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? S.node_tbl[i] : NIL;

@@ -93,6 +93,134 @@ MPLX_HD int roots_upto_quad(double c2, double c1, double c0, double *r) {
   return 0;
 }
 
+// ---- control-specialised evaluators.
+// A primitive built from (state, control input) has structurally zero leading coefficients
+// (VEL c0..c3, ACC c0..c2, JRK c0..c1, SNP c0).  With t >= 0 finite every such term is +0.0, and
+// (+0.0 + x) equals x except that it turns -0.0 into +0.0; "x + 0.0" reproduces exactly that, so
+// these return bit-identical results to pos_at/vel_at/acc_at/jrk_at without the dead multiplies
+// and divisions (checked bit-for-bit by tests/cpp/test_math_host.cpp).
+template <int CONTROL>
+MPLX_HD double pos_at_c(const double *c, double t) {
+  if constexpr (CONTROL == CTRL_VEL) {
+    return (c[4] * t + 0.0) + c[5];
+  } else if constexpr (CONTROL == CTRL_ACC) {
+    return ((c[3] / 2 * t * t + 0.0) + c[4] * t) + c[5];
+  } else if constexpr (CONTROL == CTRL_JRK) {
+    double t2 = t * t, t3 = t2 * t;
+    return (((c[2] / 6 * t3 + 0.0) + c[3] / 2 * t * t) + c[4] * t) + c[5];
+  } else {
+    double t2 = t * t, t3 = t2 * t, t4 = t3 * t;
+    return ((((c[1] / 24 * t4 + 0.0) + c[2] / 6 * t3) + c[3] / 2 * t * t) + c[4] * t) + c[5];
+  }
+}
+template <int CONTROL>
+MPLX_HD double vel_at_c(const double *c, double t) {
+  if constexpr (CONTROL == CTRL_VEL) {
+    return c[4] + 0.0;
+  } else if constexpr (CONTROL == CTRL_ACC) {
+    return (c[3] * t + 0.0) + c[4];
+  } else if constexpr (CONTROL == CTRL_JRK) {
+    return ((c[2] / 2 * t * t + 0.0) + c[3] * t) + c[4];
+  } else {
+    double t2 = t * t, t3 = t2 * t;
+    return (((c[1] / 6 * t3 + 0.0) + c[2] / 2 * t * t) + c[3] * t) + c[4];
+  }
+}
+template <int CONTROL>
+MPLX_HD double acc_at_c(const double *c, double t) {
+  if constexpr (CONTROL == CTRL_VEL) {
+    return 0.0;
+  } else if constexpr (CONTROL == CTRL_ACC) {
+    return c[3] + 0.0;
+  } else if constexpr (CONTROL == CTRL_JRK) {
+    return (c[2] * t + 0.0) + c[3];
+  } else {
+    return ((c[1] / 2 * t * t + 0.0) + c[2] * t) + c[3];
+  }
+}
+template <int CONTROL>
+MPLX_HD double jrk_at_c(const double *c, double t) {
+  if constexpr (CONTROL == CTRL_VEL || CONTROL == CTRL_ACC) {
+    return 0.0;
+  } else if constexpr (CONTROL == CTRL_JRK) {
+    return c[2] + 0.0;
+  } else {
+    return (c[1] * t + 0.0) + c[2];
+  }
+}
+// number of non-zero pre-divided coefficients per axis and their packing q' = {c_first/.., ..., c4, c5}
+constexpr int nq_c(int control) { return control == CTRL_VEL ? 2 : control == CTRL_ACC ? 3 : control == CTRL_JRK ? 4 : 5; }
+// pack the pre-divided non-zero coefficients of one axis (same divisions as pos_at)
+template <int CONTROL>
+MPLX_HD void pack_q_c(const double *c, double *q) {
+  if constexpr (CONTROL == CTRL_VEL) {
+    q[0] = c[4]; q[1] = c[5];
+  } else if constexpr (CONTROL == CTRL_ACC) {
+    q[0] = c[3] / 2; q[1] = c[4]; q[2] = c[5];
+  } else if constexpr (CONTROL == CTRL_JRK) {
+    q[0] = c[2] / 6; q[1] = c[3] / 2; q[2] = c[4]; q[3] = c[5];
+  } else {
+    q[0] = c[1] / 24; q[1] = c[2] / 6; q[2] = c[3] / 2; q[3] = c[4]; q[4] = c[5];
+  }
+}
+template <int CONTROL>
+MPLX_HD double pos_at_qc(const double *q, double t) {
+  if constexpr (CONTROL == CTRL_VEL) {
+    return (q[0] * t + 0.0) + q[1];
+  } else if constexpr (CONTROL == CTRL_ACC) {
+    return ((q[0] * t * t + 0.0) + q[1] * t) + q[2];
+  } else if constexpr (CONTROL == CTRL_JRK) {
+    double t2 = t * t, t3 = t2 * t;
+    return (((q[0] * t3 + 0.0) + q[1] * t * t) + q[2] * t) + q[3];
+  } else {
+    double t2 = t * t, t3 = t2 * t, t4 = t3 * t;
+    return ((((q[0] * t4 + 0.0) + q[1] * t3) + q[2] * t * t) + q[3] * t) + q[4];
+  }
+}
+
+// max |d^k p| on [0,T] with the control-specialised evaluators (same scan as max_abs_deriv)
+template <int K, int CONTROL>
+MPLX_HD double max_abs_deriv_c(const double *c, double T) {
+  double r[2];
+  int n;
+  if (K == 1)
+    n = roots_upto_quad(c[1] / 2, c[2], c[3], r);
+  else if (K == 2)
+    n = roots_upto_quad(c[0] / 2, c[1], c[2], r);
+  else
+    n = roots_upto_quad(0.0, c[0], c[1], r);
+  auto f = [&](double t) { return K == 1 ? vel_at_c<CONTROL>(c, t) : K == 2 ? acc_at_c<CONTROL>(c, t) : jrk_at_c<CONTROL>(c, t); };
+  double mx = fmax(fabs(f(0.0)), fabs(f(T)));
+  for (int i = 0; i < n; i++) {
+    if (r[i] > 0 && r[i] < T) {
+      double v = fabs(f(r[i]));
+      mx = v > mx ? v : mx;
+    } else if (r[i] >= T)
+      break;
+  }
+  return mx;
+}
+template <int CONTROL>
+MPLX_HD bool validate_and_maxv_c(const double c[3][6], double T, double mv, double ma, double mj, double *max_v_out) {
+  double vx = max_abs_deriv_c<1, CONTROL>(c[0], T), vy = max_abs_deriv_c<1, CONTROL>(c[1], T), vz = max_abs_deriv_c<1, CONTROL>(c[2], T);
+  double max_v = 0;
+  if (vx > max_v) max_v = vx;
+  if (vy > max_v) max_v = vy;
+  if (vz > max_v) max_v = vz;
+  *max_v_out = max_v;
+  constexpr bool chk_v = CONTROL == CTRL_ACC || CONTROL == CTRL_JRK || CONTROL == CTRL_SNP;
+  constexpr bool chk_a = CONTROL == CTRL_JRK || CONTROL == CTRL_SNP;
+  constexpr bool chk_j = CONTROL == CTRL_SNP;
+  if (chk_v && mv > 0 && (vx > mv || vy > mv || vz > mv)) return false;
+  if (chk_a && ma > 0)
+    for (int i = 0; i < 3; i++)
+      if (max_abs_deriv_c<2, CONTROL>(c[i], T) > ma) return false;
+  if (chk_j && mj > 0)
+    for (int i = 0; i < 3; i++)
+      if (max_abs_deriv_c<3, CONTROL>(c[i], T) > mj) return false;
+  return true;
+}
+
 // max |d^k p| on [0,T] for k = 1 (vel), 2 (acc), 3 (jrk): end points plus the interior
 // stationary points, scanning the roots in formula order and stopping at the first root >= T.
 // Control-built primitives have c0 == 0, so the stationary-point polynomial is at most quadratic.

@@ -362,6 +362,12 @@ class VoxelMapPlanner:
         ctx.check(ctx.lib.mplx_result_timing(ctx.h, q, C.byref(b), C.byref(e), C.byref(s)))
         return b.value, e.value, s.value
 
+    def queryCycles(self, q=0):
+        ctx = self._ctx()
+        cyc = (C.c_uint64 * 8)()
+        ctx.check(ctx.lib.mplx_result_cycles(ctx.h, q, cyc))
+        return dict(zip(("pop", "expand", "commit", "evict", "refill", "activate"), [int(x) for x in cyc[:6]]))
+
     # ---- results
     def getTrajCost(self):
         return self.traj_cost_

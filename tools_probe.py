@@ -14,7 +14,36 @@ if which == 'single':
     for it in range(2):
         ok = pl.plan(util.gpu_wp(start), util.gpu_wp(goal)); r = pl.getResult()
         print('C2 ACC', ok, r.cost, r.n_expanded, 'kernel ms', pl.lastKernelMs(), 'us/exp', 1e3 * pl.lastKernelMs() / r.n_expanded, 'refill', r.n_refill, 'evict', r.n_evict)
+        print('   cycles/exp', {k: round(v / r.n_expanded) for k, v in pl.queryCycles().items()})
     U5 = mapgen.control_lattice(1.0, 2, True)
     mu, pl = util.make_gpu(grid, origin, res, U5, v_max=2.0, a_max=1.0, j_max=1.0, max_expand=20000, max_nodes=1 << 21, max_edges=1 << 23, max_log=1 << 22)
     ok = pl.plan(util.gpu_wp(start, control=orc.JRK), util.gpu_wp(goal, control=orc.JRK)); r = pl.getResult()
     print('C2 JRK cap20000', r.status, r.n_expanded, 'kernel ms', pl.lastKernelMs(), 'us/exp', 1e3 * pl.lastKernelMs() / r.n_expanded, 'refill', r.n_refill, 'evict', r.n_evict)
+    print('   cycles/exp', {k: round(v / r.n_expanded) for k, v in pl.queryCycles().items()})
+if which == 'batch':
+    nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    slots = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    grid, origin, res, start, goal, rng = mapgen.benchmark_map(512)
+    U = mapgen.control_lattice(1.0, 1, True)
+    qrng = mapgen.SplitMix64(20250620 + 7919)
+    queries = mapgen.random_queries(grid, origin, res, nq, qrng, min_dist=10.0)
+    per_q = 450_000
+    mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, n_slots=slots, max_nodes=per_q * nq, max_edges=per_q * nq * 9 // 2, max_log=per_q * nq * 5 // 4)
+    starts = [util.gpu_wp(s) for s, g in queries]; goals = [util.gpu_wp(g) for s, g in queries]
+    t = time.time(); R = pl.planBatch(starts, goals); wall = time.time() - t
+    ne = np.array([r.n_expanded for r in R], dtype=np.float64)
+    st = np.bincount([r.status for r in R], minlength=5)
+    T = np.array([pl.queryTiming(q) for q in range(nq)])
+    dur = T[:, 1] - T[:, 0]
+    print('wall', wall, 'kernel ms', pl.lastKernelMs(), 'status', st, 'expansions', ne.sum(), 'exp/s', ne.sum() / (pl.lastKernelMs() * 1e-3))
+    print('makespan', T[:, 1].max(), 'sum dur', dur.sum(), 'utilisation', dur.sum() / (min(slots, nq) * T[:, 1].max()))
+    us = 1e6 * dur / np.maximum(ne, 1)
+    print('us/exp percentiles 5/50/95', np.percentile(us, [5, 50, 95]), 'weighted mean', 1e6 * dur.sum() / ne.sum())
+    idx = np.argsort(-dur)[:8]
+    for i in idx:
+        print('  long query', i, 'exp', int(ne[i]), 'dur', round(dur[i], 3), 'begin', round(T[i, 0], 3), 'us/exp', round(us[i], 2), 'refill', R[i].n_refill, 'evict', R[i].n_evict,
+              {k: round(v / ne[i]) for k, v in pl.queryCycles(int(i)).items()})
+    # concurrency over time
+    for frac in (0.1, 0.25, 0.5, 0.75, 0.9):
+        tt = frac * T[:, 1].max()
+        print('  t=%.2f running %d' % (tt, int(((T[:, 0] <= tt) & (T[:, 1] > tt)).sum())))
