@@ -206,6 +206,15 @@ def main():
                          "kernel": "astar_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
                          "bytes_per_expansion": alg / max(n_exp, 1)},
         }
+        # HBM traffic of the same launch from the committed rocprofv3 PMC passes (cannot be collected
+        # inside this process); only attached when the profile is of this workload
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if args.lattice == "acc" and args.queries == 1024 and n == 512 and world == 1:
+                out["roofline"]["traffic"] = (tr["FETCH_SIZE_KB"] + tr["WRITE_SIZE_KB"]) * 1024.0
+                out["roofline"]["traffic_source"] = tr["profile"]
+        except Exception:
+            pass
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(grid, origin, res, control, U, max_expand, queries, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -4,7 +4,7 @@
 //   node pool  : records of rec_bytes(control) bytes, 8192 per chunk.  Record = hot part
 //                {g f64, h f64, flags u32, pred u32, key int32[nk]} in the first 64/80 B, then the
 //                first-arrival state (ns doubles) and t.  One 64 B load answers "same key? g? h?".
-//   edge pool  : predecessor records {parent u32, next u32, action u32}, 32768 per chunk.
+//   edge pool  : predecessor records {parent u32, next u32, action u32}, 65536 per chunk.
 //   open pool  : OPEN-log records {f f64, g f64, id u32, next u32}, 16384 per chunk.
 //   hash table : 64-bit slots {tag16 | query16 | node id32}, open addressing, shared by all queries
 //                of the batch (the query index is part of the slot), cleared once per batch.
@@ -25,8 +25,8 @@ constexpr uint32_t CLAIM_BASE = 0xFFFF0000u;  // table id field >= CLAIM_BASE: c
 constexpr uint32_t FLAG_CLOSED = 1u, FLAG_OPENED = 2u;
 constexpr int MAX_TRAJ = 1024;
 
-constexpr int NODE_CH_LOG = 13, EDGE_CH_LOG = 15, OPEN_CH_LOG = 14;
-constexpr int MAX_NODE_CH = 512, MAX_EDGE_CH = 512, MAX_OPEN_CH = 512;  // per query: 4M nodes, 16M edges, 8M log
+constexpr int NODE_CH_LOG = 13, EDGE_CH_LOG = 16, OPEN_CH_LOG = 14;
+constexpr int MAX_NODE_CH = 512, MAX_EDGE_CH = 512, MAX_OPEN_CH = 512;  // per query: 4M nodes, 33M edges, 8M log
 constexpr int EDGE_BYTES = 12, OPEN_BYTES = 24;
 
 constexpr int rec_hot_bytes(int control) { return control == CTRL_SNP ? 80 : 64; }
