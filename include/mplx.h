@@ -31,7 +31,8 @@ extern "C" {
 #define MPLX_PLAN_NO_PATH 1         /* OPEN ran empty */
 #define MPLX_PLAN_START_OCCUPIED 2  /* ENV_->is_free(start.pos) failed */
 #define MPLX_PLAN_MAX_EXPAND 3      /* max_expand reached */
-#define MPLX_PLAN_POOL_FULL 4       /* per-query device pool exhausted (raise mplx_set_capacity) */
+#define MPLX_PLAN_POOL_FULL 4       /* a shared device pool is exhausted (raise mplx_set_capacity) */
+#define MPLX_PLAN_INTERNAL 5        /* 64-bit key-hash collision inside one speculative batch (never observed) */
 
 /* Control kinds = union of use_pos|use_vel|use_acc|use_jrk bits of a Waypoint
  * (mpl_test_node/src/map_planner_node.cpp:155-171 sets the bits; Control::VEL..SNP). */
@@ -128,6 +129,9 @@ int mplx_planner_config(mplx_ctx *ctx, const mplx_config *cfg);
 /* device pools: number of queries in flight (workgroups) and the TOTAL capacities shared by all
  * queries of one batch -- states, predecessor records, OPEN-log entries (0 = keep current) */
 int mplx_set_capacity(mplx_ctx *ctx, int32_t n_slots, uint64_t total_nodes, uint64_t total_edges, uint64_t total_open_log);
+/* speculative multi-node expansion (results are identical either way): -1 auto (on when
+ * n_u <= 128), 0 = sequential kernel (one node per iteration), 2 = on */
+int mplx_set_speculation(mplx_ctx *ctx, int32_t mode);
 /* f-width of one coarse OPEN bucket (0 = default w*dt/2); the fine level divides it by 1024 */
 int mplx_set_bucket_width(mplx_ctx *ctx, double width);
 

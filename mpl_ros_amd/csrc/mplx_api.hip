@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "mplx_kernels.h"
+#include "mplx_spec.h"
 
 using namespace mplx;
 
@@ -40,6 +41,7 @@ struct mplx_ctx {
   std::vector<double> U;
   double *dU = nullptr, *dUcost = nullptr;
   double bucket_width = 0;
+  int speculation = -1;  // -1 auto, 0/1 off, else on
   // capacities (shared by all queries of a batch)
   int32_t n_slots = 1;
   uint64_t cap_nodes = 1u << 20, cap_edges = 1u << 22, cap_log = 1u << 21;
@@ -281,6 +283,11 @@ extern "C" int mplx_set_bucket_width(mplx_ctx *c, double w) {
   c->bucket_width = w;
   return MPLX_OK;
 }
+extern "C" int mplx_set_speculation(mplx_ctx *c, int32_t mode) {
+  if (!c) return MPLX_ERR_ARG;
+  c->speculation = mode;
+  return MPLX_OK;
+}
 extern "C" int mplx_set_record(mplx_ctx *c, uint32_t cap) {
   if (!c) return MPLX_ERR_ARG;
   c->cap_rec = cap;
@@ -402,6 +409,16 @@ static void launch_expand(int control, int grid, hipStream_t s, const SearchPara
     case CTRL_ACC: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_ACC>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o); break;
     case CTRL_JRK: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_JRK>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o); break;
     default: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_SNP>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o); break;
+  }
+}
+
+template <int UL, int K>
+static void launch_spec(int control, int grid, hipStream_t s, const SearchParams &P) {
+  switch (control) {
+    case CTRL_VEL: hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_VEL>), dim3(grid), dim3(UL * K), 0, s, P); break;
+    case CTRL_ACC: hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_ACC>), dim3(grid), dim3(UL * K), 0, s, P); break;
+    case CTRL_JRK: hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_JRK>), dim3(grid), dim3(UL * K), 0, s, P); break;
+    default: hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_SNP>), dim3(grid), dim3(UL * K), 0, s, P); break;
   }
 }
 
@@ -552,10 +569,17 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   HIPCHK(c, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), c->stream));
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-  switch (pick_block(P.n_u)) {
-    case 64: launch_astar<64>(P.control, slots, c->stream, P); break;
-    case 128: launch_astar<128>(P.control, slots, c->stream, P); break;
-    default: launch_astar<256>(P.control, slots, c->stream, P); break;
+  const bool spec = c->speculation < 0 ? P.n_u <= 128 : c->speculation > 1;
+  if (spec && P.n_u <= 64) {
+    launch_spec<64, 4>(P.control, slots, c->stream, P);   // 4 expansion units of one wave each
+  } else if (spec && P.n_u <= 128) {
+    launch_spec<128, 2>(P.control, slots, c->stream, P);  // 2 expansion units of two waves each
+  } else {
+    switch (pick_block(P.n_u)) {
+      case 64: launch_astar<64>(P.control, slots, c->stream, P); break;
+      case 128: launch_astar<128>(P.control, slots, c->stream, P); break;
+      default: launch_astar<256>(P.control, slots, c->stream, P); break;
+    }
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));

@@ -41,7 +41,7 @@ struct EdgeRec {  // predecessor record (EDGE_BYTES)
 };
 static_assert(sizeof(OpenRec) == OPEN_BYTES && sizeof(EdgeRec) == EDGE_BYTES, "record sizes");
 
-template <int BLOCK>
+template <int BLOCK, int NQROWS = 15, int KUNITS = 1>
 struct Smem {
   // OPEN near set
   double near_f[NC], near_g[NC];
@@ -50,15 +50,15 @@ struct Smem {
   // chunk tables of the running query
   uint32_t node_tbl[MAX_NODE_CH], edge_tbl[MAX_EDGE_CH], open_tbl[MAX_OPEN_CH];
   // expansion scratch
-  double q[15][BLOCK];  // pre-divided non-zero polynomial coefficients per primitive (3 axes x nq_c)
+  double q[NQROWS][BLOCK];  // pre-divided non-zero polynomial coefficients per primitive (3 axes x nq_c)
   double dts[BLOCK];
-  uint8_t owner[OWN];   // primitive that owns flattened sample e
+  uint8_t owner[KUNITS][OWN / KUNITS];  // per expansion unit: primitive that owns flattened sample e
   uint32_t cnt_s[BLOCK];  // samples per primitive (n+1), 0 if skipped
-  uint32_t offs[BLOCK + 1];
+  uint32_t offs[KUNITS][BLOCK / KUNITS + 1];
   uint32_t blk[BLOCK];  // first blocked sample: (i << 1) | inside
   unsigned long long dupset[2 * BLOCK];
-  double cur[13];       // state of the node being expanded (p,v,a,j,t)
-  int32_t cur_key[MAX_KEY];
+  double cur[KUNITS][13];       // state of the node(s) being expanded (p,v,a,j,t)
+  int32_t cur_key[KUNITS][MAX_KEY];
   HeurParams hp;
   // scan / reduce scratch
   uint32_t wsum[BLOCK / 64 + 1];
@@ -85,8 +85,8 @@ struct Smem {
 #define MPLX_TIC(var) const unsigned long long var = __builtin_readcyclecounter()
 #define MPLX_TOC(S, k, var) do { if (threadIdx.x == 0) (S).cyc[k] += __builtin_readcyclecounter() - (var); } while (0)
 
-template <int BLOCK>
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, Smem<BLOCK> &S, int tid, uint32_t &total) {
+template <int BLOCK, class SM>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, SM &S, int tid, uint32_t &total) {
   const int lane = tid & 63, wave = tid >> 6;
   uint32_t x = v;
 #pragma unroll
@@ -113,8 +113,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, Smem<BLOCK> &S, 
   }
 }
 
-template <int BLOCK>
-__device__ __forceinline__ bool block_any(bool p, Smem<BLOCK> &S, int tid) {
+template <int BLOCK, class SM>
+__device__ __forceinline__ bool block_any(bool p, SM &S, int tid) {
   unsigned long long b = __ballot(p);
   if constexpr (BLOCK == 64) {
     return b != 0ull;
@@ -126,6 +126,42 @@ __device__ __forceinline__ bool block_any(bool p, Smem<BLOCK> &S, int tid) {
     for (int w = 0; w < BLOCK / 64; w++) r = r || (S.wsum[w] != 0);
     __syncthreads();
     return r;
+  }
+}
+
+// exclusive scan inside an expansion unit of UL lanes (a unit is UL/64 consecutive waves); every
+// thread of the workgroup must call it (one workgroup barrier when a unit spans several waves)
+template <int UL, int BLOCK, class SM>
+__device__ __forceinline__ uint32_t unit_excl_scan(uint32_t v, SM &S, int tid, uint32_t &total) {
+  if constexpr (UL == BLOCK) {
+    return block_excl_scan<BLOCK>(v, S, tid, total);
+  } else {
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if constexpr (UL == 64) {
+      total = __shfl(x, 63, 64);
+      return x - v;
+    } else {
+      if (lane == 63) S.wsum[wave] = x;
+      __syncthreads();
+      constexpr int WPU = UL / 64;
+      const int w0 = (wave / WPU) * WPU;
+      uint32_t base = 0, tot = 0;
+#pragma unroll
+      for (int w = 0; w < WPU; w++) {
+        uint32_t t = S.wsum[w0 + w];
+        if (w0 + w < wave) base += t;
+        tot += t;
+      }
+      total = tot;
+      __syncthreads();
+      return base + x - v;
+    }
   }
 }
 
@@ -145,19 +181,23 @@ struct LaneSucc {
   uint32_t reads;
 };
 
-template <int BLOCK, int CONTROL>
-__device__ __forceinline__ void expand_phases(const SearchParams &P, Smem<BLOCK> &S, int tid, LaneSucc &L) {
+// One expansion unit = UL consecutive threads expanding one node (unit index ku, lane index lu inside
+// the unit); the workgroup holds BLOCK / UL units.  `live` false: the unit idles (it still takes part
+// in the workgroup barriers).
+template <int UL, int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int tid, bool live_unit, LaneSucc &L) {
   constexpr int NQ = nq_c(CONTROL);
+  const int ku = tid / UL, lu = tid % UL;
   const double T = P.dt;
   L.valid = false;
   L.blocked = false;
   L.reads = 0;
   uint32_t my_cnt = 0;
-  if (tid < P.n_u) {
+  if (live_unit && lu < P.n_u) {
     double c[3][6];
-    const double *u = P.U + 3 * tid;
+    const double *u = P.U + 3 * lu;
 #pragma unroll
-    for (int ax = 0; ax < 3; ax++) prim_build_axis(CONTROL, S.cur[ax], S.cur[3 + ax], S.cur[6 + ax], S.cur[9 + ax], u[ax], c[ax]);
+    for (int ax = 0; ax < 3; ax++) prim_build_axis(CONTROL, S.cur[ku][ax], S.cur[ku][3 + ax], S.cur[ku][6 + ax], S.cur[ku][9 + ax], u[ax], c[ax]);
 #pragma unroll
     for (int ax = 0; ax < 3; ax++) {
       L.tn.p[ax] = pos_at_c<CONTROL>(c[ax], T);
@@ -168,7 +208,7 @@ __device__ __forceinline__ void expand_phases(const SearchParams &P, Smem<BLOCK>
     state_key_c<CONTROL>(L.tn, L.key);
     bool same = true;
 #pragma unroll
-    for (int i = 0; i < key_len_c(CONTROL); i++) same = same && (L.key[i] == S.cur_key[i]);
+    for (int i = 0; i < key_len_c(CONTROL); i++) same = same && (L.key[i] == S.cur_key[ku][i]);
     double max_v;
 #ifdef MPLX_GENERIC_VALIDATE
     bool ok = !same && validate_and_maxv(CONTROL, c, T, P.v_max, P.a_max, P.j_max, &max_v);
@@ -192,24 +232,25 @@ __device__ __forceinline__ void expand_phases(const SearchParams &P, Smem<BLOCK>
   S.cnt_s[tid] = my_cnt;
   S.blk[tid] = 0xFFFFFFFFu;
   uint32_t total;
-  uint32_t off = block_excl_scan<BLOCK>(my_cnt, S, tid, total);
-  S.offs[tid] = off;
-  if (tid == BLOCK - 1) S.offs[BLOCK] = total;
-  // owner map: flattened sample e -> primitive
-  for (uint32_t i = 0; i < my_cnt && off + i < (uint32_t)OWN; i++) S.owner[off + i] = (uint8_t)tid;
+  uint32_t off = unit_excl_scan<UL, BLOCK>(my_cnt, S, tid, total);
+  S.offs[ku][lu] = off;
+  if (lu == UL - 1) S.offs[ku][UL] = total;
+  // owner map: flattened sample e -> primitive (index inside the unit)
+  constexpr uint32_t OWNU = sizeof(S.owner[0]);
+  for (uint32_t i = 0; i < my_cnt && off + i < OWNU; i++) S.owner[ku][off + i] = (uint8_t)lu;
   __syncthreads();
   // phase 2: flattened (primitive, sample) pairs, UNR voxel loads in flight per lane
   const int8_t *__restrict__ map = P.map.data;
   const int dx = P.map.dim[0], dy = P.map.dim[1], dz = P.map.dim[2];
   constexpr int UNR = 6;
-  for (uint32_t e0 = tid; e0 < total; e0 += BLOCK * UNR) {
+  for (uint32_t e0 = lu; e0 < total; e0 += UL * UNR) {
     int pp[UNR];
     uint32_t ii[UNR];
     int8_t vv[UNR];
     bool inside[UNR], live[UNR];
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
-      const uint32_t e = e0 + r * BLOCK;
+      const uint32_t e = e0 + r * UL;
       live[r] = e < total;
       inside[r] = false;
       vv[r] = 0;
@@ -217,27 +258,28 @@ __device__ __forceinline__ void expand_phases(const SearchParams &P, Smem<BLOCK>
       ii[r] = 0;
       if (live[r]) {
         int p;
-        if (e < (uint32_t)OWN) {
-          p = S.owner[e];
+        if (e < OWNU) {
+          p = S.owner[ku][e];
         } else {
-          int lo = 0, hi = BLOCK;  // largest p with offs[p] <= e
+          int lo = 0, hi = UL;  // largest p with offs[p] <= e
           while (hi - lo > 1) {
             int mid = (lo + hi) >> 1;
-            if (S.offs[mid] <= e) lo = mid; else hi = mid;
+            if (S.offs[ku][mid] <= e) lo = mid; else hi = mid;
           }
           p = lo;
         }
-        const uint32_t i = e - S.offs[p];
-        const double t = (double)i * S.dts[p];
+        const uint32_t i = e - S.offs[ku][p];
+        const int pc = ku * UL + p;  // column of primitive p
+        const double t = (double)i * S.dts[pc];
         int32_t cell[3];
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) {
           double qq[NQ];
 #pragma unroll
-          for (int k = 0; k < NQ; k++) qq[k] = S.q[ax * NQ + k][p];
+          for (int k = 0; k < NQ; k++) qq[k] = S.q[ax * NQ + k][pc];
           cell[ax] = float_to_cell(pos_at_qc<CONTROL>(qq, t), P.map.origin[ax], P.map.res);
         }
-        pp[r] = p;
+        pp[r] = pc;
         ii[r] = i;
         inside[r] = !(cell[0] < 0 || cell[0] >= dx || cell[1] < 0 || cell[1] >= dy || cell[2] < 0 || cell[2] >= dz);
         if (inside[r]) vv[r] = map[(size_t)cell[0] + (size_t)dx * cell[1] + (size_t)dx * dy * cell[2]];
@@ -264,20 +306,20 @@ __device__ __forceinline__ void expand_phases(const SearchParams &P, Smem<BLOCK>
 // ------------------------------------------------------------------ expand_kernel (unit-test entry)
 template <int BLOCK, int CONTROL>
 __global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const State *nodes, const double *node_t, int K, SuccOut *out) {
-  __shared__ Smem<BLOCK> S;
+  __shared__ Smem<BLOCK, 3 * nq_c(CONTROL)> S;
   const int tid = threadIdx.x;
   for (int k = blockIdx.x; k < K; k += gridDim.x) {
-    if (tid < 12) S.cur[tid] = ((const double *)&nodes[k])[tid];
-    if (tid == 12) S.cur[12] = node_t[k];
+    if (tid < 12) S.cur[0][tid] = ((const double *)&nodes[k])[tid];
+    if (tid == 12) S.cur[0][12] = node_t[k];
     __syncthreads();
     if (tid == 0) {
       State s;
-      for (int i = 0; i < 12; i++) ((double *)&s)[i] = S.cur[i];
-      state_key_c<CONTROL>(s, S.cur_key);
+      for (int i = 0; i < 12; i++) ((double *)&s)[i] = S.cur[0][i];
+      state_key_c<CONTROL>(s, S.cur_key[0]);
     }
     __syncthreads();
     LaneSucc L;
-    expand_phases<BLOCK, CONTROL>(P, S, tid, L);
+    expand_unit<BLOCK, BLOCK, CONTROL>(P, S, tid, true, L);
     if (tid < P.n_u) {
       SuccOut &o = out[(size_t)k * P.n_u + tid];
       for (int ax = 0; ax < 3; ax++) {
@@ -287,7 +329,7 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const Sta
         o.jrk[ax] = L.tn.j[ax];
       }
       o.yaw = 0;
-      o.t = S.cur[12] + P.dt;
+      o.t = S.cur[0][12] + P.dt;
       o.control = P.control;
       o.enable_t = 0;
       o.cost = L.valid ? (L.blocked ? INFINITY : P.ucost[tid]) : 0.0;
@@ -303,10 +345,10 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const Sta
 }
 
 // ------------------------------------------------------------------ chunked pool access
-template <int BLOCK, int CONTROL>
+template <int BLOCK, int CONTROL, class SM = Smem<BLOCK, 3 * nq_c(CONTROL)>>
 struct QView {
   const SearchParams &P;
-  Smem<BLOCK> &S;
+  SM &S;
   uint32_t *bkt_head;
   __device__ __forceinline__ char *node(uint32_t i) const {
     return P.node_pool + (((size_t)S.node_tbl[i >> NODE_CH_LOG] << NODE_CH_LOG) + (i & ((1u << NODE_CH_LOG) - 1))) * rec_bytes(CONTROL);
@@ -339,8 +381,8 @@ __device__ __forceinline__ bool ensure_chunks(uint32_t *tbl, uint32_t &owned, ui
 }
 
 // where does entry (f,g,id) belong?  -1: near set; [0,NB): fine bucket; [NB,2NB): coarse bucket
-template <int BLOCK>
-__device__ __forceinline__ int classify(const Smem<BLOCK> &S, double w1, double f, double g, uint32_t id) {
+template <class SM>
+__device__ __forceinline__ int classify(const SM &S, double w1, double f, double g, uint32_t id) {
   const int b1 = bucket_idx(f, S.f_base, w1);
   if (b1 != S.cur1) return b1 < S.cur1 ? -1 : NB + b1;
   const int b0 = bucket_idx(f, S.lo1, w1 * (1.0 / NB));
@@ -349,8 +391,8 @@ __device__ __forceinline__ int classify(const Smem<BLOCK> &S, double w1, double 
 }
 
 // link log entry idx into far bucket `code` (fine or coarse)
-template <int BLOCK, int CONTROL>
-__device__ __forceinline__ void far_link(const QView<BLOCK, CONTROL> &Q, int code, uint32_t idx) {
+template <int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ void far_link(const QView<BLOCK, CONTROL, SM> &Q, int code, uint32_t idx) {
   atomicAdd(&Q.S.cnt[0][code], 1u);  // cnt is [2][NB]: code indexes it flat
   uint32_t old = atomicExch(&Q.bkt_head[(size_t)code * NSUB + (idx & (NSUB - 1))], idx);
   Q.open(idx)->next = old;
@@ -358,9 +400,9 @@ __device__ __forceinline__ void far_link(const QView<BLOCK, CONTROL> &Q, int cod
 
 // rare: the near/far boundary must drop below the active coarse bucket -> hand every fine bucket
 // back to the coarse level so that the fine level can be re-bound to a lower coarse bucket
-template <int BLOCK, int CONTROL>
-__device__ __forceinline__ void demote_fine(const QView<BLOCK, CONTROL> &Q, int tid) {
-  Smem<BLOCK> &S = Q.S;
+template <int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ void demote_fine(const QView<BLOCK, CONTROL, SM> &Q, int tid) {
+  SM &S = Q.S;
   const int c1 = NB + S.cur1;
   for (int b = 0; b < NB; b++) {
     if (S.cnt[0][b] == 0) continue;  // uniform
@@ -383,9 +425,9 @@ __device__ __forceinline__ void demote_fine(const QView<BLOCK, CONTROL> &Q, int 
 // ------------------------------------------------------------------ near-set eviction (split)
 // Moves roughly the upper half of the near set (under the total order) back to the far buckets and
 // lowers the near/far boundary accordingly.  Any split point keeps the structure exact.
-template <int BLOCK, int CONTROL>
-__device__ __forceinline__ void evict_half(const QView<BLOCK, CONTROL> &Q, int tid) {
-  Smem<BLOCK> &S = Q.S;
+template <int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ void evict_half(const QView<BLOCK, CONTROL, SM> &Q, int tid) {
+  SM &S = Q.S;
   const double w1 = Q.P.bucket_width;
   const uint32_t n = S.n_near;
   if (n < 2) return;
@@ -497,7 +539,7 @@ __device__ __forceinline__ void evict_half(const QView<BLOCK, CONTROL> &Q, int t
       uint32_t i = tid + r * BLOCK;
       if (i < n) {
         ef[r] = S.near_f[i]; eg[r] = S.near_g[i]; eid[r] = S.near_id[i]; eix[r] = S.near_idx[i];
-        const int code = classify<BLOCK>(S, w1, ef[r], eg[r], eid[r]);
+        const int code = classify(S, w1, ef[r], eg[r], eid[r]);
         if (code < 0) {
           keepmask |= 1u << r;
           nkeep++;
@@ -523,8 +565,8 @@ __device__ __forceinline__ void evict_half(const QView<BLOCK, CONTROL> &Q, int t
 }
 
 // lowest non-empty bucket of a level (NB if none)
-template <int BLOCK>
-__device__ __forceinline__ int lowest_bucket(Smem<BLOCK> &S, int level, int tid) {
+template <int BLOCK, class SM>
+__device__ __forceinline__ int lowest_bucket(SM &S, int level, int tid) {
   int b = NB;
   for (int i = tid; i < NB; i += BLOCK)
     if (S.cnt[level][i] > 0) { b = i; break; }
@@ -544,9 +586,9 @@ __device__ __forceinline__ int lowest_bucket(Smem<BLOCK> &S, int level, int tid)
 // pull every entry of far bucket `code`; entries that classify as near go to the near set, the
 // rest are re-linked where they belong.  `to_near` false: activation of a coarse bucket (nothing
 // is near because cur0 == -1).
-template <int BLOCK, int CONTROL>
-__device__ __forceinline__ void pull_bucket(const QView<BLOCK, CONTROL> &Q, int code, int tid) {
-  Smem<BLOCK> &S = Q.S;
+template <int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ void pull_bucket(const QView<BLOCK, CONTROL, SM> &Q, int code, int tid) {
+  SM &S = Q.S;
   const double w1 = Q.P.bucket_width;
   uint32_t cur = NIL;
   if (tid < NSUB) cur = atomicExch(&Q.bkt_head[(size_t)code * NSUB + tid], NIL);
@@ -562,7 +604,7 @@ __device__ __forceinline__ void pull_bucket(const QView<BLOCK, CONTROL> &Q, int 
     }
     if (cur != NIL) {
       const OpenRec r = *Q.open(cur);
-      const int c = classify<BLOCK>(S, w1, r.f, r.g, r.id);
+      const int c = classify(S, w1, r.f, r.g, r.id);
       if (c < 0) {
         uint32_t pos = atomicAdd(&S.n_near, 1u);
         S.near_f[pos] = r.f; S.near_g[pos] = r.g; S.near_id[pos] = r.id; S.near_idx[pos] = cur;
@@ -579,9 +621,9 @@ __device__ __forceinline__ void pull_bucket(const QView<BLOCK, CONTROL> &Q, int 
 }
 
 // near set empty: bring in the lowest far entries.  false when OPEN is empty.
-template <int BLOCK, int CONTROL>
-__device__ __forceinline__ bool refill(const QView<BLOCK, CONTROL> &Q, int tid) {
-  Smem<BLOCK> &S = Q.S;
+template <int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ bool refill(const QView<BLOCK, CONTROL, SM> &Q, int tid) {
+  SM &S = Q.S;
   for (int guard = 0; guard < 4 * NB; guard++) {
     const int b0 = lowest_bucket<BLOCK>(S, 0, tid);
     if (b0 < NB) {
@@ -619,15 +661,15 @@ __device__ __forceinline__ bool refill(const QView<BLOCK, CONTROL> &Q, int tid) 
 }
 
 // ------------------------------------------------------------------ push one OPEN entry (log append + near/far)
-template <int BLOCK, int CONTROL>
-__device__ __forceinline__ void open_push(const QView<BLOCK, CONTROL> &Q, uint32_t idx, double f, double g, uint32_t id) {
-  Smem<BLOCK> &S = Q.S;
+template <int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ void open_push(const QView<BLOCK, CONTROL, SM> &Q, uint32_t idx, double f, double g, uint32_t id) {
+  SM &S = Q.S;
   if (f != f) f = INFINITY;  // never let a NaN into the order
   OpenRec *r = Q.open(idx);
   r->f = f;
   r->g = g;
   r->id = id;
-  const int code = classify<BLOCK>(S, Q.P.bucket_width, f, g, id);
+  const int code = classify(S, Q.P.bucket_width, f, g, id);
   if (code < 0) {
     uint32_t pos = atomicAdd(&S.n_near, 1u);
     S.near_f[pos] = f; S.near_g[pos] = g; S.near_id[pos] = id; S.near_idx[pos] = idx;
@@ -640,11 +682,11 @@ __device__ __forceinline__ void open_push(const QView<BLOCK, CONTROL> &Q, uint32
 // `act`: this lane commits a finite-cost successor.  With all keys distinct the lanes commit in
 // parallel; node / edge / log ids come from prefix sums in lane order, so they equal the ids a
 // sequential loop over the control inputs would assign.
-template <int BLOCK, int CONTROL>
-__device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64) {
-  using V = QView<BLOCK, CONTROL>;
+template <int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64) {
+  using V = QView<BLOCK, CONTROL, SM>;
   const SearchParams &P = Q.P;
-  Smem<BLOCK> &S = Q.S;
+  SM &S = Q.S;
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   int role = 0;  // 1 found, 2 creator
   uint32_t id = NIL;
@@ -714,7 +756,7 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL> &Q, 
     double *st = V::state(rec);
 #pragma unroll
     for (int i = 0; i < ns; i++) st[i] = i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3];
-    st[ns] = S.cur[12] + P.dt;
+    st[ns] = S.cur[0][12] + P.dt;
 #ifdef MPLX_NO_HSPEC
     hspec = P.eps == 0.0 ? 0.0 : get_heur(S.hp, CONTROL, L.tn, L.key, nk);
 #endif
@@ -760,10 +802,10 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL> &Q, 
 
 // ------------------------------------------------------------------ pop the minimum valid OPEN entry
 // On success S.cur_id / S.cur_g / S.cur / S.cur_key describe the node to expand and it is closed.
-template <int BLOCK, int CONTROL>
-__device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL> &Q, int tid) {
-  using V = QView<BLOCK, CONTROL>;
-  Smem<BLOCK> &S = Q.S;
+template <int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL, SM> &Q, int tid) {
+  using V = QView<BLOCK, CONTROL, SM>;
+  SM &S = Q.S;
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   for (;;) {
     if (S.n_near == 0) {
@@ -817,9 +859,9 @@ __device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL> &Q, int tid)
     // stale?  (node improved since this entry was pushed, or already closed)
     const bool ok = __double_as_longlong(rg) == __double_as_longlong(bg) && !(fl & FLAG_CLOSED);
     if (ok) {
-      if (tid <= ns) S.cur[tid < ns ? tid : 12] = sval;
-      if (tid >= ns && tid < 12) S.cur[tid] = 0.0;
-      if (tid < nk) S.cur_key[tid] = kval;
+      if (tid <= ns) S.cur[0][tid < ns ? tid : 12] = sval;
+      if (tid >= ns && tid < 12) S.cur[0][tid] = 0.0;
+      if (tid < nk) S.cur_key[0][tid] = kval;
       if (tid == 0) {
         S.cur_id = bi;
         S.cur_g = bg;
@@ -834,7 +876,7 @@ __device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL> &Q, int tid)
 // ------------------------------------------------------------------ astar_kernel
 template <int BLOCK, int CONTROL>
 __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
-  __shared__ Smem<BLOCK> S;
+  __shared__ Smem<BLOCK, 3 * nq_c(CONTROL)> S;
   using V = QView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
@@ -945,7 +987,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         }
         LaneSucc L;
         MPLX_TIC(tx);
-        expand_phases<BLOCK, CONTROL>(P, S, tid, L);
+        expand_unit<BLOCK, BLOCK, CONTROL>(P, S, tid, true, L);
         MPLX_TOC(S, 1, tx);
         MPLX_TIC(tc);
         const bool act = L.valid && !L.blocked;
@@ -990,8 +1032,8 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         // ---- termination tests, in the order of the reference loop: goal, max_expand (empty OPEN: next pop)
         if (tid == 0) {
           State s;
-          for (int i = 0; i < 12; i++) ((double *)&s)[i] = S.cur[i];
-          if (S.cur[12] >= P.t_max || is_goal_state(s, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc))
+          for (int i = 0; i < 12; i++) ((double *)&s)[i] = S.cur[0][i];
+          if (S.cur[0][12] >= P.t_max || is_goal_state(s, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc))
             S.status = 0;
           else if (P.max_expand > 0 && S.c_expanded >= (unsigned long long)P.max_expand)
             S.status = 3;

@@ -286,6 +286,11 @@ class VoxelMapPlanner:
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_bucket_width(ctx.h, float(width)))
 
+    def setSpeculation(self, mode):
+        """-1 auto, 0 sequential kernel, 2 speculative multi-node expansion (same results)."""
+        ctx = self._ctx()
+        ctx.check(ctx.lib.mplx_set_speculation(ctx.h, int(mode)))
+
     def setRecord(self, cap):
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_record(ctx.h, int(cap)))
@@ -366,7 +371,7 @@ class VoxelMapPlanner:
         ctx = self._ctx()
         cyc = (C.c_uint64 * 8)()
         ctx.check(ctx.lib.mplx_result_cycles(ctx.h, q, cyc))
-        return dict(zip(("pop", "expand", "commit", "evict", "refill", "activate"), [int(x) for x in cyc[:6]]))
+        return dict(zip(("pop", "expand", "commit", "evict", "refill", "activate", "ordered", "batches"), [int(x) for x in cyc[:8]]))
 
     # ---- results
     def getTrajCost(self):

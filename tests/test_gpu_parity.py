@@ -81,13 +81,17 @@ def test_map_query_matches_float_to_int(skir):
     assert np.array_equal(mu.getMap().reshape(grid.shape), grid)
 
 
-def test_plan_skir_reference_query(skir):
+SPEC = pytest.mark.parametrize("spec", [0, 2], ids=["sequential", "speculative"])
+
+
+@SPEC
+def test_plan_skir_reference_query(skir, spec):
     """The one runnable reference scenario: maps/skir/skir.bag + launch/map_planner_node/test.launch.skir."""
     grid, origin, res = skir
     U = mapgen.control_lattice(1.0, 1, True)
     kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5)
     P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
-    mu, pl = util.make_gpu(grid, origin, res, U, record=1 << 16, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, record=1 << 16, spec=spec, **kw)
     r, c = util.compare_plan(P, pl, ((5.5, 5.5, 0.5), (1, 0, 0)), ((1.5, 1.5, 5.5),), orc.ACC)
     ids_o, pos_o = P.expanded()
     assert np.array_equal(pl.getExpandedIds(), ids_o)
@@ -96,47 +100,51 @@ def test_plan_skir_reference_query(skir):
     assert r.status == 0 and r.cost == 59.0 and r.n_expanded == 333
 
 
+@SPEC
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_plan_acc_synthetic(seed):
+def test_plan_acc_synthetic(seed, spec):
     grid, origin, res = util.small_map(96, seed=seed, occupancy=0.10)
     mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
     mapgen.carve_bubble(grid, (8.55, 8.55, 8.55), origin, res, 3)
     U = mapgen.control_lattice(1.0, 1, True)
     kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5)
     P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
-    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, spec=spec, **kw)
     util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0)), ((8.55, 8.55, 8.55),), orc.ACC)
 
 
-def test_plan_jrk_capped():
+@SPEC
+def test_plan_jrk_capped(spec):
     grid, origin, res = util.small_map(96, seed=4, occupancy=0.10)
     mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
     U = mapgen.control_lattice(1.0, 2, True)
     kw = dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=3000)
     P = util.make_oracle(grid, origin, res, orc.JRK, U, **kw)
-    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, spec=spec, **kw)
     r, c = util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0), (0, 0, 0)), ((8.55, 8.55, 8.55),), orc.JRK)
 
 
-def test_plan_jrk_reaches_goal():
+@SPEC
+def test_plan_jrk_reaches_goal(spec):
     grid, origin, res = util.small_map(64, seed=5, occupancy=0.05)
     mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
     mapgen.carve_bubble(grid, (4.55, 4.55, 3.05), origin, res, 3)
     U = mapgen.control_lattice(1.0, 1, True)
     kw = dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=50000)
     P = util.make_oracle(grid, origin, res, orc.JRK, U, **kw)
-    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, spec=spec, **kw)
     util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0), (0, 0, 0)), ((4.55, 4.55, 3.05),), orc.JRK)
 
 
-def test_start_occupied_and_unreachable():
+@SPEC
+def test_start_occupied_and_unreachable(spec):
     grid, origin, res = util.small_map(32, seed=9, occupancy=0.05)
     grid[:, :, :] = np.where(grid > 0, grid, 0)
     occ = np.argwhere(grid > 0)[0]
     U = mapgen.control_lattice(1.0, 1, True)
     kw = dict(v_max=2.0, a_max=1.0)
     P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
-    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, spec=spec, **kw)
     p_occ = ((occ[2] + 0.5) * res, (occ[1] + 0.5) * res, (occ[0] + 0.5) * res)
     util.compare_plan(P, pl, (p_occ, (0, 0, 0)), ((1.0, 1.0, 1.0),), orc.ACC)
     # goal walled in: OPEN runs empty (velocity-bounded lattice in a closed box is finite)
@@ -145,12 +153,13 @@ def test_start_occupied_and_unreachable():
     g2[8:16, 8, 8:16] = 100; g2[8:16, 15, 8:16] = 100
     g2[8, 8:16, 8:16] = 100; g2[15, 8:16, 8:16] = 100
     P = util.make_oracle(g2, origin, res, orc.ACC, U, **kw)
-    mu, pl = util.make_gpu(g2, origin, res, U, **kw)
+    mu, pl = util.make_gpu(g2, origin, res, U, spec=spec, **kw)
     r, c = util.compare_plan(P, pl, ((1.15, 1.15, 1.15), (0, 0, 0)), ((0.25, 0.25, 0.25),), orc.ACC)
     assert r.status == 1
 
 
-def test_duplicate_controls_take_the_ordered_path():
+@SPEC
+def test_duplicate_controls_take_the_ordered_path(spec):
     """Two identical control inputs give two successors with one key: the commit must serialise."""
     grid, origin, res = util.small_map(48, seed=11, occupancy=0.05)
     mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
@@ -158,18 +167,19 @@ def test_duplicate_controls_take_the_ordered_path():
     U = np.vstack([U, U[5:9], U[20:22] + 1e-4])  # exact and near duplicates
     kw = dict(v_max=2.0, a_max=1.0, max_expand=400)
     P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
-    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, spec=spec, **kw)
     util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0)), ((3.55, 3.55, 3.05),), orc.ACC)
 
 
-def test_plan_batch_matches_single_queries():
+@SPEC
+def test_plan_batch_matches_single_queries(spec):
     grid, origin, res = util.small_map(96, seed=21, occupancy=0.10)
     U = mapgen.control_lattice(1.0, 1, True)
     kw = dict(v_max=2.0, a_max=1.0)
     P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
     rng = mapgen.SplitMix64(77)
     queries = mapgen.random_queries(grid, origin, res, 24, rng, min_dist=4.0)
-    mu, pl = util.make_gpu(grid, origin, res, U, n_slots=8, record=1 << 15, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, n_slots=8, record=1 << 15, spec=spec, **kw)
     starts = [util.gpu_wp(s) for s, g in queries]
     goals = [util.gpu_wp(g) for s, g in queries]
     res_b = pl.planBatch(starts, goals)
@@ -186,7 +196,8 @@ def test_plan_batch_matches_single_queries():
             assert np.array_equal(tg.actions, to["actions"]) and np.array_equal(tg.node_ids, to["node_ids"])
 
 
-def test_near_far_open_structure_under_pressure():
+@SPEC
+def test_near_far_open_structure_under_pressure(spec):
     """Tiny bucket width / eps=0 (Dijkstra: massive f ties) stress refill, eviction and tie-breaking."""
     grid, origin, res = util.small_map(64, seed=31, occupancy=0.08)
     mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
@@ -194,6 +205,6 @@ def test_near_far_open_structure_under_pressure():
     for eps, width, me in ((0.0, 0.0, 4000), (1.0, 1e-3, 6000), (1.0, 500.0, 6000), (3.0, 0.0, 6000)):
         kw = dict(v_max=2.0, a_max=1.0, eps=eps, max_expand=me)
         P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
-        mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+        mu, pl = util.make_gpu(grid, origin, res, U, spec=spec, **kw)
         pl.setBucketWidth(width)
         util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0)), ((5.55, 5.55, 5.05),), orc.ACC)

@@ -20,7 +20,7 @@ def make_oracle(grid, origin, res, control, U, **kw):
 
 def make_gpu(grid, origin, res, U, v_max=-1.0, a_max=-1.0, j_max=-1.0, dt=1.0, w=10.0, eps=1.0, tol_pos=0.5,
              tol_vel=-1.0, tol_acc=-1.0, max_expand=-1, heur_ignore_dynamics=False, t_max=float("inf"),
-             n_slots=1, max_nodes=1 << 20, max_edges=1 << 22, max_log=1 << 21, record=0):
+             n_slots=1, max_nodes=1 << 20, max_edges=1 << 22, max_log=1 << 21, record=0, spec=-1):
     from mpl_ros_amd.planner import VoxelMapPlanner, VoxelMapUtil
     mu = VoxelMapUtil()
     dz, dy, dx = grid.shape
@@ -33,6 +33,7 @@ def make_gpu(grid, origin, res, U, v_max=-1.0, a_max=-1.0, j_max=-1.0, dt=1.0, w
     pl.setTmax(t_max)
     pl.setU(U)
     pl.setCapacity(n_slots, max_nodes, max_edges, max_log)
+    pl.setSpeculation(spec)
     if record:
         pl.setRecord(record)
     return mu, pl

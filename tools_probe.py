@@ -7,16 +7,18 @@ from tests import util
 from oracle import orc
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'single'
+import os
+SPEC = int(os.environ.get('SPEC', '-1'))
 if which == 'single':
     grid, origin, res, start, goal, rng = mapgen.benchmark_map(256)
     U = mapgen.control_lattice(1.0, 1, True)
-    mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, max_nodes=1 << 21, max_edges=1 << 23, max_log=1 << 22)
+    mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, max_nodes=1 << 21, max_edges=1 << 23, max_log=1 << 22, spec=SPEC)
     for it in range(2):
         ok = pl.plan(util.gpu_wp(start), util.gpu_wp(goal)); r = pl.getResult()
         print('C2 ACC', ok, r.cost, r.n_expanded, 'kernel ms', pl.lastKernelMs(), 'us/exp', 1e3 * pl.lastKernelMs() / r.n_expanded, 'refill', r.n_refill, 'evict', r.n_evict)
         print('   cycles/exp', {k: round(v / r.n_expanded) for k, v in pl.queryCycles().items()})
     U5 = mapgen.control_lattice(1.0, 2, True)
-    mu, pl = util.make_gpu(grid, origin, res, U5, v_max=2.0, a_max=1.0, j_max=1.0, max_expand=20000, max_nodes=1 << 21, max_edges=1 << 23, max_log=1 << 22)
+    mu, pl = util.make_gpu(grid, origin, res, U5, v_max=2.0, a_max=1.0, j_max=1.0, max_expand=20000, max_nodes=1 << 21, max_edges=1 << 23, max_log=1 << 22, spec=SPEC)
     ok = pl.plan(util.gpu_wp(start, control=orc.JRK), util.gpu_wp(goal, control=orc.JRK)); r = pl.getResult()
     print('C2 JRK cap20000', r.status, r.n_expanded, 'kernel ms', pl.lastKernelMs(), 'us/exp', 1e3 * pl.lastKernelMs() / r.n_expanded, 'refill', r.n_refill, 'evict', r.n_evict)
     print('   cycles/exp', {k: round(v / r.n_expanded) for k, v in pl.queryCycles().items()})
@@ -28,7 +30,7 @@ if which == 'batch':
     qrng = mapgen.SplitMix64(20250620 + 7919)
     queries = mapgen.random_queries(grid, origin, res, nq, qrng, min_dist=10.0)
     per_q = 450_000
-    mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, n_slots=slots, max_nodes=per_q * nq, max_edges=per_q * nq * 9 // 2, max_log=per_q * nq * 5 // 4)
+    mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, n_slots=slots, max_nodes=per_q * nq, max_edges=per_q * nq * 9 // 2, max_log=per_q * nq * 5 // 4, spec=SPEC)
     starts = [util.gpu_wp(s) for s, g in queries]; goals = [util.gpu_wp(g) for s, g in queries]
     t = time.time(); R = pl.planBatch(starts, goals); wall = time.time() - t
     ne = np.array([r.n_expanded for r in R], dtype=np.float64)
