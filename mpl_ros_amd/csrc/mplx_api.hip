@@ -308,7 +308,7 @@ static void fill_params(const mplx_ctx *c, SearchParams &P) {
   P.U = c->dU;
   P.ucost = c->dUcost;
   P.map = map_dev(c);
-  P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt / 2.0 : 1.0);
+  P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt * 2.0 : 1.0);
 }
 
 template <typename T>
@@ -412,14 +412,14 @@ static void launch_expand(int control, int grid, hipStream_t s, const SearchPara
   }
 }
 
-template <int UL, int K>
+// speculative kernel: built for the ACC and JRK state kinds (the reference's lattices); BTN = batch
+// table slots >= 2 x (K x n_u)
+template <int UL, int K, int BTN>
 static void launch_spec(int control, int grid, hipStream_t s, const SearchParams &P) {
-  switch (control) {
-    case CTRL_VEL: hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_VEL>), dim3(grid), dim3(UL * K), 0, s, P); break;
-    case CTRL_ACC: hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_ACC>), dim3(grid), dim3(UL * K), 0, s, P); break;
-    case CTRL_JRK: hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_JRK>), dim3(grid), dim3(UL * K), 0, s, P); break;
-    default: hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_SNP>), dim3(grid), dim3(UL * K), 0, s, P); break;
-  }
+  if (control == CTRL_ACC)
+    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_ACC, BTN>), dim3(grid), dim3(UL * K), 0, s, P);
+  else
+    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_JRK, BTN>), dim3(grid), dim3(UL * K), 0, s, P);
 }
 
 static int check_ready(mplx_ctx *c) {
@@ -569,11 +569,16 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   HIPCHK(c, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), c->stream));
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-  const bool spec = c->speculation < 0 ? P.n_u <= 128 : c->speculation > 1;
-  if (spec && P.n_u <= 64) {
-    launch_spec<64, 4>(P.control, slots, c->stream, P);   // 4 expansion units of one wave each
-  } else if (spec && P.n_u <= 128) {
-    launch_spec<128, 2>(P.control, slots, c->stream, P);  // 2 expansion units of two waves each
+  const bool spec_ok = (P.control == CTRL_ACC || P.control == CTRL_JRK) && P.n_u <= 128;
+  const bool spec = spec_ok && (c->speculation < 0 || c->speculation > 1);
+  if (spec && P.n_u <= 32 && c->speculation != 4) {
+    launch_spec<64, 8, 512>(P.control, slots, c->stream, P);   // 8 expansion units of one wave each
+  } else if (spec && P.n_u <= 32) {
+    launch_spec<64, 4, 256>(P.control, slots, c->stream, P);   // 4 expansion units of one wave each
+  } else if (spec && P.n_u <= 64) {
+    launch_spec<64, 4, 512>(P.control, slots, c->stream, P);
+  } else if (spec) {
+    launch_spec<128, 2, 512>(P.control, slots, c->stream, P);  // 2 expansion units of two waves each
   } else {
     switch (pick_block(P.n_u)) {
       case 64: launch_astar<64>(P.control, slots, c->stream, P); break;

@@ -56,7 +56,7 @@ struct Smem {
   uint32_t cnt_s[BLOCK];  // samples per primitive (n+1), 0 if skipped
   uint32_t offs[KUNITS][BLOCK / KUNITS + 1];
   uint32_t blk[BLOCK];  // first blocked sample: (i << 1) | inside
-  unsigned long long dupset[2 * BLOCK];
+  unsigned long long dupset[KUNITS > 1 ? 2 : 2 * BLOCK];  // unused by the multi-unit kernel
   double cur[KUNITS][13];       // state of the node(s) being expanded (p,v,a,j,t)
   int32_t cur_key[KUNITS][MAX_KEY];
   HeurParams hp;
@@ -67,6 +67,7 @@ struct Smem {
   uint32_t hist[64];
   // scalars
   uint32_t n_near, n_nodes, n_edges, n_log;
+  uint32_t reserve;  // near-set slots one iteration may need (successors pushed + candidates returned)
   uint32_t node_chunks, edge_chunks, open_chunks;  // chunks owned
   int32_t cur1, cur0;  // active coarse bucket, active fine bucket inside it
   double lo1;          // f of the lower edge of coarse bucket cur1
@@ -596,7 +597,7 @@ __device__ __forceinline__ void pull_bucket(const QView<BLOCK, CONTROL, SM> &Q, 
   __syncthreads();
   for (;;) {
     if (!block_any<BLOCK>(cur != NIL, S, tid)) break;
-    while (S.n_near > (uint32_t)(NC - BLOCK)) {
+    while (S.n_near + (uint32_t)NSUB > (uint32_t)NC) {
       MPLX_TIC(te);
       evict_half(Q, tid);
       __syncthreads();
@@ -894,6 +895,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
     for (int i = tid; i < 2 * NB; i += BLOCK) S.cnt[0][i] = 0;
     if (tid == 0) {
       S.n_near = 0; S.n_nodes = 0; S.n_edges = 0; S.n_log = 0;
+      S.reserve = (uint32_t)P.n_u;
       S.node_chunks = S.edge_chunks = S.open_chunks = 0;
       S.cur1 = 0; S.cur0 = 0; S.lo1 = 0.0; S.ts_f = INFINITY; S.ts_g = INFINITY; S.ts_id = 0xFFFFFFFFu;
       S.status = -1;
@@ -963,7 +965,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
       __syncthreads();
       // ---- main loop
       for (;;) {
-        while (S.n_near > (uint32_t)(NC - BLOCK)) {
+        while (S.n_near + S.reserve > (uint32_t)NC) {
           MPLX_TIC(te);
           evict_half(Q, tid);
           __syncthreads();

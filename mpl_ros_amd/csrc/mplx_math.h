@@ -559,15 +559,22 @@ MPLX_HD bool is_goal_state(const State &s, const State &goal, int goal_control, 
   return goaled;
 }
 
-// 64-bit mix of a key tuple (table index + tag); not part of any result
+// 64-bit mix of a key tuple (table index + tag); not part of any result.  Two independent 32-bit
+// multiply-xorshift lanes (32-bit multiplies are 4x cheaper than 64-bit ones on CDNA).
 MPLX_HD uint64_t key_hash64(const int32_t *k, int n) {
-  uint64_t h = 0x9E3779B97F4A7C15ULL;
+  uint32_t a = 0x9E3779B9u, b = 0x85EBCA6Bu;
   for (int i = 0; i < n; i++) {
-    h ^= (uint64_t)(uint32_t)k[i] + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2);
-    h *= 0xD6E8FEB86659FD93ULL;
-    h ^= h >> 32;
+    const uint32_t x = (uint32_t)k[i];
+    a = (a ^ x) * 0x01000193u;
+    a ^= a >> 15;
+    b = (b + x) * 0xC2B2AE35u;
+    b ^= b >> 13;
   }
-  return h;
+  a = (a ^ (b >> 3)) * 0x2C1B3C6Du;
+  a ^= a >> 12;
+  b = (b ^ (a << 7)) * 0x297A2D39u;
+  b ^= b >> 15;
+  return ((uint64_t)a << 32) | (uint64_t)b;
 }
 
 }  // namespace mplx

@@ -20,13 +20,23 @@
 
 namespace mplx {
 
-template <int UL, int K, int CONTROL>
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain
+// outstanding global-memory operations (vmcnt), so a returning global atomic issued before it
+// keeps overlapping.  Used where units hand data to each other through LDS exclusively.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int UL, int K, int CONTROL, int BTN>
 struct SmemSpec : Smem<UL * K, 3 * nq_c(CONTROL), K> {
-  static constexpr int BLOCK = UL * K, BT = 2 * UL * K, NK = key_len_c(CONTROL);
+  static constexpr int BLOCK = UL * K, BT = BTN, NK = key_len_c(CONTROL);
   // candidates in pop order
   double cand_f[K], cand_g[K];
-  uint32_t cand_id[K], cand_idx[K];
+  uint32_t cand_id[K], cand_idx[K], cand_pos[K];
   int32_t cand_live[K];
+  uint32_t cand_fl[K];  // node flags of candidate k when its record was fetched
   int32_t n_cand;
   uint32_t u_succ[K], u_fin[K], u_reads[K];  // per-unit successor / finite-successor / voxel-read totals
   int32_t unit_seq[K];                       // two lanes of the unit share a key -> lane-by-lane commit
@@ -34,47 +44,65 @@ struct SmemSpec : Smem<UL * K, 3 * nq_c(CONTROL), K> {
   // batch table: one entry per distinct successor key of the batch
   unsigned long long bt_hash[BT];
   uint32_t bt_leader[BT];  // smallest thread index sharing the entry (= first in commit order)
-  uint32_t bt_id[BT], bt_flags[BT], bt_pred[BT];
+  uint32_t bt_id[BT], bt_flags[BT], bt_pred[BT], bt_dirty[BT];
   unsigned long long bt_tslot[BT];
   double bt_g[BT], bt_h[BT];
   int32_t lane_key[UL * K][NK];
-  // smallest entry pushed by the units committed so far in this batch
-  double mp_f, mp_g;
-  uint32_t mp_id;
-  int32_t stop;
+  int32_t u_goal[K];  // candidate k satisfies the goal test (evaluated ahead of its commit)
+  int32_t u_cut[K];   // first later candidate preceded by an entry unit k pushes (K if none)
+  int32_t batch_dep;  // units interact through a shared state -> ordered, unit-by-unit commit
+  int32_t cut_at;     // first candidate preceded by an entry pushed in this batch (K if none)
+  // wave-local top-K of the near set
+  double sel_f[UL * K / 64][K], sel_g[UL * K / 64][K];
+  uint32_t sel_id[UL * K / 64][K], sel_pos[UL * K / 64][K];
 };
 
-// commit the successors of unit `ku_commit`; `active`: this lane commits now.  Workgroup-uniform.
-template <int UL, int K, int CONTROL, class SM, class V>
+// Commit the successors of candidate `kc`; `active`: this lane commits now (all active lanes belong
+// to unit kc).  Chunk capacity for the whole batch was reserved before the ordered loop, ids come
+// from a scan inside the unit, and the only workgroup barrier is the one the caller places between
+// two units.  A far-bucket link is left pending in (pend_idx, pend_old): the caller stores
+// open(pend_idx)->next = pend_old after the ordered loop, so the atomicExch latency overlaps it.
+struct LanePre {   // per-lane values of the ordered commit that do not depend on the other units
+  double tg, pf;   // tentative g through this candidate, f of the entry it would push
+  int code;        // where that entry goes (near / fine / coarse bucket)
+  int cut;         // first later candidate such an entry would precede (K if none)
+};
+
+template <int UL, int K, int CONTROL, bool PAR, class SM, class V>
 __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, int q, int kc, bool active, int my_slot,
-                                                  const LaneSucc &L, double hspec) {
+                                                  const LaneSucc &L, double hspec, const LanePre &pre, uint32_t &pend_idx, uint32_t &pend_old) {
   constexpr int BLOCK = UL * K;
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   const SearchParams &P = Q.P;
   const int lu = tid % UL;
   const bool isnew = active && S.bt_id[my_slot] == NIL;
-  uint32_t total;
-  uint32_t sc = block_excl_scan<BLOCK>((isnew ? 1u : 0u) | (active ? 1u << 12 : 0u), S, tid, total);
-  const uint32_t n_new = total & 0xFFFu, n_fin = total >> 12;
-  const uint32_t base_nodes = S.n_nodes, base_edges = S.n_edges;
-  if (tid == 0) {
-    bool ok = ensure_chunks(S.node_tbl, S.node_chunks, base_nodes + n_new, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks) &&
-              ensure_chunks(S.edge_tbl, S.edge_chunks, base_edges + n_fin, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks) &&
-              ensure_chunks(S.open_tbl, S.open_chunks, S.n_log + n_fin, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
-    if (!ok) S.status = 4;  // MPLX_PLAN_POOL_FULL
+  if (active && pend_idx != NIL) {  // lane-by-lane mode can reach here twice: settle the earlier link
+    Q.open(pend_idx)->next = pend_old;
+    pend_idx = NIL;
   }
-  __syncthreads();
-  if (S.status >= 0) return;
+  double old_g = INFINITY, tg = 0.0;
+  uint32_t fl = 0, old_pred = NIL, id = NIL;
   bool improved = false;
-  double tg = 0.0, hval = 0.0;
-  uint32_t id = NIL;
   if (active) {
-    char *rec;
-    double old_g;
-    uint32_t fl, old_pred;
+    if (!isnew) {
+      id = S.bt_id[my_slot];
+      old_g = S.bt_g[my_slot];
+      fl = S.bt_flags[my_slot];
+      old_pred = S.bt_pred[my_slot];
+    }
+    tg = pre.tg;
+    improved = tg < old_g;
+  }
+  // PAR: every committing unit at once (units proven independent), ids from a workgroup scan in
+  // (unit, lane) order = the order the unit-by-unit loop would assign
+  uint32_t total;
+  const uint32_t packed = (isnew ? 1u : 0u) | (active ? 1u << 10 : 0u) | (improved ? 1u << 20 : 0u);
+  const uint32_t sc = PAR ? block_excl_scan<BLOCK>(packed, S, tid, total) : unit_excl_scan<UL, BLOCK>(packed, S, tid, total);
+  const uint32_t base_nodes = S.n_nodes, base_edges = S.n_edges, base_log = S.n_log;
+  if (active) {
     if (isnew) {  // first arrival at this key: create the state (this lane is the entry's leader)
-      id = base_nodes + (sc & 0xFFFu);
-      rec = Q.node(id);
+      id = base_nodes + (sc & 0x3FFu);
+      char *rec = Q.node(id);
       int32_t *kk = V::key(rec);
 #pragma unroll
       for (int i = 0; i < nk; i++) kk[i] = L.key[i];
@@ -87,27 +115,14 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
       S.bt_h[my_slot] = hspec;
       const unsigned long long h64 = S.bt_hash[my_slot];
       st_u64(&P.table[S.bt_tslot[my_slot]], (((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32)) | id);
-      old_g = INFINITY;
-      fl = 0;
-      old_pred = NIL;
-      hval = hspec;
-    } else {
-      id = S.bt_id[my_slot];
-      rec = Q.node(id);
-      old_g = S.bt_g[my_slot];
-      fl = S.bt_flags[my_slot];
-      old_pred = S.bt_pred[my_slot];
-      hval = S.bt_h[my_slot];
     }
-    const uint32_t eidx = base_edges + (sc >> 12);
+    const uint32_t eidx = base_edges + ((sc >> 10) & 0x3FFu);
     EdgeRec *e = Q.edge(eidx);
     e->parent = S.cand_id[kc];
     e->next = old_pred;
     e->action = (uint32_t)lu;
-    V::pred(rec) = eidx;
     S.bt_pred[my_slot] = eidx;
-    tg = S.cand_g[kc] + P.ucost[lu];
-    improved = tg < old_g;
+    S.bt_dirty[my_slot] = 1;  // g / flags / newest predecessor reach the record once, after the ordered loop
     if (improved) {
       if (fl & FLAG_CLOSED) {  // re-open
         fl &= ~FLAG_CLOSED;
@@ -117,53 +132,42 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
       fl |= FLAG_OPENED;
     }
     if (improved || isnew) {
-      const double ng = improved ? tg : old_g;
-      V::g(rec) = ng;
-      V::flags(rec) = fl;
-      S.bt_g[my_slot] = ng;
+      S.bt_g[my_slot] = improved ? tg : old_g;
       S.bt_flags[my_slot] = fl;
     }
+    if (improved) {
+      const double pf = pre.pf;
+      const uint32_t idx = base_log + (sc >> 20);
+      OpenRec *r = Q.open(idx);
+      r->f = pf;
+      r->g = tg;
+      r->id = id;
+      const int code = pre.code;
+      if (code < 0) {
+        uint32_t pos = atomicAdd(&S.n_near, 1u);
+        S.near_f[pos] = pf; S.near_g[pos] = tg; S.near_id[pos] = id; S.near_idx[pos] = idx;
+      } else {
+        atomicAdd(&S.cnt[0][code], 1u);
+        pend_old = atomicExch(&Q.bkt_head[(size_t)code * NSUB + (idx & (NSUB - 1))], idx);
+        pend_idx = idx;
+      }
+      if (!PAR && pre.cut < K) atomicMin(&S.cut_at, pre.cut);  // this entry precedes a later candidate: cut there
+    }
   }
-  uint32_t total_p;
-  uint32_t sp = block_excl_scan<BLOCK>(improved ? 1u : 0u, S, tid, total_p);
-  const uint32_t base_log = S.n_log;
-  double pf = INFINITY, pg = INFINITY;
-  uint32_t pi = 0xFFFFFFFFu;
-  if (improved) {
-    pf = tg + P.eps * hval;
-    if (pf != pf) pf = INFINITY;
-    pg = tg;
-    pi = id;
-    open_push(Q, base_log + sp, pf, pg, pi);
+  // the unit's first lane publishes the new totals (in lane-by-lane mode that lane may be inactive:
+  // totals come from the scan, which every lane of the unit sees)
+  if (PAR ? tid == 0 : tid == kc * UL) {
+    S.n_nodes = base_nodes + (total & 0x3FFu);
+    S.n_edges = base_edges + ((total >> 10) & 0x3FFu);
+    S.n_log = base_log + (total >> 20);
+    S.c_push += total >> 20;
   }
-  // smallest pushed entry of this commit -> batch minimum
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    double of = __shfl_xor(pf, d, 64), og = __shfl_xor(pg, d, 64);
-    uint32_t oi = __shfl_xor(pi, d, 64);
-    if (entry_less(of, og, oi, pf, pg, pi)) { pf = of; pg = og; pi = oi; }
-  }
-  if ((tid & 63) == 0) {
-    S.red_f[tid >> 6] = pf;
-    S.red_g[tid >> 6] = pg;
-    S.red_id[tid >> 6] = pi;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 0; w < BLOCK / 64; w++)
-      if (entry_less(S.red_f[w], S.red_g[w], S.red_id[w], S.mp_f, S.mp_g, S.mp_id)) { S.mp_f = S.red_f[w]; S.mp_g = S.red_g[w]; S.mp_id = S.red_id[w]; }
-    S.n_nodes = base_nodes + n_new;
-    S.n_edges = base_edges + n_fin;
-    S.n_log = base_log + total_p;
-    S.c_push += total_p;
-  }
-  __syncthreads();
 }
 
-template <int UL, int K, int CONTROL>
+template <int UL, int K, int CONTROL, int BTN>
 __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
   constexpr int BLOCK = UL * K;
-  using SM = SmemSpec<UL, K, CONTROL>;
+  using SM = SmemSpec<UL, K, CONTROL, BTN>;
   constexpr int BT = SM::BT;
   __shared__ SM S;
   using V = QView<BLOCK, CONTROL, SM>;
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
     for (int i = tid; i < 2 * NB; i += BLOCK) S.cnt[0][i] = 0;
     if (tid == 0) {
       S.n_near = 0; S.n_nodes = 0; S.n_edges = 0; S.n_log = 0;
+      S.reserve = (uint32_t)(K * P.n_u + K);
       S.node_chunks = S.edge_chunks = S.open_chunks = 0;
       S.cur1 = 0; S.cur0 = 0; S.lo1 = 0.0; S.ts_f = INFINITY; S.ts_g = INFINITY; S.ts_id = 0xFFFFFFFFu;
       S.status = -1;
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       __syncthreads();
       // ---- main loop: one batch of up to K expansions per iteration
       for (;;) {
-        while (S.n_near > (uint32_t)(NC - BLOCK - K)) {
+        while (S.n_near + S.reserve > (uint32_t)NC) {
           MPLX_TIC(te);
           evict_half(Q, tid);
           __syncthreads();
@@ -269,53 +274,70 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
           __syncthreads();
         }
+        // top up: a batch wants K entries; pulling the next far bucket early keeps the structure exact
+        for (int guard = 0; guard < 8 && S.n_near < (uint32_t)K; guard++) {
+          __syncthreads();
+          if (!refill(Q, tid)) break;
+          __syncthreads();
+        }
         // ---- 1. the K smallest OPEN entries, in order
         if (tid == 0) {
           S.cyc[7]++;  // batches
           S.n_cand = 0;
-          S.stop = 0;
-          S.mp_f = INFINITY; S.mp_g = INFINITY; S.mp_id = 0xFFFFFFFFu;
+          S.cut_at = K;
+          S.batch_dep = 0;
         }
         if (tid < K) {
           S.cand_live[tid] = 0;
           S.unit_seq[tid] = 0;
           S.cur_slot[tid] = NIL;
           S.u_succ[tid] = S.u_fin[tid] = S.u_reads[tid] = 0;
+          S.u_goal[tid] = 0;
+          S.u_cut[tid] = K;
         }
         __syncthreads();
-        for (int k = 0; k < K; k++) {
+        {
+          // rank every near entry among all of them (strict total order -> unique ranks): ranks
+          // 0..K-1 are the candidates in pop order, the others move to position rank-K (which also
+          // leaves the near set sorted).  No serial section.
           const uint32_t n = S.n_near;
-          if (n == 0) break;  // uniform
-          double bf = INFINITY, bg = INFINITY;
-          uint32_t bi = 0xFFFFFFFFu, bp = NIL;
-          for (uint32_t i = tid; i < n; i += BLOCK) {
-            double f = S.near_f[i], g = S.near_g[i];
-            uint32_t id = S.near_id[i];
-            if (bp == NIL || entry_less(f, g, id, bf, bg, bi)) { bf = f; bg = g; bi = id; bp = i; }
-          }
+          const uint32_t kc = n < (uint32_t)K ? n : (uint32_t)K;
+          constexpr int PERT = (NC + BLOCK - 1) / BLOCK;
+          double ef[PERT], eg[PERT];
+          uint32_t ei[PERT], ex[PERT], rk[PERT];
 #pragma unroll
-          for (int d = 32; d >= 1; d >>= 1) {
-            double of = __shfl_xor(bf, d, 64), og = __shfl_xor(bg, d, 64);
-            uint32_t oi = __shfl_xor(bi, d, 64), op = __shfl_xor(bp, d, 64);
-            if (op != NIL && (bp == NIL || entry_less(of, og, oi, bf, bg, bi))) { bf = of; bg = og; bi = oi; bp = op; }
+          for (int r = 0; r < PERT; r++) {
+            const uint32_t i = tid + r * BLOCK;
+            const bool v = i < n;
+            ef[r] = v ? S.near_f[i] : INFINITY;
+            eg[r] = v ? S.near_g[i] : INFINITY;
+            ei[r] = v ? S.near_id[i] : 0xFFFFFFFFu;
+            ex[r] = v ? S.near_idx[i] : NIL;
+            rk[r] = 0;
           }
-          if ((tid & 63) == 0) {
-            S.red_f[tid >> 6] = bf; S.red_g[tid >> 6] = bg; S.red_id[tid >> 6] = bi; S.red_pos[tid >> 6] = bp;
+          for (uint32_t j = 0; j < n; j++) {
+            const double f = S.near_f[j], g = S.near_g[j];
+            const uint32_t id = S.near_id[j];
+#pragma unroll
+            for (int r = 0; r < PERT; r++)
+              if (entry_less(f, g, id, ef[r], eg[r], ei[r])) rk[r]++;
           }
           __syncthreads();
-          if (tid == 0) {
-            for (int w = 1; w < BLOCK / 64; w++) {
-              uint32_t op = S.red_pos[w];
-              if (op != NIL && (bp == NIL || entry_less(S.red_f[w], S.red_g[w], S.red_id[w], bf, bg, bi))) {
-                bf = S.red_f[w]; bg = S.red_g[w]; bi = S.red_id[w]; bp = op;
+#pragma unroll
+          for (int r = 0; r < PERT; r++) {
+            const uint32_t i = tid + r * BLOCK;
+            if (i < n) {
+              if (rk[r] < kc) {
+                S.cand_f[rk[r]] = ef[r]; S.cand_g[rk[r]] = eg[r]; S.cand_id[rk[r]] = ei[r]; S.cand_idx[rk[r]] = ex[r];
+              } else {
+                const uint32_t pos = rk[r] - kc;
+                S.near_f[pos] = ef[r]; S.near_g[pos] = eg[r]; S.near_id[pos] = ei[r]; S.near_idx[pos] = ex[r];
               }
             }
-            S.cand_f[k] = bf; S.cand_g[k] = bg; S.cand_id[k] = bi; S.cand_idx[k] = S.near_idx[bp];
-            const uint32_t last = n - 1;
-            S.near_f[bp] = S.near_f[last]; S.near_g[bp] = S.near_g[last];
-            S.near_id[bp] = S.near_id[last]; S.near_idx[bp] = S.near_idx[last];
-            S.n_near = last;
-            S.n_cand = k + 1;
+          }
+          if (tid == 0) {
+            S.n_cand = (int32_t)kc;
+            S.n_near = n - kc;
           }
           __syncthreads();
         }
@@ -331,8 +353,17 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             if (lu <= ns) S.cur[ku][lu < ns ? lu : 12] = V::state(rec)[lu];
             if (lu >= ns && lu < 12) S.cur[ku][lu] = 0.0;
             if (lu < nk) S.cur_key[ku][lu] = V::key(rec)[lu];
-            if (lu == 0) S.cand_live[ku] = 1;
+            if (lu == 0) {
+              S.cand_live[ku] = 1;
+              S.cand_fl[ku] = fl;
+            }
           }
+        }
+        __syncthreads();
+        if (live_unit && lu == 0) {  // goal test of the candidate (applied when, and if, it is committed)
+          State sgoal;
+          for (int i = 0; i < 12; i++) ((double *)&sgoal)[i] = S.cur[ku][i];
+          S.u_goal[ku] = (S.cur[ku][12] >= P.t_max || is_goal_state(sgoal, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) ? 1 : 0;
         }
         __syncthreads();
         MPLX_TOC(S, 0, tp);
@@ -360,11 +391,17 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         for (int i = tid; i < BT; i += BLOCK) {
           S.bt_hash[i] = 0ull;
           S.bt_leader[i] = NIL;
+          S.bt_dirty[i] = 0;
         }
+        unsigned long long v0 = TBL_EMPTY;
+        size_t pos0 = 0;
         if (act) {
           h64 = key_hash64(L.key, nk);
 #pragma unroll
           for (int i = 0; i < nk; i++) S.lane_key[tid][i] = L.key[i];
+          // first probe of the state-space table: issued now, consumed after the batch table is built
+          pos0 = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
+          v0 = ld_u64(&P.table[pos0]);
         }
         __syncthreads();
         if (act) {
@@ -388,22 +425,33 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             for (int i = 0; i < nk; i++) eq = eq && (S.lane_key[leader][i] == L.key[i]);
             if (!eq) S.status = 5;                                    // 64-bit key-hash collision inside a batch
             if ((int)(leader / UL) == ku) S.unit_seq[ku] = 1;       // two lanes of one unit, one key
+            S.batch_dep = 1;                                          // a state reached from two lanes of the batch
           } else {
             const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
             const size_t mask = (size_t)P.table_mask;
-            size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & mask;
-            unsigned long long v0 = ld_u64(&P.table[pos]);
-            if (P.eps != 0.0) hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);  // overlaps the probe
+            size_t pos = pos0;
             const unsigned long long claim = tagq | (unsigned long long)(CLAIM_BASE + (uint32_t)tid);
+            // second round trip (claim the empty slot, or fetch the record the slot names) goes out
+            // before the heuristic is computed, so its latency hides behind the f64 work
+            unsigned long long cas0 = 0;
+            bool did_cas0 = false;
+            if (v0 == TBL_EMPTY) {
+              cas0 = atomicCAS(&P.table[pos], TBL_EMPTY, claim);
+              did_cas0 = true;
+            } else if ((uint32_t)v0 < CLAIM_BASE && (v0 & 0xFFFFFFFF00000000ull) == tagq) {
+              __builtin_prefetch(Q.node((uint32_t)v0), 0, 3);
+            }
+            if (P.eps != 0.0) hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
             bool first = true;
             for (;;) {
               unsigned long long v = first ? v0 : ld_u64(&P.table[pos]);
-              first = false;
               if (v == TBL_EMPTY) {
-                unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, claim);
+                unsigned long long old = (first && did_cas0) ? cas0 : atomicCAS(&P.table[pos], TBL_EMPTY, claim);
+                first = false;
                 if (old == TBL_EMPTY) {
                   S.bt_id[my_slot] = NIL;  // new state; created when its first sharer commits
                   S.bt_tslot[my_slot] = (unsigned long long)pos;
+                  S.bt_h[my_slot] = hspec;  // of the leader's state = the state the node will be created with
                   S.bt_g[my_slot] = INFINITY;
                   S.bt_flags[my_slot] = 0;
                   S.bt_pred[my_slot] = NIL;
@@ -411,6 +459,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
                 }
                 v = old;
               }
+              first = false;
               const uint32_t vid = (uint32_t)v;
               if (vid < CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
                 char *r = Q.node(vid);
@@ -442,57 +491,138 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           for (;;) {
             const unsigned long long o = S.bt_hash[sl];
             if (o == 0ull) break;
-            if (o == hv) { S.cur_slot[ku] = (uint32_t)sl; break; }
+            if (o == hv) { S.cur_slot[ku] = (uint32_t)sl; S.batch_dep = 1; break; }
             sl = (sl + 1) & (BT - 1);
           }
         }
         __syncthreads();
+        LanePre pre;
+        pre.tg = 0.0; pre.pf = INFINITY; pre.code = -1; pre.cut = K;
+        if (act) {
+          const bool nw = S.bt_id[my_slot] == NIL;
+          const double hv = S.bt_h[my_slot];
+          pre.tg = S.cand_g[ku] + P.ucost[lu];
+          pre.pf = pre.tg + P.eps * hv;
+          if (pre.pf != pre.pf) pre.pf = INFINITY;
+          // a state created by this batch gets an id above every existing one: ties on (f, g) never favour it
+          const uint32_t pid = nw ? 0xFFFFFFFFu : S.bt_id[my_slot];
+          pre.code = classify(S, P.bucket_width, pre.pf, pre.tg, pid);
+          for (int k2 = ku + 1; k2 < K; k2++)
+            if (k2 < n_cand && entry_less(pre.pf, pre.tg, pid, S.cand_f[k2], S.cand_g[k2], S.cand_id[k2])) {
+              pre.cut = k2;
+              break;
+            }
+          // valid when no state of the batch is shared between lanes (bt_g still is the fetched value)
+          if (pre.cut < K && pre.tg < S.bt_g[my_slot]) atomicMin(&S.u_cut[ku], pre.cut);
+        }
         MPLX_TOC(S, 2, tc);
         if (S.status >= 0) break;
         // ---- 3. ordered commit
         MPLX_TIC(to);
-        int k_stop = n_cand;
-        for (int k = 0; k < n_cand; k++) {
-          if (!S.cand_live[k]) continue;  // stale entry: dropped, like a pop that skips it
-          if (!entry_less(S.cand_f[k], S.cand_g[k], S.cand_id[k], S.mp_f, S.mp_g, S.mp_id)) {
-            k_stop = k;  // something pushed by this batch now precedes candidate k: cut here
-            break;
-          }
-          if (tid == 0) {
-            const uint32_t cur = S.cand_id[k];
-            char *rec = Q.node(cur);
-            V::flags(rec) = V::flags(rec) | FLAG_CLOSED;
-            if (S.cur_slot[k] != NIL) S.bt_flags[S.cur_slot[k]] |= FLAG_CLOSED;
-            S.c_expanded++;
-            S.c_closed++;
-            S.c_hash = S.c_hash * 0x100000001B3ull + (unsigned long long)(cur + 1u);
-            if (P.rec_ids && S.c_expanded <= P.cap_rec) P.rec_ids[(size_t)q * P.cap_rec + (S.c_expanded - 1)] = (int32_t)cur;
-            S.c_prims += (unsigned long long)P.n_u;
-            S.c_succ += S.u_succ[k];
-            S.c_succ_finite += S.u_fin[k];
-            S.c_reads += S.u_reads[k];
-            S.cur_id = cur;
-          }
-          __syncthreads();
-          if (!S.unit_seq[k]) {
-            spec_commit_lanes<UL, K, CONTROL>(Q, S, tid, q, k, act && ku == k, my_slot, L, hspec);
-          } else {
-            for (int i = 0; i < P.n_u && S.status < 0; i++)
-              spec_commit_lanes<UL, K, CONTROL>(Q, S, tid, q, k, act && ku == k && lu == i, my_slot, L, hspec);
-          }
-          if (S.status >= 0) { k_stop = k + 1; break; }  // pool full
-          if (tid == 0) {
-            State s;
-            for (int i = 0; i < 12; i++) ((double *)&s)[i] = S.cur[k][i];
-            if (S.cur[k][12] >= P.t_max || is_goal_state(s, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc))
-              S.status = 0;
-            else if (P.max_expand > 0 && S.c_expanded >= (unsigned long long)P.max_expand)
-              S.status = 3;
-          }
-          __syncthreads();
-          if (S.status >= 0) { k_stop = k + 1; break; }
+        if (tid == 0) {  // chunk capacity for everything this batch can create
+          const uint32_t room = (uint32_t)BLOCK;
+          bool ok = ensure_chunks(S.node_tbl, S.node_chunks, S.n_nodes + room, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks) &&
+                    ensure_chunks(S.edge_tbl, S.edge_chunks, S.n_edges + room, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks) &&
+                    ensure_chunks(S.open_tbl, S.open_chunks, S.n_log + room, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
+          if (!ok) S.status = 4;  // MPLX_PLAN_POOL_FULL
         }
         __syncthreads();
+        if (S.status >= 0) break;
+        int k_stop = n_cand, n_commit = 0;
+        const unsigned long long expanded0 = S.c_expanded;
+        uint32_t pend_idx = NIL, pend_old = NIL;  // far-bucket link whose atomicExch is still in flight
+        const bool parallel_commit = !S.batch_dep;
+        if (parallel_commit) {
+          // no state is touched by two lanes of the batch and no candidate is a successor inside it:
+          // the units cannot see each other, so which of them commit follows from the per-unit cut
+          // points alone, and they commit together
+          int cut = K, st_after = -1;
+          for (int k = 0; k < n_cand; k++) {
+            if (!S.cand_live[k]) continue;
+            if (k >= cut) { k_stop = k; break; }
+            n_commit++;
+            const int uc = S.u_cut[k];
+            cut = uc < cut ? uc : cut;
+            if (S.u_goal[k]) { st_after = 0; k_stop = k + 1; break; }
+            if (P.max_expand > 0 && expanded0 + (unsigned long long)n_commit >= (unsigned long long)P.max_expand) { st_after = 3; k_stop = k + 1; break; }
+          }
+          const bool mine = ku < k_stop && S.cand_live[ku < K ? ku : 0];
+          if (mine && lu == 0) V::flags(Q.node(S.cand_id[ku])) = S.cand_fl[ku] | FLAG_CLOSED;
+          __syncthreads();  // everyone has read status / u_cut before they change
+          spec_commit_lanes<UL, K, CONTROL, true>(Q, S, tid, q, ku, act && mine, my_slot, L, hspec, pre, pend_idx, pend_old);
+          if (tid == 0 && st_after >= 0) S.status = st_after;
+        }
+        for (int k = 0; k < (parallel_commit ? 0 : n_cand); k++) {
+          if (!S.cand_live[k]) continue;  // stale entry: dropped, like a pop that skips it
+          if (k >= S.cut_at) {            // something pushed by this batch now precedes candidate k
+            k_stop = k;
+            break;
+          }
+          n_commit++;
+          if (tid == k * UL) {
+            const uint32_t cur = S.cand_id[k];
+            // flags cannot have changed since they were fetched: any unit of this batch that improved
+            // this node pushed an entry that precedes it and cut the batch before it
+            if (S.cur_slot[k] != NIL) {  // also a successor of this batch: the batch table owns its flags
+              S.bt_flags[S.cur_slot[k]] |= FLAG_CLOSED;
+              S.bt_dirty[S.cur_slot[k]] = 1;
+            } else {
+              V::flags(Q.node(cur)) = S.cand_fl[k] | FLAG_CLOSED;
+            }
+            if (S.u_goal[k])
+              S.status = 0;
+            else if (P.max_expand > 0 && expanded0 + (unsigned long long)n_commit >= (unsigned long long)P.max_expand)
+              S.status = 3;
+          }
+          if (S.cur_slot[k] != NIL) lds_barrier();  // (uniform) its closed flag must precede its own successors' relax
+          if (!S.unit_seq[k]) {
+            spec_commit_lanes<UL, K, CONTROL, false>(Q, S, tid, q, k, act && ku == k, my_slot, L, hspec, pre, pend_idx, pend_old);
+          } else {
+            for (int i = 0; i < P.n_u; i++) {
+              spec_commit_lanes<UL, K, CONTROL, false>(Q, S, tid, q, k, act && ku == k && lu == i, my_slot, L, hspec, pre, pend_idx, pend_old);
+              lds_barrier();
+            }
+          }
+          lds_barrier();
+          if (S.status >= 0) { k_stop = k + 1; break; }
+        }
+        if (pend_idx != NIL) Q.open(pend_idx)->next = pend_old;
+        lds_barrier();
+        // write the batch table back: one store per field and state, whatever number of units touched it
+        for (int i = tid; i < BT; i += BLOCK) {
+          if (S.bt_dirty[i] && S.bt_id[i] != NIL) {
+            char *rec = Q.node(S.bt_id[i]);
+            V::g(rec) = S.bt_g[i];
+            V::flags(rec) = S.bt_flags[i];
+            V::pred(rec) = S.bt_pred[i];
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {  // counters of the committed units, in commit order (accumulated in registers)
+          unsigned long long ne = S.c_expanded, hh = S.c_hash, nsu = 0, nfi = 0, nrd = 0, ncm = 0;
+          uint32_t last = S.cur_id;
+          for (int k = 0; k < k_stop; k++) {
+            if (!S.cand_live[k]) continue;
+            const uint32_t cur = S.cand_id[k];
+            ne++;
+            ncm++;
+            hh = hh * 0x100000001B3ull + (unsigned long long)(cur + 1u);
+            if (P.rec_ids && ne <= P.cap_rec) P.rec_ids[(size_t)q * P.cap_rec + (ne - 1)] = (int32_t)cur;
+            nsu += S.u_succ[k];
+            nfi += S.u_fin[k];
+            nrd += S.u_reads[k];
+            last = cur;
+          }
+          S.c_expanded = ne;
+          S.c_closed += ncm;
+          S.c_hash = hh;
+          S.c_prims += ncm * (unsigned long long)P.n_u;
+          S.c_succ += nsu;
+          S.c_succ_finite += nfi;
+          S.c_reads += nrd;
+          S.cur_id = last;
+          if (!parallel_commit) S.cyc[3]++;  // batches that needed the unit-by-unit commit
+        }
         // candidates behind a cut go back to OPEN untouched
         if (tid == 0 && S.status < 0) {
           for (int k = k_stop; k < n_cand; k++) {
