@@ -50,6 +50,7 @@ struct SmemSpec : Smem<UL * K, 3 * nq_c(CONTROL), K> {
   int32_t lane_key[UL * K][NK];
   int32_t u_goal[K];  // candidate k satisfies the goal test (evaluated ahead of its commit)
   int32_t u_cut[K];   // first later candidate preceded by an entry unit k pushes (K if none)
+  uint32_t n_sorted;  // near_[0, n_sorted) is in ascending order (left so by the previous selection)
   int32_t batch_dep;  // units interact through a shared state -> ordered, unit-by-unit commit
   int32_t cut_at;     // first candidate preceded by an entry pushed in this batch (K if none)
   // wave-local top-K of the near set
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
     if (tid == 0) {
       S.n_near = 0; S.n_nodes = 0; S.n_edges = 0; S.n_log = 0;
       S.reserve = (uint32_t)(K * P.n_u + K);
+      S.n_sorted = 0;
       S.node_chunks = S.edge_chunks = S.open_chunks = 0;
       S.cur1 = 0; S.cur0 = 0; S.lo1 = 0.0; S.ts_f = INFINITY; S.ts_g = INFINITY; S.ts_id = 0xFFFFFFFFu;
       S.status = -1;
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         while (S.n_near + S.reserve > (uint32_t)NC) {
           MPLX_TIC(te);
           evict_half(Q, tid);
+          if (tid == 0) S.n_sorted = 0;
           __syncthreads();
           MPLX_TOC(S, 3, te);
         }
@@ -272,12 +275,17 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             __syncthreads();
             break;
           }
+          if (tid == 0) S.n_sorted = 0;  // a refill may split the near set
           __syncthreads();
         }
         // top up: a batch wants K entries; pulling the next far bucket early keeps the structure exact
+        const unsigned long long evict0 = S.c_evict;
         for (int guard = 0; guard < 8 && S.n_near < (uint32_t)K; guard++) {
           __syncthreads();
+          const uint32_t before = S.n_near;
           if (!refill(Q, tid)) break;
+          if (tid == 0 && S.c_evict != evict0) S.n_sorted = 0;  // only an eviction inside the pull reorders; appends keep the prefix
+          (void)before;
           __syncthreads();
         }
         // ---- 1. the K smallest OPEN entries, in order
@@ -315,7 +323,24 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             ex[r] = v ? S.near_idx[i] : NIL;
             rk[r] = 0;
           }
-          for (uint32_t j = 0; j < n; j++) {
+          // near_[0, ns) is sorted (previous selection), near_[ns, n) are the entries appended since:
+          // rank = (#sorted entries before me: my index, or a binary search) + (#appended entries before me)
+          const uint32_t ns_ = S.n_sorted <= n ? S.n_sorted : 0u;
+#pragma unroll
+          for (int r = 0; r < PERT; r++) {
+            const uint32_t i = tid + r * BLOCK;
+            if (i < ns_) {
+              rk[r] = i;
+            } else if (i < n) {
+              uint32_t lo = 0, hi = ns_;  // number of sorted entries that precede mine
+              while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (entry_less(S.near_f[mid], S.near_g[mid], S.near_id[mid], ef[r], eg[r], ei[r])) lo = mid + 1; else hi = mid;
+              }
+              rk[r] = lo;
+            }
+          }
+          for (uint32_t j = ns_; j < n; j++) {
             const double f = S.near_f[j], g = S.near_g[j];
             const uint32_t id = S.near_id[j];
 #pragma unroll
@@ -338,6 +363,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           if (tid == 0) {
             S.n_cand = (int32_t)kc;
             S.n_near = n - kc;
+            S.n_sorted = n - kc;
           }
           __syncthreads();
         }
