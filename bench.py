@@ -203,7 +203,7 @@ def main():
             "map_setup_s": {"generate": round(t_gen, 3), "broadcast": round(t_bcast, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "astar_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
+                         "kernel": "astar_spec_kernel<64,8,ACC,512>" if control == ACC else "astar_spec_kernel<128,2,JRK,512>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
                          "bytes_per_expansion": alg / max(n_exp, 1)},
         }
         # HBM traffic of the same launch from the committed rocprofv3 PMC passes (cannot be collected
