@@ -122,8 +122,12 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
     e->parent = S.cand_id[kc];
     e->next = old_pred;
     e->action = (uint32_t)lu;
-    S.bt_pred[my_slot] = eidx;
-    S.bt_dirty[my_slot] = 1;  // g / flags / newest predecessor reach the record once, after the ordered loop
+    if (PAR) {
+      V::pred(Q.node(id)) = eidx;  // independent units: nobody else touches this state in the batch
+    } else {
+      S.bt_pred[my_slot] = eidx;
+      S.bt_dirty[my_slot] = 1;  // g / flags / newest predecessor reach the record once, after the ordered loop
+    }
     if (improved) {
       if (fl & FLAG_CLOSED) {  // re-open
         fl &= ~FLAG_CLOSED;
@@ -133,8 +137,14 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
       fl |= FLAG_OPENED;
     }
     if (improved || isnew) {
-      S.bt_g[my_slot] = improved ? tg : old_g;
-      S.bt_flags[my_slot] = fl;
+      if (PAR) {
+        char *rec2 = Q.node(id);
+        V::g(rec2) = improved ? tg : old_g;
+        V::flags(rec2) = fl;
+      } else {
+        S.bt_g[my_slot] = improved ? tg : old_g;
+        S.bt_flags[my_slot] = fl;
+      }
     }
     if (improved) {
       const double pf = pre.pf;
@@ -291,6 +301,13 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         // ---- 1. the K smallest OPEN entries, in order
         if (tid == 0) {
           S.cyc[7]++;  // batches
+          {  // chunk capacity for everything this batch can create
+            const uint32_t room = (uint32_t)(K * P.n_u + K);
+            bool ok = ensure_chunks(S.node_tbl, S.node_chunks, S.n_nodes + room, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks) &&
+                      ensure_chunks(S.edge_tbl, S.edge_chunks, S.n_edges + room, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks) &&
+                      ensure_chunks(S.open_tbl, S.open_chunks, S.n_log + room, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
+            if (!ok) S.status = 4;  // MPLX_PLAN_POOL_FULL
+          }
           S.n_cand = 0;
           S.cut_at = K;
           S.batch_dep = 0;
@@ -545,15 +562,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         if (S.status >= 0) break;
         // ---- 3. ordered commit
         MPLX_TIC(to);
-        if (tid == 0) {  // chunk capacity for everything this batch can create
-          const uint32_t room = (uint32_t)BLOCK;
-          bool ok = ensure_chunks(S.node_tbl, S.node_chunks, S.n_nodes + room, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks) &&
-                    ensure_chunks(S.edge_tbl, S.edge_chunks, S.n_edges + room, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks) &&
-                    ensure_chunks(S.open_tbl, S.open_chunks, S.n_log + room, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
-          if (!ok) S.status = 4;  // MPLX_PLAN_POOL_FULL
-        }
-        __syncthreads();
-        if (S.status >= 0) break;
+        lds_barrier();  // the per-unit cut points (atomicMin above) are complete
         int k_stop = n_cand, n_commit = 0;
         const unsigned long long expanded0 = S.c_expanded;
         uint32_t pend_idx = NIL, pend_old = NIL;  // far-bucket link whose atomicExch is still in flight
@@ -563,13 +572,22 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           // the units cannot see each other, so which of them commit follows from the per-unit cut
           // points alone, and they commit together
           int cut = K, st_after = -1;
-          for (int k = 0; k < n_cand; k++) {
-            if (!S.cand_live[k]) continue;
+          int lv[K], uc_[K], ug[K];
+#pragma unroll
+          for (int k = 0; k < K; k++) {  // independent LDS reads first
+            lv[k] = S.cand_live[k];
+            uc_[k] = S.u_cut[k];
+            ug[k] = S.u_goal[k];
+          }
+#pragma unroll
+          for (int k = 0; k < K; k++) {
+            if (k >= n_cand) break;
+            if (!lv[k]) continue;
             if (k >= cut) { k_stop = k; break; }
             n_commit++;
-            const int uc = S.u_cut[k];
+            const int uc = uc_[k];
             cut = uc < cut ? uc : cut;
-            if (S.u_goal[k]) { st_after = 0; k_stop = k + 1; break; }
+            if (ug[k]) { st_after = 0; k_stop = k + 1; break; }
             if (P.max_expand > 0 && expanded0 + (unsigned long long)n_commit >= (unsigned long long)P.max_expand) { st_after = 3; k_stop = k + 1; break; }
           }
           const bool mine = ku < k_stop && S.cand_live[ku < K ? ku : 0];
@@ -613,14 +631,16 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           if (S.status >= 0) { k_stop = k + 1; break; }
         }
         if (pend_idx != NIL) Q.open(pend_idx)->next = pend_old;
-        lds_barrier();
-        // write the batch table back: one store per field and state, whatever number of units touched it
-        for (int i = tid; i < BT; i += BLOCK) {
-          if (S.bt_dirty[i] && S.bt_id[i] != NIL) {
-            char *rec = Q.node(S.bt_id[i]);
-            V::g(rec) = S.bt_g[i];
-            V::flags(rec) = S.bt_flags[i];
-            V::pred(rec) = S.bt_pred[i];
+        if (!parallel_commit) {
+          lds_barrier();
+          // write the batch table back: one store per field and state, whatever number of units touched it
+          for (int i = tid; i < BT; i += BLOCK) {
+            if (S.bt_dirty[i] && S.bt_id[i] != NIL) {
+              char *rec = Q.node(S.bt_id[i]);
+              V::g(rec) = S.bt_g[i];
+              V::flags(rec) = S.bt_flags[i];
+              V::pred(rec) = S.bt_pred[i];
+            }
           }
         }
         __syncthreads();

@@ -9,10 +9,11 @@ from oracle import orc
 which = sys.argv[1] if len(sys.argv) > 1 else 'single'
 import os
 SPEC = int(os.environ.get('SPEC', '-1'))
+HID = bool(int(os.environ.get('HID', '0')))
 if which == 'single':
     grid, origin, res, start, goal, rng = mapgen.benchmark_map(256)
     U = mapgen.control_lattice(1.0, 1, True)
-    mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, max_nodes=1 << 21, max_edges=1 << 23, max_log=1 << 22, spec=SPEC)
+    mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, max_nodes=1 << 22, max_edges=1 << 24, max_log=1 << 23, spec=SPEC, heur_ignore_dynamics=HID)
     for it in range(2):
         ok = pl.plan(util.gpu_wp(start), util.gpu_wp(goal)); r = pl.getResult()
         print('C2 ACC', ok, r.cost, r.n_expanded, 'kernel ms', pl.lastKernelMs(), 'us/exp', 1e3 * pl.lastKernelMs() / r.n_expanded, 'refill', r.n_refill, 'evict', r.n_evict)
