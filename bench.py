@@ -215,7 +215,7 @@ def main():
                 out["roofline"]["traffic_source"] = tr["profile"]
         except Exception:
             pass
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(grid, origin, res, control, U, max_expand, queries, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

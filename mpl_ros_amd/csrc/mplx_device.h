@@ -26,7 +26,7 @@ constexpr uint32_t FLAG_CLOSED = 1u, FLAG_OPENED = 2u;
 constexpr int MAX_TRAJ = 1024;
 
 constexpr int NODE_CH_LOG = 13, EDGE_CH_LOG = 16, OPEN_CH_LOG = 14;
-constexpr int MAX_NODE_CH = 1024, MAX_EDGE_CH = 512, MAX_OPEN_CH = 1024;  // per query: 8M nodes, 33M edges, 16M log
+constexpr int MAX_NODE_CH = 1024, MAX_EDGE_CH = 2048, MAX_OPEN_CH = 1024;  // per query: 8M nodes, 134M edges, 16M log
 constexpr int EDGE_BYTES = 12, OPEN_BYTES = 24;
 
 constexpr int rec_hot_bytes(int control) { return control == CTRL_SNP ? 80 : 64; }

@@ -46,6 +46,9 @@ if which == 'batch':
     for i in idx:
         print('  long query', i, 'exp', int(ne[i]), 'dur', round(dur[i], 3), 'begin', round(T[i, 0], 3), 'us/exp', round(us[i], 2), 'refill', R[i].n_refill, 'evict', R[i].n_evict,
               {k: round(v / ne[i]) for k, v in pl.queryCycles(int(i)).items()})
+    for i in np.where(np.array([r.status for r in R]) == 4)[0]:
+        print('  POOL_FULL query', i, 'exp', R[i].n_expanded, 'nodes', R[i].n_nodes, 'edges', R[i].n_edges, 'push', R[i].n_push)
+    print('  totals nodes', sum(r.n_nodes for r in R), 'edges', sum(r.n_edges for r in R), 'push', sum(r.n_push for r in R))
     # concurrency over time
     for frac in (0.1, 0.25, 0.5, 0.75, 0.9):
         tt = frac * T[:, 1].max()
