@@ -162,8 +162,9 @@ int mplx_result_nodes(mplx_ctx *ctx, mplx_waypoint *coords, double *g, double *h
 /* device-clock begin / end (seconds since the first query of the batch started) and workgroup of query q */
 int mplx_result_timing(mplx_ctx *ctx, int q, double *t_begin_s, double *t_end_s, int32_t *slot);
 /* shader-clock cycles query q spent in: [0] pop (incl. refill), [1] expand (primitives + voxels),
- * [2] commit (dedup, relax, push), [3] near-set eviction, [4] refill, [5] coarse-bucket activation */
-int mplx_result_cycles(mplx_ctx *ctx, int q, uint64_t cyc[8]);
+ * [2] successor look-up (+ commit in the one-node kernel), [3] near-set eviction, [4] refill,
+ * [5] coarse-bucket activation, [6] ordered commit; counts: [7] batches, [8] batches committed unit by unit */
+int mplx_result_cycles(mplx_ctx *ctx, int q, uint64_t cyc[10]);
 /* duration (ms, HIP events on the context's stream) of the last search / expand kernel launch */
 int mplx_last_kernel_ms(const mplx_ctx *ctx, float *ms);
 const char *mplx_version(void);

@@ -414,12 +414,12 @@ static void launch_expand(int control, int grid, hipStream_t s, const SearchPara
 
 // speculative kernel: built for the ACC and JRK state kinds (the reference's lattices); BTN = batch
 // table slots >= 2 x (K x n_u)
-template <int UL, int K, int BTN>
+template <int UL, int K, int BTN, int NCAP>
 static void launch_spec(int control, int grid, hipStream_t s, const SearchParams &P) {
   if (control == CTRL_ACC)
-    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_ACC, BTN>), dim3(grid), dim3(UL * K), 0, s, P);
+    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_ACC, BTN, NCAP>), dim3(grid), dim3(UL * K), 0, s, P);
   else
-    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_JRK, BTN>), dim3(grid), dim3(UL * K), 0, s, P);
+    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_JRK, BTN, NCAP>), dim3(grid), dim3(UL * K), 0, s, P);
 }
 
 static int check_ready(mplx_ctx *c) {
@@ -571,14 +571,14 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   const bool spec_ok = (P.control == CTRL_ACC || P.control == CTRL_JRK) && P.n_u <= 128;
   const bool spec = spec_ok && (c->speculation < 0 || c->speculation > 1);
-  if (spec && P.n_u <= 32 && c->speculation != 4) {
-    launch_spec<64, 8, 512>(P.control, slots, c->stream, P);   // 8 expansion units of one wave each
+  if (spec && P.n_u <= 32 && c->speculation == 8) {
+    launch_spec<64, 8, 512, 512>(P.control, slots, c->stream, P);    // 8 expansion units of one wave each
   } else if (spec && P.n_u <= 32) {
-    launch_spec<64, 4, 256>(P.control, slots, c->stream, P);   // 4 expansion units of one wave each
+    launch_spec<32, 16, 1024, 1024>(P.control, slots, c->stream, P); // 16 units, two per wave
   } else if (spec && P.n_u <= 64) {
-    launch_spec<64, 4, 512>(P.control, slots, c->stream, P);
+    launch_spec<64, 4, 512, 512>(P.control, slots, c->stream, P);
   } else if (spec) {
-    launch_spec<128, 2, 512>(P.control, slots, c->stream, P);  // 2 expansion units of two waves each
+    launch_spec<128, 2, 512, 512>(P.control, slots, c->stream, P);   // 2 expansion units of two waves each
   } else {
     switch (pick_block(P.n_u)) {
       case 64: launch_astar<64>(P.control, slots, c->stream, P); break;
@@ -709,9 +709,9 @@ extern "C" int mplx_result_timing(mplx_ctx *c, int q, double *t_begin_s, double 
   return MPLX_OK;
 }
 
-extern "C" int mplx_result_cycles(mplx_ctx *c, int q, uint64_t cyc[8]) {
+extern "C" int mplx_result_cycles(mplx_ctx *c, int q, uint64_t cyc[10]) {
   if (!c || q < 0 || q >= c->last_nq || !cyc) return fail(c, MPLX_ERR_ARG, "no such query");
-  for (int i = 0; i < 8; i++) cyc[i] = c->last_out[q].cyc[i];
+  for (int i = 0; i < 10; i++) cyc[i] = c->last_out[q].cyc[i];
   return MPLX_OK;
 }
 

@@ -53,7 +53,7 @@ struct QueryOut {
   unsigned long long n_expanded, n_closed, n_nodes, n_edges, n_primitives, n_succ, n_succ_finite, voxel_reads, n_push,
       n_reopen, n_refill, n_evict, expand_hash;
   unsigned long long t_begin, t_end;  // wall_clock64() ticks (100 MHz)
-  unsigned long long cyc[8];          // s_memtime cycles: pop, expand, commit, evict, refill, activate, -, -
+  unsigned long long cyc[10];         // s_memtime cycles: pop, expand, look-up, evict, refill, activate, commit; counts: batches, ordered batches, -
   uint32_t n_recorded, slot;
 };
 

@@ -41,18 +41,23 @@ struct EdgeRec {  // predecessor record (EDGE_BYTES)
 };
 static_assert(sizeof(OpenRec) == OPEN_BYTES && sizeof(EdgeRec) == EDGE_BYTES, "record sizes");
 
-template <int BLOCK, int NQROWS = 15, int KUNITS = 1>
+template <int BLOCK, int KUNITS = 1, int NCAP_ = NC>
 struct Smem {
+  static constexpr int NCAP = NCAP_;  // near-set capacity
   // OPEN near set
-  double near_f[NC], near_g[NC];
-  uint32_t near_id[NC], near_idx[NC];
+  double near_f[NCAP_], near_g[NCAP_];
+  uint32_t near_id[NCAP_], near_idx[NCAP_];
   uint32_t cnt[2][NB];  // entries per bucket: [0] fine level (inside coarse bucket cur1), [1] coarse level
   // chunk tables of the running query
   uint32_t node_tbl[MAX_NODE_CH], edge_tbl[MAX_EDGE_CH], open_tbl[MAX_OPEN_CH];
   // expansion scratch
-  double q[NQROWS][BLOCK];  // pre-divided non-zero polynomial coefficients per primitive (3 axes x nq_c)
+  // pre-divided non-zero polynomial coefficients (pack_q_c) of a sample's primitive, split into the
+  // part that only depends on the control input (per query) and the part that only depends on the
+  // node being expanded (per unit): no per-primitive staging
+  double uq[3][BLOCK / KUNITS];  // q[0] of control input i per axis: U[i][ax] / {1, 2, 6, 24}
+  double qn[KUNITS][3][5];       // q[1..] of the node per axis
   double dts[BLOCK];
-  uint8_t owner[KUNITS][OWN / KUNITS];  // per expansion unit: primitive that owns flattened sample e
+  uint8_t owner[KUNITS][KUNITS > 1 ? 640 : OWN];  // per expansion unit: primitive that owns flattened sample e
   uint32_t cnt_s[BLOCK];  // samples per primitive (n+1), 0 if skipped
   uint32_t offs[KUNITS][BLOCK / KUNITS + 1];
   uint32_t blk[BLOCK];  // first blocked sample: (i << 1) | inside
@@ -80,7 +85,7 @@ struct Smem {
   uint32_t tmp_u;
   double tmp_d0;
   unsigned long long c_expanded, c_closed, c_prims, c_succ, c_succ_finite, c_reads, c_push, c_reopen, c_refill, c_evict, c_hash;
-  unsigned long long cyc[8];
+  unsigned long long cyc[10];
 };
 
 #define MPLX_TIC(var) const unsigned long long var = __builtin_readcyclecounter()
@@ -137,6 +142,17 @@ __device__ __forceinline__ uint32_t unit_excl_scan(uint32_t v, SM &S, int tid, u
   if constexpr (UL == BLOCK) {
     return block_excl_scan<BLOCK>(v, S, tid, total);
   } else {
+    if constexpr (UL < 64) {  // several units per wave: segmented scan, no barrier
+      const int ls = tid % UL;
+      uint32_t x = v;
+#pragma unroll
+      for (int d = 1; d < UL; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, UL);
+        if (ls >= d) x += y;
+      }
+      total = __shfl(x, UL - 1, UL);
+      return x - v;
+    }
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t x = v;
 #pragma unroll
@@ -220,15 +236,15 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
       int n = (int)ceil(max_v * T / P.map.res);
       my_cnt = (uint32_t)(n + 1);
       S.dts[tid] = n > 0 ? T / n : 0.0;
-#pragma unroll
-      for (int ax = 0; ax < 3; ax++) {
-        double qc[NQ];
-        pack_q_c<CONTROL>(c[ax], qc);
-#pragma unroll
-        for (int k = 0; k < NQ; k++) S.q[ax * NQ + k][tid] = qc[k];
-      }
       L.valid = true;
     }
+  }
+  if (live_unit && lu < 3) {  // node part of the pre-divided coefficients of axis lu
+    double c0[6], qc[5];
+    prim_build_axis(CONTROL, S.cur[ku][lu], S.cur[ku][3 + lu], S.cur[ku][6 + lu], S.cur[ku][9 + lu], 0.0, c0);
+    pack_q_c<CONTROL>(c0, qc);
+#pragma unroll
+    for (int k = 1; k < NQ; k++) S.qn[ku][lu][k] = qc[k];
   }
   S.cnt_s[tid] = my_cnt;
   S.blk[tid] = 0xFFFFFFFFu;
@@ -276,8 +292,9 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
 #pragma unroll
         for (int ax = 0; ax < 3; ax++) {
           double qq[NQ];
+          qq[0] = S.uq[ax][p];
 #pragma unroll
-          for (int k = 0; k < NQ; k++) qq[k] = S.q[ax * NQ + k][pc];
+          for (int k = 1; k < NQ; k++) qq[k] = S.qn[ku][ax][k];
           cell[ax] = float_to_cell(pos_at_qc<CONTROL>(qq, t), P.map.origin[ax], P.map.res);
         }
         pp[r] = pc;
@@ -304,11 +321,24 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
   }
 }
 
+// control-input part of the pre-divided coefficients (per launch configuration)
+template <int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ void fill_uq(const SearchParams &P, SM &S, int tid) {
+  for (int i = tid; i < 3 * P.n_u; i += BLOCK) {
+    const int pi = i / 3, ax = i % 3;
+    double c0[6], qc[5];
+    prim_build_axis(CONTROL, 0.0, 0.0, 0.0, 0.0, P.U[3 * pi + ax], c0);
+    pack_q_c<CONTROL>(c0, qc);
+    S.uq[ax][pi] = qc[0];
+  }
+}
+
 // ------------------------------------------------------------------ expand_kernel (unit-test entry)
 template <int BLOCK, int CONTROL>
 __global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const State *nodes, const double *node_t, int K, SuccOut *out) {
-  __shared__ Smem<BLOCK, 3 * nq_c(CONTROL)> S;
+  __shared__ Smem<BLOCK> S;
   const int tid = threadIdx.x;
+  fill_uq<BLOCK, CONTROL>(P, S, tid);
   for (int k = blockIdx.x; k < K; k += gridDim.x) {
     if (tid < 12) S.cur[0][tid] = ((const double *)&nodes[k])[tid];
     if (tid == 12) S.cur[0][12] = node_t[k];
@@ -346,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const Sta
 }
 
 // ------------------------------------------------------------------ chunked pool access
-template <int BLOCK, int CONTROL, class SM = Smem<BLOCK, 3 * nq_c(CONTROL)>>
+template <int BLOCK, int CONTROL, class SM = Smem<BLOCK>>
 struct QView {
   const SearchParams &P;
   SM &S;
@@ -531,7 +561,7 @@ __device__ __forceinline__ void evict_half(const QView<BLOCK, CONTROL, SM> &Q, i
     }
     __syncthreads();
     // partition: every thread reads its strided entries, then the kept ones are re-packed
-    constexpr int PER = (NC + BLOCK - 1) / BLOCK;
+    constexpr int PER = (SM::NCAP + BLOCK - 1) / BLOCK;
     double ef[PER], eg[PER];
     uint32_t eid[PER], eix[PER];
     uint32_t keepmask = 0, nkeep = 0;
@@ -597,7 +627,7 @@ __device__ __forceinline__ void pull_bucket(const QView<BLOCK, CONTROL, SM> &Q, 
   __syncthreads();
   for (;;) {
     if (!block_any<BLOCK>(cur != NIL, S, tid)) break;
-    while (S.n_near + (uint32_t)NSUB > (uint32_t)NC) {
+    while (S.n_near + (uint32_t)NSUB > (uint32_t)SM::NCAP) {
       MPLX_TIC(te);
       evict_half(Q, tid);
       __syncthreads();
@@ -877,11 +907,12 @@ __device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL, SM> &Q, int 
 // ------------------------------------------------------------------ astar_kernel
 template <int BLOCK, int CONTROL>
 __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
-  __shared__ Smem<BLOCK, 3 * nq_c(CONTROL)> S;
+  __shared__ Smem<BLOCK> S;
   using V = QView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
+  fill_uq<BLOCK, CONTROL>(P, S, tid);
   for (;;) {
     if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
     __syncthreads();
@@ -899,7 +930,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
       S.node_chunks = S.edge_chunks = S.open_chunks = 0;
       S.cur1 = 0; S.cur0 = 0; S.lo1 = 0.0; S.ts_f = INFINITY; S.ts_g = INFINITY; S.ts_id = 0xFFFFFFFFu;
       S.status = -1;
-      for (int i = 0; i < 8; i++) S.cyc[i] = 0;
+      for (int i = 0; i < 10; i++) S.cyc[i] = 0;
       S.c_expanded = S.c_closed = S.c_prims = S.c_succ = S.c_succ_finite = S.c_reads = 0;
       S.c_push = S.c_reopen = S.c_refill = S.c_evict = 0;
       S.c_hash = 0;
@@ -965,7 +996,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
       __syncthreads();
       // ---- main loop
       for (;;) {
-        while (S.n_near + S.reserve > (uint32_t)NC) {
+        while (S.n_near + S.reserve > (uint32_t)NC) {  // Smem<BLOCK>::NCAP == NC here
           MPLX_TIC(te);
           evict_half(Q, tid);
           __syncthreads();
@@ -1102,7 +1133,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
       o.slot = blockIdx.x;
       o.t_begin = t_begin;
       o.t_end = wall_clock64();
-      for (int i = 0; i < 8; i++) o.cyc[i] = S.cyc[i];
+      for (int i = 0; i < 10; i++) o.cyc[i] = S.cyc[i];
     }
     for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)
       P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? S.node_tbl[i] : NIL;

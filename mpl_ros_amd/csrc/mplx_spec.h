@@ -29,8 +29,8 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int UL, int K, int CONTROL, int BTN>
-struct SmemSpec : Smem<UL * K, 3 * nq_c(CONTROL), K> {
+template <int UL, int K, int CONTROL, int BTN, int NCAP_>
+struct SmemSpec : Smem<UL * K, K, NCAP_> {
   static constexpr int BLOCK = UL * K, BT = BTN, NK = key_len_c(CONTROL);
   // candidates in pop order
   double cand_f[K], cand_g[K];
@@ -53,9 +53,6 @@ struct SmemSpec : Smem<UL * K, 3 * nq_c(CONTROL), K> {
   uint32_t n_sorted;  // near_[0, n_sorted) is in ascending order (left so by the previous selection)
   int32_t batch_dep;  // units interact through a shared state -> ordered, unit-by-unit commit
   int32_t cut_at;     // first candidate preceded by an entry pushed in this batch (K if none)
-  // wave-local top-K of the near set
-  double sel_f[UL * K / 64][K], sel_g[UL * K / 64][K];
-  uint32_t sel_id[UL * K / 64][K], sel_pos[UL * K / 64][K];
 };
 
 // Commit the successors of candidate `kc`; `active`: this lane commits now (all active lanes belong
@@ -175,16 +172,17 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
   }
 }
 
-template <int UL, int K, int CONTROL, int BTN>
+template <int UL, int K, int CONTROL, int BTN, int NCAP_>
 __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
   constexpr int BLOCK = UL * K;
-  using SM = SmemSpec<UL, K, CONTROL, BTN>;
+  using SM = SmemSpec<UL, K, CONTROL, BTN, NCAP_>;
   constexpr int BT = SM::BT;
   __shared__ SM S;
   using V = QView<BLOCK, CONTROL, SM>;
   const int tid = threadIdx.x, ku = tid / UL, lu = tid % UL;
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
+  fill_uq<BLOCK, CONTROL>(P, S, tid);
   for (;;) {
     if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
     __syncthreads();
@@ -203,7 +201,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       S.node_chunks = S.edge_chunks = S.open_chunks = 0;
       S.cur1 = 0; S.cur0 = 0; S.lo1 = 0.0; S.ts_f = INFINITY; S.ts_g = INFINITY; S.ts_id = 0xFFFFFFFFu;
       S.status = -1;
-      for (int i = 0; i < 8; i++) S.cyc[i] = 0;
+      for (int i = 0; i < 10; i++) S.cyc[i] = 0;
       S.c_expanded = S.c_closed = S.c_prims = S.c_succ = S.c_succ_finite = S.c_reads = 0;
       S.c_push = S.c_reopen = S.c_refill = S.c_evict = 0;
       S.c_hash = 0;
@@ -270,7 +268,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       __syncthreads();
       // ---- main loop: one batch of up to K expansions per iteration
       for (;;) {
-        while (S.n_near + S.reserve > (uint32_t)NC) {
+        while (S.n_near + S.reserve > (uint32_t)SM::NCAP) {
           MPLX_TIC(te);
           evict_half(Q, tid);
           if (tid == 0) S.n_sorted = 0;
@@ -327,7 +325,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           // leaves the near set sorted).  No serial section.
           const uint32_t n = S.n_near;
           const uint32_t kc = n < (uint32_t)K ? n : (uint32_t)K;
-          constexpr int PERT = (NC + BLOCK - 1) / BLOCK;
+          constexpr int PERT = (SM::NCAP + BLOCK - 1) / BLOCK;
           double ef[PERT], eg[PERT];
           uint32_t ei[PERT], ex[PERT], rk[PERT];
 #pragma unroll
@@ -667,7 +665,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           S.c_succ_finite += nfi;
           S.c_reads += nrd;
           S.cur_id = last;
-          if (!parallel_commit) S.cyc[3]++;  // batches that needed the unit-by-unit commit
+          if (!parallel_commit) S.cyc[8]++;  // batches that needed the unit-by-unit commit
         }
         // candidates behind a cut go back to OPEN untouched
         if (tid == 0 && S.status < 0) {
@@ -738,7 +736,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       o.slot = blockIdx.x;
       o.t_begin = t_begin;
       o.t_end = wall_clock64();
-      for (int i = 0; i < 8; i++) o.cyc[i] = S.cyc[i];
+      for (int i = 0; i < 10; i++) o.cyc[i] = S.cyc[i];
     }
     for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)
       P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? S.node_tbl[i] : NIL;

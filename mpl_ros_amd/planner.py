@@ -369,9 +369,9 @@ class VoxelMapPlanner:
 
     def queryCycles(self, q=0):
         ctx = self._ctx()
-        cyc = (C.c_uint64 * 8)()
+        cyc = (C.c_uint64 * 10)()
         ctx.check(ctx.lib.mplx_result_cycles(ctx.h, q, cyc))
-        return dict(zip(("pop", "expand", "commit", "evict", "refill", "activate", "ordered", "batches"), [int(x) for x in cyc[:8]]))
+        return dict(zip(("pop", "expand", "commit", "evict", "refill", "activate", "ordered", "batches", "dep_batches"), [int(x) for x in cyc[:9]]))
 
     # ---- results
     def getTrajCost(self):

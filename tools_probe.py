@@ -17,12 +17,12 @@ if which == 'single':
     for it in range(2):
         ok = pl.plan(util.gpu_wp(start), util.gpu_wp(goal)); r = pl.getResult()
         print('C2 ACC', ok, r.cost, r.n_expanded, 'kernel ms', pl.lastKernelMs(), 'us/exp', 1e3 * pl.lastKernelMs() / r.n_expanded, 'refill', r.n_refill, 'evict', r.n_evict)
-        cy = pl.queryCycles(); print('   cycles/exp', {k: round(v / r.n_expanded) for k, v in cy.items()}, 'exp/batch', round(r.n_expanded / max(cy.get('batches', 0), 1), 3))
+        cy = pl.queryCycles(); print('   cycles/exp', {k: round(v / r.n_expanded) for k, v in cy.items()}, 'exp/batch', round(r.n_expanded / max(cy.get('batches', 0), 1), 3), 'dep frac', round(cy.get('dep_batches', 0) / max(cy.get('batches', 0), 1), 3))
     U5 = mapgen.control_lattice(1.0, 2, True)
     mu, pl = util.make_gpu(grid, origin, res, U5, v_max=2.0, a_max=1.0, j_max=1.0, max_expand=20000, max_nodes=1 << 21, max_edges=1 << 23, max_log=1 << 22, spec=SPEC)
     ok = pl.plan(util.gpu_wp(start, control=orc.JRK), util.gpu_wp(goal, control=orc.JRK)); r = pl.getResult()
     print('C2 JRK cap20000', r.status, r.n_expanded, 'kernel ms', pl.lastKernelMs(), 'us/exp', 1e3 * pl.lastKernelMs() / r.n_expanded, 'refill', r.n_refill, 'evict', r.n_evict)
-    cy = pl.queryCycles(); print('   cycles/exp', {k: round(v / r.n_expanded) for k, v in cy.items()}, 'exp/batch', round(r.n_expanded / max(cy.get('batches', 0), 1), 3))
+    cy = pl.queryCycles(); print('   cycles/exp', {k: round(v / r.n_expanded) for k, v in cy.items()}, 'exp/batch', round(r.n_expanded / max(cy.get('batches', 0), 1), 3), 'dep frac', round(cy.get('dep_batches', 0) / max(cy.get('batches', 0), 1), 3))
 if which == 'batch':
     nq = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     slots = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
