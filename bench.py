@@ -48,7 +48,8 @@ def main():
     ap.add_argument("--queries", type=int, default=1024, help="queries per GPU per step")
     ap.add_argument("--map", type=int, default=512, help="voxel map edge length")
     ap.add_argument("--lattice", choices=["acc", "jrk"], default="acc")
-    ap.add_argument("--max-expand", type=int, default=0, help="per-query expansion cap (default: none for acc, 20000 for jrk)")
+    ap.add_argument("--max-expand", type=int, default=0,
+                    help="per-query expansion cap setMaxNum (default: 2 000 000 for acc = the BASELINE.md C3 cap, 20000 for jrk)")
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--max-nodes", type=int, default=0, help="mean states per query used to size the shared pools")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 disables)")
@@ -100,7 +101,9 @@ def main():
     # ---- planner: C4 parameters
     if control == ACC:
         U = mapgen.control_lattice(1.0, 1, True)
-        max_expand = args.max_expand if args.max_expand > 0 else -1
+        # BASELINE.md bounds wall time with max_num = 2 000 000 expansions (C3); the same cap is applied to
+        # the C4 queries: one of the 1024 random pairs has a goal that is not reachable within it
+        max_expand = args.max_expand if args.max_expand > 0 else 2_000_000
         per_q = args.max_nodes or 450_000  # mean states per query (tail up to ~2 M; the pools are shared)
         caps = dict(nodes=per_q * args.queries, edges=per_q * args.queries * 9 // 2, log=per_q * args.queries * 5 // 4)
         slots = args.slots or 1024
@@ -203,7 +206,7 @@ def main():
             "map_setup_s": {"generate": round(t_gen, 3), "broadcast": round(t_bcast, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "astar_spec_kernel<64,8,ACC,512>" if control == ACC else "astar_spec_kernel<128,2,JRK,512>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
+                         "kernel": "astar_spec_kernel<32,16,ACC>" if control == ACC else "astar_spec_kernel<128,2,JRK>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
                          "bytes_per_expansion": alg / max(n_exp, 1)},
         }
         # HBM traffic of the same launch from the committed rocprofv3 PMC passes (cannot be collected

@@ -13,7 +13,7 @@
 //      table" carries g / flags / newest-predecessor of every state touched by the batch from unit to
 //      unit, so a unit sees exactly the state space the sequential loop would have shown it.
 // The pop sequence, node ids, edge order and all results are therefore identical to the sequential
-// loop (and to astar_kernel); only wall time changes.  Measured on the CPU oracle, 99.9 % of popped
+// loop (and to astar_kernel); only wall time changes.  Measured on a CPU run of the same search, 99.9 % of popped
 // nodes were last touched >= 15 expansions earlier, so cuts are rare.
 #pragma once
 #include "mplx_kernels.h"

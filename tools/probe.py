@@ -1,7 +1,7 @@
 """Latency probe (GPU box): per-expansion latency of single queries and the batch schedule."""
-import sys, time, json
+import os, sys, time, json
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpl_ros_amd import mapgen
 from tests import util
 from oracle import orc
