@@ -132,7 +132,7 @@ int mplx_set_capacity(mplx_ctx *ctx, int32_t n_slots, uint64_t total_nodes, uint
 /* speculative multi-node expansion (results are identical either way): -1 auto (on when
  * n_u <= 128), 0 = sequential kernel (one node per iteration), 2 = on */
 int mplx_set_speculation(mplx_ctx *ctx, int32_t mode);
-/* f-width of one coarse OPEN bucket (0 = default 2*w*dt); the fine level divides it by 1024 */
+/* f-width of one coarse OPEN bucket (0 = default 8*w*dt); the fine level divides it by 1024 */
 int mplx_set_bucket_width(mplx_ctx *ctx, double width);
 
 /* ---- env_map::get_succ for K nodes in one launch (unit-testable kernel entry).

@@ -308,7 +308,7 @@ static void fill_params(const mplx_ctx *c, SearchParams &P) {
   P.U = c->dU;
   P.ucost = c->dUcost;
   P.map = map_dev(c);
-  P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt * 2.0 : 1.0);
+  P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt * 8.0 : 1.0);
 }
 
 template <typename T>

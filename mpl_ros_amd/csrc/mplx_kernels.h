@@ -57,7 +57,8 @@ struct Smem {
   double uq[3][BLOCK / KUNITS];  // q[0] of control input i per axis: U[i][ax] / {1, 2, 6, 24}
   double qn[KUNITS][3][5];       // q[1..] of the node per axis
   double dts[BLOCK];
-  uint8_t owner[KUNITS][KUNITS > 1 ? 640 : OWN];  // per expansion unit: primitive that owns flattened sample e
+  uint16_t owner[KUNITS][KUNITS > 1 ? 576 : OWN];  // per unit: flattened sample e -> (primitive << 8) | sample index
+  int32_t slow[KUNITS];  // unit has more samples than the owner map covers -> generic sample loop
   uint32_t cnt_s[BLOCK];  // samples per primitive (n+1), 0 if skipped
   uint32_t offs[KUNITS][BLOCK / KUNITS + 1];
   uint32_t blk[BLOCK];  // first blocked sample: (i << 1) | inside
@@ -206,6 +207,9 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
   constexpr int NQ = nq_c(CONTROL);
   const int ku = tid / UL, lu = tid % UL;
   const double T = P.dt;
+#ifdef MPLX_FINE_TIMERS
+  MPLX_TIC(tf0);
+#endif
   L.valid = false;
   L.blocked = false;
   L.reads = 0;
@@ -246,73 +250,123 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
 #pragma unroll
     for (int k = 1; k < NQ; k++) S.qn[ku][lu][k] = qc[k];
   }
+#ifdef MPLX_FINE_TIMERS
+  MPLX_TOC(S, 3, tf0);
+  MPLX_TIC(tf1);
+#endif
   S.cnt_s[tid] = my_cnt;
   S.blk[tid] = 0xFFFFFFFFu;
   uint32_t total;
   uint32_t off = unit_excl_scan<UL, BLOCK>(my_cnt, S, tid, total);
   S.offs[ku][lu] = off;
   if (lu == UL - 1) S.offs[ku][UL] = total;
-  // owner map: flattened sample e -> primitive (index inside the unit)
-  constexpr uint32_t OWNU = sizeof(S.owner[0]);
-  for (uint32_t i = 0; i < my_cnt && off + i < OWNU; i++) S.owner[ku][off + i] = (uint8_t)lu;
+  // owner map: flattened sample e -> (primitive, sample index); one LDS read replaces a search
+  constexpr uint32_t OWNU = sizeof(S.owner[0]) / sizeof(uint16_t);
+  if (lu == 0) S.slow[ku] = 0;
+  for (uint32_t i = 0; i < my_cnt && i < 256u && off + i < OWNU; i++) S.owner[ku][off + i] = (uint16_t)((lu << 8) | i);
   __syncthreads();
+  if (my_cnt > 256u || (lu == UL - 1 && total > OWNU)) S.slow[ku] = 1;
+  __syncthreads();
+#ifdef MPLX_FINE_TIMERS
+  MPLX_TOC(S, 5, tf1);
+  MPLX_TIC(tf2);
+#endif
   // phase 2: flattened (primitive, sample) pairs, UNR voxel loads in flight per lane
   const int8_t *__restrict__ map = P.map.data;
   const int dx = P.map.dim[0], dy = P.map.dim[1], dz = P.map.dim[2];
   constexpr int UNR = 6;
-  for (uint32_t e0 = lu; e0 < total; e0 += UL * UNR) {
-    int pp[UNR];
-    uint32_t ii[UNR];
-    int8_t vv[UNR];
-    bool inside[UNR], live[UNR];
+  if (!S.slow[ku]) {
+    // Staged over the UNR pairs of a lane (all LDS reads of a stage are independent, one wait per
+    // stage), branch-free: dead slots recompute the last live pair, outside cells read voxel 0, and
+    // both are masked when the result is recorded.
+    double qnr[3][NQ];  // node part of the coefficients: loop invariant
 #pragma unroll
-    for (int r = 0; r < UNR; r++) {
-      const uint32_t e = e0 + r * UL;
-      live[r] = e < total;
-      inside[r] = false;
-      vv[r] = 0;
-      pp[r] = 0;
-      ii[r] = 0;
-      if (live[r]) {
-        int p;
-        if (e < OWNU) {
-          p = S.owner[ku][e];
-        } else {
-          int lo = 0, hi = UL;  // largest p with offs[p] <= e
-          while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (S.offs[ku][mid] <= e) lo = mid; else hi = mid;
-          }
-          p = lo;
+    for (int ax = 0; ax < 3; ax++)
+#pragma unroll
+      for (int k = 1; k < NQ; k++) qnr[ax][k] = S.qn[ku][ax][k];
+    const double ox = P.map.origin[0], oy = P.map.origin[1], oz = P.map.origin[2], rs = P.map.res;
+    for (uint32_t e0 = lu; e0 < total; e0 += UL * UNR) {
+      uint32_t o[UNR];
+#pragma unroll
+      for (int r = 0; r < UNR; r++) {
+        const uint32_t e = e0 + r * UL;
+        o[r] = S.owner[ku][e < total ? e : total - 1];
+      }
+      double dtr[UNR], u0[UNR], u1[UNR], u2[UNR];
+#pragma unroll
+      for (int r = 0; r < UNR; r++) {
+        const int pl = (int)(o[r] >> 8);
+        dtr[r] = S.dts[ku * UL + pl];
+        u0[r] = S.uq[0][pl];
+        u1[r] = S.uq[1][pl];
+        u2[r] = S.uq[2][pl];
+      }
+      int32_t cx[UNR], cy[UNR], cz[UNR];
+#pragma unroll
+      for (int r = 0; r < UNR; r++) {
+        const double t = (double)(o[r] & 255u) * dtr[r];
+        double qq[NQ];
+#pragma unroll
+        for (int k = 1; k < NQ; k++) qq[k] = qnr[0][k];
+        qq[0] = u0[r];
+        cx[r] = float_to_cell(pos_at_qc<CONTROL>(qq, t), ox, rs);
+#pragma unroll
+        for (int k = 1; k < NQ; k++) qq[k] = qnr[1][k];
+        qq[0] = u1[r];
+        cy[r] = float_to_cell(pos_at_qc<CONTROL>(qq, t), oy, rs);
+#pragma unroll
+        for (int k = 1; k < NQ; k++) qq[k] = qnr[2][k];
+        qq[0] = u2[r];
+        cz[r] = float_to_cell(pos_at_qc<CONTROL>(qq, t), oz, rs);
+      }
+      int8_t vv[UNR];
+      bool inside[UNR];
+#pragma unroll
+      for (int r = 0; r < UNR; r++) {
+        inside[r] = !(cx[r] < 0 || cx[r] >= dx || cy[r] < 0 || cy[r] >= dy || cz[r] < 0 || cz[r] >= dz);
+        const int sx = min(max(cx[r], 0), dx - 1), sy = min(max(cy[r], 0), dy - 1), sz = min(max(cz[r], 0), dz - 1);
+        vv[r] = map[(size_t)sx + (size_t)dx * sy + (size_t)dx * dy * sz];  // always a valid address
+      }
+#pragma unroll
+      for (int r = 0; r < UNR; r++) {
+        if (e0 + r * UL < total) {
+          const int pc = ku * UL + (int)(o[r] >> 8);
+          const uint32_t i = o[r] & 255u;
+          if (!inside[r])
+            atomicMin(&S.blk[pc], i << 1);
+          else if (vv[r] > 0)
+            atomicMin(&S.blk[pc], (i << 1) | 1u);
         }
-        const uint32_t i = e - S.offs[ku][p];
-        const int pc = ku * UL + p;  // column of primitive p
-        const double t = (double)i * S.dts[pc];
-        int32_t cell[3];
-#pragma unroll
-        for (int ax = 0; ax < 3; ax++) {
-          double qq[NQ];
-          qq[0] = S.uq[ax][p];
-#pragma unroll
-          for (int k = 1; k < NQ; k++) qq[k] = S.qn[ku][ax][k];
-          cell[ax] = float_to_cell(pos_at_qc<CONTROL>(qq, t), P.map.origin[ax], P.map.res);
-        }
-        pp[r] = pc;
-        ii[r] = i;
-        inside[r] = !(cell[0] < 0 || cell[0] >= dx || cell[1] < 0 || cell[1] >= dy || cell[2] < 0 || cell[2] >= dz);
-        if (inside[r]) vv[r] = map[(size_t)cell[0] + (size_t)dx * cell[1] + (size_t)dx * dy * cell[2]];
       }
     }
-#pragma unroll
-    for (int r = 0; r < UNR; r++) {
-      if (live[r]) {
-        if (!inside[r])
-          atomicMin(&S.blk[pp[r]], ii[r] << 1);
-        else if (vv[r] > 0)
-          atomicMin(&S.blk[pp[r]], (ii[r] << 1) | 1u);
+  } else {
+    for (uint32_t e = lu; e < total; e += UL) {  // generic: search the primitive, any sample count
+      int lo = 0, hi = UL;  // largest p with offs[p] <= e
+      while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (S.offs[ku][mid] <= e) lo = mid; else hi = mid;
       }
+      const int pl = lo, pc = ku * UL + pl;
+      const uint32_t i = e - S.offs[ku][pl];
+      const double t = (double)i * S.dts[pc];
+      int32_t cell[3];
+#pragma unroll
+      for (int ax = 0; ax < 3; ax++) {
+        double qq[NQ];
+        qq[0] = S.uq[ax][pl];
+#pragma unroll
+        for (int k = 1; k < NQ; k++) qq[k] = S.qn[ku][ax][k];
+        cell[ax] = float_to_cell(pos_at_qc<CONTROL>(qq, t), P.map.origin[ax], P.map.res);
+      }
+      if (cell[0] < 0 || cell[0] >= dx || cell[1] < 0 || cell[1] >= dy || cell[2] < 0 || cell[2] >= dz)
+        atomicMin(&S.blk[pc], i << 1);
+      else if (map[(size_t)cell[0] + (size_t)dx * cell[1] + (size_t)dx * dy * cell[2]] > 0)
+        atomicMin(&S.blk[pc], (i << 1) | 1u);
     }
   }
+#ifdef MPLX_FINE_TIMERS
+  MPLX_TOC(S, 9, tf2);   // thread 0's own phase-2 work, before waiting for the other units
+#endif
   __syncthreads();
   if (L.valid) {
     uint32_t code = S.blk[tid];

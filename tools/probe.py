@@ -53,3 +53,12 @@ if which == 'batch':
     for frac in (0.1, 0.25, 0.5, 0.75, 0.9):
         tt = frac * T[:, 1].max()
         print('  t=%.2f running %d' % (tt, int(((T[:, 0] <= tt) & (T[:, 1] > tt)).sum())))
+if which == 'width':
+    grid, origin, res, start, goal, rng = mapgen.benchmark_map(256)
+    U = mapgen.control_lattice(1.0, 1, True)
+    for wmul in (2.0, 4.0, 8.0, 16.0, 32.0):
+        mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, max_nodes=1 << 22, max_edges=1 << 24, max_log=1 << 23, spec=SPEC)
+        pl.setBucketWidth(10.0 * wmul)
+        ok = pl.plan(util.gpu_wp(start), util.gpu_wp(goal)); r = pl.getResult()
+        cy = pl.queryCycles()
+        print('width', 10.0 * wmul, 'us/exp', round(1e3 * pl.lastKernelMs() / r.n_expanded, 3), 'refill', r.n_refill, 'evict', r.n_evict, {k: round(v / r.n_expanded) for k, v in cy.items() if k in ('pop', 'expand', 'commit', 'ordered', 'refill', 'evict')}, 'exp/batch', round(r.n_expanded / max(cy['batches'], 1), 2), r.n_expanded)
