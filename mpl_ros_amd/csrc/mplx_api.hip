@@ -32,6 +32,7 @@ struct mplx_ctx {
   // map
   int8_t *map = nullptr;
   bool own_map = false;
+  uint32_t *bricks = nullptr;  // bit-packed occupancy in 8^3 bricks, rebuilt whenever the grid changes
   int32_t dim[3] = {0, 0, 0};
   double origin[3] = {0, 0, 0};
   double res = 0;
@@ -126,6 +127,7 @@ extern "C" void mplx_ctx_destroy(mplx_ctx *c) {
   free_pools(c);
   free_batch(c);
   if (c->own_map) (void)hipFree(c->map);
+  (void)hipFree(c->bricks);
   (void)hipFree(c->dU);
   (void)hipFree(c->dUcost);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -150,6 +152,7 @@ extern "C" int mplx_set_stream(mplx_ctx *c, void *s) {
 }
 
 // ------------------------------------------------------------------ map
+static int build_bricks(mplx_ctx *c);
 static int set_map_meta(mplx_ctx *c, const int32_t dim[3], const double origin[3], double res) {
   if (!dim || !origin || dim[0] <= 0 || dim[1] <= 0 || dim[2] <= 0 || !(res > 0)) return fail(c, MPLX_ERR_ARG, "bad map geometry");
   for (int i = 0; i < 3; i++) {
@@ -171,7 +174,7 @@ extern "C" int mplx_map_set(mplx_ctx *c, const int8_t *data, const int32_t dim[3
   HIPCHK(c, hipMalloc((void **)&c->map, n));
   HIPCHK(c, hipMemcpyAsync(c->map, data, n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return MPLX_OK;
+  return build_bricks(c);
 }
 extern "C" int mplx_map_set_device(mplx_ctx *c, const void *dptr, const int32_t dim[3], const double origin[3], double res) {
   if (!c || !dptr) return fail(c, MPLX_ERR_ARG, "null argument");
@@ -181,7 +184,7 @@ extern "C" int mplx_map_set_device(mplx_ctx *c, const void *dptr, const int32_t 
   if (c->own_map) (void)hipFree(c->map);
   c->map = (int8_t *)dptr;
   c->own_map = false;
-  return MPLX_OK;
+  return build_bricks(c);  // the caller guarantees the buffer is complete (e.g. broadcast + synchronize done)
 }
 extern "C" int mplx_map_free_unknown(mplx_ctx *c) {
   if (!c || !c->map) return fail(c, MPLX_ERR_ARG, "no map");
@@ -209,9 +212,24 @@ extern "C" int mplx_map_info(const mplx_ctx *c, int32_t dim[3], double origin[3]
   if (res) *res = c->res;
   return MPLX_OK;
 }
+// (re)build the bricked occupancy bitmap from the byte grid
+static int build_bricks(mplx_ctx *c) {
+  const int nb0 = (c->dim[0] + 7) / 8, nb1 = (c->dim[1] + 7) / 8, nb2 = (c->dim[2] + 7) / 8;
+  (void)hipFree(c->bricks);
+  c->bricks = nullptr;
+  const size_t nwords = (size_t)nb0 * nb1 * nb2 * 16;
+  HIPCHK(c, hipMalloc((void **)&c->bricks, nwords * sizeof(uint32_t)));
+  hipLaunchKernelGGL(brick_pack_kernel, dim3(4096), dim3(256), 0, c->stream, c->map, c->dim[0], c->dim[1], c->dim[2], nb0, nb1, nb2, c->bricks);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+
 static MapDev map_dev(const mplx_ctx *c) {
   MapDev m;
   m.data = c->map;
+  m.bricks = c->bricks;
+  m.nb[0] = (c->dim[0] + 7) / 8; m.nb[1] = (c->dim[1] + 7) / 8; m.nb[2] = (c->dim[2] + 7) / 8;
   for (int i = 0; i < 3; i++) {
     m.dim[i] = c->dim[i];
     m.origin[i] = c->origin[i];

@@ -33,8 +33,12 @@ constexpr int rec_hot_bytes(int control) { return control == CTRL_SNP ? 80 : 64;
 constexpr int rec_bytes(int control) { return control == CTRL_SNP ? 192 : control == CTRL_JRK ? 160 : 128; }
 
 struct MapDev {
-  const int8_t *data;
+  const int8_t *data;      // the caller's grid, x fastest (MapUtil layout)
+  const uint32_t *bricks;  // occupancy (value > 0) bit-packed in 8x8x8 bricks of 64 B: brick (bx,by,bz) at
+                           // bx + nb0*(by + nb1*bz), bit (x&7) + 8*(y&7) + 64*(z&7); 1/8 of the bytes, and the
+                           // <= 1-voxel steps of a primitive's samples mostly stay inside one 64 B line
   int32_t dim[3];
+  int32_t nb[3];           // bricks per axis
   double origin[3];
   double res;
 };

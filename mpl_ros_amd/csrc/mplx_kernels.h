@@ -167,7 +167,7 @@ __device__ __forceinline__ uint32_t unit_excl_scan(uint32_t v, SM &S, int tid, u
     } else {
       if (lane == 63) S.wsum[wave] = x;
       __syncthreads();
-      constexpr int WPU = UL / 64;
+      constexpr int WPU = UL / 64 > 0 ? UL / 64 : 1;
       const int w0 = (wave / WPU) * WPU;
       uint32_t base = 0, tot = 0;
 #pragma unroll
@@ -273,7 +273,9 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
 #endif
   // phase 2: flattened (primitive, sample) pairs, UNR voxel loads in flight per lane
   const int8_t *__restrict__ map = P.map.data;
+  const uint32_t *__restrict__ bricks = P.map.bricks;
   const int dx = P.map.dim[0], dy = P.map.dim[1], dz = P.map.dim[2];
+  const int nb0 = P.map.nb[0], nb1 = P.map.nb[1];
   constexpr int UNR = 6;
   if (!S.slow[ku]) {
     // Staged over the UNR pairs of a lane (all LDS reads of a stage are independent, one wait per
@@ -319,13 +321,16 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
         qq[0] = u2[r];
         cz[r] = float_to_cell(pos_at_qc<CONTROL>(qq, t), oz, rs);
       }
-      int8_t vv[UNR];
+      int32_t vv[UNR];
       bool inside[UNR];
 #pragma unroll
       for (int r = 0; r < UNR; r++) {
         inside[r] = !(cx[r] < 0 || cx[r] >= dx || cy[r] < 0 || cy[r] >= dy || cz[r] < 0 || cz[r] >= dz);
         const int sx = min(max(cx[r], 0), dx - 1), sy = min(max(cy[r], 0), dy - 1), sz = min(max(cz[r], 0), dz - 1);
-        vv[r] = map[(size_t)sx + (size_t)dx * sy + (size_t)dx * dy * sz];  // always a valid address
+        // occupancy bit from the bricked bitmap (always a valid address)
+        const size_t brick = (size_t)(sx >> 3) + (size_t)nb0 * ((size_t)(sy >> 3) + (size_t)nb1 * (size_t)(sz >> 3));
+        const uint32_t bit = (uint32_t)(sx & 7) | ((uint32_t)(sy & 7) << 3) | ((uint32_t)(sz & 7) << 6);
+        vv[r] = (int32_t)((bricks[brick * 16 + (bit >> 5)] >> (bit & 31u)) & 1u);
       }
 #pragma unroll
       for (int r = 0; r < UNR; r++) {
@@ -1196,6 +1201,23 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
 }
 
 // ------------------------------------------------------------------ small utility kernels
+// occupancy bitmap in 8x8x8 bricks; one thread per 32-bit word (4 rows of 8 voxels)
+__global__ void brick_pack_kernel(const int8_t *map, int dx, int dy, int dz, int nb0, int nb1, int nb2, uint32_t *bricks) {
+  const size_t nwords = (size_t)nb0 * nb1 * nb2 * 16;
+  for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = w >> 4;
+    const int wi = (int)(w & 15);
+    const int bx = (int)(b % nb0), by = (int)((b / nb0) % nb1), bz = (int)(b / ((size_t)nb0 * nb1));
+    uint32_t word = 0;
+    for (int k = 0; k < 32; k++) {
+      const int bit = wi * 32 + k;
+      const int x = bx * 8 + (bit & 7), y = by * 8 + ((bit >> 3) & 7), z = bz * 8 + (bit >> 6);
+      if (x < dx && y < dy && z < dz && map[(size_t)x + (size_t)dx * y + (size_t)dx * dy * z] > 0) word |= 1u << k;
+    }
+    bricks[w] = word;
+  }
+}
+
 __global__ void free_unknown_kernel(int8_t *map, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t stride = (size_t)gridDim.x * blockDim.x;
