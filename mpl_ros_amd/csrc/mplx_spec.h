@@ -52,6 +52,7 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   int32_t u_cut[K];   // first later candidate preceded by an entry unit k pushes (K if none)
   uint32_t n_sorted;  // near_[0, n_sorted) is in ascending order (left so by the previous selection)
   int32_t batch_dep;  // units interact through a shared state -> ordered, unit-by-unit commit
+  int32_t dep_cause;  // (debug statistics) 1 shared successor, 2 candidate is a successor, 4 a sharer modifies the state
   int32_t cut_at;     // first candidate preceded by an entry pushed in this batch (K if none)
 };
 
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           S.n_cand = 0;
           S.cut_at = K;
           S.batch_dep = 0;
+          S.dep_cause = 0;
         }
         if (tid < K) {
           S.cand_live[tid] = 0;
@@ -467,6 +469,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             if (!eq) S.status = 5;                                    // 64-bit key-hash collision inside a batch
             if ((int)(leader / UL) == ku) S.unit_seq[ku] = 1;       // two lanes of one unit, one key
             S.batch_dep = 1;                                          // a state reached from two lanes of the batch
+#ifdef MPLX_DEP_STATS
+            atomicOr(&S.dep_cause, 1);
+#endif
           } else {
             const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
             const size_t mask = (size_t)P.table_mask;
@@ -532,7 +537,14 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           for (;;) {
             const unsigned long long o = S.bt_hash[sl];
             if (o == 0ull) break;
-            if (o == hv) { S.cur_slot[ku] = (uint32_t)sl; S.batch_dep = 1; break; }
+            if (o == hv) {
+              S.cur_slot[ku] = (uint32_t)sl;
+              S.batch_dep = 1;
+#ifdef MPLX_DEP_STATS
+              atomicOr(&S.dep_cause, 2);
+#endif
+              break;
+            }
             sl = (sl + 1) & (BT - 1);
           }
         }
@@ -555,12 +567,27 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             }
           // valid when no state of the batch is shared between lanes (bt_g still is the fetched value)
           if (pre.cut < K && pre.tg < S.bt_g[my_slot]) atomicMin(&S.u_cut[ku], pre.cut);
+#ifdef MPLX_DEP_STATS
+          if (pre.tg < S.bt_g[my_slot]) S.bt_dirty[my_slot] = 2;  // some sharer modifies this state
+#endif
         }
         MPLX_TOC(S, 2, tc);
         if (S.status >= 0) break;
         // ---- 3. ordered commit
         MPLX_TIC(to);
         lds_barrier();  // the per-unit cut points (atomicMin above) are complete
+#ifdef MPLX_DEP_STATS
+        if (act && S.bt_leader[my_slot] != (uint32_t)tid && S.bt_dirty[my_slot] == 2) atomicOr(&S.dep_cause, 4);
+        lds_barrier();
+        if (tid == 0) {
+          const int dc = S.dep_cause;
+          if (dc & 1) S.cyc[3]++;
+          if (dc & 2) S.cyc[5]++;
+          if (dc & 4) S.cyc[9]++;
+        }
+        for (int i = tid; i < BT; i += BLOCK) S.bt_dirty[i] = 0;
+        lds_barrier();
+#endif
         int k_stop = n_cand, n_commit = 0;
         const unsigned long long expanded0 = S.c_expanded;
         uint32_t pend_idx = NIL, pend_old = NIL;  // far-bucket link whose atomicExch is still in flight
