@@ -595,8 +595,10 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
     launch_spec<32, 16, 1024, 1024>(P.control, slots, c->stream, P); // 16 units, two per wave
   } else if (spec && P.n_u <= 64) {
     launch_spec<64, 4, 512, 512>(P.control, slots, c->stream, P);
-  } else if (spec) {
+  } else if (spec && c->speculation == 2) {
     launch_spec<128, 2, 512, 512>(P.control, slots, c->stream, P);   // 2 expansion units of two waves each
+  } else if (spec) {
+    launch_spec<128, 4, 1024, 1024>(P.control, slots, c->stream, P); // 4 expansion units of two waves each
   } else {
     switch (pick_block(P.n_u)) {
       case 64: launch_astar<64>(P.control, slots, c->stream, P); break;
