@@ -452,3 +452,54 @@ class VoxelMapPlanner:
         isg = np.zeros(n, dtype=np.int32)
         ctx.check(ctx.lib.mplx_heuristic_batch(ctx.h, n, S, C.byref(g), h.ctypes.data, isg.ctypes.data))
         return h, isg
+
+
+# ---------------------------------------------------------------------------------------------
+# 2-D planners (OccMapUtil / OccMapPlanner, used by distance_map_planner_node.cpp:56,146-156):
+# the 2-D lattice is the 3-D path with z frozen -- one layer of voxels whose centre plane is z = 0,
+# control inputs (ux, uy, 0).  Every z term of the polynomial, key, cost and heuristic arithmetic is
+# an exact +0.0, so states, keys, costs and the expansion order equal those of a genuinely 2-D run.
+class Waypoint2D(Waypoint3D):
+    """Waypoint<2>: only the first two components of pos/vel/acc/jrk are meaningful."""
+
+    def __init__(self, control=0):
+        super().__init__(control)
+
+    def to_c(self):
+        for a in (self.pos, self.vel, self.acc, self.jrk):
+            if len(a) == 2:
+                a.resize(3, refcheck=False)
+            a[2] = 0.0
+        return super().to_c()
+
+
+class OccMapUtil(VoxelMapUtil):
+    """MapUtil<2>: setMap(ori (2), dim (2), data, res)."""
+
+    def setMap(self, ori, dim, data, res):
+        res = float(res)
+        super().setMap((float(ori[0]), float(ori[1]), -0.5 * res), (int(dim[0]), int(dim[1]), 1), data, res)
+
+    def getDim(self):
+        return super().getDim()[:2]
+
+    def getOrigin(self):
+        return super().getOrigin()[:2]
+
+    def query(self, pts):
+        p = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)
+        cells, st = super().query(np.hstack([p, np.zeros((p.shape[0], 1))]))
+        return cells[:, :2], st
+
+
+class OccMapPlanner(VoxelMapPlanner):
+    """PlannerBase<2, Waypoint2D> + MapPlanner<2>."""
+
+    def setU(self, U):
+        U = np.asarray(U, dtype=np.float64)
+        U = U.reshape(-1, U.shape[-1])
+        if U.shape[1] == 2:
+            U = np.hstack([U, np.zeros((U.shape[0], 1))])
+        if np.any(U[:, 2] != 0):
+            raise ValueError("OccMapPlanner needs planar control inputs")
+        super().setU(U)

@@ -208,3 +208,40 @@ def test_near_far_open_structure_under_pressure(spec):
         mu, pl = util.make_gpu(grid, origin, res, U, spec=spec, **kw)
         pl.setBucketWidth(width)
         util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0)), ((5.55, 5.55, 5.05),), orc.ACC)
+
+
+def test_occ_map_planner_2d():
+    """OccMapPlanner (2-D) = the 3-D path with z frozen; checked against the oracle on the same embedding."""
+    from mpl_ros_amd.planner import OccMapPlanner, OccMapUtil, Waypoint2D
+    rng = np.random.default_rng(8)
+    g2 = np.zeros((120, 160), dtype=np.int8)  # (dy, dx)
+    for _ in range(60):
+        x, y, w, h = rng.integers(5, 150), rng.integers(5, 110), rng.integers(2, 10), rng.integers(2, 10)
+        g2[y:y + h, x:x + w] = 100
+    g2[5:15, 5:15] = 0
+    g2[100:112, 140:152] = 0
+    res, origin2 = 0.1, (0.0, 0.0)
+    U = mapgen.control_lattice(1.0, 1, False)  # 9 planar inputs (map_planner_node.cpp:116-118)
+    mu = OccMapUtil()
+    mu.setMap(origin2, (160, 120), g2.ravel(), res)
+    pl = OccMapPlanner(False)
+    pl.setMapUtil(mu)
+    pl.setVmax(2.0); pl.setAmax(1.0); pl.setDt(1.0); pl.setTol(0.5)
+    pl.setU(U[:, :2])
+    pl.setCapacity(1, 1 << 20, 1 << 22, 1 << 21)
+    s, g = Waypoint2D(orc.ACC), Waypoint2D(orc.ACC)
+    s.pos[:2] = (1.05, 1.05)
+    g.pos[:2] = (14.55, 10.55)
+    ok = pl.plan(s, g)
+    r = pl.getResult()
+    P = util.make_oracle(g2.reshape(1, 120, 160), (0.0, 0.0, -0.05), res, orc.ACC, U, v_max=2.0, a_max=1.0, tol_pos=0.5)
+    st = P.plan(orc.waypoint((1.05, 1.05, 0.0)), orc.waypoint((14.55, 10.55, 0.0)))
+    ids_o, _ = P.expanded()
+    assert ok == (st == 0) and r.status == st
+    assert r.n_expanded == len(ids_o) and r.expand_hash == util.expand_hash(ids_o)
+    assert r.cost == P.traj_cost
+    tr = pl.getTraj()
+    assert np.array_equal(tr.actions, P.traj()["actions"])
+    assert all(w.pos[2] == 0.0 and w.vel[2] == 0.0 for w in tr.getWaypoints())
+    cells, state = mu.query([(1.05, 1.05), (0.0, 0.0), (16.5, 3.0)])
+    assert tuple(cells[0]) == (10, 10) and state[0] == 0 and state[1] == 3 and state[2] == 3
