@@ -1,0 +1,80 @@
+// The reference driver mpl_test_node/src/map_planner_node.cpp:63-214 without ROS: same calls against
+// the mplx shim headers (read map, setMap, freeUnknown, control set with the accumulate-by-du loops,
+// start/goal Waypoint3D via use_* flags, planner setters, plan(), getTraj(), getCloseSet()).
+// usage: map_planner_driver <map.bin> dx dy dz ox oy oz res sx sy sz svx svy svz gx gy gz
+// Prints one JSON line that tests/test_cpp_shim.py compares with the oracle.
+#include <mpl_planner/planner/map_planner.h>
+
+#include <cstdlib>
+#include <fstream>
+
+int main(int argc, char **argv) {
+  if (argc < 18) { printf("usage\n"); return 2; }
+  const int dx = atoi(argv[2]), dy = atoi(argv[3]), dz = atoi(argv[4]);
+  const Vec3f ori(atof(argv[5]), atof(argv[6]), atof(argv[7]));
+  const decimal_t res = atof(argv[8]);
+  std::vector<signed char> map((size_t)dx * dy * dz);
+  std::ifstream f(argv[1], std::ios::binary);
+  f.read((char *)map.data(), map.size());
+
+  // Initialize map util
+  std::shared_ptr<MPL::VoxelMapUtil> map_util(new MPL::VoxelMapUtil);
+  try {
+    map_util->setMap(ori, Vec3i(dx, dy, dz), map, res);
+  } catch (const std::exception &e) {
+    printf("{\"error\": \"%s\"}\n", e.what());
+    return 3;
+  }
+  // Free unknown space
+  map_util->freeUnknown();
+
+  // Initialize planner
+  double dt = 1.0, v_max = 2.0, a_max = 1.0, u = 1.0;
+  int num = 1;
+  // Set control input
+  vec_E<VecDf> U;
+  const decimal_t du = u / num;
+  for (decimal_t ddx = -u; ddx <= u; ddx += du)
+    for (decimal_t ddy = -u; ddy <= u; ddy += du)
+      for (decimal_t ddz = -u; ddz <= u; ddz += du) U.push_back(Vec3f(ddx, ddy, ddz));
+
+  // Set start and goal
+  Waypoint3D start;
+  start.pos = Vec3f(atof(argv[9]), atof(argv[10]), atof(argv[11]));
+  start.vel = Vec3f(atof(argv[12]), atof(argv[13]), atof(argv[14]));
+  start.acc = Vec3f(0, 0, 0);
+  start.jrk = Vec3f(0, 0, 0);
+  start.yaw = 0;
+  start.use_pos = true;
+  start.use_vel = true;
+  start.use_acc = false;
+  start.use_jrk = false;
+  start.use_yaw = false;
+
+  Waypoint3D goal(start.control);  // initialized with the same control as start
+  goal.pos = Vec3f(atof(argv[15]), atof(argv[16]), atof(argv[17]));
+  goal.vel = Vec3f(0, 0, 0);
+  goal.acc = Vec3f(0, 0, 0);
+  goal.jrk = Vec3f(0, 0, 0);
+
+  std::unique_ptr<MPL::VoxelMapPlanner> planner_ptr;
+  planner_ptr.reset(new MPL::VoxelMapPlanner(false));
+  planner_ptr->setMapUtil(map_util);  // Set collision checking function
+  planner_ptr->setVmax(v_max);        // Set max velocity
+  planner_ptr->setAmax(a_max);        // Set max acceleration (as control input)
+  planner_ptr->setYawmax(-1);         // Set yaw threshold
+  planner_ptr->setDt(dt);             // Set dt for each primitive
+  planner_ptr->setU(U);               // Set control input
+  planner_ptr->setTol(0.5);           // Tolerance for goal region
+
+  bool valid = planner_ptr->plan(start, goal);
+  auto traj = planner_ptr->getTraj();
+  printf("{\"valid\": %s, \"closed\": %zu, \"expanded\": %zu, \"cost\": %.17g, \"total_time\": %.17g, \"n_prim\": %zu, \"waypoints\": [",
+         valid ? "true" : "false", planner_ptr->getCloseSet().size(), planner_ptr->getExpandedNum(),
+         valid ? planner_ptr->getTrajCost() : -1.0, traj.getTotalTime(), traj.getPrimitives().size());
+  auto ws = traj.getWaypoints();
+  for (size_t i = 0; i < ws.size(); i++)
+    printf("%s[%.17g, %.17g, %.17g, %.17g, %.17g, %.17g]", i ? ", " : "", ws[i].pos(0), ws[i].pos(1), ws[i].pos(2), ws[i].vel(0), ws[i].vel(1), ws[i].vel(2));
+  printf("], \"free_start\": %s}\n", map_util->isFree(start.pos) ? "true" : "false");
+  return 0;
+}

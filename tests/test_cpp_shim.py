@@ -1,0 +1,64 @@
+"""The C++ host side (include/mpl_shim: the MPL class names over the C-ABI).
+
+tests/cpp/map_planner_driver.cpp repeats the reference driver map_planner_node.cpp:63-214 call for call.
+CPU: it compiles against the shim headers and links libmplx.so, and fails loudly without a GPU.
+GPU: on the reference's skir map + launch query it reproduces the oracle's plan."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "mpl_ros_amd", "csrc")
+
+
+def build_driver(tmp_path):
+    exe = str(tmp_path / "map_planner_driver")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "include", "mpl_shim"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "map_planner_driver.cpp"),
+                           os.path.join(LIBDIR, "libmplx.so"), "-Wl,-rpath," + LIBDIR])
+    return exe
+
+
+def skir_args(tmp_path, skir):
+    grid, origin, res = skir
+    path = str(tmp_path / "skir.bin")
+    grid.tofile(path)
+    dz, dy, dx = grid.shape
+    return [path, str(dx), str(dy), str(dz)] + [repr(float(o)) for o in origin] + [repr(res)] + \
+           ["5.5", "5.5", "0.5", "1.0", "0.0", "0.0", "1.5", "1.5", "5.5"]
+
+
+def test_shim_compiles_links_and_fails_loudly_without_gpu(tmp_path, skir):
+    import torch
+    exe = build_driver(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    out = subprocess.run([exe] + skir_args(tmp_path, skir), capture_output=True, text=True)
+    assert out.returncode == 3 and "no HIP device" in out.stdout
+
+
+@pytest.mark.gpu
+def test_reference_driver_through_the_shim(tmp_path, skir):
+    from mpl_ros_amd import mapgen
+    from oracle import orc
+    from tests import util
+    exe = build_driver(tmp_path)
+    out = subprocess.run([exe] + skir_args(tmp_path, skir), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    grid, origin, res = skir
+    P = util.make_oracle(grid, origin, res, orc.ACC, mapgen.control_lattice(1.0, 1, True), v_max=2.0, a_max=1.0, tol_pos=0.5)
+    st = P.plan(orc.waypoint((5.5, 5.5, 0.5), vel=(1, 0, 0)), orc.waypoint((1.5, 1.5, 5.5)))
+    assert st == 0 and r["valid"] and r["free_start"]
+    assert r["closed"] == P.num_closed() and r["expanded"] == len(P.expanded()[0])
+    assert r["cost"] == P.traj_cost
+    tr = P.traj()
+    assert r["n_prim"] == tr["n"] and r["total_time"] == float(tr["n"])
+    # joints re-evaluated from the returned primitives: start of each segment is the stored parent state
+    for w, wo in zip(r["waypoints"][:-1], tr["wps"][:-1]):
+        assert w == list(wo.pos) + list(wo.vel)
+    assert np.allclose(r["waypoints"][-1][:3], list(tr["wps"][-1].pos), atol=1e-2)  # node merge quantisation
