@@ -136,6 +136,20 @@ __device__ __forceinline__ bool block_any(bool p, SM &S, int tid) {
   }
 }
 
+// Synchronise the lanes of one expansion unit.  A unit of <= 64 lanes lives inside one wave, whose
+// LDS operations execute in program order: ordering them is enough and no workgroup barrier is
+// needed, so units never wait for each other inside the expansion.  Larger units span waves.
+template <int UL>
+__device__ __forceinline__ void unit_sync() {
+  if constexpr (UL <= 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
 // exclusive scan inside an expansion unit of UL lanes (a unit is UL/64 consecutive waves); every
 // thread of the workgroup must call it (one workgroup barrier when a unit spans several waves)
 template <int UL, int BLOCK, class SM>
@@ -264,9 +278,9 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
   constexpr uint32_t OWNU = sizeof(S.owner[0]) / sizeof(uint16_t);
   if (lu == 0) S.slow[ku] = 0;
   for (uint32_t i = 0; i < my_cnt && i < 256u && off + i < OWNU; i++) S.owner[ku][off + i] = (uint16_t)((lu << 8) | i);
-  __syncthreads();
+  unit_sync<UL>();
   if (my_cnt > 256u || (lu == UL - 1 && total > OWNU)) S.slow[ku] = 1;
-  __syncthreads();
+  unit_sync<UL>();
 #ifdef MPLX_FINE_TIMERS
   MPLX_TOC(S, 5, tf1);
   MPLX_TIC(tf2);
@@ -372,7 +386,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
 #ifdef MPLX_FINE_TIMERS
   MPLX_TOC(S, 9, tf2);   // thread 0's own phase-2 work, before waiting for the other units
 #endif
-  __syncthreads();
+  unit_sync<UL>();
   if (L.valid) {
     uint32_t code = S.blk[tid];
     L.blocked = code != 0xFFFFFFFFu;

@@ -402,13 +402,13 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             }
           }
         }
-        __syncthreads();
+        unit_sync<UL>();
         if (live_unit && lu == 0) {  // goal test of the candidate (applied when, and if, it is committed)
           State sgoal;
           for (int i = 0; i < 12; i++) ((double *)&sgoal)[i] = S.cur[ku][i];
           S.u_goal[ku] = (S.cur[ku][12] >= P.t_max || is_goal_state(sgoal, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) ? 1 : 0;
         }
-        __syncthreads();
+        unit_sync<UL>();
         MPLX_TOC(S, 0, tp);
         // ---- 2b. expand all live units concurrently
         MPLX_TIC(tx);
