@@ -14,8 +14,8 @@
 #include <string>
 #include <vector>
 
+#define MPLX_UTILITY_KERNELS
 #include "mplx_kernels.h"
-#include "mplx_spec.h"
 
 using namespace mplx;
 
@@ -430,15 +430,9 @@ static void launch_expand(int control, int grid, hipStream_t s, const SearchPara
   }
 }
 
-// speculative kernel: built for the ACC and JRK state kinds (the reference's lattices); BTN = batch
-// table slots >= 2 x (K x n_u)
-template <int UL, int K, int BTN, int NCAP>
-static void launch_spec(int control, int grid, hipStream_t s, const SearchParams &P) {
-  if (control == CTRL_ACC)
-    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_ACC, BTN, NCAP>), dim3(grid), dim3(UL * K), 0, s, P);
-  else
-    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_JRK, BTN, NCAP>), dim3(grid), dim3(UL * K), 0, s, P);
-}
+// speculative kernels live in their own translation unit (mplx_spec_launch.hip) so the two halves of
+// the device code compile in parallel; returns false when no variant fits (control kind / lattice size)
+bool mplx_launch_spec(int speculation, int grid, hipStream_t s, const mplx::SearchParams &P);
 
 static int check_ready(mplx_ctx *c) {
   if (!c) return MPLX_ERR_ARG;
@@ -587,19 +581,8 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   HIPCHK(c, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), c->stream));
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-  const bool spec_ok = (P.control == CTRL_ACC || P.control == CTRL_JRK) && P.n_u <= 128;
-  const bool spec = spec_ok && (c->speculation < 0 || c->speculation > 1);
-  if (spec && P.n_u <= 32 && c->speculation == 8) {
-    launch_spec<64, 8, 512, 512>(P.control, slots, c->stream, P);    // 8 expansion units of one wave each
-  } else if (spec && P.n_u <= 32) {
-    launch_spec<32, 16, 1024, 1024>(P.control, slots, c->stream, P); // 16 units, two per wave
-  } else if (spec && P.n_u <= 64) {
-    launch_spec<64, 4, 512, 512>(P.control, slots, c->stream, P);
-  } else if (spec && c->speculation == 2) {
-    launch_spec<128, 2, 512, 512>(P.control, slots, c->stream, P);   // 2 expansion units of two waves each
-  } else if (spec) {
-    launch_spec<128, 4, 1024, 1024>(P.control, slots, c->stream, P); // 4 expansion units of two waves each
-  } else {
+  const bool spec = c->speculation < 0 || c->speculation > 1;
+  if (!(spec && mplx_launch_spec(c->speculation, slots, c->stream, P))) {
     switch (pick_block(P.n_u)) {
       case 64: launch_astar<64>(P.control, slots, c->stream, P); break;
       case 128: launch_astar<128>(P.control, slots, c->stream, P); break;

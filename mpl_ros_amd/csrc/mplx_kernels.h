@@ -1214,7 +1214,8 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
   }
 }
 
-// ------------------------------------------------------------------ small utility kernels
+// ------------------------------------------------------------------ small utility kernels (one translation unit only)
+#ifdef MPLX_UTILITY_KERNELS
 // occupancy bitmap in 8x8x8 bricks; one thread per 32-bit word (4 rows of 8 voxels)
 __global__ void brick_pack_kernel(const int8_t *map, int dx, int dy, int dz, int nb0, int nb1, int nb2, uint32_t *bricks) {
   const size_t nwords = (size_t)nb0 * nb1 * nb2 * 16;
@@ -1265,5 +1266,7 @@ __global__ void heuristic_kernel(SearchParams P, HeurParams hp, int n, const Sta
   h[i] = get_heur(hp, P.control, states[i], key, nk);
   isg[i] = (ts[i] >= P.t_max || is_goal_state(states[i], hp.goal, hp.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) ? 1 : 0;
 }
+
+#endif  // MPLX_UTILITY_KERNELS
 
 }  // namespace mplx
