@@ -48,12 +48,16 @@ def main():
     ap.add_argument("--queries", type=int, default=1024, help="queries per GPU per step")
     ap.add_argument("--map", type=int, default=512, help="voxel map edge length")
     ap.add_argument("--lattice", choices=["acc", "jrk"], default="acc")
+    ap.add_argument("--single", action="store_true",
+                    help="BASELINE.md C3: ONE query (2.05,2.05,2.05)->(49.15,49.15,49.15) on the 512^3 map instead of the C4 batch")
     ap.add_argument("--max-expand", type=int, default=0,
                     help="per-query expansion cap setMaxNum (default: 2 000 000 for acc = the BASELINE.md C3 cap, 20000 for jrk)")
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--max-nodes", type=int, default=0, help="mean states per query used to size the shared pools")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 disables)")
     args = ap.parse_args()
+    if args.single:
+        args.queries = 1
 
     import torch
     import torch.distributed as dist
@@ -109,7 +113,7 @@ def main():
         slots = args.slots or 1024
     else:
         U = mapgen.control_lattice(1.0, 2, True)
-        max_expand = args.max_expand if args.max_expand > 0 else 20000
+        max_expand = args.max_expand if args.max_expand > 0 else (2_000_000 if args.single else 20000)
         per_q = args.max_nodes or max(1 << 16, max_expand * 16)
         caps = dict(nodes=per_q * args.queries, edges=per_q * args.queries * 2, log=per_q * args.queries * 5 // 4)
         slots = args.slots or 768
@@ -127,7 +131,12 @@ def main():
 
     # ---- queries: rank-specific stream, free cell centres >= 10 m apart
     qrng = mapgen.SplitMix64(20250620 + 7919 * (rank + 1))
-    queries = mapgen.random_queries(grid, origin, res, args.queries, qrng, min_dist=10.0)
+    if args.single:
+        g = {256: 23.55, 512: 49.15}.get(n, round((n - 20) * res, 2) + 0.05)
+        queries = [((2.05, 2.05, 2.05), (g, g, g))]  # the bubbles carved by benchmark_map()
+        args.queries = 1
+    else:
+        queries = mapgen.random_queries(grid, origin, res, args.queries, qrng, min_dist=10.0)
 
     def wp(p):
         w = Waypoint3D(control)
@@ -190,7 +199,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"C4-{args.lattice.upper()}: {args.queries} independent start/goal queries per GPU on one shared "
+                "workload": (f"C3-{args.lattice.upper()}: single query (2.05,..)->({queries[0][1][0]},..) on a " if args.single else
+                             f"C4-{args.lattice.upper()}: {args.queries} independent start/goal queries per GPU on one shared ") +
                             f"{n}^3 random-box voxel map (10% occupied, seed 20250620), {U.shape[0]}-primitive {args.lattice} lattice, "
                             f"dt 1 v_max 2 a_max 1 tol 0.5" + (f", max_expand {max_expand}" if max_expand > 0 else ""),
                 "queries_per_gpu": args.queries,
@@ -206,7 +216,7 @@ def main():
             "map_setup_s": {"generate": round(t_gen, 3), "broadcast": round(t_bcast, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "astar_spec_kernel<32,16,ACC>" if control == ACC else "astar_spec_kernel<128,2,JRK>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
+                         "kernel": "astar_spec_kernel<32,16,ACC>" if control == ACC else "astar_spec_kernel<128,4,JRK>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
                          "bytes_per_expansion": alg / max(n_exp, 1)},
         }
         # HBM traffic of the same launch from the committed rocprofv3 PMC passes (cannot be collected
@@ -219,7 +229,11 @@ def main():
         except Exception:
             pass
         if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(grid, origin, res, control, U, max_expand, queries, args.cpu_seconds)
+            # a single capped query is sampled on the CPU with a smaller cap (same search, stopped earlier)
+            cpu_cap = min(max_expand, 250_000) if (args.single and max_expand > 0) else max_expand
+            out["cpu_baseline"] = cpu_baseline(grid, origin, res, control, U, cpu_cap, queries, args.cpu_seconds)
+            if cpu_cap != max_expand:
+                out["cpu_baseline"]["sample"] += f"; CPU run capped at {cpu_cap} expansions"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

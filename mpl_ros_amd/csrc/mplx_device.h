@@ -1,11 +1,11 @@
 // mplx_device.h -- shared POD layouts between the host API (mplx_api.hip) and the kernels.
 //
 // HBM layout of the search state (all queries of a batch share three chunked pools and one hash table):
-//   node pool  : records of rec_bytes(control) bytes, 8192 per chunk.  Record = hot part
+//   node pool  : records of rec_bytes(control) bytes, 32768 per chunk.  Record = hot part
 //                {g f64, h f64, flags u32, pred u32, key int32[nk]} in the first 64/80 B, then the
 //                first-arrival state (ns doubles) and t.  One 64 B load answers "same key? g? h?".
 //   edge pool  : predecessor records {parent u32, next u32, action u32}, 65536 per chunk.
-//   open pool  : OPEN-log records {f f64, g f64, id u32, next u32}, 16384 per chunk.
+//   open pool  : OPEN-log records {f f64, g f64, id u32, next u32}, 32768 per chunk.
 //   hash table : 64-bit slots {tag16 | query16 | node id32}, open addressing, shared by all queries
 //                of the batch (the query index is part of the slot), cleared once per batch.
 // A query owns chunks through three small chunk tables that live in LDS while it runs; chunks are
@@ -25,8 +25,8 @@ constexpr uint32_t CLAIM_BASE = 0xFFFF0000u;  // table id field >= CLAIM_BASE: c
 constexpr uint32_t FLAG_CLOSED = 1u, FLAG_OPENED = 2u;
 constexpr int MAX_TRAJ = 1024;
 
-constexpr int NODE_CH_LOG = 13, EDGE_CH_LOG = 16, OPEN_CH_LOG = 14;
-constexpr int MAX_NODE_CH = 1024, MAX_EDGE_CH = 2048, MAX_OPEN_CH = 1024;  // per query: 8M nodes, 134M edges, 16M log
+constexpr int NODE_CH_LOG = 15, EDGE_CH_LOG = 16, OPEN_CH_LOG = 15;
+constexpr int MAX_NODE_CH = 1024, MAX_EDGE_CH = 2048, MAX_OPEN_CH = 1024;  // per query: 33M nodes, 134M edges, 33M log
 constexpr int EDGE_BYTES = 12, OPEN_BYTES = 24;
 
 constexpr int rec_hot_bytes(int control) { return control == CTRL_SNP ? 80 : 64; }
