@@ -18,6 +18,12 @@
 #pragma once
 #include "mplx_kernels.h"
 
+#ifdef MPLX_LOOKUP_TIMERS
+#define MPLX_T2(S, k, var) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); (S).cyc2[k] += now_ - (var); var = now_; } } while (0)
+#else
+#define MPLX_T2(S, k, var) do { } while (0)
+#endif
+
 namespace mplx {
 
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain
@@ -45,15 +51,20 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   unsigned long long bt_hash[BT];
   uint32_t bt_leader[BT];  // smallest thread index sharing the entry (= first in commit order)
   uint32_t bt_id[BT], bt_flags[BT], bt_pred[BT], bt_dirty[BT];
+  uint32_t bt_share[BT];   // lanes besides the leader that reach the entry: count << 16 | (sum of their thread indices); bit 31: a candidate of the batch
   unsigned long long bt_tslot[BT];
   double bt_g[BT], bt_h[BT];
   int32_t lane_key[UL * K][NK];
   int32_t u_goal[K];  // candidate k satisfies the goal test (evaluated ahead of its commit)
   int32_t u_cut[K];   // first later candidate preceded by an entry unit k pushes (K if none)
   uint32_t n_sorted;  // near_[0, n_sorted) is in ascending order (left so by the previous selection)
-  int32_t batch_dep;  // units interact through a shared state -> ordered, unit-by-unit commit
+  int32_t batch_dep;  // units interact through a state one of them MODIFIES -> ordered, unit-by-unit commit
+  int32_t any_shared; // some state is reached by two lanes (they only append predecessor edges unless batch_dep)
   int32_t dep_cause;  // (debug statistics) 1 shared successor, 2 candidate is a successor, 4 a sharer modifies the state
   int32_t cut_at;     // first candidate preceded by an entry pushed in this batch (K if none)
+#ifdef MPLX_LOOKUP_TIMERS
+  unsigned long long cyc2[16];
+#endif
 };
 
 // Commit the successors of candidate `kc`; `active`: this lane commits now (all active lanes belong
@@ -68,7 +79,7 @@ struct LanePre {   // per-lane values of the ordered commit that do not depend o
 };
 
 template <int UL, int K, int CONTROL, bool PAR, class SM, class V>
-__device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, int q, int kc, bool active, int my_slot,
+__device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, int q, int kc, bool active, int my_slot, int k_stop,
                                                   const LaneSucc &L, double hspec, const LanePre &pre, uint32_t &pend_idx, uint32_t &pend_old) {
   constexpr int BLOCK = UL * K;
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
@@ -98,6 +109,19 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
   const uint32_t packed = (isnew ? 1u : 0u) | (active ? 1u << 10 : 0u) | (improved ? 1u << 20 : 0u);
   const uint32_t sc = PAR ? block_excl_scan<BLOCK>(packed, S, tid, total) : unit_excl_scan<UL, BLOCK>(packed, S, tid, total);
   const uint32_t base_nodes = S.n_nodes, base_edges = S.n_edges, base_log = S.n_log;
+  uint32_t chain_next = old_pred;
+  bool write_pred = true;
+  if (PAR && S.any_shared) {  // (uniform) two lanes append an edge to one state: chain them in thread order
+    const uint32_t share = active ? S.bt_share[my_slot] : 0u;
+    const bool two = ((share >> 16) & 0x7FFFu) == 1u;
+    const bool lead = two && S.bt_leader[my_slot] == (uint32_t)tid;
+    if (lead && (int)((share & 0xFFFFu) / UL) < k_stop) {  // the other lane commits too and becomes the newest predecessor
+      S.bt_pred[my_slot] = base_edges + ((sc >> 10) & 0x3FFu);
+      write_pred = false;
+    }
+    lds_barrier();
+    if (two && !lead) chain_next = S.bt_pred[my_slot];
+  }
   if (active) {
     if (isnew) {  // first arrival at this key: create the state (this lane is the entry's leader)
       id = base_nodes + (sc & 0x3FFu);
@@ -118,10 +142,10 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
     const uint32_t eidx = base_edges + ((sc >> 10) & 0x3FFu);
     EdgeRec *e = Q.edge(eidx);
     e->parent = S.cand_id[kc];
-    e->next = old_pred;
+    e->next = chain_next;
     e->action = (uint32_t)lu;
     if (PAR) {
-      V::pred(Q.node(id)) = eidx;  // independent units: nobody else touches this state in the batch
+      if (write_pred) V::pred(Q.node(id)) = eidx;  // nobody else modifies this state in the batch
     } else {
       S.bt_pred[my_slot] = eidx;
       S.bt_dirty[my_slot] = 1;  // g / flags / newest predecessor reach the record once, after the ordered loop
@@ -203,6 +227,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       S.cur1 = 0; S.cur0 = 0; S.lo1 = 0.0; S.ts_f = INFINITY; S.ts_g = INFINITY; S.ts_id = 0xFFFFFFFFu;
       S.status = -1;
       for (int i = 0; i < 10; i++) S.cyc[i] = 0;
+#ifdef MPLX_LOOKUP_TIMERS
+      for (int i = 0; i < 16; i++) S.cyc2[i] = 0;
+#endif
       S.c_expanded = S.c_closed = S.c_prims = S.c_succ = S.c_succ_finite = S.c_reads = 0;
       S.c_push = S.c_reopen = S.c_refill = S.c_evict = 0;
       S.c_hash = 0;
@@ -310,6 +337,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           S.n_cand = 0;
           S.cut_at = K;
           S.batch_dep = 0;
+          S.any_shared = 0;
           S.dep_cause = 0;
         }
         if (tid < K) {
@@ -429,12 +457,14 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         // ---- 2c. batch table: one entry per distinct successor key; its leader looks the key up in
         //          the state space (or claims a slot) and computes the heuristic of a new state
         MPLX_TIC(tc);
+        unsigned long long t2 = __builtin_readcyclecounter();
         unsigned long long h64 = 0;
         int my_slot = 0;
         for (int i = tid; i < BT; i += BLOCK) {
           S.bt_hash[i] = 0ull;
           S.bt_leader[i] = NIL;
           S.bt_dirty[i] = 0;
+          S.bt_share[i] = 0;
         }
         unsigned long long v0 = TBL_EMPTY;
         size_t pos0 = 0;
@@ -447,6 +477,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           v0 = ld_u64(&P.table[pos0]);
         }
         __syncthreads();
+        MPLX_T2(S, 0, t2);
         if (act) {
           const unsigned long long hv = h64 | 1ull;
           int sl = (int)(h64 >> 7) & (BT - 1);
@@ -459,6 +490,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           atomicMin(&S.bt_leader[sl], (uint32_t)tid);
         }
         __syncthreads();
+        MPLX_T2(S, 1, t2);
         double hspec = 0.0;
         if (act) {
           const uint32_t leader = S.bt_leader[my_slot];
@@ -468,7 +500,10 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             for (int i = 0; i < nk; i++) eq = eq && (S.lane_key[leader][i] == L.key[i]);
             if (!eq) S.status = 5;                                    // 64-bit key-hash collision inside a batch
             if ((int)(leader / UL) == ku) S.unit_seq[ku] = 1;       // two lanes of one unit, one key
-            S.batch_dep = 1;                                          // a state reached from two lanes of the batch
+            // a state reached from two lanes of the batch: harmless while both only append a predecessor
+            // edge (decided once g is known); three lanes on one state take the ordered path
+            if (atomicAdd(&S.bt_share[my_slot], 0x10000u + (uint32_t)tid) != 0u) S.batch_dep = 1;
+            S.any_shared = 1;
 #ifdef MPLX_DEP_STATS
             atomicOr(&S.dep_cause, 1);
 #endif
@@ -487,7 +522,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             } else if ((uint32_t)v0 < CLAIM_BASE && (v0 & 0xFFFFFFFF00000000ull) == tagq) {
               __builtin_prefetch(Q.node((uint32_t)v0), 0, 3);
             }
+            MPLX_T2(S, 2, t2);
             if (P.eps != 0.0) hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
+            MPLX_T2(S, 3, t2);
             bool first = true;
             for (;;) {
               unsigned long long v = first ? v0 : ld_u64(&P.table[pos]);
@@ -528,6 +565,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             }
           }
         }
+        MPLX_T2(S, 4, t2);
         // does a candidate itself appear among the successors of the batch?  (its closed flag must
         // reach the units committed after it)
         if (lu == 0 && live_unit) {
@@ -539,7 +577,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             if (o == 0ull) break;
             if (o == hv) {
               S.cur_slot[ku] = (uint32_t)sl;
-              S.batch_dep = 1;
+              atomicOr(&S.bt_share[sl], 0x80000000u);  // its closed flag matters to a lane that would re-open it
 #ifdef MPLX_DEP_STATS
               atomicOr(&S.dep_cause, 2);
 #endif
@@ -549,6 +587,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
         }
         __syncthreads();
+        MPLX_T2(S, 5, t2);
         LanePre pre;
         pre.tg = 0.0; pre.pf = INFINITY; pre.code = -1; pre.cut = K;
         if (act) {
@@ -560,17 +599,23 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           // a state created by this batch gets an id above every existing one: ties on (f, g) never favour it
           const uint32_t pid = nw ? 0xFFFFFFFFu : S.bt_id[my_slot];
           pre.code = classify(S, P.bucket_width, pre.pf, pre.tg, pid);
-          for (int k2 = ku + 1; k2 < K; k2++)
-            if (k2 < n_cand && entry_less(pre.pf, pre.tg, pid, S.cand_f[k2], S.cand_g[k2], S.cand_id[k2])) {
-              pre.cut = k2;
-              break;
+          {  // candidates are in ascending order: "my entry precedes candidate k2" is monotone in k2
+            int lo = ku + 1, hi = n_cand;
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (entry_less(pre.pf, pre.tg, pid, S.cand_f[mid], S.cand_g[mid], S.cand_id[mid])) hi = mid; else lo = mid + 1;
             }
+            if (lo < n_cand) pre.cut = lo;
+          }
           // valid when no state of the batch is shared between lanes (bt_g still is the fetched value)
           if (pre.cut < K && pre.tg < S.bt_g[my_slot]) atomicMin(&S.u_cut[ku], pre.cut);
+          // a shared state (or a candidate's own state) that this lane creates or improves: units interact
+          if (S.bt_share[my_slot] != 0u && (nw || pre.tg < S.bt_g[my_slot])) S.batch_dep = 1;
 #ifdef MPLX_DEP_STATS
           if (pre.tg < S.bt_g[my_slot]) S.bt_dirty[my_slot] = 2;  // some sharer modifies this state
 #endif
         }
+        MPLX_T2(S, 6, t2);
         MPLX_TOC(S, 2, tc);
         if (S.status >= 0) break;
         // ---- 3. ordered commit
@@ -592,34 +637,59 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         const unsigned long long expanded0 = S.c_expanded;
         uint32_t pend_idx = NIL, pend_old = NIL;  // far-bucket link whose atomicExch is still in flight
         const bool parallel_commit = !S.batch_dep;
+        MPLX_T2(S, 7, t2);
         if (parallel_commit) {
           // no state is touched by two lanes of the batch and no candidate is a successor inside it:
           // the units cannot see each other, so which of them commit follows from the per-unit cut
           // points alone, and they commit together
-          int cut = K, st_after = -1;
-          int lv[K], uc_[K], ug[K];
+          // (every wave evaluates this redundantly: lane k holds unit k, ballots make the result uniform)
+          int st_after = -1;
+          {
+            const int l = tid & 63;
+            const bool inb = l < K && l < n_cand;
+            const bool lvk = inb && S.cand_live[inb ? l : 0] != 0;
+            const int uck = lvk ? S.u_cut[l] : K;
+            const bool ugk = lvk && S.u_goal[l] != 0;
+            int c = uck;  // inclusive prefix minimum of the cut points of the live units
 #pragma unroll
-          for (int k = 0; k < K; k++) {  // independent LDS reads first
-            lv[k] = S.cand_live[k];
-            uc_[k] = S.u_cut[k];
-            ug[k] = S.u_goal[k];
-          }
-#pragma unroll
-          for (int k = 0; k < K; k++) {
-            if (k >= n_cand) break;
-            if (!lv[k]) continue;
-            if (k >= cut) { k_stop = k; break; }
-            n_commit++;
-            const int uc = uc_[k];
-            cut = uc < cut ? uc : cut;
-            if (ug[k]) { st_after = 0; k_stop = k + 1; break; }
-            if (P.max_expand > 0 && expanded0 + (unsigned long long)n_commit >= (unsigned long long)P.max_expand) { st_after = 3; k_stop = k + 1; break; }
+            for (int d = 1; d < K; d <<= 1) {
+              const int y = __shfl_up(c, d, 64);
+              if (l >= d) c = y < c ? y : c;
+            }
+            int cex = __shfl_up(c, 1, 64);  // cut point set by the units before mine
+            if (l == 0) cex = K;
+            const unsigned long long livem = __ballot(lvk);
+            const unsigned long long le = ~0ull >> (63 - l);
+            const int cnt = __popcll(livem & le);  // live units up to and including mine
+            const bool stop_a = lvk && l >= cex;   // an earlier unit's entry precedes this candidate
+            const bool ok = lvk && l < cex;
+            const bool stop_b = ok && ugk;          // goal reached when this unit is committed
+            const bool stop_c = ok && !ugk && P.max_expand > 0 && expanded0 + (unsigned long long)cnt >= (unsigned long long)P.max_expand;
+            const unsigned long long ma = __ballot(stop_a), mb = __ballot(stop_b), mc = __ballot(stop_c);
+            const unsigned long long many = ma | mb | mc;
+            if (many) {
+              const int first = __ffsll((long long)many) - 1;
+              const unsigned long long bit = 1ull << first;
+              if (ma & bit) {
+                k_stop = first;
+                n_commit = __popcll(livem & (bit - 1ull));
+              } else {
+                k_stop = first + 1;
+                n_commit = __popcll(livem & (bit | (bit - 1ull)));
+                st_after = (mb & bit) ? 0 : 3;
+              }
+            } else {
+              n_commit = __popcll(livem);
+            }
           }
           const bool mine = ku < k_stop && S.cand_live[ku < K ? ku : 0];
           if (mine && lu == 0) V::flags(Q.node(S.cand_id[ku])) = S.cand_fl[ku] | FLAG_CLOSED;
+          MPLX_T2(S, 8, t2);
           __syncthreads();  // everyone has read status / u_cut before they change
-          spec_commit_lanes<UL, K, CONTROL, true>(Q, S, tid, q, ku, act && mine, my_slot, L, hspec, pre, pend_idx, pend_old);
+          MPLX_T2(S, 9, t2);
+          spec_commit_lanes<UL, K, CONTROL, true>(Q, S, tid, q, ku, act && mine, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
           if (tid == 0 && st_after >= 0) S.status = st_after;
+          MPLX_T2(S, 10, t2);
         }
         for (int k = 0; k < (parallel_commit ? 0 : n_cand); k++) {
           if (!S.cand_live[k]) continue;  // stale entry: dropped, like a pop that skips it
@@ -645,16 +715,17 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
           if (S.cur_slot[k] != NIL) lds_barrier();  // (uniform) its closed flag must precede its own successors' relax
           if (!S.unit_seq[k]) {
-            spec_commit_lanes<UL, K, CONTROL, false>(Q, S, tid, q, k, act && ku == k, my_slot, L, hspec, pre, pend_idx, pend_old);
+            spec_commit_lanes<UL, K, CONTROL, false>(Q, S, tid, q, k, act && ku == k, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
           } else {
             for (int i = 0; i < P.n_u; i++) {
-              spec_commit_lanes<UL, K, CONTROL, false>(Q, S, tid, q, k, act && ku == k && lu == i, my_slot, L, hspec, pre, pend_idx, pend_old);
+              spec_commit_lanes<UL, K, CONTROL, false>(Q, S, tid, q, k, act && ku == k && lu == i, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
               lds_barrier();
             }
           }
           lds_barrier();
           if (S.status >= 0) { k_stop = k + 1; break; }
         }
+        MPLX_T2(S, 11, t2);
         if (pend_idx != NIL) Q.open(pend_idx)->next = pend_old;
         if (!parallel_commit) {
           lds_barrier();
@@ -669,40 +740,53 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
         }
         __syncthreads();
-        if (tid == 0) {  // counters of the committed units, in commit order (accumulated in registers)
-          unsigned long long ne = S.c_expanded, hh = S.c_hash, nsu = 0, nfi = 0, nrd = 0, ncm = 0;
-          uint32_t last = S.cur_id;
-          for (int k = 0; k < k_stop; k++) {
-            if (!S.cand_live[k]) continue;
-            const uint32_t cur = S.cand_id[k];
-            ne++;
-            ncm++;
-            hh = hh * 0x100000001B3ull + (unsigned long long)(cur + 1u);
-            if (P.rec_ids && ne <= P.cap_rec) P.rec_ids[(size_t)q * P.cap_rec + (ne - 1)] = (int32_t)cur;
-            nsu += S.u_succ[k];
-            nfi += S.u_fin[k];
-            nrd += S.u_reads[k];
-            last = cur;
+        MPLX_T2(S, 12, t2);
+        if (tid < 64) {  // counters of the committed units, in commit order; lane k holds unit k
+          const int l = tid;
+          const bool inb = l < K && l < n_cand && S.cand_live[l < K ? l : 0] != 0;
+          const bool done = inb && l < k_stop;
+          const bool back = inb && l >= k_stop && S.status < 0;  // behind a cut: returns to OPEN untouched
+          const uint32_t cur = l < K ? S.cand_id[l] : 0u;
+          const unsigned long long m = __ballot(done), mb = __ballot(back);
+          const unsigned long long below = (1ull << l) - 1ull;
+          const unsigned long long ne0 = S.c_expanded;
+          uint32_t su = done ? S.u_succ[l] : 0u, fi = done ? S.u_fin[l] : 0u, rd = done ? S.u_reads[l] : 0u;
+#pragma unroll
+          for (int d = 1; d < K; d <<= 1) {
+            su += __shfl_xor(su, d, 64);
+            fi += __shfl_xor(fi, d, 64);
+            rd += __shfl_xor(rd, d, 64);
           }
-          S.c_expanded = ne;
-          S.c_closed += ncm;
-          S.c_hash = hh;
-          S.c_prims += ncm * (unsigned long long)P.n_u;
-          S.c_succ += nsu;
-          S.c_succ_finite += nfi;
-          S.c_reads += nrd;
-          S.cur_id = last;
-          if (!parallel_commit) S.cyc[8]++;  // batches that needed the unit-by-unit commit
-        }
-        // candidates behind a cut go back to OPEN untouched
-        if (tid == 0 && S.status < 0) {
-          for (int k = k_stop; k < n_cand; k++) {
-            if (!S.cand_live[k]) continue;
-            const uint32_t pos = S.n_near++;
-            S.near_f[pos] = S.cand_f[k]; S.near_g[pos] = S.cand_g[k]; S.near_id[pos] = S.cand_id[k]; S.near_idx[pos] = S.cand_idx[k];
+          if (done && P.rec_ids) {
+            const unsigned long long at = ne0 + (unsigned long long)__popcll(m & below);
+            if (at < P.cap_rec) P.rec_ids[(size_t)q * P.cap_rec + at] = (int32_t)cur;
+          }
+          if (back) {
+            const uint32_t pos = S.n_near + (uint32_t)__popcll(mb & below);
+            S.near_f[pos] = S.cand_f[l]; S.near_g[pos] = S.cand_g[l]; S.near_id[pos] = cur; S.near_idx[pos] = S.cand_idx[l];
+          }
+          unsigned long long hh = S.c_hash;
+#pragma unroll
+          for (int k = 0; k < K; k++) {  // the running hash of the expansion order is a serial chain
+            const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)cur, k);
+            if ((m >> k) & 1ull) hh = hh * 0x100000001B3ull + (unsigned long long)(ck + 1u);
+          }
+          if (m && l == 63 - __clzll((long long)m)) S.cur_id = cur;
+          if (l == 0) {
+            const unsigned long long ncm = (unsigned long long)__popcll(m);
+            S.c_expanded = ne0 + ncm;
+            S.c_closed += ncm;
+            S.c_hash = hh;
+            S.c_prims += ncm * (unsigned long long)P.n_u;
+            S.c_succ += su;
+            S.c_succ_finite += fi;
+            S.c_reads += rd;
+            S.n_near += (uint32_t)__popcll(mb);
+            if (!parallel_commit) S.cyc[8]++;  // batches that needed the unit-by-unit commit
           }
         }
         __syncthreads();
+        MPLX_T2(S, 13, t2);
         MPLX_TOC(S, 6, to);
         if (S.status >= 0) break;
       }
@@ -764,6 +848,11 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       o.t_begin = t_begin;
       o.t_end = wall_clock64();
       for (int i = 0; i < 10; i++) o.cyc[i] = S.cyc[i];
+#ifdef MPLX_LOOKUP_TIMERS
+      printf("cyc2 q%d batches %llu:", q, S.cyc[7]);
+      for (int i = 0; i < 14; i++) printf(" %llu", S.cyc2[i] / (S.cyc[7] ? S.cyc[7] : 1ull));
+      printf("\n");
+#endif
     }
     for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)
       P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? S.node_tbl[i] : NIL;

@@ -371,7 +371,7 @@ class VoxelMapPlanner:
         ctx = self._ctx()
         cyc = (C.c_uint64 * 10)()
         ctx.check(ctx.lib.mplx_result_cycles(ctx.h, q, cyc))
-        return dict(zip(("pop", "expand", "commit", "evict", "refill", "activate", "ordered", "batches", "dep_batches"), [int(x) for x in cyc[:9]]))
+        return dict(zip(("pop", "expand", "lookup", "evict", "refill", "activate", "commit", "batches", "dep_batches"), [int(x) for x in cyc[:9]]))
 
     # ---- results
     def getTrajCost(self):

@@ -13,11 +13,14 @@ HID = bool(int(os.environ.get('HID', '0')))
 if which == 'single':
     grid, origin, res, start, goal, rng = mapgen.benchmark_map(256)
     U = mapgen.control_lattice(1.0, 1, True)
-    mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, max_nodes=1 << 22, max_edges=1 << 24, max_log=1 << 23, spec=SPEC, heur_ignore_dynamics=HID)
+    BIG = int(os.environ.get('BIG', '0'))
+    mn = 460_000_000 if BIG else 1 << 22
+    mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, max_nodes=mn, max_edges=(mn * 9 // 2) if BIG else 1 << 24, max_log=(mn * 5 // 4) if BIG else 1 << 23, spec=SPEC, heur_ignore_dynamics=HID)
     for it in range(2):
         ok = pl.plan(util.gpu_wp(start), util.gpu_wp(goal)); r = pl.getResult()
         print('C2 ACC', ok, r.cost, r.n_expanded, 'kernel ms', pl.lastKernelMs(), 'us/exp', 1e3 * pl.lastKernelMs() / r.n_expanded, 'refill', r.n_refill, 'evict', r.n_evict)
         cy = pl.queryCycles(); print('   cycles/exp', {k: round(v / r.n_expanded) for k, v in cy.items()}, 'exp/batch', round(r.n_expanded / max(cy.get('batches', 0), 1), 3), 'dep frac', round(cy.get('dep_batches', 0) / max(cy.get('batches', 0), 1), 3))
+    if BIG: sys.exit(0)
     U5 = mapgen.control_lattice(1.0, 2, True)
     mu, pl = util.make_gpu(grid, origin, res, U5, v_max=2.0, a_max=1.0, j_max=1.0, max_expand=20000, max_nodes=1 << 21, max_edges=1 << 23, max_log=1 << 22, spec=SPEC)
     ok = pl.plan(util.gpu_wp(start, control=orc.JRK), util.gpu_wp(goal, control=orc.JRK)); r = pl.getResult()
@@ -61,4 +64,4 @@ if which == 'width':
         pl.setBucketWidth(10.0 * wmul)
         ok = pl.plan(util.gpu_wp(start), util.gpu_wp(goal)); r = pl.getResult()
         cy = pl.queryCycles()
-        print('width', 10.0 * wmul, 'us/exp', round(1e3 * pl.lastKernelMs() / r.n_expanded, 3), 'refill', r.n_refill, 'evict', r.n_evict, {k: round(v / r.n_expanded) for k, v in cy.items() if k in ('pop', 'expand', 'commit', 'ordered', 'refill', 'evict')}, 'exp/batch', round(r.n_expanded / max(cy['batches'], 1), 2), r.n_expanded)
+        print('width', 10.0 * wmul, 'us/exp', round(1e3 * pl.lastKernelMs() / r.n_expanded, 3), 'refill', r.n_refill, 'evict', r.n_evict, {k: round(v / r.n_expanded) for k, v in cy.items() if k in ('pop', 'expand', 'lookup', 'commit', 'refill', 'evict')}, 'exp/batch', round(r.n_expanded / max(cy['batches'], 1), 2), r.n_expanded)
