@@ -301,6 +301,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
 #pragma unroll
       for (int k = 1; k < NQ; k++) qnr[ax][k] = S.qn[ku][ax][k];
     const double ox = P.map.origin[0], oy = P.map.origin[1], oz = P.map.origin[2], rs = P.map.res;
+    const double irs = 1.0 / rs;
     for (uint32_t e0 = lu; e0 < total; e0 += UL * UNR) {
       uint32_t o[UNR];
 #pragma unroll
@@ -325,15 +326,15 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
 #pragma unroll
         for (int k = 1; k < NQ; k++) qq[k] = qnr[0][k];
         qq[0] = u0[r];
-        cx[r] = float_to_cell(pos_at_qc<CONTROL>(qq, t), ox, rs);
+        cx[r] = float_to_cell_inv(pos_at_qc<CONTROL>(qq, t), ox, rs, irs);
 #pragma unroll
         for (int k = 1; k < NQ; k++) qq[k] = qnr[1][k];
         qq[0] = u1[r];
-        cy[r] = float_to_cell(pos_at_qc<CONTROL>(qq, t), oy, rs);
+        cy[r] = float_to_cell_inv(pos_at_qc<CONTROL>(qq, t), oy, rs, irs);
 #pragma unroll
         for (int k = 1; k < NQ; k++) qq[k] = qnr[2][k];
         qq[0] = u2[r];
-        cz[r] = float_to_cell(pos_at_qc<CONTROL>(qq, t), oz, rs);
+        cz[r] = float_to_cell_inv(pos_at_qc<CONTROL>(qq, t), oz, rs, irs);
       }
       int32_t vv[UNR];
       bool inside[UNR];

@@ -321,6 +321,19 @@ MPLX_HD void state_key_c(const State &s, int32_t *key) {
 
 // MapUtil::floatToInt: round((pt - origin)/res - 0.5)
 MPLX_HD int32_t float_to_cell(double p, double origin, double res) { return (int32_t)round((p - origin) / res - 0.5); }
+// d / r from inv = 1.0 / r without the hardware division sequence: q0 = RN(d inv), e = d - q0 r (exact in
+// an FMA), q = RN(q0 + e inv).  With inv the correctly rounded reciprocal and q0 a faithful quotient
+// this is the correctly rounded quotient (Markstein's theorem), i.e. bit-identical to d / r; the
+// host test checks it against `/` on 10^7 lattice and random points per resolution.  3 instructions
+// instead of ~12 in the voxel sampling loop, which is bound by f64 issue.
+MPLX_HD double div_by_inv(double d, double r, double inv) {
+  const double q0 = d * inv;
+  const double e = fma(-q0, r, d);
+  return fma(e, inv, q0);
+}
+MPLX_HD int32_t float_to_cell_inv(double p, double origin, double res, double inv_res) {
+  return (int32_t)round(div_by_inv(p - origin, res, inv_res) - 0.5);
+}
 
 // ------------------------------------------------------------------ polynomial real roots
 // Derivative-chain isolation + safeguarded Newton/bisection, basic arithmetic only (deterministic
@@ -426,12 +439,15 @@ MPLX_HD int poly_roots_above(const double *a, double lo, double *roots) {
     return 0;
   } else {
     if (a[N] == 0.0) return poly_roots_above<N - 1>(a, lo, roots);
-    double m = 0.0;
+    // Cauchy bound 1 + max_i |a_i / a_N|.  Division is sign-symmetric and monotone, so the maximum of the
+    // rounded quotients is the rounded quotient of the maximum: one division, same bits.
+    double mx = 0.0;
 #pragma unroll
     for (int i = 0; i < N; i++) {
-      double q = fabs(a[i] / a[N]);
-      if (q > m) m = q;
+      const double q = fabs(a[i]);
+      if (q > mx) mx = q;
     }
+    const double m = mx / fabs(a[N]);
     double hi = 1.0 + m;
     if (!(hi > lo)) return 0;
     return poly_roots_in<N>(a, lo, hi, roots);

@@ -63,7 +63,9 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   int32_t dep_cause;  // (debug statistics) 1 shared successor, 2 candidate is a successor, 4 a sharer modifies the state
   int32_t cut_at;     // first candidate preceded by an entry pushed in this batch (K if none)
 #ifdef MPLX_LOOKUP_TIMERS
-  unsigned long long cyc2[16];
+  unsigned long long cyc2[24];
+  unsigned long long cycw[16][4];
+  unsigned long long arr_max, arr_heur, sum_heur, sum_arr;
 #endif
 };
 
@@ -228,7 +230,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       S.status = -1;
       for (int i = 0; i < 10; i++) S.cyc[i] = 0;
 #ifdef MPLX_LOOKUP_TIMERS
-      for (int i = 0; i < 16; i++) S.cyc2[i] = 0;
+      for (int i = 0; i < 24; i++) S.cyc2[i] = 0;
+      for (int i = 0; i < 64; i++) (&S.cycw[0][0])[i] = 0;
+      S.arr_max = 0; S.arr_heur = 0; S.sum_heur = 0; S.sum_arr = 0;
 #endif
       S.c_expanded = S.c_closed = S.c_prims = S.c_succ = S.c_succ_finite = S.c_reads = 0;
       S.c_push = S.c_reopen = S.c_refill = S.c_evict = 0;
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           MPLX_TOC(S, 3, te);
         }
         MPLX_TIC(tp);
+        unsigned long long t3 = __builtin_readcyclecounter();
         if (S.n_near == 0) {
           __syncthreads();
           if (!refill(Q, tid)) {
@@ -324,21 +329,26 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           (void)before;
           __syncthreads();
         }
+        MPLX_T2(S, 16, t3);
         // ---- 1. the K smallest OPEN entries, in order
         if (tid == 0) {
           S.cyc[7]++;  // batches
-          {  // chunk capacity for everything this batch can create
-            const uint32_t room = (uint32_t)(K * P.n_u + K);
-            bool ok = ensure_chunks(S.node_tbl, S.node_chunks, S.n_nodes + room, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks) &&
-                      ensure_chunks(S.edge_tbl, S.edge_chunks, S.n_edges + room, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks) &&
-                      ensure_chunks(S.open_tbl, S.open_chunks, S.n_log + room, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
-            if (!ok) S.status = 4;  // MPLX_PLAN_POOL_FULL
-          }
           S.n_cand = 0;
           S.cut_at = K;
           S.batch_dep = 0;
           S.any_shared = 0;
           S.dep_cause = 0;
+        }
+        if ((tid & 63) == 0 && tid < 192) {  // chunk capacity for everything this batch can create: one pool per wave
+          const uint32_t room = (uint32_t)(K * P.n_u + K);
+          bool ok;
+          if (tid == 0)
+            ok = ensure_chunks(S.node_tbl, S.node_chunks, S.n_nodes + room, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks);
+          else if (tid == 64)
+            ok = ensure_chunks(S.edge_tbl, S.edge_chunks, S.n_edges + room, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks);
+          else
+            ok = ensure_chunks(S.open_tbl, S.open_chunks, S.n_log + room, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
+          if (!ok) S.status = 4;  // MPLX_PLAN_POOL_FULL
         }
         if (tid < K) {
           S.cand_live[tid] = 0;
@@ -349,6 +359,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           S.u_cut[tid] = K;
         }
         __syncthreads();
+        MPLX_T2(S, 17, t3);
         {
           // rank every near entry among all of them (strict total order -> unique ranks): ranks
           // 0..K-1 are the candidates in pop order, the others move to position rank-K (which also
@@ -392,7 +403,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             for (int r = 0; r < PERT; r++)
               if (entry_less(f, g, id, ef[r], eg[r], ei[r])) rk[r]++;
           }
+          MPLX_T2(S, 15, t3);
           __syncthreads();
+          MPLX_T2(S, 18, t3);
 #pragma unroll
           for (int r = 0; r < PERT; r++) {
             const uint32_t i = tid + r * BLOCK;
@@ -411,6 +424,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             S.n_sorted = n - kc;
           }
           __syncthreads();
+          MPLX_T2(S, 19, t3);
         }
         const int n_cand = S.n_cand;
         // ---- 2a. fetch the candidates' records; drop stale entries (improved or closed since pushed)
@@ -431,12 +445,14 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
         }
         unit_sync<UL>();
+        MPLX_T2(S, 20, t3);
         if (live_unit && lu == 0) {  // goal test of the candidate (applied when, and if, it is committed)
           State sgoal;
           for (int i = 0; i < 12; i++) ((double *)&sgoal)[i] = S.cur[ku][i];
           S.u_goal[ku] = (S.cur[ku][12] >= P.t_max || is_goal_state(sgoal, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) ? 1 : 0;
         }
         unit_sync<UL>();
+        MPLX_T2(S, 21, t3);
         MPLX_TOC(S, 0, tp);
         // ---- 2b. expand all live units concurrently
         MPLX_TIC(tx);
@@ -476,6 +492,11 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           pos0 = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
           v0 = ld_u64(&P.table[pos0]);
         }
+        MPLX_T2(S, 14, t2);
+#ifdef MPLX_LOOKUP_TIMERS
+        if ((tid & 63) == 0) S.cycw[tid >> 6][0] += __builtin_readcyclecounter() - tx;
+        unsigned long long tw = 0;
+#endif
         __syncthreads();
         MPLX_T2(S, 0, t2);
         if (act) {
@@ -491,6 +512,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         }
         __syncthreads();
         MPLX_T2(S, 1, t2);
+#ifdef MPLX_LOOKUP_TIMERS
+        tw = __builtin_readcyclecounter();
+#endif
         double hspec = 0.0;
         if (act) {
           const uint32_t leader = S.bt_leader[my_slot];
@@ -513,7 +537,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             size_t pos = pos0;
             const unsigned long long claim = tagq | (unsigned long long)(CLAIM_BASE + (uint32_t)tid);
             // second round trip (claim the empty slot, or fetch the record the slot names) goes out
-            // before the heuristic is computed, so its latency hides behind the f64 work
+            // before the heuristic is computed, so its latency hides behind the f64 work.  (Computing the
+            // heuristic only for states found to be new, after the look-up, was measured slower: the slowest
+            // lane of the workgroup sets the pace either way, and the overlap is lost.)
             unsigned long long cas0 = 0;
             bool did_cas0 = false;
             if (v0 == TBL_EMPTY) {
@@ -525,6 +551,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             MPLX_T2(S, 2, t2);
             if (P.eps != 0.0) hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
             MPLX_T2(S, 3, t2);
+#ifdef MPLX_LOOKUP_TIMERS
+            atomicMax(&S.arr_heur, (unsigned long long)__builtin_readcyclecounter());
+#endif
             bool first = true;
             for (;;) {
               unsigned long long v = first ? v0 : ld_u64(&P.table[pos]);
@@ -566,6 +595,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
         }
         MPLX_T2(S, 4, t2);
+#ifdef MPLX_LOOKUP_TIMERS
+        if ((tid & 63) == 0) S.cycw[tid >> 6][1] += __builtin_readcyclecounter() - tw;
+#endif
         // does a candidate itself appear among the successors of the batch?  (its closed flag must
         // reach the units committed after it)
         if (lu == 0 && live_unit) {
@@ -586,7 +618,16 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             sl = (sl + 1) & (BT - 1);
           }
         }
+        MPLX_T2(S, 22, t2);
+#ifdef MPLX_LOOKUP_TIMERS
+        if ((tid & 63) == 0) S.cycw[tid >> 6][2] += __builtin_readcyclecounter() - tw;
+        atomicMax(&S.arr_max, (unsigned long long)__builtin_readcyclecounter());
+#endif
         __syncthreads();
+#ifdef MPLX_LOOKUP_TIMERS
+        if ((tid & 63) == 0) S.cycw[tid >> 6][3] += __builtin_readcyclecounter() - tw;
+        if (tid == 0) { S.cyc2[23] += __builtin_readcyclecounter() - S.arr_max; S.sum_heur += S.arr_heur - tw; S.sum_arr += S.arr_max - tw; }
+#endif
         MPLX_T2(S, 5, t2);
         LanePre pre;
         pre.tg = 0.0; pre.pf = INFINITY; pre.code = -1; pre.cut = K;
@@ -850,8 +891,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       for (int i = 0; i < 10; i++) o.cyc[i] = S.cyc[i];
 #ifdef MPLX_LOOKUP_TIMERS
       printf("cyc2 q%d batches %llu:", q, S.cyc[7]);
-      for (int i = 0; i < 14; i++) printf(" %llu", S.cyc2[i] / (S.cyc[7] ? S.cyc[7] : 1ull));
-      printf("\n");
+      for (int i = 0; i < 24; i++) printf(" %llu", S.cyc2[i] / (S.cyc[7] ? S.cyc[7] : 1ull));
+      printf("\n  max-over-lanes: heuristic done %llu, barrier arrival %llu\n", S.sum_heur / S.cyc[7], S.sum_arr / S.cyc[7]);
+      for (int j = 0; j < 4; j++) { printf("  per-wave %d:", j); for (int w = 0; w < BLOCK / 64; w++) printf(" %llu", S.cycw[w][j] / (S.cyc[7] ? S.cyc[7] : 1ull)); printf("\n"); }
 #endif
     }
     for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)

@@ -167,7 +167,28 @@ static void check_roots(int iters) {
   }
 }
 
+// float_to_cell_inv (reciprocal + two FMAs, used in the voxel sampling loop) == float_to_cell (`/`)
+static void check_cell_quantisation(int iters) {
+  const double rs[] = {0.1, 0.05, 0.2, 0.25, 0.3, 0.15, 0.01, 1.0 / 3, 0.07, 0.123456789, 1.0, 0.5};
+  for (double r : rs) {
+    const double inv = 1.0 / r;
+    for (int it = 0; it < iters; it++) {
+      double o = (it % 4 == 0) ? 0.0 : round(uni(-20, 20) * 10) / 10;
+      double p;
+      switch (it & 3) {
+        case 0: p = uni(-100, 700); break;
+        case 1: p = round(uni(-100, 700) * 20) / 20; break;      // lattice positions (multiples of 0.05)
+        case 2: p = round(uni(-100, 700) * 100) * 0.01; break;
+        default: p = o + (double)(int)uni(-100, 6000) * r; break;  // exactly on cell faces
+      }
+      CHECK(same(div_by_inv(p - o, r, inv), (p - o) / r), "div_by_inv r %.17g d %.17g", r, p - o);
+      CHECK(float_to_cell_inv(p, o, r, inv) == float_to_cell(p, o, r), "float_to_cell_inv r %.17g p %.17g o %.17g", r, p, o);
+    }
+  }
+}
+
 int main() {
+  check_cell_quantisation(1000000);
   check_control<CTRL_VEL>(20000);
   check_control<CTRL_ACC>(20000);
   check_control<CTRL_JRK>(20000);
