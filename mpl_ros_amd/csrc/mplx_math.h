@@ -439,15 +439,27 @@ MPLX_HD int poly_roots_above(const double *a, double lo, double *roots) {
     return 0;
   } else {
     if (a[N] == 0.0) return poly_roots_above<N - 1>(a, lo, roots);
-    // Cauchy bound 1 + max_i |a_i / a_N|.  Division is sign-symmetric and monotone, so the maximum of the
-    // rounded quotients is the rounded quotient of the maximum: one division, same bits.
-    double mx = 0.0;
+    // Bound on |root|.  Cauchy: 1 + max_i |a_i / a_N| -- division is
+    // sign-symmetric and monotone, so the maximum of the rounded quotients is the rounded quotient of the
+    // maximum: one division, same bits.  With a zero coefficient below the leading one (both heuristic
+    // polynomials): 1 + sqrt(sum_i |a_i| / |a_N|), a far shorter bracket.
+    double m;
+    bool gap = false;
+    if constexpr (N >= 2) gap = a[N - 1] == 0.0;
+    if (gap) {
+      double sum = 0.0;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-      const double q = fabs(a[i]);
-      if (q > mx) mx = q;
+      for (int i = 0; i < N; i++) sum += fabs(a[i]);
+      m = sqrt(sum / fabs(a[N]));
+    } else {
+      double mx = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; i++) {
+        const double q = fabs(a[i]);
+        if (q > mx) mx = q;
+      }
+      m = mx / fabs(a[N]);
     }
-    const double m = mx / fabs(a[N]);
     double hi = 1.0 + m;
     if (!(hi > lo)) return 0;
     return poly_roots_in<N>(a, lo, hi, roots);

@@ -134,11 +134,19 @@ int orc_poly_roots_above(const double *a_in, int n_in, double lo, double *roots)
   for (int i = 0; i <= n; i++) a[i] = a_in[i];
   while (n > 0 && a[n] == 0.0) n--;
   if (n == 0) return 0;
-  /* Cauchy bound on |root| */
+  /* bound on |root|: Cauchy's 1 + max|a_i/a_n|; when the coefficient below the leading one is zero (true
+   * of both heuristic polynomials) |x| >= 1 gives |sum_{i<n} a_i x^i| <= S |x|^(n-2) with S = sum|a_i|,
+   * so every root has |x| <= max(1, sqrt(S/|a_n|)) -- a far shorter bracket, fewer iterations. */
   double m = 0.0;
-  for (int i = 0; i < n; i++) {
-    double q = fabs(a[i] / a[n]);
-    if (q > m) m = q;
+  if (n >= 2 && a[n - 1] == 0.0) {
+    double sum = 0.0;
+    for (int i = 0; i < n; i++) sum += fabs(a[i]);
+    m = sqrt(sum / fabs(a[n]));
+  } else {
+    for (int i = 0; i < n; i++) {
+      double q = fabs(a[i] / a[n]);
+      if (q > m) m = q;
+    }
   }
   double hi = 1.0 + m;
   if (!(hi > lo)) return 0;
