@@ -218,6 +218,7 @@ static int build_bricks(mplx_ctx *c) {
   (void)hipFree(c->bricks);
   c->bricks = nullptr;
   const size_t nwords = (size_t)nb0 * nb1 * nb2 * 16;
+  if (nwords > ((size_t)1 << 30)) return fail(c, MPLX_ERR_ARG, "map too large: more than 2^26 bricks (2^35 voxels)");  // kernels index the bitmap with 32 bits
   HIPCHK(c, hipMalloc((void **)&c->bricks, nwords * sizeof(uint32_t)));
   hipLaunchKernelGGL(brick_pack_kernel, dim3(4096), dim3(256), 0, c->stream, c->map, c->dim[0], c->dim[1], c->dim[2], nb0, nb1, nb2, c->bricks);
   HIPCHK(c, hipGetLastError());
@@ -359,7 +360,8 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   if (nch < 1) nch = 1;
   if (ech < 1) ech = 1;
   if (och < 1) och = 1;
-  if (nch > 0x7FFFFFFFull || ech > 0x7FFFFFFFull || och > 0x7FFFFFFFull) return fail(c, MPLX_ERR_ARG, "capacity too large");
+  // chunk ids are 16 bits in the kernels' LDS chunk tables: 2.1 G nodes / 4.3 G edges / 2.1 G log records
+  if (nch > 0xFFFFull || ech > 0xFFFFull || och > 0xFFFFull) return fail(c, MPLX_ERR_ARG, "capacity too large (more than 65535 chunks in a pool)");
   const uint64_t T = next_pow2(2ull * (nch << NODE_CH_LOG));
   int r;
 #define PA(ptr, cnt) if ((r = pool_alloc(c, &(ptr), (cnt))) != MPLX_OK) { free_pools(c); return r; }

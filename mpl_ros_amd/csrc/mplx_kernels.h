@@ -49,7 +49,7 @@ struct Smem {
   uint32_t near_id[NCAP_], near_idx[NCAP_];
   uint32_t cnt[2][NB];  // entries per bucket: [0] fine level (inside coarse bucket cur1), [1] coarse level
   // chunk tables of the running query
-  uint32_t node_tbl[MAX_NODE_CH], edge_tbl[MAX_EDGE_CH], open_tbl[MAX_OPEN_CH];
+  uint16_t node_tbl[MAX_NODE_CH], edge_tbl[MAX_EDGE_CH], open_tbl[MAX_OPEN_CH];  // pool chunk ids (the host keeps pools below 65536 chunks)
   // expansion scratch
   // pre-divided non-zero polynomial coefficients (pack_q_c) of a sample's primitive, split into the
   // part that only depends on the control input (per query) and the part that only depends on the
@@ -57,9 +57,11 @@ struct Smem {
   double uq[3][BLOCK / KUNITS];  // q[0] of control input i per axis: U[i][ax] / {1, 2, 6, 24}
   double qn[KUNITS][3][5];       // q[1..] of the node per axis
   double dts[BLOCK];
-  uint16_t owner[KUNITS][KUNITS > 1 ? 576 : OWN];  // per unit: flattened sample e -> (primitive << 8) | sample index
+  // per unit: flattened sample e -> (primitive << 8) | sample index; 12 samples per lane of the unit
+  // (at least 576 = 27 x 21 + 9) before the generic loop takes over
+  uint16_t owner[KUNITS][KUNITS > 1 ? (BLOCK / KUNITS * 12 > 576 ? BLOCK / KUNITS * 12 : 576) : OWN];
   int32_t slow[KUNITS];  // unit has more samples than the owner map covers -> generic sample loop
-  uint32_t cnt_s[BLOCK];  // samples per primitive (n+1), 0 if skipped
+  uint32_t node_blk[KUNITS];  // the unit's node cell (sample 0 of every primitive): 0 free, 1 occupied, 2 outside the map
   uint32_t offs[KUNITS][BLOCK / KUNITS + 1];
   uint32_t blk[BLOCK];  // first blocked sample: (i << 1) | inside
   unsigned long long dupset[KUNITS > 1 ? 2 : 2 * BLOCK];  // unused by the multi-unit kernel
@@ -227,7 +229,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
   L.valid = false;
   L.blocked = false;
   L.reads = 0;
-  uint32_t my_cnt = 0;
+  uint32_t my_cnt = 0, my_pairs = 0;
   if (live_unit && lu < P.n_u) {
     double c[3][6];
     const double *u = P.U + 3 * lu;
@@ -253,6 +255,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
     if (ok) {
       int n = (int)ceil(max_v * T / P.map.res);
       my_cnt = (uint32_t)(n + 1);
+      my_pairs = (uint32_t)n;  // sample 0 is the node itself: tested once per unit, below
       S.dts[tid] = n > 0 ? T / n : 0.0;
       L.valid = true;
     }
@@ -268,18 +271,37 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
   MPLX_TOC(S, 3, tf0);
   MPLX_TIC(tf1);
 #endif
-  S.cnt_s[tid] = my_cnt;
+  // Sample 0 of every primitive is the node position (p(0) = c5): one cell test per unit instead of
+  // n_u, by a lane that has no primitive when there is one.  The load is consumed after phase 2.
+  const int nl = P.n_u < UL ? P.n_u : 0;
+  uint32_t node_code = 0;
+  if (live_unit && lu == nl) {
+    int32_t c[3];
+    bool in = true;
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+      c[ax] = float_to_cell(S.cur[ku][ax], P.map.origin[ax], P.map.res);
+      in = in && c[ax] >= 0 && c[ax] < P.map.dim[ax];
+    }
+    if (in) {
+      const uint32_t brick = (uint32_t)(c[0] >> 3) + (uint32_t)P.map.nb[0] * ((uint32_t)(c[1] >> 3) + (uint32_t)P.map.nb[1] * (uint32_t)(c[2] >> 3));
+      const uint32_t bit = (uint32_t)(c[0] & 7) | ((uint32_t)(c[1] & 7) << 3) | ((uint32_t)(c[2] & 7) << 6);
+      node_code = (P.map.bricks[brick * 16u + (bit >> 5)] >> (bit & 31u)) & 1u;
+    } else {
+      node_code = 2;
+    }
+  }
   S.blk[tid] = 0xFFFFFFFFu;
   uint32_t total;
-  uint32_t off = unit_excl_scan<UL, BLOCK>(my_cnt, S, tid, total);
+  uint32_t off = unit_excl_scan<UL, BLOCK>(my_pairs, S, tid, total);
   S.offs[ku][lu] = off;
   if (lu == UL - 1) S.offs[ku][UL] = total;
   // owner map: flattened sample e -> (primitive, sample index); one LDS read replaces a search
   constexpr uint32_t OWNU = sizeof(S.owner[0]) / sizeof(uint16_t);
   if (lu == 0) S.slow[ku] = 0;
-  for (uint32_t i = 0; i < my_cnt && i < 256u && off + i < OWNU; i++) S.owner[ku][off + i] = (uint16_t)((lu << 8) | i);
+  for (uint32_t i = 0; i < my_pairs && i < 255u && off + i < OWNU; i++) S.owner[ku][off + i] = (uint16_t)((lu << 8) | (i + 1));
   unit_sync<UL>();
-  if (my_cnt > 256u || (lu == UL - 1 && total > OWNU)) S.slow[ku] = 1;
+  if (my_pairs > 255u || (lu == UL - 1 && total > OWNU)) S.slow[ku] = 1;
   unit_sync<UL>();
 #ifdef MPLX_FINE_TIMERS
   MPLX_TOC(S, 5, tf1);
@@ -290,7 +312,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
   const uint32_t *__restrict__ bricks = P.map.bricks;
   const int dx = P.map.dim[0], dy = P.map.dim[1], dz = P.map.dim[2];
   const int nb0 = P.map.nb[0], nb1 = P.map.nb[1];
-  constexpr int UNR = 6;
+  constexpr int UNR = 4;
   if (!S.slow[ku]) {
     // Staged over the UNR pairs of a lane (all LDS reads of a stage are independent, one wait per
     // stage), branch-free: dead slots recompute the last live pair, outside cells read voxel 0, and
@@ -326,15 +348,15 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
 #pragma unroll
         for (int k = 1; k < NQ; k++) qq[k] = qnr[0][k];
         qq[0] = u0[r];
-        cx[r] = float_to_cell_inv(pos_at_qc<CONTROL>(qq, t), ox, rs, irs);
+        cx[r] = float_to_cell_inv(pos_at_qc_cell<CONTROL>(qq, t), ox, rs, irs);
 #pragma unroll
         for (int k = 1; k < NQ; k++) qq[k] = qnr[1][k];
         qq[0] = u1[r];
-        cy[r] = float_to_cell_inv(pos_at_qc<CONTROL>(qq, t), oy, rs, irs);
+        cy[r] = float_to_cell_inv(pos_at_qc_cell<CONTROL>(qq, t), oy, rs, irs);
 #pragma unroll
         for (int k = 1; k < NQ; k++) qq[k] = qnr[2][k];
         qq[0] = u2[r];
-        cz[r] = float_to_cell_inv(pos_at_qc<CONTROL>(qq, t), oz, rs, irs);
+        cz[r] = float_to_cell_inv(pos_at_qc_cell<CONTROL>(qq, t), oz, rs, irs);
       }
       int32_t vv[UNR];
       bool inside[UNR];
@@ -343,9 +365,10 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
         inside[r] = !(cx[r] < 0 || cx[r] >= dx || cy[r] < 0 || cy[r] >= dy || cz[r] < 0 || cz[r] >= dz);
         const int sx = min(max(cx[r], 0), dx - 1), sy = min(max(cy[r], 0), dy - 1), sz = min(max(cz[r], 0), dz - 1);
         // occupancy bit from the bricked bitmap (always a valid address)
-        const size_t brick = (size_t)(sx >> 3) + (size_t)nb0 * ((size_t)(sy >> 3) + (size_t)nb1 * (size_t)(sz >> 3));
+        // (32-bit word index: the host refuses maps with more than 2^26 bricks)
+        const uint32_t brick = (uint32_t)(sx >> 3) + (uint32_t)nb0 * ((uint32_t)(sy >> 3) + (uint32_t)nb1 * (uint32_t)(sz >> 3));
         const uint32_t bit = (uint32_t)(sx & 7) | ((uint32_t)(sy & 7) << 3) | ((uint32_t)(sz & 7) << 6);
-        vv[r] = (int32_t)((bricks[brick * 16 + (bit >> 5)] >> (bit & 31u)) & 1u);
+        vv[r] = (int32_t)((bricks[brick * 16u + (bit >> 5)] >> (bit & 31u)) & 1u);
       }
 #pragma unroll
       for (int r = 0; r < UNR; r++) {
@@ -367,7 +390,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
         if (S.offs[ku][mid] <= e) lo = mid; else hi = mid;
       }
       const int pl = lo, pc = ku * UL + pl;
-      const uint32_t i = e - S.offs[ku][pl];
+      const uint32_t i = e - S.offs[ku][pl] + 1u;  // samples 1..n (sample 0: the node cell test)
       const double t = (double)i * S.dts[pc];
       int32_t cell[3];
 #pragma unroll
@@ -387,9 +410,12 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
 #ifdef MPLX_FINE_TIMERS
   MPLX_TOC(S, 9, tf2);   // thread 0's own phase-2 work, before waiting for the other units
 #endif
+  if (live_unit && lu == nl) S.node_blk[ku] = node_code;
   unit_sync<UL>();
   if (L.valid) {
     uint32_t code = S.blk[tid];
+    const uint32_t nb = S.node_blk[ku];
+    if (nb) code = nb == 2u ? 0u : 1u;  // blocked at sample 0 (outside: no voxel read)
     L.blocked = code != 0xFFFFFFFFu;
     L.reads = L.blocked ? (code >> 1) + (code & 1u) : my_cnt;
   }
@@ -474,13 +500,13 @@ struct QView {
 };
 
 // thread 0: make sure the query owns chunks for `need` items of a pool; false when the pool is exhausted
-__device__ __forceinline__ bool ensure_chunks(uint32_t *tbl, uint32_t &owned, uint32_t need, int ch_log, int max_ch, uint32_t *next, uint32_t pool_chunks) {
+__device__ __forceinline__ bool ensure_chunks(uint16_t *tbl, uint32_t &owned, uint32_t need, int ch_log, int max_ch, uint32_t *next, uint32_t pool_chunks) {
   const uint32_t want = (need + (1u << ch_log) - 1) >> ch_log;
   while (owned < want) {
     if (owned >= (uint32_t)max_ch) return false;
     uint32_t c = atomicAdd(next, 1u);
     if (c >= pool_chunks) return false;
-    tbl[owned++] = c;
+    tbl[owned++] = (uint16_t)c;
   }
   return true;
 }

@@ -178,6 +178,24 @@ MPLX_HD double pos_at_qc(const double *q, double t) {
   }
 }
 
+// Position for the voxel test only: pos_at_qc without the "+ 0.0" terms.  Those only turn a -0.0
+// partial sum into +0.0; a zero of either sign gives the same (p - origin) / res - 0.5 and so the
+// same cell (p - origin is -origin for both when origin != 0, and +-0 / res - 0.5 = -0.5 otherwise).
+template <int CONTROL>
+MPLX_HD double pos_at_qc_cell(const double *q, double t) {
+  if constexpr (CONTROL == CTRL_VEL) {
+    return q[0] * t + q[1];
+  } else if constexpr (CONTROL == CTRL_ACC) {
+    return (q[0] * t * t + q[1] * t) + q[2];
+  } else if constexpr (CONTROL == CTRL_JRK) {
+    double t2 = t * t, t3 = t2 * t;
+    return ((q[0] * t3 + q[1] * t * t) + q[2] * t) + q[3];
+  } else {
+    double t2 = t * t, t3 = t2 * t, t4 = t3 * t;
+    return (((q[0] * t4 + q[1] * t3) + q[2] * t * t) + q[3] * t) + q[4];
+  }
+}
+
 // max |d^k p| on [0,T] with the control-specialised evaluators (same scan as max_abs_deriv)
 template <int K, int CONTROL>
 MPLX_HD double max_abs_deriv_c(const double *c, double T) {
