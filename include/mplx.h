@@ -124,6 +124,23 @@ int mplx_map_info(const mplx_ctx *ctx, int32_t dim[3], double origin[3], double 
  * cells: n x 3 int32; state: 0 free, 1 occupied, 2 unknown, 3 outside */
 int mplx_map_query(mplx_ctx *ctx, int n, const double *pts, int32_t *cells, int8_t *state);
 
+/* MapUtil::dilate(const vec_Veci& neighbours), map_planner_node.cpp:75-85: every occupied voxel marks
+ * voxel + offset occupied (100) when that is inside the map; evaluated on a copy, so dilation does not
+ * cascade.  offsets: n_offsets x 3 int32.  The grid set with mplx_map_set_device is modified in place. */
+int mplx_map_dilate(mplx_ctx *ctx, int n_offsets, const int32_t *offsets);
+/* MapUtil::isFree / isOccupied / isUnknown / isOutside(const Veci&), map_replanner_node.cpp:180,217,
+ * for n cells (n x 3 int32); state: 0 free, 1 occupied, 2 unknown, 3 outside */
+int mplx_map_cells(mplx_ctx *ctx, int n, const int32_t *cells, int8_t *state);
+/* MapUtil::rayTrace(pt1, pt2), map_replanner_node.cpp:177,208: the distinct cells met when walking from
+ * pt1 to pt2 in steps of 0.8 cell, stopping at the map border.  Geometry only (no voxel is read).
+ * cells: cap x 3 int32; *n_out = number of cells of the ray (may exceed cap: call again). */
+int mplx_map_raytrace(const mplx_ctx *ctx, const double p1[3], const double p2[3], int32_t *cells, int cap, int *n_out);
+/* MapUtil::getCloud / getFreeCloud / getUnknownCloud, map_display.cpp:244,256,266: voxel centres
+ * (n + 0.5) res + origin of the occupied (which 0) / free (1) / unknown (2) voxels, x outermost and z
+ * innermost like the in-tree twin voxel_grid.cpp:18-29,205-207.  pts: cap x 3 f64 (may be NULL with
+ * cap 0 to query the size); *n_out = number of voxels of the class. */
+int mplx_map_cloud(mplx_ctx *ctx, int which, double *pts, uint64_t cap, uint64_t *n_out);
+
 /* ---- planner configuration ---- */
 int mplx_planner_config(mplx_ctx *ctx, const mplx_config *cfg);
 /* device pools: number of queries in flight (workgroups) and the TOTAL capacities shared by all

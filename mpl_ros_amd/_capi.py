@@ -50,6 +50,7 @@ class Result(C.Structure):
 EXPORTS = [
     "mplx_ctx_create", "mplx_ctx_destroy", "mplx_last_error", "mplx_set_stream",
     "mplx_map_set", "mplx_map_set_device", "mplx_map_free_unknown", "mplx_map_get", "mplx_map_info", "mplx_map_query",
+    "mplx_map_dilate", "mplx_map_cells", "mplx_map_raytrace", "mplx_map_cloud",
     "mplx_planner_config", "mplx_set_capacity", "mplx_set_bucket_width", "mplx_set_speculation",
     "mplx_expand_batch", "mplx_heuristic_batch", "mplx_plan", "mplx_plan_batch",
     "mplx_result_traj", "mplx_set_record", "mplx_result_expanded", "mplx_result_nodes", "mplx_result_timing", "mplx_result_cycles",
@@ -87,6 +88,10 @@ def load():
     L.mplx_map_get.argtypes = [P, C.c_void_p]
     L.mplx_map_info.argtypes = [P, I3, D3, D3]
     L.mplx_map_query.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mplx_map_dilate.argtypes = [P, C.c_int, C.c_void_p]
+    L.mplx_map_cells.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p]
+    L.mplx_map_raytrace.argtypes = [P, D3, D3, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.mplx_map_cloud.argtypes = [P, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.mplx_planner_config.argtypes = [P, C.POINTER(Config)]
     L.mplx_set_capacity.argtypes = [P, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]
     L.mplx_set_bucket_width.argtypes = [P, C.c_double]

@@ -238,6 +238,131 @@ static MapDev map_dev(const mplx_ctx *c) {
   m.res = c->res;
   return m;
 }
+extern "C" int mplx_map_dilate(mplx_ctx *c, int n_off, const int32_t *off) {
+  if (!c || !c->map || n_off < 0 || (n_off > 0 && !off)) return fail(c, MPLX_ERR_ARG, "bad argument");
+  if (n_off == 0) return MPLX_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)c->dim[0] * c->dim[1] * c->dim[2];
+  int8_t *out = nullptr;
+  int32_t *doff = nullptr;
+  HIPCHK(c, hipMalloc((void **)&out, n));
+  if (hipMalloc((void **)&doff, sizeof(int32_t) * 3 * (size_t)n_off) != hipSuccess) {
+    (void)hipFree(out);
+    return fail(c, MPLX_ERR_HIP, "hipMalloc failed");
+  }
+  hipError_t e = hipMemcpyAsync(doff, off, sizeof(int32_t) * 3 * (size_t)n_off, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(dilate_kernel, dim3(8192), dim3(256), 0, c->stream, c->map, out, c->dim[0], c->dim[1], c->dim[2], n_off, doff);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) {
+    if (c->own_map) {  // swap buffers
+      e = hipStreamSynchronize(c->stream);
+      if (e == hipSuccess) {
+        (void)hipFree(c->map);
+        c->map = out;
+        out = nullptr;
+      }
+    } else {           // the caller's buffer: results go back into it
+      e = hipMemcpyAsync(c->map, out, n, hipMemcpyDeviceToDevice, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+  }
+  (void)hipFree(out);
+  (void)hipFree(doff);
+  if (e != hipSuccess) return fail(c, MPLX_ERR_HIP, "%s", hipGetErrorString(e));
+  return build_bricks(c);
+}
+extern "C" int mplx_map_cells(mplx_ctx *c, int n, const int32_t *cells, int8_t *state) {
+  if (!c || !c->map || n < 0 || (n > 0 && (!cells || !state))) return fail(c, MPLX_ERR_ARG, "bad argument");
+  if (n == 0) return MPLX_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  int32_t *dc = nullptr;
+  int8_t *ds = nullptr;
+  HIPCHK(c, hipMalloc((void **)&dc, sizeof(int32_t) * 3 * (size_t)n));
+  if (hipMalloc((void **)&ds, (size_t)n) != hipSuccess) {
+    (void)hipFree(dc);
+    return fail(c, MPLX_ERR_HIP, "hipMalloc failed");
+  }
+  hipError_t e = hipMemcpyAsync(dc, cells, sizeof(int32_t) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(map_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, map_dev(c), n, dc, ds);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(state, ds, (size_t)n, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(dc);
+  (void)hipFree(ds);
+  if (e != hipSuccess) return fail(c, MPLX_ERR_HIP, "%s", hipGetErrorString(e));
+  return MPLX_OK;
+}
+// host-side geometry: reads no voxel (same f64 expressions as the device's float_to_cell)
+extern "C" int mplx_map_raytrace(const mplx_ctx *c, const double p1[3], const double p2[3], int32_t *cells, int cap, int *n_out) {
+  if (!c || !c->map || !p1 || !p2 || !n_out || cap < 0 || (cap > 0 && !cells)) return MPLX_ERR_ARG;
+  double diff[3], m = 0.0;
+  for (int i = 0; i < 3; i++) {
+    diff[i] = p2[i] - p1[i];
+    const double q = fabs(diff[i] / c->res);
+    if (q > m) m = q;
+  }
+  const double k = 0.8;
+  const int max_diff = (int)(m / k);
+  const double sstep = 1.0 / max_diff;
+  int32_t prev[3] = {-1, -1, -1};
+  int cnt = 0;
+  for (int n = 1; n < max_diff; n++) {
+    int32_t pn[3];
+    bool outside = false;
+    for (int i = 0; i < 3; i++) {
+      const double pt = p1[i] + diff[i] * sstep * n;
+      pn[i] = float_to_cell(pt, c->origin[i], c->res);
+      if (pn[i] < 0 || pn[i] >= c->dim[i]) outside = true;
+    }
+    if (outside) break;
+    if (pn[0] != prev[0] || pn[1] != prev[1] || pn[2] != prev[2]) {
+      if (cnt < cap) {
+        cells[3 * cnt] = pn[0]; cells[3 * cnt + 1] = pn[1]; cells[3 * cnt + 2] = pn[2];
+      }
+      cnt++;
+    }
+    prev[0] = pn[0]; prev[1] = pn[1]; prev[2] = pn[2];
+  }
+  *n_out = cnt;
+  return MPLX_OK;
+}
+extern "C" int mplx_map_cloud(mplx_ctx *c, int which, double *pts, uint64_t cap, uint64_t *n_out) {
+  if (!c || !c->map || which < 0 || which > 2 || !n_out || (cap > 0 && !pts)) return fail(c, MPLX_ERR_ARG, "bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int ncol = c->dim[0] * c->dim[1];
+  uint32_t *counts = nullptr;
+  unsigned long long *offs = nullptr, *dtotal = nullptr;
+  double *dpts = nullptr;
+  hipError_t e = hipMalloc((void **)&counts, sizeof(uint32_t) * (size_t)ncol);
+  if (e == hipSuccess) e = hipMalloc((void **)&offs, sizeof(unsigned long long) * (size_t)ncol);
+  if (e == hipSuccess) e = hipMalloc((void **)&dtotal, sizeof(unsigned long long));
+  unsigned long long total = 0;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(cloud_count_kernel, dim3((ncol + 255) / 256 < 4096 ? (ncol + 255) / 256 : 4096), dim3(256), 0, c->stream, map_dev(c), which, counts);
+    hipLaunchKernelGGL(cloud_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, offs, ncol, dtotal);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, dtotal, sizeof(total), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  const uint64_t nw = total < cap ? total : cap;
+  if (e == hipSuccess && nw > 0) {
+    e = hipMalloc((void **)&dpts, sizeof(double) * 3 * nw);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(cloud_write_kernel, dim3((ncol + 255) / 256 < 4096 ? (ncol + 255) / 256 : 4096), dim3(256), 0, c->stream, map_dev(c), which, offs, (unsigned long long)nw, dpts);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(pts, dpts, sizeof(double) * 3 * nw, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  (void)hipFree(counts); (void)hipFree(offs); (void)hipFree(dtotal); (void)hipFree(dpts);
+  if (e != hipSuccess) return fail(c, MPLX_ERR_HIP, "%s", hipGetErrorString(e));
+  *n_out = total;
+  return MPLX_OK;
+}
 extern "C" int mplx_map_query(mplx_ctx *c, int n, const double *pts, int32_t *cells, int8_t *state) {
   if (!c || !c->map || n < 0 || !pts || !cells || !state) return fail(c, MPLX_ERR_ARG, "bad argument");
   if (n == 0) return MPLX_OK;

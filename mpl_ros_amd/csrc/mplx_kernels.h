@@ -1267,6 +1267,99 @@ __global__ void free_unknown_kernel(int8_t *map, size_t n) {
     if (map[i] == -1) map[i] = 0;
 }
 
+// MapUtil::dilate: every occupied voxel marks voxel + offset (inside the map) occupied, on a copy.
+// Gather form: a voxel becomes occupied (100) when voxel - offset is inside and occupied.  One
+// thread per voxel, x fastest (coalesced row reads; the neighbour rows come from L1/L2): 1 B read +
+// 1 B written per voxel of HBM traffic.
+__global__ void dilate_kernel(const int8_t *__restrict__ in, int8_t *__restrict__ out, int dx, int dy, int dz, int n_off, const int32_t *__restrict__ off) {
+  const size_t n = (size_t)dx * dy * dz;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int8_t v = in[i];
+    if (v <= 0) {
+      const int x = (int)(i % dx), y = (int)((i / dx) % dy), z = (int)(i / ((size_t)dx * dy));
+      for (int k = 0; k < n_off; k++) {
+        const int sx = x - off[3 * k], sy = y - off[3 * k + 1], sz = z - off[3 * k + 2];
+        if (sx < 0 || sx >= dx || sy < 0 || sy >= dy || sz < 0 || sz >= dz) continue;
+        if (in[(size_t)sx + (size_t)dx * sy + (size_t)dx * dy * sz] > 0) {
+          v = 100;
+          break;
+        }
+      }
+    }
+    out[i] = v;
+  }
+}
+
+// MapUtil::isFree/isOccupied/isUnknown/isOutside(const Veci&) for n cells
+__global__ void map_cells_kernel(MapDev m, int n, const int32_t *cells, int8_t *state) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t cx = cells[3 * i], cy = cells[3 * i + 1], cz = cells[3 * i + 2];
+  int8_t s = 3;
+  if (cx >= 0 && cx < m.dim[0] && cy >= 0 && cy < m.dim[1] && cz >= 0 && cz < m.dim[2]) {
+    int8_t v = m.data[(size_t)cx + (size_t)m.dim[0] * cy + (size_t)m.dim[0] * m.dim[1] * cz];
+    s = v == 0 ? 0 : (v > 0 ? 1 : 2);
+  }
+  state[i] = s;
+}
+
+// MapUtil::getCloud / getFreeCloud / getUnknownCloud: voxel centres (n + 0.5) res + origin of the
+// voxels of one class, in the order of the reference's loops (x outermost, z innermost).
+// which: 0 occupied (> 0), 1 free (== 0), 2 unknown (< 0).  Pass 1 counts per (x, y) column.
+__device__ __forceinline__ bool cloud_match(int8_t v, int which) { return which == 0 ? v > 0 : which == 1 ? v == 0 : v < 0; }
+__global__ void cloud_count_kernel(MapDev m, int which, uint32_t *counts) {
+  const int ncol = m.dim[0] * m.dim[1];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncol; c += gridDim.x * blockDim.x) {
+    const int x = c % m.dim[0], y = c / m.dim[0];  // consecutive threads: consecutive x (coalesced)
+    uint32_t k = 0;
+    for (int z = 0; z < m.dim[2]; z++) k += cloud_match(m.data[(size_t)x + (size_t)m.dim[0] * y + (size_t)m.dim[0] * m.dim[1] * z], which) ? 1u : 0u;
+    counts[(size_t)x * m.dim[1] + y] = k;  // stored in output (x-major) order
+  }
+}
+// exclusive scan of counts (one workgroup, 1024 threads, chunked with a carry); total -> *total
+__global__ __launch_bounds__(1024) void cloud_scan_kernel(const uint32_t *counts, unsigned long long *offs, int n, unsigned long long *total) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const unsigned long long v = i < n ? counts[i] : 0ull;
+    unsigned long long x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      unsigned long long y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    unsigned long long pre = carry;
+    for (int w = 0; w < wave; w++) pre += wsum[w];
+    if (i < n) offs[i] = pre + x - v;
+    __syncthreads();
+    if (tid == 1023) carry = pre + x;
+    __syncthreads();
+  }
+  if (tid == 0) *total = carry;
+}
+__global__ void cloud_write_kernel(MapDev m, int which, const unsigned long long *offs, unsigned long long cap, double *pts) {
+  const int ncol = m.dim[0] * m.dim[1];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncol; c += gridDim.x * blockDim.x) {
+    const int x = c % m.dim[0], y = c / m.dim[0];
+    unsigned long long o = offs[(size_t)x * m.dim[1] + y];
+    for (int z = 0; z < m.dim[2]; z++) {
+      if (!cloud_match(m.data[(size_t)x + (size_t)m.dim[0] * y + (size_t)m.dim[0] * m.dim[1] * z], which)) continue;
+      if (o < cap) {
+        pts[3 * o] = ((double)x + 0.5) * m.res + m.origin[0];
+        pts[3 * o + 1] = ((double)y + 0.5) * m.res + m.origin[1];
+        pts[3 * o + 2] = ((double)z + 0.5) * m.res + m.origin[2];
+      }
+      o++;
+    }
+  }
+}
+
 __global__ void map_query_kernel(MapDev m, int n, const double *pts, int32_t *cells, int8_t *state) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

@@ -58,6 +58,9 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   int32_t u_goal[K];  // candidate k satisfies the goal test (evaluated ahead of its commit)
   int32_t u_cut[K];   // first later candidate preceded by an entry unit k pushes (K if none)
   uint32_t n_sorted;  // near_[0, n_sorted) is in ascending order (left so by the previous selection)
+  // the entries appended since, sorted (selection scratch)
+  double app_f[128], app_g[128];
+  uint32_t app_id[128], app_rank[128];
   int32_t batch_dep;  // units interact through a state one of them MODIFIES -> ordered, unit-by-unit commit
   int32_t any_shared; // some state is reached by two lanes (they only append predecessor edges unless batch_dep)
   int32_t dep_cause;  // (debug statistics) 1 shared successor, 2 candidate is a successor, 4 a sharer modifies the state
@@ -382,26 +385,63 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           // near_[0, ns) is sorted (previous selection), near_[ns, n) are the entries appended since:
           // rank = (#sorted entries before me: my index, or a binary search) + (#appended entries before me)
           const uint32_t ns_ = S.n_sorted <= n ? S.n_sorted : 0u;
-#pragma unroll
-          for (int r = 0; r < PERT; r++) {
-            const uint32_t i = tid + r * BLOCK;
-            if (i < ns_) {
-              rk[r] = i;
-            } else if (i < n) {
-              uint32_t lo = 0, hi = ns_;  // number of sorted entries that precede mine
-              while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (entry_less(S.near_f[mid], S.near_g[mid], S.near_id[mid], ef[r], eg[r], ei[r])) lo = mid + 1; else hi = mid;
-              }
-              rk[r] = lo;
+          const uint32_t na = n - ns_;
+          auto rank_in_prefix = [&](int r) {  // number of sorted entries that precede entry r of this thread
+            uint32_t lo = 0, hi = ns_;
+            while (lo < hi) {
+              const uint32_t mid = (lo + hi) >> 1;
+              if (entry_less(S.near_f[mid], S.near_g[mid], S.near_id[mid], ef[r], eg[r], ei[r])) lo = mid + 1; else hi = mid;
             }
-          }
-          for (uint32_t j = ns_; j < n; j++) {
-            const double f = S.near_f[j], g = S.near_g[j];
-            const uint32_t id = S.near_id[j];
+            return lo;
+          };
+          if (na <= 128u) {  // (uniform) the usual case: a few dozen entries pushed by the previous batch
+            // sort the appended entries among themselves (all pairs, G threads per entry), then every
+            // entry finds the number of appended entries before it with a binary search
+            const uint32_t G = na <= 64u ? BLOCK / 64 : BLOCK / 128;
+            const uint32_t a = (uint32_t)tid / G, part = (uint32_t)tid % G;
+            uint32_t cnt = 0;
+            double af = 0.0, ag = 0.0;
+            uint32_t ai = 0;
+            if (a < na) {
+              af = S.near_f[ns_ + a]; ag = S.near_g[ns_ + a]; ai = S.near_id[ns_ + a];
+              for (uint32_t j = part; j < na; j += G)
+                if (entry_less(S.near_f[ns_ + j], S.near_g[ns_ + j], S.near_id[ns_ + j], af, ag, ai)) cnt++;
+            }
 #pragma unroll
-            for (int r = 0; r < PERT; r++)
-              if (entry_less(f, g, id, ef[r], eg[r], ei[r])) rk[r]++;
+            for (int d = 1; d < BLOCK / 64; d <<= 1)
+              if ((uint32_t)d < G) cnt += __shfl_xor(cnt, d, 64);
+            if (a < na && part == 0) {
+              S.app_f[cnt] = af; S.app_g[cnt] = ag; S.app_id[cnt] = ai;
+              S.app_rank[a] = cnt;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < PERT; r++) {
+              const uint32_t i = tid + r * BLOCK;
+              if (i < ns_) {
+                uint32_t lo = 0, hi = na;  // appended entries that precede mine
+                while (lo < hi) {
+                  const uint32_t mid = (lo + hi) >> 1;
+                  if (entry_less(S.app_f[mid], S.app_g[mid], S.app_id[mid], ef[r], eg[r], ei[r])) lo = mid + 1; else hi = mid;
+                }
+                rk[r] = i + lo;
+              } else if (i < n) {
+                rk[r] = rank_in_prefix(r) + S.app_rank[i - ns_];
+              }
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < PERT; r++) {
+              const uint32_t i = tid + r * BLOCK;
+              if (i < ns_) rk[r] = i; else if (i < n) rk[r] = rank_in_prefix(r);
+            }
+            for (uint32_t j = ns_; j < n; j++) {
+              const double f = S.near_f[j], g = S.near_g[j];
+              const uint32_t id = S.near_id[j];
+#pragma unroll
+              for (int r = 0; r < PERT; r++)
+                if (entry_less(f, g, id, ef[r], eg[r], ei[r])) rk[r]++;
+            }
           }
           MPLX_T2(S, 15, t3);
           __syncthreads();

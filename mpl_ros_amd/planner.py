@@ -216,6 +216,53 @@ class VoxelMapUtil:
     def isOutside(self, pt):
         return int(self.query([pt])[1][0]) == 3
 
+    def isUnknown(self, pt):
+        return int(self.query([pt])[1][0]) == 2
+
+    # ---- integer-cell forms (MapUtil::isFree(const Veci&) ..., map_replanner_node.cpp:180,217)
+    def cellStates(self, cells):
+        """state (0 free, 1 occupied, 2 unknown, 3 outside) of n cells (n,3) in one launch"""
+        c = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 3)
+        st = np.empty(c.shape[0], dtype=np.int8)
+        self.ctx.check(self.ctx.lib.mplx_map_cells(self.ctx.h, c.shape[0], c.ctypes.data, st.ctypes.data))
+        return st
+
+    def isFreeCell(self, pn):
+        return int(self.cellStates([pn])[0]) == 0
+
+    def isOccupiedCell(self, pn):
+        return int(self.cellStates([pn])[0]) == 1
+
+    def dilate(self, neighbours):
+        """MapUtil::dilate(const vec_Veci&), map_planner_node.cpp:75-85"""
+        o = np.ascontiguousarray(neighbours, dtype=np.int32).reshape(-1, 3)
+        self.ctx.check(self.ctx.lib.mplx_map_dilate(self.ctx.h, o.shape[0], o.ctypes.data))
+
+    def rayTrace(self, pt1, pt2):
+        """MapUtil::rayTrace, map_replanner_node.cpp:177,208: cells (n,3) between two points"""
+        a = (C.c_double * 3)(*[float(v) for v in pt1]); b = (C.c_double * 3)(*[float(v) for v in pt2])
+        n = C.c_int(0)
+        self.ctx.check(self.ctx.lib.mplx_map_raytrace(self.ctx.h, a, b, None, 0, C.byref(n)))
+        out = np.empty((max(n.value, 1), 3), dtype=np.int32)
+        self.ctx.check(self.ctx.lib.mplx_map_raytrace(self.ctx.h, a, b, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def _cloud(self, which):
+        n = C.c_uint64(0)
+        self.ctx.check(self.ctx.lib.mplx_map_cloud(self.ctx.h, which, None, 0, C.byref(n)))
+        out = np.empty((max(n.value, 1), 3), dtype=np.float64)
+        self.ctx.check(self.ctx.lib.mplx_map_cloud(self.ctx.h, which, out.ctypes.data, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def getCloud(self):          # map_display.cpp:244
+        return self._cloud(0)
+
+    def getFreeCloud(self):      # map_display.cpp:256
+        return self._cloud(1)
+
+    def getUnknownCloud(self):   # map_display.cpp:266
+        return self._cloud(2)
+
 
 class VoxelMapPlanner:
     """PlannerBase<3, Waypoint3D> + MapPlanner<3> over the device back-end."""

@@ -415,6 +415,89 @@ void orc_free_unknown(orc_planner *p) {
   for (size_t i = 0; i < n; i++)
     if (p->map[i] == -1) p->map[i] = 0;
 }
+/* [UNVERIFIED map_util.h dilate(const vec_Veci&); IN-TREE call map_planner_node.cpp:75-85]  every
+ * occupied voxel marks voxel + offset occupied (val_occ = 100, voxel_grid.h:43-45) when that is inside
+ * the map; written to a copy so that dilation does not cascade (scatter form, as upstream loops). */
+void orc_map_dilate(orc_planner *p, int n_off, const int32_t *off) {
+  size_t n = (size_t)p->dim[0] * p->dim[1] * p->dim[2];
+  int8_t *out = (int8_t *)malloc(n);
+  memcpy(out, p->map, n);
+  for (int z = 0; z < p->dim[2]; z++)
+    for (int y = 0; y < p->dim[1]; y++)
+      for (int x = 0; x < p->dim[0]; x++) {
+        if (!(p->map[(size_t)x + (size_t)p->dim[0] * y + (size_t)p->dim[0] * p->dim[1] * z] > 0)) continue;
+        for (int k = 0; k < n_off; k++) {
+          int tx = x + off[3 * k], ty = y + off[3 * k + 1], tz = z + off[3 * k + 2];
+          if (tx < 0 || tx >= p->dim[0] || ty < 0 || ty >= p->dim[1] || tz < 0 || tz >= p->dim[2]) continue;
+          out[(size_t)tx + (size_t)p->dim[0] * ty + (size_t)p->dim[0] * p->dim[1] * tz] = 100;
+        }
+      }
+  free(p->map);
+  p->map = out;
+}
+void orc_map_get(const orc_planner *p, int8_t *out) { memcpy(out, p->map, (size_t)p->dim[0] * p->dim[1] * p->dim[2]); }
+/* [UNVERIFIED map_util.h isFree/isOccupied/isUnknown/isOutside(const Veci&); IN-TREE calls
+ * map_replanner_node.cpp:180,217]  0 free (== 0), 1 occupied (> 0), 2 unknown, 3 outside */
+int orc_map_cell_state(const orc_planner *p, const int32_t pn[3]) {
+  if (pn[0] < 0 || pn[0] >= p->dim[0] || pn[1] < 0 || pn[1] >= p->dim[1] || pn[2] < 0 || pn[2] >= p->dim[2]) return 3;
+  int8_t v = p->map[(size_t)pn[0] + (size_t)p->dim[0] * pn[1] + (size_t)p->dim[0] * p->dim[1] * pn[2]];
+  return v == 0 ? 0 : (v > 0 ? 1 : 2);
+}
+/* [UNVERIFIED map_util.h rayTrace(pt1, pt2); IN-TREE calls map_replanner_node.cpp:177,208]  walk from
+ * pt1 towards pt2 in max_diff = int(|diff/res|_inf / 0.8) equal steps (end points excluded), stop at
+ * the first cell outside the map, emit a cell when it differs from the previous one. */
+int orc_map_raytrace(const orc_planner *p, const double p1[3], const double p2[3], int32_t *cells, int cap) {
+  double diff[3], m = 0.0;
+  for (int i = 0; i < 3; i++) {
+    diff[i] = p2[i] - p1[i];
+    double q = fabs(diff[i] / p->res);
+    if (q > m) m = q;
+  }
+  double k = 0.8;
+  int max_diff = (int)(m / k);
+  double s = 1.0 / max_diff;
+  double step[3] = {diff[0] * s, diff[1] * s, diff[2] * s};
+  int32_t prev[3] = {-1, -1, -1};
+  int cnt = 0;
+  for (int n = 1; n < max_diff; n++) {
+    double pt[3] = {p1[0] + step[0] * n, p1[1] + step[1] * n, p1[2] + step[2] * n};
+    int32_t pn[3];
+    for (int i = 0; i < 3; i++) pn[i] = (int32_t)round((pt[i] - p->origin[i]) / p->res - 0.5);
+    if (pn[0] < 0 || pn[0] >= p->dim[0] || pn[1] < 0 || pn[1] >= p->dim[1] || pn[2] < 0 || pn[2] >= p->dim[2]) break;
+    if (pn[0] != prev[0] || pn[1] != prev[1] || pn[2] != prev[2]) {
+      if (cnt < cap) {
+        cells[3 * cnt] = pn[0];
+        cells[3 * cnt + 1] = pn[1];
+        cells[3 * cnt + 2] = pn[2];
+      }
+      cnt++;
+    }
+    prev[0] = pn[0];
+    prev[1] = pn[1];
+    prev[2] = pn[2];
+  }
+  return cnt;
+}
+/* [UNVERIFIED map_util.h getCloud/getFreeCloud/getUnknownCloud; IN-TREE twin voxel_grid.cpp:18-29 (loop
+ * order x, y, z) and :205-207 (intToFloat = (n + 0.5) res + origin); calls map_display.cpp:244,256,266]
+ * which: 0 occupied, 1 free, 2 unknown.  Returns the number of voxels of the class. */
+uint64_t orc_map_cloud(const orc_planner *p, int which, double *pts, uint64_t cap) {
+  uint64_t cnt = 0;
+  for (int x = 0; x < p->dim[0]; x++)
+    for (int y = 0; y < p->dim[1]; y++)
+      for (int z = 0; z < p->dim[2]; z++) {
+        int8_t v = p->map[(size_t)x + (size_t)p->dim[0] * y + (size_t)p->dim[0] * p->dim[1] * z];
+        int match = which == 0 ? v > 0 : which == 1 ? v == 0 : v < 0;
+        if (!match) continue;
+        if (cnt < cap) {
+          pts[3 * cnt] = ((double)x + 0.5) * p->res + p->origin[0];
+          pts[3 * cnt + 1] = ((double)y + 0.5) * p->res + p->origin[1];
+          pts[3 * cnt + 2] = ((double)z + 0.5) * p->res + p->origin[2];
+        }
+        cnt++;
+      }
+  return cnt;
+}
 /* [UNVERIFIED map_util.h floatToInt] round((pt - origin)/res - 0.5) */
 void orc_float_to_int(const orc_planner *p, const double pt[3], int32_t pn[3]) {
   for (int i = 0; i < 3; i++) pn[i] = (int32_t)round((pt[i] - p->origin[i]) / p->res - 0.5);

@@ -94,6 +94,12 @@ void orc_destroy(orc_planner *);
 /* copy-in map; values: free 0, occupied >0, unknown -1 */
 void orc_set_map(orc_planner *, const int8_t *data, const int32_t dim[3], const double origin[3], double res);
 void orc_free_unknown(orc_planner *);
+/* MapUtil helpers next to the search */
+void orc_map_dilate(orc_planner *, int n_offsets, const int32_t *offsets);
+void orc_map_get(const orc_planner *, int8_t *out);
+int orc_map_cell_state(const orc_planner *, const int32_t pn[3]);
+int orc_map_raytrace(const orc_planner *, const double p1[3], const double p2[3], int32_t *cells, int cap);
+uint64_t orc_map_cloud(const orc_planner *, int which, double *pts, uint64_t cap);
 void orc_set_config(orc_planner *, const orc_config *cfg);
 void orc_set_goal(orc_planner *, const orc_waypoint *goal);
 void orc_float_to_int(const orc_planner *, const double pt[3], int32_t pn[3]);

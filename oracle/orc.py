@@ -65,6 +65,14 @@ def lib():
         L.orc_destroy.argtypes = [P]
         L.orc_set_map.argtypes = [P, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_double]
         L.orc_free_unknown.argtypes = [P]
+        L.orc_map_dilate.argtypes = [P, C.c_int, C.c_void_p]
+        L.orc_map_get.argtypes = [P, C.c_void_p]
+        L.orc_map_cell_state.argtypes = [P, C.POINTER(C.c_int32)]
+        L.orc_map_cell_state.restype = C.c_int
+        L.orc_map_raytrace.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.c_int]
+        L.orc_map_raytrace.restype = C.c_int
+        L.orc_map_cloud.argtypes = [P, C.c_int, C.c_void_p, C.c_uint64]
+        L.orc_map_cloud.restype = C.c_uint64
         L.orc_set_config.argtypes = [P, C.POINTER(Config)]
         L.orc_set_goal.argtypes = [P, C.POINTER(Waypoint)]
         L.orc_float_to_int.argtypes = [P, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
@@ -145,10 +153,36 @@ class Planner:
         g = np.ascontiguousarray(grid, dtype=np.int8)
         dim = (C.c_int32 * 3)(g.shape[2], g.shape[1], g.shape[0])
         ori = (C.c_double * 3)(*[float(o) for o in origin])
+        self._shape = g.shape
         self.L.orc_set_map(self.h, g.ctypes.data, dim, ori, float(res))
 
     def free_unknown(self):
         self.L.orc_free_unknown(self.h)
+
+    def dilate(self, offsets):
+        o = np.ascontiguousarray(offsets, dtype=np.int32).reshape(-1, 3)
+        self.L.orc_map_dilate(self.h, o.shape[0], o.ctypes.data)
+
+    def get_map(self):
+        g = np.empty(self._shape, dtype=np.int8)
+        self.L.orc_map_get(self.h, g.ctypes.data)
+        return g
+
+    def cell_state(self, pn):
+        return int(self.L.orc_map_cell_state(self.h, (C.c_int32 * 3)(*[int(v) for v in pn])))
+
+    def ray_trace(self, p1, p2):
+        a = (C.c_double * 3)(*[float(v) for v in p1]); b = (C.c_double * 3)(*[float(v) for v in p2])
+        n = self.L.orc_map_raytrace(self.h, a, b, None, 0)
+        out = np.empty((max(n, 1), 3), dtype=np.int32)
+        self.L.orc_map_raytrace(self.h, a, b, out.ctypes.data, n)
+        return out[:n]
+
+    def cloud(self, which=0):
+        n = int(self.L.orc_map_cloud(self.h, which, None, 0))
+        out = np.empty((max(n, 1), 3), dtype=np.float64)
+        self.L.orc_map_cloud(self.h, which, out.ctypes.data, n)
+        return out[:n]
 
     def set_config(self, control, U, dt=1.0, v_max=-1.0, a_max=-1.0, j_max=-1.0, w=10.0, eps=1.0,
                    tol_pos=0.5, tol_vel=-1.0, tol_acc=-1.0, t_max=float("inf"), max_expand=-1,

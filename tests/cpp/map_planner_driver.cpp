@@ -5,6 +5,7 @@
 // Prints one JSON line that tests/test_cpp_shim.py compares with the oracle.
 #include <mpl_planner/planner/map_planner.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <fstream>
 
@@ -27,6 +28,20 @@ int main(int argc, char **argv) {
   }
   // Free unknown space
   map_util->freeUnknown();
+  // Inflate obstacle using robot radius (>0)  -- map_planner_node.cpp:72-85
+  double robot_r = 0.0;
+  if (robot_r > 0) {
+    vec_Vec3i ns;
+    int rn = std::ceil(robot_r / map_util->getRes());
+    for (int nx = -rn; nx <= rn; nx++) {
+      for (int ny = -rn; ny <= rn; ny++) {
+        if (nx == 0 && ny == 0) continue;
+        if (std::hypot(nx, ny) > rn) continue;
+        ns.push_back(Vec3i(nx, ny, 0));
+      }
+    }
+    map_util->dilate(ns);
+  }
 
   // Initialize planner
   double dt = 1.0, v_max = 2.0, a_max = 1.0, u = 1.0;
@@ -75,6 +90,12 @@ int main(int argc, char **argv) {
   auto ws = traj.getWaypoints();
   for (size_t i = 0; i < ws.size(); i++)
     printf("%s[%.17g, %.17g, %.17g, %.17g, %.17g, %.17g]", i ? ", " : "", ws[i].pos(0), ws[i].pos(1), ws[i].pos(2), ws[i].vel(0), ws[i].vel(1), ws[i].vel(2));
-  printf("], \"free_start\": %s}\n", map_util->isFree(start.pos) ? "true" : "false");
+  // the replanner's obstacle probe (map_replanner_node.cpp:177-184): cells of the start-goal ray that are occupied
+  vec_Vec3i pns = map_util->rayTrace(start.pos, goal.pos);
+  size_t ray_occ = 0;
+  for (const auto &pn : pns)
+    if (map_util->isOccupied(pn)) ray_occ++;
+  printf("], \"free_start\": %s, \"ray_cells\": %zu, \"ray_occupied\": %zu, \"cloud\": %zu}\n", map_util->isFree(start.pos) ? "true" : "false",
+         pns.size(), ray_occ, map_util->getCloud().size());
   return 0;
 }

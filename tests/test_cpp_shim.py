@@ -62,3 +62,7 @@ def test_reference_driver_through_the_shim(tmp_path, skir):
     for w, wo in zip(r["waypoints"][:-1], tr["wps"][:-1]):
         assert w == list(wo.pos) + list(wo.vel)
     assert np.allclose(r["waypoints"][-1][:3], list(tr["wps"][-1].pos), atol=1e-2)  # node merge quantisation
+    # MapUtil helpers through the shim: the replanner's ray probe and the display cloud
+    ray = P.ray_trace((5.5, 5.5, 0.5), (1.5, 1.5, 5.5))
+    assert r["ray_cells"] == len(ray) and r["ray_occupied"] == sum(P.cell_state(c) == 1 for c in ray)
+    assert r["cloud"] == len(P.cloud(0))
