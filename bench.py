@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--max-nodes", type=int, default=0, help="mean states per query used to size the shared pools")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 disables)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0 = all cores, at most 64; a single query uses 1)")
     args = ap.parse_args()
     if args.single:
         args.queries = 1
@@ -231,7 +232,8 @@ def main():
         if args.cpu_seconds > 0 and world == 1:
             # a single capped query is sampled on the CPU with a smaller cap (same search, stopped earlier)
             cpu_cap = min(max_expand, 250_000) if (args.single and max_expand > 0) else max_expand
-            out["cpu_baseline"] = cpu_baseline(grid, origin, res, control, U, cpu_cap, queries, args.cpu_seconds)
+            nthr = 1 if args.single else (args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 64))
+            out["cpu_baseline"] = cpu_baseline(grid, origin, res, control, U, cpu_cap, queries, args.cpu_seconds, nthr)
             if cpu_cap != max_expand:
                 out["cpu_baseline"]["sample"] += f"; CPU run capped at {cpu_cap} expansions"
         print(json.dumps(out), flush=True)
@@ -240,29 +242,55 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(grid, origin, res, control, U, max_expand, queries, budget_s):
+def cpu_baseline(grid, origin, res, control, U, max_expand, queries, budget_s, threads=1):
     """The CPU oracle (oracle/, a restatement -- kind "port") on a bounded sample of the same
-    queries, one host core, steady clock around plan() only."""
+    queries: `threads` host threads, one query at a time each (the reference planner is
+    single-threaded; independent queries are the only parallelism it offers), steady clock around
+    the plan() calls only.  value = expansions of the sample / wall time of the sample."""
+    import threading
     from oracle import orc
-    P = orc.Planner()
-    P.set_map(grid, origin, res)
     kw = dict(dt=1.0, v_max=2.0, a_max=1.0, tol_pos=0.5, max_expand=max_expand)
     if control == orc.JRK:
         kw["j_max"] = 1.0
-    P.set_config(control, U, **kw)
-    n_exp, t_plan, nq = 0, 0.0, 0
-    for s, g in queries:
-        P.reset_counters()
-        t0 = time.perf_counter()
-        P.plan(orc.waypoint(s, control=control), orc.waypoint(g, control=control))
-        t_plan += time.perf_counter() - t0
-        n_exp += P.counters()["n_expansions"]
-        nq += 1
-        if t_plan >= budget_s:
-            break
-    return {"value": n_exp / t_plan, "unit": "expansions/s", "cores": 1, "kind": "port",
-            "sample": f"first {nq} of the {len(queries)} queries of rank 0 ({n_exp} expansions, {t_plan:.1f} s of plan())",
-            "plan_ms_mean_per_query": 1e3 * t_plan / nq}
+    threads = max(1, min(threads, len(queries)))
+    planners = []
+    for _ in range(threads):  # ctypes releases the GIL inside plan(): the threads run in parallel
+        P = orc.Planner()
+        P.set_map(grid, origin, res)
+        P.set_config(control, U, **kw)
+        planners.append(P)
+    lock = threading.Lock()
+    state = {"next": 0, "n_exp": 0, "nq": 0, "busy": 0.0}
+    t_start = time.perf_counter()
+
+    def work(P):
+        while True:
+            with lock:
+                i = state["next"]
+                if i >= len(queries) or time.perf_counter() - t_start >= budget_s:
+                    return
+                state["next"] = i + 1
+            s, g = queries[i]
+            P.reset_counters()
+            t0 = time.perf_counter()
+            P.plan(orc.waypoint(s, control=control), orc.waypoint(g, control=control))
+            dt = time.perf_counter() - t0
+            with lock:
+                state["n_exp"] += P.counters()["n_expansions"]
+                state["nq"] += 1
+                state["busy"] += dt
+
+    ths = [threading.Thread(target=work, args=(P,)) for P in planners]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    wall = time.perf_counter() - t_start
+    n_exp, nq = state["n_exp"], state["nq"]
+    return {"value": n_exp / wall, "unit": "expansions/s", "cores": threads, "kind": "port",
+            "value_per_core": n_exp / state["busy"],
+            "sample": f"first {nq} of the {len(queries)} queries of rank 0 ({n_exp} expansions, {wall:.1f} s wall, {state['busy']:.1f} core-s of plan())",
+            "plan_ms_mean_per_query": 1e3 * state["busy"] / nq}
 
 
 if __name__ == "__main__":

@@ -218,8 +218,13 @@ struct LaneSucc {
 // One expansion unit = UL consecutive threads expanding one node (unit index ku, lane index lu inside
 // the unit); the workgroup holds BLOCK / UL units.  `live` false: the unit idles (it still takes part
 // in the workgroup barriers).
-template <int UL, int BLOCK, int CONTROL, class SM>
-__device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int tid, bool live_unit, LaneSucc &L) {
+struct NoHook {
+  __device__ __forceinline__ void operator()(const LaneSucc &) const {}
+};
+// `after_phase1(L)` runs once the successor state and key of the lane's primitive are known (L.valid),
+// before the voxel sampling: the caller can start memory traffic that depends on the key only.
+template <int UL, int BLOCK, int CONTROL, class SM, class Hook = NoHook>
+__device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int tid, bool live_unit, LaneSucc &L, Hook after_phase1 = Hook()) {
   constexpr int NQ = nq_c(CONTROL);
   const int ku = tid / UL, lu = tid % UL;
   const double T = P.dt;
@@ -260,6 +265,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
       L.valid = true;
     }
   }
+  after_phase1(L);
   if (live_unit && lu < 3) {  // node part of the pre-divided coefficients of axis lu
     double c0[6], qc[5];
     prim_build_axis(CONTROL, S.cur[ku][lu], S.cur[ku][3 + lu], S.cur[ku][6 + lu], S.cur[ku][9 + lu], 0.0, c0);

@@ -497,7 +497,17 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         // ---- 2b. expand all live units concurrently
         MPLX_TIC(tx);
         LaneSucc L;
-        expand_unit<UL, BLOCK, CONTROL>(P, S, tid, live_unit, L);
+        // first probe of the state-space table: issued as soon as the successor's key exists, i.e. before
+        // its voxels are sampled (a blocked successor wastes one load), consumed after the batch table is built
+        unsigned long long h64 = 0, v0 = TBL_EMPTY;
+        size_t pos0 = 0;
+        expand_unit<UL, BLOCK, CONTROL>(P, S, tid, live_unit, L, [&](const LaneSucc &l) {
+          if (l.valid) {
+            h64 = key_hash64(l.key, nk);
+            pos0 = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
+            v0 = ld_u64(&P.table[pos0]);
+          }
+        });
         const bool act = L.valid && !L.blocked;
         {
           uint32_t tot, treads;
@@ -514,7 +524,6 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         //          the state space (or claims a slot) and computes the heuristic of a new state
         MPLX_TIC(tc);
         unsigned long long t2 = __builtin_readcyclecounter();
-        unsigned long long h64 = 0;
         int my_slot = 0;
         for (int i = tid; i < BT; i += BLOCK) {
           S.bt_hash[i] = 0ull;
@@ -522,15 +531,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           S.bt_dirty[i] = 0;
           S.bt_share[i] = 0;
         }
-        unsigned long long v0 = TBL_EMPTY;
-        size_t pos0 = 0;
         if (act) {
-          h64 = key_hash64(L.key, nk);
 #pragma unroll
           for (int i = 0; i < nk; i++) S.lane_key[tid][i] = L.key[i];
-          // first probe of the state-space table: issued now, consumed after the batch table is built
-          pos0 = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
-          v0 = ld_u64(&P.table[pos0]);
         }
         MPLX_T2(S, 14, t2);
 #ifdef MPLX_LOOKUP_TIMERS
