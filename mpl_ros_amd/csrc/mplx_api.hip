@@ -495,6 +495,7 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   PA(P.open_pool, (size_t)(och << OPEN_CH_LOG) * OPEN_BYTES);
   PA(P.table, (size_t)T);
   PA(P.bkt_head, (size_t)slots * 2 * NB * NSUB);
+  HIPCHK(c, hipMemsetAsync(P.bkt_head, 0xFF, sizeof(uint32_t) * (size_t)slots * 2 * NB * NSUB, c->stream));  // all heads NIL; queries leave them so
   PA(P.chunk_next, 4);
 #undef PA
   P.node_chunks = (uint32_t)nch;

@@ -16,7 +16,7 @@
 namespace mplx {
 
 constexpr int NB = 1024;          // OPEN buckets per level (coarse level 1, fine level 0)
-constexpr int NSUB = 64;          // sub-lists per bucket (parallel pull, one per lane of a wave)
+constexpr int NSUB = 256;         // sub-lists per bucket (walked in parallel, one per thread, when a bucket is pulled)
 constexpr int NC = 512;           // near OPEN capacity (LDS)
 constexpr int OWN = 2048;         // LDS (primitive, sample) owner map; larger expansions fall back to a search
 constexpr uint32_t NIL = 0xFFFFFFFFu;

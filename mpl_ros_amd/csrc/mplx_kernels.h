@@ -543,19 +543,32 @@ __device__ __forceinline__ void demote_fine(const QView<BLOCK, CONTROL, SM> &Q, 
   const int c1 = NB + S.cur1;
   for (int b = 0; b < NB; b++) {
     if (S.cnt[0][b] == 0) continue;  // uniform
-    uint32_t cur = NIL, moved = 0;
-    if (tid < NSUB) cur = atomicExch(&Q.bkt_head[(size_t)b * NSUB + tid], NIL);
-    while (cur != NIL) {
-      const uint32_t nxt = Q.open(cur)->next;
-      uint32_t old = atomicExch(&Q.bkt_head[(size_t)c1 * NSUB + (cur & (NSUB - 1))], cur);
-      Q.open(cur)->next = old;
-      moved++;
-      cur = nxt;
+    uint32_t moved = 0;
+    for (int sub = tid; sub < NSUB; sub += BLOCK) {
+      uint32_t cur = atomicExch(&Q.bkt_head[(size_t)b * NSUB + sub], NIL);
+      while (cur != NIL) {
+        const uint32_t nxt = Q.open(cur)->next;
+        uint32_t old = atomicExch(&Q.bkt_head[(size_t)c1 * NSUB + (cur & (NSUB - 1))], cur);
+        Q.open(cur)->next = old;
+        moved++;
+        cur = nxt;
+      }
     }
     if (moved) atomicAdd(&S.cnt[1][S.cur1], moved);
     __syncthreads();
     if (tid == 0) S.cnt[0][b] = 0;
     __syncthreads();
+  }
+}
+
+// End of a query: leave every far-bucket head of this workgroup slot empty (NIL) for the next query.
+// The host clears the array once when it allocates it; a head can only be non-empty in a bucket whose
+// counter is non-zero, so only those buckets are touched -- no 2 x NB x NSUB reset per query.
+template <int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ void clear_buckets(const QView<BLOCK, CONTROL, SM> &Q, int tid) {
+  for (int b = tid; b < 2 * NB; b += BLOCK) {
+    if (Q.S.cnt[0][b] == 0) continue;
+    for (int sub = 0; sub < NSUB; sub++) Q.bkt_head[(size_t)b * NSUB + sub] = NIL;
   }
 }
 
@@ -727,13 +740,17 @@ template <int BLOCK, int CONTROL, class SM>
 __device__ __forceinline__ void pull_bucket(const QView<BLOCK, CONTROL, SM> &Q, int code, int tid) {
   SM &S = Q.S;
   const double w1 = Q.P.bucket_width;
-  uint32_t cur = NIL;
-  if (tid < NSUB) cur = atomicExch(&Q.bkt_head[(size_t)code * NSUB + tid], NIL);
   uint32_t pulled = 0;
+  // min(BLOCK, NSUB) sub-lists are walked at a time, one per thread: every hop is a dependent HBM
+  // read, so the walk time is (longest sub-list) x (memory latency)
+  constexpr int WIDE = BLOCK < NSUB ? BLOCK : NSUB;
+  for (int base = 0; base < NSUB; base += WIDE) {
+  uint32_t cur = NIL;
+  if (tid < WIDE) cur = atomicExch(&Q.bkt_head[(size_t)code * NSUB + base + tid], NIL);
   __syncthreads();
   for (;;) {
     if (!block_any<BLOCK>(cur != NIL, S, tid)) break;
-    while (S.n_near + (uint32_t)NSUB > (uint32_t)SM::NCAP) {
+    while (S.n_near + (uint32_t)WIDE > (uint32_t)SM::NCAP) {
       MPLX_TIC(te);
       evict_half(Q, tid);
       __syncthreads();
@@ -752,6 +769,7 @@ __device__ __forceinline__ void pull_bucket(const QView<BLOCK, CONTROL, SM> &Q, 
       cur = r.next;
     }
     __syncthreads();
+  }
   }
   if (pulled) atomicSub(&S.cnt[0][code], pulled);
   __syncthreads();
@@ -1028,7 +1046,6 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
     const QueryIn &in = P.queries[q];
     const unsigned long long t_begin = wall_clock64();
     // ---- reset the workgroup's OPEN structure
-    for (int i = tid; i < 2 * NB * NSUB; i += BLOCK) Q.bkt_head[i] = NIL;
     for (int i = tid; i < 2 * NB; i += BLOCK) S.cnt[0][i] = 0;
     if (tid == 0) {
       S.n_near = 0; S.n_nodes = 0; S.n_edges = 0; S.n_log = 0;
@@ -1181,6 +1198,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         if (S.status >= 0) break;
       }
       goal_id = S.cur_id;
+      clear_buckets(Q, tid);
     }
     __syncthreads();
     // ---- recoverTraj + results (thread 0)

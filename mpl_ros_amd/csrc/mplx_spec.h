@@ -222,7 +222,6 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
     const QueryIn &in = P.queries[q];
     const unsigned long long t_begin = wall_clock64();
     // ---- reset the workgroup's OPEN structure
-    for (int i = tid; i < 2 * NB * NSUB; i += BLOCK) Q.bkt_head[i] = NIL;
     for (int i = tid; i < 2 * NB; i += BLOCK) S.cnt[0][i] = 0;
     if (tid == 0) {
       S.n_near = 0; S.n_nodes = 0; S.n_edges = 0; S.n_log = 0;
@@ -876,6 +875,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       }
     }
     const uint32_t goal_id = searched ? S.cur_id : NIL;
+    if (searched) clear_buckets(Q, tid);
     __syncthreads();
     // ---- recoverTraj + results (thread 0)
     if (tid == 0) {

@@ -34,7 +34,7 @@ if which == 'batch':
     qrng = mapgen.SplitMix64(20250620 + 7919)
     queries = mapgen.random_queries(grid, origin, res, nq, qrng, min_dist=10.0)
     per_q = 450_000
-    mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, n_slots=slots, max_nodes=per_q * nq, max_edges=per_q * nq * 9 // 2, max_log=per_q * nq * 5 // 4, spec=SPEC)
+    mu, pl = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, n_slots=slots, max_expand=int(os.environ.get('CAP', '-1')), max_nodes=per_q * nq, max_edges=per_q * nq * 9 // 2, max_log=per_q * nq * 5 // 4, spec=SPEC)
     starts = [util.gpu_wp(s) for s, g in queries]; goals = [util.gpu_wp(g) for s, g in queries]
     t = time.time(); R = pl.planBatch(starts, goals); wall = time.time() - t
     ne = np.array([r.n_expanded for r in R], dtype=np.float64)
