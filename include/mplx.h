@@ -175,6 +175,13 @@ int mplx_result_expanded(mplx_ctx *ctx, int q, uint32_t cap, int32_t *ids, uint3
  * filters on `closed` / `opened`), g, h.  Arrays sized n_nodes; NULLs allowed. */
 int mplx_result_nodes(mplx_ctx *ctx, mplx_waypoint *coords, double *g, double *h, int32_t *closed, int32_t *opened);
 
+/* StateSpace predecessor lists of the LAST single mplx_plan(): the reference keeps pred_coord /
+ * pred_action_id / pred_action_cost per node (poly_map_planner.h:70-86) and getAllPrimitives()
+ * (poly_map_replanner_node.cpp:184,234) walks them.  For every node in id order its predecessor edges in
+ * arrival order (the order of the reference's push_back): child / parent are node ids, action indexes U (edge cost = J(U[action]) + w dt).
+ * Arrays sized mplx_result.n_edges (NULLs allowed); *n = number of edges of the state space. */
+int mplx_result_edges(mplx_ctx *ctx, int32_t *child, int32_t *parent, int32_t *action, uint64_t cap, uint64_t *n);
+
 /* ---- measurement ---- */
 /* device-clock begin / end (seconds since the first query of the batch started) and workgroup of query q */
 int mplx_result_timing(mplx_ctx *ctx, int q, double *t_begin_s, double *t_end_s, int32_t *slot);

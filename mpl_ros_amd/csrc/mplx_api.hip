@@ -61,7 +61,7 @@ struct mplx_ctx {
   QueryOut *d_out = nullptr;
   QueryIn *d_in = nullptr;
   int32_t *d_traj_nodes = nullptr, *d_traj_actions = nullptr, *d_rec = nullptr, *d_next = nullptr, *d_order = nullptr;
-  uint32_t *d_node_tables = nullptr;
+  uint32_t *d_node_tables = nullptr, *d_edge_tables = nullptr;
   double *d_traj_states = nullptr;
   int batch_cap = 0;
   uint32_t batch_rec = 0;
@@ -113,9 +113,9 @@ static void free_pools(mplx_ctx *c) {
 static void free_batch(mplx_ctx *c) {
   (void)hipFree(c->d_out); (void)hipFree(c->d_in); (void)hipFree(c->d_traj_nodes); (void)hipFree(c->d_traj_actions);
   (void)hipFree(c->d_traj_states); (void)hipFree(c->d_rec); (void)hipFree(c->d_next); (void)hipFree(c->d_order);
-  (void)hipFree(c->d_node_tables);
+  (void)hipFree(c->d_node_tables); (void)hipFree(c->d_edge_tables);
   c->d_out = nullptr; c->d_in = nullptr; c->d_traj_nodes = c->d_traj_actions = c->d_rec = c->d_next = c->d_order = nullptr;
-  c->d_node_tables = nullptr;
+  c->d_node_tables = nullptr; c->d_edge_tables = nullptr;
   c->d_traj_states = nullptr;
   c->batch_cap = 0;
 }
@@ -522,6 +522,7 @@ static int ensure_batch(mplx_ctx *c, int nq) {
   HIPCHK(c, hipMalloc((void **)&c->d_next, sizeof(int32_t)));
   HIPCHK(c, hipMalloc((void **)&c->d_order, sizeof(int32_t) * nq));
   HIPCHK(c, hipMalloc((void **)&c->d_node_tables, sizeof(uint32_t) * (size_t)nq * MAX_NODE_CH));
+  HIPCHK(c, hipMalloc((void **)&c->d_edge_tables, sizeof(uint32_t) * (size_t)nq * MAX_EDGE_CH));
   if (c->cap_rec) HIPCHK(c, hipMalloc((void **)&c->d_rec, sizeof(int32_t) * (size_t)nq * c->cap_rec));
   c->batch_cap = nq;
   c->batch_rec = c->cap_rec;
@@ -702,6 +703,7 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   P.traj_nodes = c->d_traj_nodes; P.traj_actions = c->d_traj_actions; P.traj_states = c->d_traj_states;
   P.rec_ids = c->cap_rec ? c->d_rec : nullptr;
   P.node_tables = c->d_node_tables;
+  P.edge_tables = c->d_edge_tables;
   P.next_query = c->d_next;
   HIPCHK(c, hipMemcpyAsync(c->d_order, order.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(P.table, 0xFF, (size_t)(P.table_mask + 1) * sizeof(unsigned long long), c->stream));
@@ -783,6 +785,65 @@ extern "C" int mplx_result_expanded(mplx_ctx *c, int q, uint32_t cap, int32_t *i
   if (cnt) HIPCHK(c, hipMemcpyAsync(ids, c->d_rec + (size_t)q * c->batch_rec, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *n = cnt;
+  return MPLX_OK;
+}
+
+// StateSpace predecessor lists of the last single plan: for every node in id order, its edges oldest first
+extern "C" int mplx_result_edges(mplx_ctx *c, int32_t *child, int32_t *parent, int32_t *action, uint64_t cap, uint64_t *n_out) {
+  if (!c || !c->last_single || !c->pools_valid || !n_out) return fail(c, MPLX_ERR_ARG, "predecessor dump needs a preceding single mplx_plan()");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n_nodes = c->last_out[0].n_nodes, n_edges = c->last_out[0].n_edges;
+  *n_out = n_edges;
+  if (n_nodes == 0 || n_edges == 0 || cap == 0) return MPLX_OK;
+  const int rb = rec_bytes(c->pool_control);
+  std::vector<uint32_t> ntbl(MAX_NODE_CH), etbl(MAX_EDGE_CH);
+  HIPCHK(c, hipMemcpyAsync(ntbl.data(), c->d_node_tables, sizeof(uint32_t) * MAX_NODE_CH, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(etbl.data(), c->d_edge_tables, sizeof(uint32_t) * MAX_EDGE_CH, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // predecessor heads of all nodes, then the query's edge records, chunk by chunk
+  std::vector<uint32_t> head(n_nodes);
+  {
+    const size_t per = (size_t)1 << NODE_CH_LOG;
+    std::vector<char> buf(per * rb);
+    for (size_t base = 0; base < n_nodes; base += per) {
+      const size_t cnt = n_nodes - base < per ? n_nodes - base : per;
+      const uint32_t ch = ntbl[base >> NODE_CH_LOG];
+      if (ch == NIL) return fail(c, MPLX_ERR_ARG, "inconsistent chunk table");
+      HIPCHK(c, hipMemcpyAsync(buf.data(), c->pools.node_pool + ((size_t)ch << NODE_CH_LOG) * rb, cnt * rb, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      for (size_t k = 0; k < cnt; k++) memcpy(&head[base + k], buf.data() + k * rb + 20, 4);
+    }
+  }
+  std::vector<EdgeRec> edges(n_edges);
+  {
+    const size_t per = (size_t)1 << EDGE_CH_LOG;
+    for (size_t base = 0; base < n_edges; base += per) {
+      const size_t cnt = n_edges - base < per ? n_edges - base : per;
+      const uint32_t ch = etbl[base >> EDGE_CH_LOG];
+      if (ch == NIL) return fail(c, MPLX_ERR_ARG, "inconsistent chunk table");
+      HIPCHK(c, hipMemcpyAsync(edges.data() + base, c->pools.edge_pool + ((size_t)ch << EDGE_CH_LOG) * EDGE_BYTES, cnt * EDGE_BYTES, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  uint64_t w = 0;
+  std::vector<uint32_t> lst;
+  for (size_t i = 0; i < n_nodes; i++) {
+    lst.clear();  // the device list is newest first; the reference's pred vectors grow by push_back
+    for (uint32_t e = head[i]; e != NIL; e = edges[e].next) {
+      if (e >= n_edges || lst.size() > n_edges) return fail(c, MPLX_ERR_ARG, "corrupt predecessor list of node %zu", i);
+      lst.push_back(e);
+    }
+    for (size_t k = lst.size(); k-- > 0;) {
+      const uint32_t e = lst[k];
+      if (w < cap) {
+        if (child) child[w] = (int32_t)i;
+        if (parent) parent[w] = (int32_t)edges[e].parent;
+        if (action) action[w] = (int32_t)edges[e].action;
+      }
+      w++;
+    }
+  }
+  *n_out = w;
   return MPLX_OK;
 }
 

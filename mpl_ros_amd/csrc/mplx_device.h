@@ -88,6 +88,7 @@ struct SearchParams {
   double *traj_states;            // nq x (MAX_TRAJ+1) x 13
   int32_t *rec_ids;               // nq x cap_rec (optional)
   uint32_t *node_tables;          // nq x MAX_NODE_CH: chunk table of each query (state-space dump)
+  uint32_t *edge_tables;          // nq x MAX_EDGE_CH: chunk table of the predecessor records
   int32_t *next_query;            // dynamic query counter
 };
 

@@ -1261,6 +1261,8 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
     }
     for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)
       P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? S.node_tbl[i] : NIL;
+    for (uint32_t i = tid; i < (uint32_t)MAX_EDGE_CH; i += BLOCK)
+      P.edge_tables[(size_t)q * MAX_EDGE_CH + i] = i < S.edge_chunks ? S.edge_tbl[i] : NIL;
     __syncthreads();
   }
 }

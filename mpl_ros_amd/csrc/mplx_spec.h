@@ -551,6 +551,11 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
           my_slot = sl;
           atomicMin(&S.bt_leader[sl], (uint32_t)tid);
+          // two lanes of ONE unit on one state (duplicate control inputs, or two inputs quantising to one
+          // key): that unit commits lane by lane when the batch takes the ordered path.  Bits 8.. of
+          // bt_dirty collect the units that reach the entry (bit 0 is the ordered path's dirty flag).
+          const uint32_t ubit = 0x100u << ku;
+          if (atomicOr(&S.bt_dirty[sl], ubit) & ubit) S.unit_seq[ku] = 1;
         }
         __syncthreads();
         MPLX_T2(S, 1, t2);
@@ -565,7 +570,6 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
 #pragma unroll
             for (int i = 0; i < nk; i++) eq = eq && (S.lane_key[leader][i] == L.key[i]);
             if (!eq) S.status = 5;                                    // 64-bit key-hash collision inside a batch
-            if ((int)(leader / UL) == ku) S.unit_seq[ku] = 1;       // two lanes of one unit, one key
             // a state reached from two lanes of the batch: harmless while both only append a predecessor
             // edge (decided once g is known); three lanes on one state take the ordered path
             if (atomicAdd(&S.bt_share[my_slot], 0x10000u + (uint32_t)tid) != 0u) S.batch_dep = 1;
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           // a shared state (or a candidate's own state) that this lane creates or improves: units interact
           if (S.bt_share[my_slot] != 0u && (nw || pre.tg < S.bt_g[my_slot])) S.batch_dep = 1;
 #ifdef MPLX_DEP_STATS
-          if (pre.tg < S.bt_g[my_slot]) S.bt_dirty[my_slot] = 2;  // some sharer modifies this state
+          if (pre.tg < S.bt_g[my_slot]) atomicOr(&S.bt_dirty[my_slot], 2u);  // some sharer modifies this state
 #endif
         }
         MPLX_T2(S, 6, t2);
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         MPLX_TIC(to);
         lds_barrier();  // the per-unit cut points (atomicMin above) are complete
 #ifdef MPLX_DEP_STATS
-        if (act && S.bt_leader[my_slot] != (uint32_t)tid && S.bt_dirty[my_slot] == 2) atomicOr(&S.dep_cause, 4);
+        if (act && S.bt_leader[my_slot] != (uint32_t)tid && (S.bt_dirty[my_slot] & 2u)) atomicOr(&S.dep_cause, 4);
         lds_barrier();
         if (tid == 0) {
           const int dc = S.dep_cause;
@@ -814,7 +818,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           lds_barrier();
           // write the batch table back: one store per field and state, whatever number of units touched it
           for (int i = tid; i < BT; i += BLOCK) {
-            if (S.bt_dirty[i] && S.bt_id[i] != NIL) {
+            if ((S.bt_dirty[i] & 1u) && S.bt_id[i] != NIL) {
               char *rec = Q.node(S.bt_id[i]);
               V::g(rec) = S.bt_g[i];
               V::flags(rec) = S.bt_flags[i];
@@ -941,6 +945,8 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
     }
     for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)
       P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? S.node_tbl[i] : NIL;
+    for (uint32_t i = tid; i < (uint32_t)MAX_EDGE_CH; i += BLOCK)
+      P.edge_tables[(size_t)q * MAX_EDGE_CH + i] = i < S.edge_chunks ? S.edge_tbl[i] : NIL;
     __syncthreads();
   }
 }

@@ -473,6 +473,35 @@ class VoxelMapPlanner:
         _, pos, _, _, closed, opened = self._nodes()
         return pos[(opened == 1) & (closed == 0)]
 
+    def getEdges(self):
+        """Predecessor lists of the state space: (child, parent, action) int32 arrays, for every node in id
+        order its edges in arrival order (StateSpace pred_coord / pred_action_id, poly_map_planner.h:70-86)."""
+        ctx = self._ctx()
+        n = int(self._result.n_edges)
+        child = np.zeros(max(n, 1), dtype=np.int32); parent = np.zeros(max(n, 1), dtype=np.int32); action = np.zeros(max(n, 1), dtype=np.int32)
+        m = C.c_uint64(0)
+        ctx.check(ctx.lib.mplx_result_edges(ctx.h, child.ctypes.data, parent.ctypes.data, action.ctypes.data, n, C.byref(m)))
+        return child[:m.value], parent[:m.value], action[:m.value]
+
+    def getAllPrimitives(self):
+        """PlannerBase::getAllPrimitives (poly_map_replanner_node.cpp:184,234): the primitive of every edge
+        of the state space, Primitive(parent state, U[action], dt)."""
+        coords, _, _, _, _, _ = self._nodes()
+        child, parent, action = self.getEdges()
+        prs = []
+        for p, a in zip(parent, action):
+            w = coords[int(p)]
+            st = [w.pos[:], w.vel[:], w.acc[:], w.jrk[:]]
+            co = np.zeros((3, 6))
+            for ax in range(3):
+                co[ax, 5] = st[0][ax]
+                if self._control >= VEL: co[ax, 4] = self._U[a][ax] if self._control == VEL else st[1][ax]
+                if self._control >= ACC: co[ax, 3] = self._U[a][ax] if self._control == ACC else st[2][ax]
+                if self._control >= JRK: co[ax, 2] = self._U[a][ax] if self._control == JRK else st[3][ax]
+                if self._control >= SNP: co[ax, 1] = self._U[a][ax]
+            prs.append(Primitive3D(co, self._dt, self._control))
+        return prs
+
     def getExpandedNodes(self):
         """Positions in expansion order (env_base::expanded_nodes_); needs setRecord()."""
         ids = self.getExpandedIds(0)

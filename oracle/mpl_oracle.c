@@ -333,7 +333,7 @@ typedef struct {
   double g, h;
   int32_t opened, closed;
   int32_t heap_pos;  /* -1 when not in heap */
-  int32_t pred_head; /* newest-first linked list into edges, -1 empty */
+  int32_t pred_head; /* linked list into edges in push_back (arrival) order, -1 empty */
   int32_t pred_tail;
 } orc_node;
 
@@ -972,6 +972,19 @@ void orc_get_node(const orc_planner *p, int id, orc_waypoint *coord, double *g, 
   if (closed) *closed = p->nodes[id].closed;
 }
 int orc_num_closed(const orc_planner *p) { return p->n_closed; }
+int orc_get_edges(const orc_planner *p, int32_t *child, int32_t *parent, int32_t *action, int cap) {
+  int w = 0;
+  for (int i = 0; i < p->n_nodes; i++)
+    for (int e = p->nodes[i].pred_head; e >= 0; e = p->edges[e].next) {
+      if (w < cap) {
+        if (child) child[w] = i;
+        if (parent) parent[w] = p->edges[e].parent;
+        if (action) action[w] = p->edges[e].action;
+      }
+      w++;
+    }
+  return w;
+}
 int orc_traj_len(const orc_planner *p) { return p->traj_len; }
 /* primitives are rebuilt from the stored parent coord + action, like upstream forward_action */
 void orc_get_traj(const orc_planner *p, orc_primitive *prs, orc_waypoint *wps, int32_t *actions, int32_t *node_ids) {

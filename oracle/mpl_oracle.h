@@ -120,6 +120,8 @@ void orc_get_expanded(const orc_planner *, int32_t *node_ids, double *pos /* n x
 int orc_num_nodes(const orc_planner *);
 void orc_get_node(const orc_planner *, int id, orc_waypoint *coord, double *g, double *h, int32_t *closed);
 int orc_num_closed(const orc_planner *);
+/* predecessor lists: for every node in id order its edges in arrival order; returns the number of edges */
+int orc_get_edges(const orc_planner *, int32_t *child, int32_t *parent, int32_t *action, int cap);
 int orc_traj_len(const orc_planner *);                      /* number of primitives */
 void orc_get_traj(const orc_planner *, orc_primitive *prs, orc_waypoint *wps /* len+1 */, int32_t *actions, int32_t *node_ids /* len+1 */);
 void orc_get_counters(const orc_planner *, orc_counters *);

@@ -89,6 +89,8 @@ def lib():
         for f in ("orc_num_expanded", "orc_num_nodes", "orc_num_closed", "orc_traj_len"):
             getattr(L, f).argtypes = [P]
         L.orc_get_expanded.argtypes = [P, C.c_void_p, C.c_void_p]
+        L.orc_get_edges.argtypes = [P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_get_edges.restype = C.c_int
         L.orc_get_node.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                    C.POINTER(C.c_int32)]
         L.orc_get_traj.argtypes = [P, C.POINTER(Primitive), C.POINTER(Waypoint), C.POINTER(C.c_int32),
@@ -247,6 +249,13 @@ class Planner:
 
     def num_closed(self):
         return self.L.orc_num_closed(self.h)
+
+    def edges(self):
+        """(child, parent, action): for every node in id order its predecessor edges, in arrival order"""
+        n = self.L.orc_get_edges(self.h, None, None, None, 0)
+        c = np.zeros(max(n, 1), dtype=np.int32); p = np.zeros(max(n, 1), dtype=np.int32); a = np.zeros(max(n, 1), dtype=np.int32)
+        self.L.orc_get_edges(self.h, c.ctypes.data, p.ctypes.data, a.ctypes.data, n)
+        return c[:n], p[:n], a[:n]
 
     def node(self, i):
         w = Waypoint()

@@ -172,6 +172,22 @@ def test_duplicate_controls_take_the_ordered_path(spec):
 
 
 @SPEC
+@pytest.mark.parametrize("copies,jitter", [(3, 0.0), (2, 2e-4), (4, 1e-4)])
+def test_many_lanes_on_one_state(spec, copies, jitter):
+    """Every control input several times (exact copies, or copies that quantise to the same key with a
+    slightly different cost): up to `copies` lanes of each unit, and lanes of several units, meet on one
+    state.  The predecessor lists (compare_plan checks every node's list) must keep the sequential order."""
+    grid, origin, res = util.small_map(48, seed=13, occupancy=0.06)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    U0 = mapgen.control_lattice(1.0, 1, True)
+    U = np.vstack([U0 + k * jitter for k in range(copies)])
+    kw = dict(v_max=2.0, a_max=1.0, max_expand=600)
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, spec=spec, **kw)
+    util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0)), ((3.55, 3.05, 3.55),), orc.ACC)
+
+
+@SPEC
 def test_plan_batch_matches_single_queries(spec):
     grid, origin, res = util.small_map(96, seed=21, occupancy=0.10)
     U = mapgen.control_lattice(1.0, 1, True)

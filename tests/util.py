@@ -88,6 +88,17 @@ def compare_plan(P, pl, start, goal, control, check_traj=True):
     assert r.n_succ == c["n_succ"] and r.n_succ_finite == c["n_succ_finite"]
     assert r.n_primitives == c["n_primitives"]
     assert r.n_reopen == c["n_reopen"]
+    # the whole state space: predecessor lists (every node, edges in arrival order), g, h, closed flags
+    co, po, ao = P.edges()
+    cg, pg, ag = pl.getEdges()
+    assert r.n_edges == len(co) == len(cg)
+    assert np.array_equal(cg, co) and np.array_equal(pg, po) and np.array_equal(ag, ao)
+    if r.n_nodes <= 60000:
+        _, _, g_g, h_g, closed_g, _ = pl._nodes()
+        g_o = np.empty(r.n_nodes); h_o = np.empty(r.n_nodes); closed_o = np.empty(r.n_nodes, dtype=np.int32)
+        for i in range(r.n_nodes):
+            _, g_o[i], h_o[i], closed_o[i] = P.node(i)
+        assert np.array_equal(g_g, g_o) and np.array_equal(h_g, h_o) and np.array_equal(closed_g, closed_o)
     if st_o == orc.OK:
         assert r.cost == P.traj_cost  # bit-exact f64
     else:
