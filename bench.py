@@ -234,6 +234,16 @@ def main():
             cpu_cap = min(max_expand, 250_000) if (args.single and max_expand > 0) else max_expand
             nthr = 1 if args.single else (args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 64))
             out["cpu_baseline"] = cpu_baseline(grid, origin, res, control, U, cpu_cap, queries, args.cpu_seconds, nthr)
+            # the CPU sample doubles as a full-size parity check of the timed GPU results (checker only):
+            # expansions, states created and path cost of every sampled query must be identical
+            pq = out["cpu_baseline"].pop("_per_query")
+            if cpu_cap == max_expand:
+                bad = [i for i, (ne, nn, cost) in pq.items()
+                       if ne != results[i].n_expanded or nn != results[i].n_nodes
+                       or not (cost == results[i].cost or (np.isinf(results[i].cost) and not np.isfinite(cost)))]
+                out["parity_sample"] = {"queries": len(pq), "mismatches": len(bad), "checked": "n_expanded, n_nodes, cost (bit-exact f64)"}
+                if bad:
+                    out["parity_sample"]["first_bad_query"] = int(bad[0])
             if cpu_cap != max_expand:
                 out["cpu_baseline"]["sample"] += f"; CPU run capped at {cpu_cap} expansions"
         print(json.dumps(out), flush=True)
@@ -260,7 +270,7 @@ def cpu_baseline(grid, origin, res, control, U, max_expand, queries, budget_s, t
         P.set_config(control, U, **kw)
         planners.append(P)
     lock = threading.Lock()
-    state = {"next": 0, "n_exp": 0, "nq": 0, "busy": 0.0}
+    state = {"next": 0, "n_exp": 0, "nq": 0, "busy": 0.0, "per_query": {}}
     t_start = time.perf_counter()
 
     def work(P):
@@ -276,9 +286,11 @@ def cpu_baseline(grid, origin, res, control, U, max_expand, queries, budget_s, t
             P.plan(orc.waypoint(s, control=control), orc.waypoint(g, control=control))
             dt = time.perf_counter() - t0
             with lock:
-                state["n_exp"] += P.counters()["n_expansions"]
+                ne = P.counters()["n_expansions"]
+                state["n_exp"] += ne
                 state["nq"] += 1
                 state["busy"] += dt
+                state["per_query"][i] = (ne, P.num_nodes(), P.traj_cost)
 
     ths = [threading.Thread(target=work, args=(P,)) for P in planners]
     for t in ths:
@@ -290,7 +302,8 @@ def cpu_baseline(grid, origin, res, control, U, max_expand, queries, budget_s, t
     return {"value": n_exp / wall, "unit": "expansions/s", "cores": threads, "kind": "port",
             "value_per_core": n_exp / state["busy"],
             "sample": f"first {nq} of the {len(queries)} queries of rank 0 ({n_exp} expansions, {wall:.1f} s wall, {state['busy']:.1f} core-s of plan())",
-            "plan_ms_mean_per_query": 1e3 * state["busy"] / nq}
+            "plan_ms_mean_per_query": 1e3 * state["busy"] / nq,
+            "_per_query": state["per_query"]}
 
 
 if __name__ == "__main__":
