@@ -487,7 +487,7 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   if (och < 1) och = 1;
   // chunk ids are 16 bits in the kernels' LDS chunk tables: 2.1 G nodes / 4.3 G edges / 2.1 G log records
   if (nch > 0xFFFFull || ech > 0xFFFFull || och > 0xFFFFull) return fail(c, MPLX_ERR_ARG, "capacity too large (more than 65535 chunks in a pool)");
-  const uint64_t T = next_pow2(2ull * (nch << NODE_CH_LOG));
+  const uint64_t T = next_pow2(4ull * (nch << NODE_CH_LOG));  // load factor <= 0.25: the slowest lane of a batch sets the pace, and its probe chain is a chain of HBM round trips
   int r;
 #define PA(ptr, cnt) if ((r = pool_alloc(c, &(ptr), (cnt))) != MPLX_OK) { free_pools(c); return r; }
   PA(P.node_pool, (size_t)(nch << NODE_CH_LOG) * rec_bytes(control));
