@@ -182,6 +182,32 @@ int mplx_result_nodes(mplx_ctx *ctx, mplx_waypoint *coords, double *g, double *h
  * Arrays sized mplx_result.n_edges (NULLs allowed); *n = number of edges of the state space. */
 int mplx_result_edges(mplx_ctx *ctx, int32_t *child, int32_t *parent, int32_t *action, uint64_t cap, uint64_t *n);
 
+/* ---- VoxelGrid (planning_ros_utils/src/mapping_utils/voxel_grid.cpp, the mapper in front of the planner:
+ *      map_replanner_node.cpp:17,181,218,329-331, cloud_to_map.cpp:11-12).  Device-resident; same
+ *      semantics as the in-tree class: float resolution, truncating floatToInt (:201-203), two grids
+ *      (map_, inflated_map_), values free 0 / occupied 100 decaying by 1 per decay(). ---- */
+typedef struct mplx_grid mplx_grid;
+int mplx_grid_create(int device, const double origin[3], const double dim[3], float res, mplx_grid **out); /* ctor :3-10 */
+void mplx_grid_destroy(mplx_grid *g);
+const char *mplx_grid_last_error(const mplx_grid *g);
+int mplx_grid_allocate(mplx_grid *g, const double new_dim_d[3], const double new_ori_d[3], int *changed);   /* :129-181 */
+int mplx_grid_info(const mplx_grid *g, int32_t dim[3], double origin_d[3], float *res);
+int mplx_grid_clear(mplx_grid *g);                                                                      /* :12-16 */
+int mplx_grid_add_cloud(mplx_grid *g, int n, const double *pts /* n x 3 */);                           /* :183-189 */
+/* addCloud(pts, ns) :191-207 -- new_obs (cap x 3): the cells of inflated_map_ that became occupied, in the
+ * order the reference's sequential loop flips them; *n_new = their number (may exceed cap) */
+int mplx_grid_add_cloud_inflate(mplx_grid *g, int n, const double *pts, int n_ns, const int32_t *ns, int32_t *new_obs, int cap, int *n_new);
+int mplx_grid_decay(mplx_grid *g);                                                                      /* :213-224 */
+int mplx_grid_clear_column(mplx_grid *g, int nx, int ny);                                               /* clear(nx, ny) :31-33 */
+int mplx_grid_fill_column(mplx_grid *g, int nx, int ny);                                                /* fill(nx, ny) :35-39 */
+int mplx_grid_fill_cell(mplx_grid *g, int nx, int ny, int nz);                                          /* fill(nx, ny, nz) :41-46 */
+/* getMap() / getInflatedMap() :71-127: VoxelMap.data (x fastest), > 0 -> 100, everything else 0 */
+int mplx_grid_get_map(mplx_grid *g, int inflated, int8_t *data);
+int mplx_grid_get_cloud(mplx_grid *g, double *pts, uint64_t cap, uint64_t *n);                         /* getCloud() :18-29 */
+/* getMap() handed to a planner context device to device (= setMap(map_util, voxel_mapper_->getMap()),
+ * map_replanner_node.cpp:186-188,224-226, without the host round trip) */
+int mplx_grid_to_map(mplx_grid *g, int inflated, mplx_ctx *ctx);
+
 /* ---- measurement ---- */
 /* device-clock begin / end (seconds since the first query of the batch started) and workgroup of query q */
 int mplx_result_timing(mplx_ctx *ctx, int q, double *t_begin_s, double *t_end_s, int32_t *slot);

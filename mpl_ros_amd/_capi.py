@@ -55,6 +55,9 @@ EXPORTS = [
     "mplx_expand_batch", "mplx_heuristic_batch", "mplx_plan", "mplx_plan_batch",
     "mplx_result_traj", "mplx_set_record", "mplx_result_expanded", "mplx_result_nodes", "mplx_result_edges", "mplx_result_timing", "mplx_result_cycles",
     "mplx_last_kernel_ms", "mplx_version",
+    "mplx_grid_create", "mplx_grid_destroy", "mplx_grid_last_error", "mplx_grid_allocate", "mplx_grid_info", "mplx_grid_clear",
+    "mplx_grid_add_cloud", "mplx_grid_add_cloud_inflate", "mplx_grid_decay", "mplx_grid_clear_column", "mplx_grid_fill_column",
+    "mplx_grid_fill_cell", "mplx_grid_get_map", "mplx_grid_get_cloud", "mplx_grid_to_map",
 ]
 
 _lib = None
@@ -109,5 +112,23 @@ def load():
     L.mplx_result_cycles.argtypes = [P, C.c_int, C.POINTER(C.c_uint64)]
     L.mplx_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float)]
     L.mplx_version.restype = C.c_char_p
+    G = C.c_void_p
+    L.mplx_grid_create.argtypes = [C.c_int, D3, D3, C.c_float, C.POINTER(G)]
+    L.mplx_grid_destroy.argtypes = [G]
+    L.mplx_grid_destroy.restype = None
+    L.mplx_grid_last_error.argtypes = [G]
+    L.mplx_grid_last_error.restype = C.c_char_p
+    L.mplx_grid_allocate.argtypes = [G, D3, D3, C.POINTER(C.c_int)]
+    L.mplx_grid_info.argtypes = [G, I3, D3, C.POINTER(C.c_float)]
+    L.mplx_grid_clear.argtypes = [G]
+    L.mplx_grid_add_cloud.argtypes = [G, C.c_int, C.c_void_p]
+    L.mplx_grid_add_cloud_inflate.argtypes = [G, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.mplx_grid_decay.argtypes = [G]
+    L.mplx_grid_clear_column.argtypes = [G, C.c_int, C.c_int]
+    L.mplx_grid_fill_column.argtypes = [G, C.c_int, C.c_int]
+    L.mplx_grid_fill_cell.argtypes = [G, C.c_int, C.c_int, C.c_int]
+    L.mplx_grid_get_map.argtypes = [G, C.c_int, C.c_void_p]
+    L.mplx_grid_get_cloud.argtypes = [G, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.mplx_grid_to_map.argtypes = [G, C.c_int, P]
     _lib = L
     return L

@@ -912,3 +912,4 @@ extern "C" int mplx_last_kernel_ms(const mplx_ctx *c, float *ms) {
   *ms = c->last_ms;
   return MPLX_OK;
 }
+#include "mplx_grid.inl"

@@ -1001,3 +1001,160 @@ void orc_get_traj(const orc_planner *p, orc_primitive *prs, orc_waypoint *wps, i
 }
 void orc_get_counters(const orc_planner *p, orc_counters *c) { *c = p->cnt; }
 void orc_reset_counters(orc_planner *p) { memset(&p->cnt, 0, sizeof(p->cnt)); }
+
+/* ------------------------------------------------------------------ VoxelGrid (map ingest)
+ * Line-by-line restatement of the in-tree planning_ros_utils/src/mapping_utils/voxel_grid.cpp (the one
+ * component of this path whose reference source IS vendored).  Arrays are indexed [x][y][z] with z
+ * fastest, like the boost::multi_array<char,3> they replace; res is a float like VoxelGrid::res_. */
+struct orc_grid {
+  int32_t dim[3], origin[3];
+  double origin_d[3];
+  float res;
+  int8_t *map, *inflated;
+};
+#define GI(g, x, y, z) (((size_t)(x) * (size_t)(g)->dim[1] + (size_t)(y)) * (size_t)(g)->dim[2] + (size_t)(z))
+static size_t grid_cells(const orc_grid *g) { return (size_t)g->dim[0] * g->dim[1] * g->dim[2]; }
+/* [IN-TREE voxel_grid.cpp:129-181] */
+int orc_grid_allocate(orc_grid *g, const double new_dim_d[3], const double new_ori_d[3]) {
+  int32_t nd[3], no[3];
+  for (int i = 0; i < 3; i++) {
+    nd[i] = (int32_t)(new_dim_d[i] / g->res);
+    no[i] = (int32_t)(new_ori_d[i] / g->res);
+  }
+  if (nd[2] == 0 && no[2] == 0) nd[2] = 1;
+  if (nd[0] == g->dim[0] && nd[1] == g->dim[1] && nd[2] == g->dim[2] && no[0] == g->origin[0] && no[1] == g->origin[1] &&
+      no[2] == g->origin[2])
+    return 0;
+  size_t n = (size_t)nd[0] * nd[1] * nd[2];
+  int8_t *nm = (int8_t *)malloc(n ? n : 1);
+  memset(nm, 0, n); /* val_free */
+  for (int l = 0; l < nd[0]; l++)
+    for (int w = 0; w < nd[1]; w++)
+      for (int h = 0; h < nd[2]; h++)
+        if (l + no[0] >= g->origin[0] && w + no[1] >= g->origin[1] && h + no[2] >= g->origin[2] && l + no[0] < g->origin[0] + g->dim[0] &&
+            w + no[1] < g->origin[1] + g->dim[1] && h + no[2] < g->origin[2] + g->dim[2]) {
+          int nl = l + no[0] - g->origin[0], nw = w + no[1] - g->origin[1], nh = h + no[2] - g->origin[2];
+          nm[((size_t)l * nd[1] + w) * nd[2] + h] = g->map[GI(g, nl, nw, nh)];
+        }
+  free(g->map);
+  free(g->inflated);
+  g->map = nm;
+  g->inflated = (int8_t *)malloc(n ? n : 1); /* inflated_map_ = new_map */
+  memcpy(g->inflated, nm, n);
+  for (int i = 0; i < 3; i++) {
+    g->dim[i] = nd[i];
+    g->origin[i] = no[i];
+    g->origin_d[i] = new_ori_d[i];
+  }
+  return 1;
+}
+/* [IN-TREE voxel_grid.cpp:3-10] */
+orc_grid *orc_grid_create(const double origin[3], const double dim[3], float res) {
+  orc_grid *g = (orc_grid *)calloc(1, sizeof(orc_grid));
+  g->res = res;
+  orc_grid_allocate(g, dim, origin);
+  return g;
+}
+void orc_grid_destroy(orc_grid *g) {
+  if (!g) return;
+  free(g->map);
+  free(g->inflated);
+  free(g);
+}
+void orc_grid_info(const orc_grid *g, int32_t dim[3], double origin_d[3], float *res) {
+  for (int i = 0; i < 3; i++) {
+    dim[i] = g->dim[i];
+    origin_d[i] = g->origin_d[i];
+  }
+  *res = g->res;
+}
+/* [IN-TREE voxel_grid.cpp:12-16] */
+void orc_grid_clear(orc_grid *g) {
+  memset(g->map, 0, grid_cells(g));
+  memset(g->inflated, 0, grid_cells(g));
+}
+/* [IN-TREE voxel_grid.cpp:201-203] ((pt - origin_d_) / res_).cast<int>(): truncation towards zero */
+static void grid_float_to_int(const orc_grid *g, const double *pt, int32_t *pn) {
+  for (int i = 0; i < 3; i++) pn[i] = (int32_t)((pt[i] - g->origin_d[i]) / g->res);
+}
+static int grid_outside(const orc_grid *g, const int32_t *pn) {
+  return pn[0] < 0 || pn[0] >= g->dim[0] || pn[1] < 0 || pn[1] >= g->dim[1] || pn[2] < 0 || pn[2] >= g->dim[2];
+}
+/* [IN-TREE voxel_grid.cpp:183-189] */
+void orc_grid_add_cloud(orc_grid *g, int n, const double *pts) {
+  for (int i = 0; i < n; i++) {
+    int32_t pn[3];
+    grid_float_to_int(g, pts + 3 * i, pn);
+    if (grid_outside(g, pn)) continue;
+    g->map[GI(g, pn[0], pn[1], pn[2])] = 100;
+  }
+}
+/* [IN-TREE voxel_grid.cpp:191-207] returns the number of newly inflated cells (new_obs, cap x 3) */
+int orc_grid_add_cloud_ns(orc_grid *g, int n, const double *pts, int n_ns, const int32_t *ns, int32_t *new_obs, int cap) {
+  int cnt = 0;
+  for (int i = 0; i < n; i++) {
+    int32_t pn[3];
+    grid_float_to_int(g, pts + 3 * i, pn);
+    if (grid_outside(g, pn)) continue;
+    if (g->map[GI(g, pn[0], pn[1], pn[2])] != 100) {
+      for (int k = 0; k < n_ns; k++) {
+        int32_t n2[3] = {pn[0] + ns[3 * k], pn[1] + ns[3 * k + 1], pn[2] + ns[3 * k + 2]};
+        if (!grid_outside(g, n2) && g->inflated[GI(g, n2[0], n2[1], n2[2])] != 100) {
+          g->inflated[GI(g, n2[0], n2[1], n2[2])] = 100;
+          if (cnt < cap) {
+            new_obs[3 * cnt] = n2[0];
+            new_obs[3 * cnt + 1] = n2[1];
+            new_obs[3 * cnt + 2] = n2[2];
+          }
+          cnt++;
+        }
+      }
+    }
+    g->map[GI(g, pn[0], pn[1], pn[2])] = 100;
+  }
+  return cnt;
+}
+/* [IN-TREE voxel_grid.cpp:213-224] */
+void orc_grid_decay(orc_grid *g) {
+  size_t n = grid_cells(g);
+  for (size_t i = 0; i < n; i++) {
+    if (g->map[i] > 0) g->map[i]--;
+    if (g->inflated[i] > 0) g->inflated[i]--;
+  }
+}
+/* [IN-TREE voxel_grid.cpp:31-46] clear(nx,ny) has no bounds test upstream; out-of-range columns are ignored here */
+void orc_grid_clear_column(orc_grid *g, int nx, int ny) {
+  if (nx < 0 || nx >= g->dim[0] || ny < 0 || ny >= g->dim[1]) return;
+  for (int nz = 0; nz < g->dim[2]; nz++) g->map[GI(g, nx, ny, nz)] = 0;
+}
+void orc_grid_fill_column(orc_grid *g, int nx, int ny) {
+  if (nx >= 0 && nx < g->dim[0] && ny >= 0 && ny < g->dim[1])
+    for (int nz = 0; nz < g->dim[2]; nz++) g->map[GI(g, nx, ny, nz)] = 100;
+}
+void orc_grid_fill_cell(orc_grid *g, int nx, int ny, int nz) {
+  if (nx >= 0 && nx < g->dim[0] && ny >= 0 && ny < g->dim[1] && nz >= 0 && nz < g->dim[2]) g->map[GI(g, nx, ny, nz)] = 100;
+}
+/* [IN-TREE voxel_grid.cpp:71-127] getMap / getInflatedMap: VoxelMap.data, x fastest; > 0 -> 100, everything else 0 */
+void orc_grid_get_map(const orc_grid *g, int inflated, int8_t *data) {
+  const int8_t *m = inflated ? g->inflated : g->map;
+  for (int x = 0; x < g->dim[0]; x++)
+    for (int y = 0; y < g->dim[1]; y++)
+      for (int z = 0; z < g->dim[2]; z++)
+        data[(size_t)x + (size_t)g->dim[0] * y + (size_t)g->dim[0] * g->dim[1] * z] = m[GI(g, x, y, z)] > 0 ? 100 : 0;
+}
+/* [IN-TREE voxel_grid.cpp:18-29, 205-207] */
+uint64_t orc_grid_get_cloud(const orc_grid *g, double *pts, uint64_t cap) {
+  uint64_t cnt = 0;
+  for (int x = 0; x < g->dim[0]; x++)
+    for (int y = 0; y < g->dim[1]; y++)
+      for (int z = 0; z < g->dim[2]; z++)
+        if (g->map[GI(g, x, y, z)] > 0) {
+          if (cnt < cap) {
+            pts[3 * cnt] = ((double)x + 0.5) * g->res + g->origin_d[0];
+            pts[3 * cnt + 1] = ((double)y + 0.5) * g->res + g->origin_d[1];
+            pts[3 * cnt + 2] = ((double)z + 0.5) * g->res + g->origin_d[2];
+          }
+          cnt++;
+        }
+  return cnt;
+}

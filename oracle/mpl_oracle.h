@@ -127,6 +127,22 @@ void orc_get_traj(const orc_planner *, orc_primitive *prs, orc_waypoint *wps /* 
 void orc_get_counters(const orc_planner *, orc_counters *);
 void orc_reset_counters(orc_planner *);
 
+/* ---- VoxelGrid (in-tree planning_ros_utils/src/mapping_utils/voxel_grid.cpp, restated line by line) ---- */
+typedef struct orc_grid orc_grid;
+orc_grid *orc_grid_create(const double origin[3], const double dim[3], float res);
+void orc_grid_destroy(orc_grid *);
+int orc_grid_allocate(orc_grid *, const double new_dim_d[3], const double new_ori_d[3]);
+void orc_grid_info(const orc_grid *, int32_t dim[3], double origin_d[3], float *res);
+void orc_grid_clear(orc_grid *);
+void orc_grid_add_cloud(orc_grid *, int n, const double *pts);
+int orc_grid_add_cloud_ns(orc_grid *, int n, const double *pts, int n_ns, const int32_t *ns, int32_t *new_obs, int cap);
+void orc_grid_decay(orc_grid *);
+void orc_grid_clear_column(orc_grid *, int nx, int ny);
+void orc_grid_fill_column(orc_grid *, int nx, int ny);
+void orc_grid_fill_cell(orc_grid *, int nx, int ny, int nz);
+void orc_grid_get_map(const orc_grid *, int inflated, int8_t *data);
+uint64_t orc_grid_get_cloud(const orc_grid *, double *pts, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

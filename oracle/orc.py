@@ -281,3 +281,81 @@ class Planner:
 
     def reset_counters(self):
         self.L.orc_reset_counters(self.h)
+
+
+class Grid:
+    """The in-tree VoxelGrid restated (oracle/mpl_oracle.c, orc_grid_*)."""
+
+    def __init__(self, origin, dim, res):
+        L = lib()
+        G = C.c_void_p
+        D3 = C.POINTER(C.c_double)
+        L.orc_grid_create.argtypes = [D3, D3, C.c_float]
+        L.orc_grid_create.restype = G
+        L.orc_grid_destroy.argtypes = [G]
+        L.orc_grid_allocate.argtypes = [G, D3, D3]
+        L.orc_grid_info.argtypes = [G, C.POINTER(C.c_int32), D3, C.POINTER(C.c_float)]
+        L.orc_grid_clear.argtypes = [G]
+        L.orc_grid_add_cloud.argtypes = [G, C.c_int, C.c_void_p]
+        L.orc_grid_add_cloud_ns.argtypes = [G, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_grid_decay.argtypes = [G]
+        for f in ("orc_grid_clear_column", "orc_grid_fill_column"):
+            getattr(L, f).argtypes = [G, C.c_int, C.c_int]
+        L.orc_grid_fill_cell.argtypes = [G, C.c_int, C.c_int, C.c_int]
+        L.orc_grid_get_map.argtypes = [G, C.c_int, C.c_void_p]
+        L.orc_grid_get_cloud.argtypes = [G, C.c_void_p, C.c_uint64]
+        L.orc_grid_get_cloud.restype = C.c_uint64
+        self.L = L
+        self.h = L.orc_grid_create((C.c_double * 3)(*[float(v) for v in origin]), (C.c_double * 3)(*[float(v) for v in dim]), float(res))
+
+    def __del__(self):
+        try:
+            self.L.orc_grid_destroy(self.h)
+        except Exception:
+            pass
+
+    def info(self):
+        dim = (C.c_int32 * 3)(); ori = (C.c_double * 3)(); res = C.c_float()
+        self.L.orc_grid_info(self.h, dim, ori, C.byref(res))
+        return tuple(dim), tuple(ori), res.value
+
+    def allocate(self, dim, ori):
+        return bool(self.L.orc_grid_allocate(self.h, (C.c_double * 3)(*[float(v) for v in dim]), (C.c_double * 3)(*[float(v) for v in ori])))
+
+    def clear(self, nx=None, ny=None):
+        if nx is None:
+            self.L.orc_grid_clear(self.h)
+        else:
+            self.L.orc_grid_clear_column(self.h, int(nx), int(ny))
+
+    def fill(self, nx, ny, nz=None):
+        if nz is None:
+            self.L.orc_grid_fill_column(self.h, int(nx), int(ny))
+        else:
+            self.L.orc_grid_fill_cell(self.h, int(nx), int(ny), int(nz))
+
+    def add_cloud(self, pts, ns=None):
+        p = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        if ns is None:
+            self.L.orc_grid_add_cloud(self.h, p.shape[0], p.ctypes.data)
+            return None
+        o = np.ascontiguousarray(ns, dtype=np.int32).reshape(-1, 3)
+        cap = max(p.shape[0] * o.shape[0], 1)
+        out = np.empty((cap, 3), dtype=np.int32)
+        n = self.L.orc_grid_add_cloud_ns(self.h, p.shape[0], p.ctypes.data, o.shape[0], o.ctypes.data, out.ctypes.data, cap)
+        return out[:n]
+
+    def decay(self):
+        self.L.orc_grid_decay(self.h)
+
+    def get_map(self, inflated=False):
+        dim, _, _ = self.info()
+        data = np.empty(dim[0] * dim[1] * dim[2], dtype=np.int8)
+        self.L.orc_grid_get_map(self.h, 1 if inflated else 0, data.ctypes.data)
+        return data
+
+    def get_cloud(self):
+        n = int(self.L.orc_grid_get_cloud(self.h, None, 0))
+        out = np.empty((max(n, 1), 3), dtype=np.float64)
+        self.L.orc_grid_get_cloud(self.h, out.ctypes.data, n)
+        return out[:n]

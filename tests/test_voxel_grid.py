@@ -1,0 +1,123 @@
+"""VoxelGrid (map ingest): the oracle follows the in-tree voxel_grid.cpp line by line; the CPU
+tests pin it on hand-checked cases, the GPU tests compare the device-resident grid with it bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import orc
+
+
+def test_oracle_grid_matches_the_in_tree_semantics():
+    # VoxelGrid(origin, dim, res): dims and integer origin by TRUNCATING division by the float resolution
+    # (voxel_grid.cpp:130-132): -5.0 / 0.2f = -24.99999962 -> -24, 10 / 0.2f = 49.9999992 -> 49
+    g = orc.Grid((-5.0, -10.0, 0.0), (10.0, 4.0, 0.0), 0.2)
+    dim, ori, res = g.info()
+    assert dim == (49, 19, 1) and ori == (-5.0, -10.0, 0.0) and res == np.float32(0.2)
+    # floatToInt truncates towards zero (:201-203): a point 0.1 cell below the origin still lands in cell 0
+    g.add_cloud([(-5.0 - 0.02, -10.0 + 0.21, 0.0), (100.0, 0.0, 0.0)])
+    m = g.get_map().reshape(1, 19, 49)  # [z][y][x]
+    assert m[0, 1, 0] == 100 and m.sum() == 100
+    # addCloud(pts, ns) (:191-207): only cells that were not occupied inflate; new_obs keeps the loop order
+    new = g.add_cloud([(-5.0 + 0.5, -10.0 + 0.5, 0.0), (-5.0 + 0.5, -10.0 + 0.5, 0.0), (-5.0 - 0.02, -10.0 + 0.21, 0.0)], [(1, 0, 0), (0, 0, 0), (-1, 0, 0)])
+    assert new.tolist() == [[3, 2, 0], [2, 2, 0], [1, 2, 0]]
+    assert g.get_map(True).reshape(1, 19, 49)[0, 2, 1:4].tolist() == [100, 100, 100]
+    # decay (:213-224): occupied values count down, getMap still reports 100 until they reach 0
+    for _ in range(99):
+        g.decay()
+    assert g.get_map().max() == 100
+    g.decay()
+    assert g.get_map().max() == 0
+    # fill / clear columns (:31-46), getCloud order x, y, z and cell centres (:18-29, :205-207)
+    g.fill(4, 3); g.fill(2, 5); g.fill(60, 1)
+    c = g.get_cloud()
+    assert np.allclose(c, [[-5.0 + 2.5 * np.float32(0.2), -10.0 + 5.5 * np.float32(0.2), 0.5 * np.float32(0.2)],
+                           [-5.0 + 4.5 * np.float32(0.2), -10.0 + 3.5 * np.float32(0.2), 0.5 * np.float32(0.2)]])
+    g.clear(2, 5)
+    assert len(g.get_cloud()) == 1
+    # allocate (:129-181): the overlap is carried over, the inflated grid restarts as a copy of the map
+    assert g.allocate((10.0, 4.0, 0.0), (-5.0, -10.0, 0.0)) is False
+    assert g.allocate((12.0, 6.0, 0.0), (-5.4, -10.4, 0.0)) is True
+    dim2, ori2, _ = g.info()
+    assert dim2 == (59, 29, 1)
+    c2 = g.get_cloud()
+    assert len(c2) == 1  # the filled column survives, shifted by the integer origin difference (2, 2)
+    assert np.array_equal(g.get_map(), g.get_map(True))
+
+
+def _rand_cloud(rng, n, lo, hi):
+    return rng.uniform(lo, hi, (n, 3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2])
+def test_device_grid_matches_oracle(seed):
+    from mpl_ros_amd.voxel_grid import VoxelGrid
+    rng = np.random.default_rng(seed)
+    origin, dim, res = (-3.0, -2.0, 0.0), (12.0, 9.0, 3.0), 0.1
+    G, O = VoxelGrid(origin, dim, res), orc.Grid(origin, dim, res)
+    assert G.info() == O.info()
+    ns = [(x, y, z) for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (0, 1)]
+
+    def same():
+        assert np.array_equal(G.getMap()["data"], O.get_map())
+        assert np.array_equal(G.getInflatedMap()["data"], O.get_map(True))
+
+    pts = _rand_cloud(rng, 20000, (-4, -3, -0.5), (10, 8, 3.5))  # some outside, many duplicates per cell
+    G.addCloud(pts); O.add_cloud(pts)
+    same()
+    assert np.array_equal(G.getCloud(), O.get_cloud())
+    for rnd in range(3):
+        pts = _rand_cloud(rng, 5000, (-4, -3, -0.5), (10, 8, 3.5))
+        pts[::7] = pts[::7][::-1]  # repeated cells in a different order
+        a, b = G.addCloud(pts, ns), O.add_cloud(pts, ns)
+        assert a.shape == b.shape and np.array_equal(a, b)  # new_obs: same cells, same (sequential) order
+        same()
+        G.decay(); O.decay()
+    for (nx, ny) in [(3, 4), (0, 0), (119, 89), (500, 1), (-1, 2)]:
+        G.fill(nx, ny); O.fill(nx, ny)
+    G.fill(5, 6, 7); O.fill(5, 6, 7)
+    G.clear(3, 4); O.clear(3, 4)
+    same()
+    assert G.allocate((14.0, 9.0, 3.0), (-3.5, -2.0, 0.0)) == O.allocate((14.0, 9.0, 3.0), (-3.5, -2.0, 0.0))
+    assert G.info() == O.info()
+    same()
+    G.clear(); O.clear()
+    same()
+
+
+@pytest.mark.gpu
+def test_replanning_cycle_stays_on_the_device():
+    """map_replanner_node.cpp:175-230 in miniature: block the previous path in the mapper, hand getMap() to
+    the planner device to device, plan again -- and the same on the CPU side."""
+    from mpl_ros_amd import mapgen
+    from mpl_ros_amd.planner import VoxelMapPlanner, VoxelMapUtil
+    from mpl_ros_amd.voxel_grid import VoxelGrid
+    from tests import util
+    rng = np.random.default_rng(3)
+    origin, dim, res = (0.0, 0.0, 0.0), (6.4, 6.4, 3.2), 0.1
+    G, O = VoxelGrid(origin, dim, res), orc.Grid(origin, dim, res)
+    pts = rng.uniform((1.0, 1.0, 0.0), (5.4, 5.4, 3.2), (1500, 3))
+    pts = pts[(np.linalg.norm(pts[:, :2] - (0.55, 0.55), axis=1) > 1.0) & (np.linalg.norm(pts[:, :2] - (5.85, 5.85), axis=1) > 1.0)]
+    G.addCloud(pts); O.add_cloud(pts)
+    U = mapgen.control_lattice(1.0, 1, True)
+    mu = VoxelMapUtil()
+    pl = VoxelMapPlanner(False)
+    start, goal = ((0.55, 0.55, 1.55), (0, 0, 0)), ((5.85, 5.85, 1.55),)
+    for cycle in range(3):
+        G.setMapUtil(mu)
+        assert np.array_equal(mu.getMap(), O.get_map())
+        gdim, gori, gres = O.info()
+        grid = O.get_map().reshape(gdim[2], gdim[1], gdim[0])
+        P = util.make_oracle(grid, gori, float(gres), orc.ACC, U, v_max=2.0, a_max=1.0)
+        pl.setMapUtil(mu)
+        pl.setVmax(2.0); pl.setAmax(1.0); pl.setDt(1.0); pl.setU(U); pl.setTol(0.5)
+        pl.setCapacity(1, 1 << 20, 1 << 22, 1 << 21)
+        r, c = util.compare_plan(P, pl, start, goal, orc.ACC)
+        if r.status != 0:
+            break
+        # block the middle of the path found, like the replanner does with fill(pn(0), pn(1))
+        tr = pl.getTraj()
+        w = tr.getWaypoints()[len(tr.getWaypoints()) // 2]
+        cx, cy = int((w.pos[0] - gori[0]) / gres), int((w.pos[1] - gori[1]) / gres)
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                G.fill(cx + dx, cy + dy); O.fill(cx + dx, cy + dy)
