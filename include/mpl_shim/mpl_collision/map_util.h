@@ -111,6 +111,14 @@ class MapUtil {
   vec_Vecf<Dim> getFreeCloud() { return cloud(1); }
   vec_Vecf<Dim> getUnknownCloud() { return cloud(2); }
 
+  /// re-read origin / dim / res from the device after the grid was replaced there (VoxelGrid::setMapUtil)
+  void syncInfo() {
+    int32_t d[3];
+    double o[3], r;
+    check(mplx_map_info(ctx(), d, o, &r));
+    for (int i = 0; i < Dim; i++) { dim_(i) = d[i]; origin_d_(i) = o[i]; }
+    res_ = r;
+  }
   /// the device context planners attach to (not part of the reference API)
   mplx_ctx *ctx() { ensure_ctx(); return ctx_; }
 

@@ -4,6 +4,7 @@
 // usage: map_planner_driver <map.bin> dx dy dz ox oy oz res sx sy sz svx svy svz gx gy gz
 // Prints one JSON line that tests/test_cpp_shim.py compares with the oracle.
 #include <mpl_planner/planner/map_planner.h>
+#include <planning_ros_utils/voxel_grid.h>
 
 #include <cmath>
 #include <cstdlib>
@@ -95,7 +96,16 @@ int main(int argc, char **argv) {
   size_t ray_occ = 0;
   for (const auto &pn : pns)
     if (map_util->isOccupied(pn)) ray_occ++;
-  printf("], \"free_start\": %s, \"ray_cells\": %zu, \"ray_occupied\": %zu, \"cloud\": %zu}\n", map_util->isFree(start.pos) ? "true" : "false",
-         pns.size(), ray_occ, map_util->getCloud().size());
+  // the replanner's mapper (map_replanner_node.cpp:329-331,186-188): cloud -> VoxelGrid -> getMap -> MapUtil
+  VoxelGrid voxel_mapper(ori, Vec3f(dx * res, dy * res, dz * res), (float)res);
+  voxel_mapper.addCloud(map_util->getCloud());
+  planning_ros_msgs::VoxelMap vm = voxel_mapper.getMap();
+  size_t grid_occ = 0;
+  for (signed char v : vm.data) grid_occ += v > 0;
+  MPL::VoxelMapUtil map_util2;
+  voxel_mapper.setMapUtil(map_util2);
+  printf("], \"free_start\": %s, \"ray_cells\": %zu, \"ray_occupied\": %zu, \"cloud\": %zu, \"grid_dim\": [%d, %d, %d], \"grid_occ\": %zu, \"grid_cloud2\": %zu}\n",
+         map_util->isFree(start.pos) ? "true" : "false", pns.size(), ray_occ, map_util->getCloud().size(), (int)vm.dim.x, (int)vm.dim.y, (int)vm.dim.z, grid_occ,
+         map_util2.getCloud().size());
   return 0;
 }

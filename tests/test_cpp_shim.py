@@ -66,3 +66,8 @@ def test_reference_driver_through_the_shim(tmp_path, skir):
     ray = P.ray_trace((5.5, 5.5, 0.5), (1.5, 1.5, 5.5))
     assert r["ray_cells"] == len(ray) and r["ray_occupied"] == sum(P.cell_state(c) == 1 for c in ray)
     assert r["cloud"] == len(P.cloud(0))
+    # the mapper through the shim: the map's own cloud fed back through VoxelGrid (float resolution, truncation)
+    G = orc.Grid(origin, (grid.shape[2] * res, grid.shape[1] * res, grid.shape[0] * res), res)
+    G.add_cloud(P.cloud(0))
+    assert tuple(r["grid_dim"]) == G.info()[0]
+    assert r["grid_occ"] == int((G.get_map() > 0).sum()) == r["grid_cloud2"]
