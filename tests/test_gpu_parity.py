@@ -261,3 +261,37 @@ def test_occ_map_planner_2d():
     assert all(w.pos[2] == 0.0 and w.vel[2] == 0.0 for w in tr.getWaypoints())
     cells, state = mu.query([(1.05, 1.05), (0.0, 0.0), (16.5, 3.0)])
     assert tuple(cells[0]) == (10, 10) and state[0] == 0 and state[1] == 3 and state[2] == 3
+
+
+@SPEC
+@pytest.mark.parametrize("seed", range(16))
+def test_random_configurations(spec, seed):
+    """Seeded sweep over what the setters expose: control kind, lattice size, dt, w, eps, limits, tolerances,
+    t_max, heuristic kind, start velocity -- every plan compared with the oracle down to the state space."""
+    rng = np.random.default_rng(1000 + seed)
+    control = [orc.VEL, orc.ACC, orc.ACC, orc.JRK][seed % 4]
+    num = int(rng.integers(1, 3)) if control != orc.JRK else 1
+    use_3d = bool(rng.integers(0, 4) > 0)
+    u = float(rng.choice([0.5, 1.0, 2.0]))
+    U = mapgen.control_lattice(u, num, use_3d)
+    n = 48
+    grid, origin, res = util.small_map(n, seed=50 + seed, occupancy=float(rng.choice([0.03, 0.08, 0.15])))
+    kw = dict(dt=float(rng.choice([0.5, 1.0])), w=float(rng.choice([1.0, 10.0, 30.0])), eps=float(rng.choice([0.0, 0.5, 1.0, 2.0])),
+              v_max=float(rng.choice([1.0, 2.0, 3.0])), a_max=float(rng.choice([-1.0, 1.0, 2.0])), tol_pos=float(rng.choice([0.3, 0.5, 1.0])),
+              max_expand=1500, heur_ignore_dynamics=bool(rng.integers(0, 5) == 0))
+    if control == orc.JRK:
+        kw["j_max"] = float(rng.choice([1.0, 2.0]))
+    if rng.integers(0, 3) == 0:
+        kw["tol_vel"] = 1.0
+    if rng.integers(0, 4) == 0:
+        kw["t_max"] = 6.0 * kw["dt"]
+    z = 1.05 if use_3d else 2.45
+    start_p, goal_p = (1.05, 1.05, z), (float(rng.choice([3.05, 3.55])), float(rng.choice([2.55, 3.55])), z if not use_3d else 2.55)
+    mapgen.carve_bubble(grid, start_p, origin, res, 3)
+    mapgen.carve_bubble(grid, goal_p, origin, res, 3)
+    v0 = (float(rng.integers(-1, 2)), 0.0, 0.0) if control != orc.VEL else (0.0, 0.0, 0.0)
+    P = util.make_oracle(grid, origin, res, control, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, spec=spec, **kw)
+    start = (start_p, v0, (0.0, 0.0, 0.0)) if control == orc.JRK else (start_p, v0)
+    r, c = util.compare_plan(P, pl, start, (goal_p,), control)
+    print(f"seed {seed}: control {control} nU {len(U)} status {r.status} expanded {r.n_expanded} nodes {r.n_nodes} edges {r.n_edges} reopen {r.n_reopen}")
