@@ -115,8 +115,9 @@ def main():
     else:
         U = mapgen.control_lattice(1.0, 2, True)
         max_expand = args.max_expand if args.max_expand > 0 else (2_000_000 if args.single else 20000)
-        per_q = args.max_nodes or max(1 << 16, max_expand * 16)
-        caps = dict(nodes=per_q * args.queries, edges=per_q * args.queries * 2, log=per_q * args.queries * 5 // 4)
+        # the 125-primitive lattice creates ~20 states and ~50 predecessor records per expansion
+        per_q = args.max_nodes or max(1 << 16, max_expand * 24)
+        caps = dict(nodes=per_q * args.queries, edges=per_q * args.queries * 7 // 2, log=per_q * args.queries * 3 // 2)
         slots = args.slots or 768
     pl = VoxelMapPlanner(False)
     pl.setMapUtil(mu)
