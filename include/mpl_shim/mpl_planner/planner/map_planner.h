@@ -11,6 +11,8 @@
 #include <mpl_basis/trajectory.h>
 #include <mpl_collision/map_util.h>
 
+#include <algorithm>
+
 namespace MPL {
 
 template <int Dim>
@@ -63,6 +65,8 @@ class MapPlanner {
     cfg.heur_ignore_dynamics = heur_ignore_dynamics_ ? 1 : 0;
     traj_ = Trajectory<Dim>();
     traj_cost_ = std::numeric_limits<decimal_t>::infinity();
+    mplx_set_record(ctx, record_cap_);  // expansion order for getExpandedNodes()
+    control_ = (Control::Control)cfg.control;
     if (mplx_planner_config(ctx, &cfg) != MPLX_OK) { printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx)); return false; }
     mplx_waypoint s = to_c(start), g = to_c(goal);
     if (mplx_plan(ctx, &s, &g, &res_) != MPLX_OK) { printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx)); return false; }
@@ -87,6 +91,38 @@ class MapPlanner {
   vec_Vecf<Dim> getCloseSet() const { return node_set(true); }
   vec_Vecf<Dim> getOpenSet() const { return node_set(false); }
   size_t getExpandedNum() const { return (size_t)res_.n_expanded; }
+  /// positions in expansion order = env_base::expanded_nodes_ (map_replanner_node.cpp:78-79,119); the first
+  /// `setExpandedRecord(cap)` expansions are kept (default 1 << 20)
+  vec_Vecf<Dim> getExpandedNodes() const {
+    vec_Vecf<Dim> ps;
+    std::vector<mplx_waypoint> coords;
+    if (!nodes(coords)) return ps;
+    std::vector<int32_t> ids((size_t)std::max<uint64_t>(1, std::min<uint64_t>(res_.n_expanded, record_cap_)));
+    uint32_t n = 0;
+    if (mplx_result_expanded(map_util_->ctx(), 0, (uint32_t)ids.size(), ids.data(), &n) != MPLX_OK) return ps;
+    for (uint32_t i = 0; i < n; i++) ps.push_back(pos_of(coords[(size_t)ids[i]]));
+    return ps;
+  }
+  void setExpandedRecord(uint32_t cap) { record_cap_ = cap; }
+  /// nodes that are linked into the graph, i.e. have at least one predecessor record (map_replanner_node.cpp:94)
+  /// [UNVERIFIED: the upstream body is not vendored; node-id order here, hash-map order upstream]
+  vec_Vecf<Dim> getLinkedNodes() const {
+    vec_Vecf<Dim> ps;
+    std::vector<mplx_waypoint> coords;
+    std::vector<int32_t> child, parent, action;
+    if (!nodes(coords) || !edges(child, parent, action)) return ps;
+    int32_t last = -1;
+    for (size_t e = 0; e < child.size(); e++)
+      if (child[e] != last) { ps.push_back(pos_of(coords[(size_t)child[e]])); last = child[e]; }
+    return ps;
+  }
+  /// the primitive of every predecessor record: Primitive(parent state, U[action], dt)
+  /// (getAllPrimitives poly_map_replanner_node.cpp:184,234; blocked successors are never stored here, so
+  /// getValidPrimitives() is the same list; getExpandedEdges(), map_replanner_node.cpp:100-102, keeps the
+  /// edges that enter an expanded (closed) node)  [UNVERIFIED selection rules: upstream bodies not vendored]
+  vec_E<Primitive<Dim>> getAllPrimitives() const { return edge_primitives(false); }
+  vec_E<Primitive<Dim>> getValidPrimitives() const { return edge_primitives(false); }
+  vec_E<Primitive<Dim>> getExpandedEdges() const { return edge_primitives(true); }
   const mplx_result &getResult() const { return res_; }
 
  protected:
@@ -97,6 +133,43 @@ class MapPlanner {
     c.control = (int32_t)w.control & 15;
     c.enable_t = w.enable_t ? 1 : 0;
     return c;
+  }
+  static Vecf<Dim> pos_of(const mplx_waypoint &w) {
+    Vecf<Dim> p;
+    for (int k = 0; k < Dim; k++) p(k) = w.pos[k];
+    return p;
+  }
+  bool nodes(std::vector<mplx_waypoint> &coords, std::vector<int32_t> *closed = nullptr) const {
+    const size_t n = (size_t)res_.n_nodes;
+    if (!n) return false;
+    coords.resize(n);
+    if (closed) closed->resize(n);
+    return mplx_result_nodes(map_util_->ctx(), coords.data(), nullptr, nullptr, closed ? closed->data() : nullptr, nullptr) == MPLX_OK;
+  }
+  bool edges(std::vector<int32_t> &child, std::vector<int32_t> &parent, std::vector<int32_t> &action) const {
+    const size_t n = (size_t)res_.n_edges;
+    child.resize(n ? n : 1); parent.resize(n ? n : 1); action.resize(n ? n : 1);
+    uint64_t m = 0;
+    if (mplx_result_edges(map_util_->ctx(), child.data(), parent.data(), action.data(), n, &m) != MPLX_OK) return false;
+    child.resize((size_t)m); parent.resize((size_t)m); action.resize((size_t)m);
+    return true;
+  }
+  vec_E<Primitive<Dim>> edge_primitives(bool into_closed_only) const {
+    vec_E<Primitive<Dim>> prs;
+    std::vector<mplx_waypoint> coords;
+    std::vector<int32_t> closed, child, parent, action;
+    if (!nodes(coords, &closed) || !edges(child, parent, action)) return prs;
+    for (size_t e = 0; e < child.size(); e++) {
+      if (into_closed_only && !closed[(size_t)child[e]]) continue;
+      const mplx_waypoint &c = coords[(size_t)parent[e]];
+      Waypoint<Dim> w(control_);
+      for (int k = 0; k < Dim; k++) { w.pos(k) = c.pos[k]; w.vel(k) = c.vel[k]; w.acc(k) = c.acc[k]; w.jrk(k) = c.jrk[k]; }
+      w.t = c.t;
+      VecDf u(Dim);
+      for (int k = 0; k < Dim; k++) u(k) = U_[3 * (size_t)action[e] + k];
+      prs.push_back(Primitive<Dim>(w, u, dt_));
+    }
+    return prs;
   }
   vec_Vecf<Dim> node_set(bool closed_set) const {
     vec_Vecf<Dim> ps;
@@ -124,6 +197,8 @@ class MapPlanner {
   Trajectory<Dim> traj_;
   decimal_t traj_cost_ = std::numeric_limits<decimal_t>::infinity();
   mplx_result res_ = mplx_result();
+  Control::Control control_ = Control::ACC;
+  uint32_t record_cap_ = 1u << 20;
 };
 
 typedef MapPlanner<2> OccMapPlanner;

@@ -85,6 +85,14 @@ int main(int argc, char **argv) {
 
   bool valid = planner_ptr->plan(start, goal);
   auto traj = planner_ptr->getTraj();
+  // the replanner's visualisation getters (map_replanner_node.cpp:78-102)
+  const size_t n_expanded_nodes = planner_ptr->getExpandedNodes().size(), n_linked = planner_ptr->getLinkedNodes().size();
+  const auto all_prs = planner_ptr->getAllPrimitives();
+  const size_t n_expanded_edges = planner_ptr->getExpandedEdges().size();
+  double prs_end_sum = 0;
+  for (const auto &pr : all_prs) prs_end_sum += pr.evaluate(pr.t()).pos(0);
+  printf("{\"expanded_nodes\": %zu, \"linked\": %zu, \"all_primitives\": %zu, \"expanded_edges\": %zu, \"prs_end_sum\": %.17g}\n", n_expanded_nodes, n_linked,
+         all_prs.size(), n_expanded_edges, prs_end_sum);
   printf("{\"valid\": %s, \"closed\": %zu, \"expanded\": %zu, \"cost\": %.17g, \"total_time\": %.17g, \"n_prim\": %zu, \"waypoints\": [",
          valid ? "true" : "false", planner_ptr->getCloseSet().size(), planner_ptr->getExpandedNum(),
          valid ? planner_ptr->getTrajCost() : -1.0, traj.getTotalTime(), traj.getPrimitives().size());

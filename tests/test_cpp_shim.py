@@ -50,6 +50,7 @@ def test_reference_driver_through_the_shim(tmp_path, skir):
     out = subprocess.run([exe] + skir_args(tmp_path, skir), capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     r = json.loads(out.stdout.strip().splitlines()[-1])
+    viz = json.loads(out.stdout.strip().splitlines()[-2])
     grid, origin, res = skir
     P = util.make_oracle(grid, origin, res, orc.ACC, mapgen.control_lattice(1.0, 1, True), v_max=2.0, a_max=1.0, tol_pos=0.5)
     st = P.plan(orc.waypoint((5.5, 5.5, 0.5), vel=(1, 0, 0)), orc.waypoint((1.5, 1.5, 5.5)))
@@ -71,3 +72,14 @@ def test_reference_driver_through_the_shim(tmp_path, skir):
     G.add_cloud(P.cloud(0))
     assert tuple(r["grid_dim"]) == G.info()[0]
     assert r["grid_occ"] == int((G.get_map() > 0).sum()) == r["grid_cloud2"]
+    # visualisation getters: expansion record, linked nodes, one primitive per predecessor record
+    co, po, ao = P.edges()
+    assert viz["expanded_nodes"] == len(P.expanded()[0]) and viz["all_primitives"] == len(co) and viz["linked"] == len(set(co.tolist()))
+    closed = [P.node(int(i))[3] for i in range(P.num_nodes())]
+    assert viz["expanded_edges"] == sum(1 for ch in co if closed[int(ch)])
+    U = mapgen.control_lattice(1.0, 1, True)
+    end_sum = 0.0
+    for par, act in zip(po, ao):  # end point x of Primitive(parent, U[action], dt = 1): p + v + u / 2, summed in the same order
+        w = P.node(int(par))[0]
+        end_sum += U[act][0] / 2 * 1.0 * 1.0 + w.vel[0] * 1.0 + w.pos[0]
+    assert abs(viz["prs_end_sum"] - end_sum) < 1e-6 * max(1.0, abs(end_sum))
