@@ -52,6 +52,6 @@ def test_product_does_not_import_the_oracle():
     pkg = os.path.join(ROOT, "mpl_ros_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".h", ".hip", ".cpp")):
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".inl")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no CPU fallback", ""), f
