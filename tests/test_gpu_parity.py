@@ -295,3 +295,48 @@ def test_random_configurations(spec, seed):
     start = (start_p, v0, (0.0, 0.0, 0.0)) if control == orc.JRK else (start_p, v0)
     r, c = util.compare_plan(P, pl, start, (goal_p,), control)
     print(f"seed {seed}: control {control} nU {len(U)} status {r.status} expanded {r.n_expanded} nodes {r.n_nodes} edges {r.n_edges} reopen {r.n_reopen}")
+
+
+@SPEC
+def test_pool_full_is_reported_and_the_context_stays_usable(spec):
+    """Pools too small for the search: MPLX_PLAN_POOL_FULL (never a truncated result); afterwards the same
+    context, re-sized, plans correctly -- the far-bucket heads were left clean by the aborted query."""
+    grid, origin, res = util.small_map(96, seed=2, occupancy=0.10)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    mapgen.carve_bubble(grid, (8.55, 8.55, 8.55), origin, res, 3)
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = dict(v_max=2.0, a_max=1.0)
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, spec=spec, max_nodes=1 << 15, max_edges=1 << 16, max_log=1 << 15, **kw)
+    s, g = ((1.05, 1.05, 1.05), (0, 0, 0)), ((8.55, 8.55, 8.55),)
+    pl.setEpsilon(0.0)  # uninformed search: far more than one chunk (32768) of states
+    ok = pl.plan(util.gpu_wp(s[0]), util.gpu_wp(g[0]))
+    assert not ok and pl.getResult().status == 4 and np.isinf(pl.getResult().cost)
+    pl.setEpsilon(1.0)
+    for _ in range(2):  # same context: bigger pools, then the query twice
+        pl.setCapacity(1, 1 << 20, 1 << 22, 1 << 21)
+        util.compare_plan(P, pl, s, g, orc.ACC)
+
+
+def test_one_context_many_configurations():
+    """One MapUtil / planner pair reused across control kinds, lattices, maps and capacities (pools are
+    re-created when the record size changes, bucket heads and tables are reused otherwise)."""
+    from mpl_ros_amd.planner import VoxelMapPlanner, VoxelMapUtil
+    mu, pl = VoxelMapUtil(), VoxelMapPlanner(False)
+    pl.setMapUtil(mu)
+    for it, (control, num, seed, cap) in enumerate([(orc.ACC, 1, 1, 1 << 20), (orc.JRK, 1, 2, 1 << 19), (orc.ACC, 2, 3, 1 << 21), (orc.VEL, 1, 4, 1 << 18),
+                                                    (orc.ACC, 1, 5, 1 << 20), (orc.JRK, 2, 6, 1 << 20)]):
+        grid, origin, res = util.small_map(64, seed=seed, occupancy=0.08)
+        mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+        mapgen.carve_bubble(grid, (4.55, 4.05, 3.55), origin, res, 3)
+        dz, dy, dx = grid.shape
+        mu.setMap(origin, (dx, dy, dz), grid.ravel(), res)
+        U = mapgen.control_lattice(1.0, num, True)
+        kw = dict(v_max=2.0, a_max=1.0, max_expand=2000)
+        if control == orc.JRK:
+            kw["j_max"] = 1.0
+        P = util.make_oracle(grid, origin, res, control, U, **kw)
+        pl.setVmax(2.0); pl.setAmax(1.0); pl.setJmax(kw.get("j_max", -1.0)); pl.setDt(1.0); pl.setU(U); pl.setTol(0.5); pl.setMaxNum(2000)
+        pl.setCapacity(1, cap, cap * 4, cap * 2)
+        start = ((1.05, 1.05, 1.05), (0, 0, 0), (0, 0, 0)) if control == orc.JRK else ((1.05, 1.05, 1.05), (0, 0, 0))
+        util.compare_plan(P, pl, start, ((4.55, 4.05, 3.55),), control)
