@@ -23,6 +23,12 @@
  * Everything else (hash resolutions, floatToInt rounding, validate_primitive, heuristic, A* loop
  * order, heap comparator, defaults) is a recollection of upstream MPL and is tagged UNVERIFIED in
  * mpl_oracle.c.  It is pinned only by analytic known answers (tests/test_oracle_kat.py).
+ *
+ * The VoxelGrid part (orc_grid_*) and MapUtil::getCloud's loop order are different: their reference
+ * source IS in-tree (planning_ros_utils/src/mapping_utils/voxel_grid.cpp) and is restated line by line,
+ * tagged IN-TREE with line ranges.  It still cannot be compiled here (boost::multi_array, Eigen and the
+ * generated planning_ros_msgs headers are absent: no oracle/_ref), so it is pinned by hand-checked cases
+ * that follow the source (tests/test_voxel_grid.py), not by running the reference.
  */
 #ifndef MPL_ORACLE_H
 #define MPL_ORACLE_H
