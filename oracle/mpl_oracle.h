@@ -26,9 +26,11 @@
  *
  * The VoxelGrid part (orc_grid_*) and MapUtil::getCloud's loop order are different: their reference
  * source IS in-tree (planning_ros_utils/src/mapping_utils/voxel_grid.cpp) and is restated line by line,
- * tagged IN-TREE with line ranges.  It still cannot be compiled here (boost::multi_array, Eigen and the
- * generated planning_ros_msgs headers are absent: no oracle/_ref), so it is pinned by hand-checked cases
- * that follow the source (tests/test_voxel_grid.py), not by running the reference.
+ * tagged IN-TREE with line ranges.  Its own build needs catkin, Eigen, boost::multi_array and generated
+ * message headers, all absent; `make -C oracle ref` compiles the reference's voxel_grid.cpp from where it lies
+ * against stand-ins for those three headers (oracle/ref_stubs/ + include/mpl_shim typedefs) into
+ * oracle/_ref/libvoxelgrid_ref.so, and tests/test_voxel_grid.py checks the restatement -- and, on the GPU,
+ * the HIP grid -- against that binary bit for bit.  For this component parity is pinned by the reference.
  */
 #ifndef MPL_ORACLE_H
 #define MPL_ORACLE_H

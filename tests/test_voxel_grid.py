@@ -1,5 +1,8 @@
 """VoxelGrid (map ingest): the oracle follows the in-tree voxel_grid.cpp line by line; the CPU
 tests pin it on hand-checked cases, the GPU tests compare the device-resident grid with it bit for bit."""
+import ctypes as C
+import os
+
 import numpy as np
 import pytest
 
@@ -41,6 +44,115 @@ def test_oracle_grid_matches_the_in_tree_semantics():
     c2 = g.get_cloud()
     assert len(c2) == 1  # the filled column survives, shifted by the integer origin difference (2, 2)
     assert np.array_equal(g.get_map(), g.get_map(True))
+
+
+class RefGrid:
+    """The reference's own VoxelGrid, compiled from /root/reference/.../voxel_grid.cpp by `make -C oracle ref`
+    (oracle/_ref/libvoxelgrid_ref.so; dependency stand-ins under oracle/ref_stubs)."""
+    PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libvoxelgrid_ref.so")
+
+    def __init__(self, origin, dim, res):
+        L = C.CDLL(self.PATH)
+        D3 = C.c_double * 3
+        L.ref_grid_create.restype = C.c_void_p
+        L.ref_grid_create.argtypes = [D3, D3, C.c_float]
+        for f in ("ref_grid_destroy", "ref_grid_clear", "ref_grid_decay"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.ref_grid_allocate.argtypes = [C.c_void_p, D3, D3]
+        L.ref_grid_add_cloud.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_grid_add_cloud_ns.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        for f in ("ref_grid_fill_column", "ref_grid_clear_column"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.ref_grid_fill_cell.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.ref_grid_get_map.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_void_p]
+        L.ref_grid_get_map.restype = C.c_uint64
+        L.ref_grid_get_cloud.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.ref_grid_get_cloud.restype = C.c_uint64
+        self.L, self.D3 = L, D3
+        self.h = L.ref_grid_create(D3(*origin), D3(*dim), res)
+
+    def info(self):
+        dim = (C.c_int32 * 3)(); ori = (C.c_double * 3)(); res = C.c_float()
+        self.L.ref_grid_get_map(self.h, 0, dim, ori, C.byref(res), None)
+        return tuple(dim), tuple(ori), res.value
+
+    def allocate(self, dim, ori):
+        return bool(self.L.ref_grid_allocate(self.h, self.D3(*dim), self.D3(*ori)))
+
+    def clear(self, nx=None, ny=None):
+        self.L.ref_grid_clear(self.h) if nx is None else self.L.ref_grid_clear_column(self.h, nx, ny)
+
+    def fill(self, nx, ny, nz=None):
+        self.L.ref_grid_fill_column(self.h, nx, ny) if nz is None else self.L.ref_grid_fill_cell(self.h, nx, ny, nz)
+
+    def add_cloud(self, pts, ns=None):
+        p = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 3)
+        if ns is None:
+            self.L.ref_grid_add_cloud(self.h, p.shape[0], p.ctypes.data)
+            return None
+        o = np.ascontiguousarray(ns, dtype=np.int32).reshape(-1, 3)
+        out = np.empty((max(p.shape[0] * o.shape[0], 1), 3), dtype=np.int32)
+        n = self.L.ref_grid_add_cloud_ns(self.h, p.shape[0], p.ctypes.data, o.shape[0], o.ctypes.data, out.ctypes.data, out.shape[0])
+        return out[:n]
+
+    def decay(self):
+        self.L.ref_grid_decay(self.h)
+
+    def get_map(self, inflated=False):
+        dim, _, _ = self.info()
+        data = np.empty(dim[0] * dim[1] * dim[2], dtype=np.int8)
+        d = (C.c_int32 * 3)(); o = (C.c_double * 3)(); r = C.c_float()
+        self.L.ref_grid_get_map(self.h, 1 if inflated else 0, d, o, C.byref(r), data.ctypes.data)
+        return data
+
+    def get_cloud(self):
+        n = int(self.L.ref_grid_get_cloud(self.h, None, 0))
+        out = np.empty((max(n, 1), 3), dtype=np.float64)
+        self.L.ref_grid_get_cloud(self.h, out.ctypes.data, n)
+        return out[:n]
+
+
+def _exercise(A, B, rng, same):
+    """the same seeded operation sequence on two VoxelGrid implementations"""
+    add_a = A.addCloud if hasattr(A, "addCloud") else A.add_cloud
+    add_b = B.addCloud if hasattr(B, "addCloud") else B.add_cloud
+    ns = [(x, y, z) for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (0, 1)]
+    pts = rng.uniform((-4, -3, -0.5), (10, 8, 3.5), (20000, 3))
+    add_a(pts); add_b(pts)
+    same()
+    for rnd in range(3):
+        pts = rng.uniform((-4, -3, -0.5), (10, 8, 3.5), (5000, 3))
+        pts[::7] = pts[::7][::-1]
+        a, b = add_a(pts, ns), add_b(pts, ns)
+        assert a.shape == b.shape and np.array_equal(a, b)
+        same()
+        A.decay(); B.decay()
+    for (nx, ny) in [(3, 4), (0, 0), (119, 89), (500, 1), (-1, 2)]:
+        A.fill(nx, ny); B.fill(nx, ny)
+    A.fill(5, 6, 7); B.fill(5, 6, 7)
+    A.clear(3, 4); B.clear(3, 4)
+    same()
+    assert A.allocate((14.0, 9.0, 3.0), (-3.5, -2.0, 0.0)) == B.allocate((14.0, 9.0, 3.0), (-3.5, -2.0, 0.0))
+    assert A.info() == B.info()
+    same()
+    A.clear(); B.clear()
+    same()
+
+
+@pytest.mark.skipif(not os.path.exists(RefGrid.PATH), reason="oracle/_ref not built (needs /root/reference: make -C oracle ref)")
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_restatement_matches_the_compiled_reference(seed):
+    """oracle/mpl_oracle.c's orc_grid_* against the reference's own voxel_grid.cpp, compiled where it lies"""
+    rng = np.random.default_rng(seed)
+    origin, dim, res = (-3.0, -2.0, 0.0), (12.0, 9.0, 3.0), [0.1, 0.2, 0.25][seed - 1]
+    O, R = orc.Grid(origin, dim, res), RefGrid(origin, dim, res)
+    assert O.info() == R.info()
+
+    def same():
+        assert np.array_equal(O.get_map(), R.get_map()) and np.array_equal(O.get_map(True), R.get_map(True))
+        assert np.array_equal(O.get_cloud(), R.get_cloud())
+
+    _exercise(O, R, rng, same)
 
 
 def _rand_cloud(rng, n, lo, hi):
@@ -121,3 +233,21 @@ def test_replanning_cycle_stays_on_the_device():
         for dx in (-1, 0, 1):
             for dy in (-1, 0, 1):
                 G.fill(cx + dx, cy + dy); O.fill(cx + dx, cy + dy)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(RefGrid.PATH), reason="oracle/_ref not built")
+@pytest.mark.parametrize("seed", [4, 5])
+def test_device_grid_matches_the_compiled_reference(seed):
+    """the device-resident grid against the reference's own voxel_grid.cpp (oracle/_ref), same operation sequence"""
+    from mpl_ros_amd.voxel_grid import VoxelGrid
+    rng = np.random.default_rng(seed)
+    origin, dim, res = (-3.0, -2.0, 0.0), (12.0, 9.0, 3.0), [0.1, 0.2][seed - 4]
+    G, R = VoxelGrid(origin, dim, res), RefGrid(origin, dim, res)
+    assert G.info() == R.info()
+
+    def same():
+        assert np.array_equal(G.getMap()["data"], R.get_map()) and np.array_equal(G.getInflatedMap()["data"], R.get_map(True))
+        assert np.array_equal(G.getCloud(), R.get_cloud())
+
+    _exercise(G, R, rng, same)
