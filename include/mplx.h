@@ -33,6 +33,8 @@ extern "C" {
 #define MPLX_PLAN_MAX_EXPAND 3      /* max_expand reached */
 #define MPLX_PLAN_POOL_FULL 4       /* a shared device pool is exhausted (raise mplx_set_capacity) */
 #define MPLX_PLAN_INTERNAL 5        /* 64-bit key-hash collision inside one speculative batch (never observed) */
+#define MPLX_PLAN_TRAJ_TOO_LONG 6   /* goal reached, mplx_result.cost is valid, but the trajectory has more than 1024
+                                       primitives (the device-side recoverTraj buffer): traj_len 0, no primitives */
 
 /* Control kinds = union of use_pos|use_vel|use_acc|use_jrk bits of a Waypoint
  * (mpl_test_node/src/map_planner_node.cpp:155-171 sets the bits; Control::VEL..SNP). */
@@ -217,6 +219,13 @@ int mplx_result_timing(mplx_ctx *ctx, int q, double *t_begin_s, double *t_end_s,
 int mplx_result_cycles(mplx_ctx *ctx, int q, uint64_t cyc[10]);
 /* duration (ms, HIP events on the context's stream) of the last search / expand kernel launch */
 int mplx_last_kernel_ms(const mplx_ctx *ctx, float *ms);
+/* name of the search kernel mplx_plan / mplx_plan_batch launches for the current configuration */
+const char *mplx_kernel_name(const mplx_ctx *ctx);
+/* Counter bumped by every mplx_plan / mplx_plan_batch on this context.  The result getters answer for the LAST
+ * plan of the context; host wrappers that share one context between several planner objects (the reference
+ * shares one MapUtil between two planners, map_replanner_node.cpp:415,427) remember the epoch of their own
+ * plan and refuse to answer from another planner's state space. */
+uint64_t mplx_plan_epoch(const mplx_ctx *ctx);
 const char *mplx_version(void);
 
 #ifdef __cplusplus

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPLX_LIB") or os.path.join(_HERE, "csrc", "libmplx.so")
 
 VEL, ACC, JRK, SNP = 1, 3, 7, 15
-PLAN_OK, PLAN_NO_PATH, PLAN_START_OCCUPIED, PLAN_MAX_EXPAND, PLAN_POOL_FULL = 0, 1, 2, 3, 4
+PLAN_OK, PLAN_NO_PATH, PLAN_START_OCCUPIED, PLAN_MAX_EXPAND, PLAN_POOL_FULL, PLAN_INTERNAL, PLAN_TRAJ_TOO_LONG = 0, 1, 2, 3, 4, 5, 6
 OK, ERR_HIP, ERR_ARG, ERR_CAPACITY = 0, -1, -2, -3
 
 
@@ -54,7 +54,7 @@ EXPORTS = [
     "mplx_planner_config", "mplx_set_capacity", "mplx_set_bucket_width", "mplx_set_speculation",
     "mplx_expand_batch", "mplx_heuristic_batch", "mplx_plan", "mplx_plan_batch",
     "mplx_result_traj", "mplx_set_record", "mplx_result_expanded", "mplx_result_nodes", "mplx_result_edges", "mplx_result_timing", "mplx_result_cycles",
-    "mplx_last_kernel_ms", "mplx_version",
+    "mplx_last_kernel_ms", "mplx_version", "mplx_kernel_name", "mplx_plan_epoch",
     "mplx_grid_create", "mplx_grid_destroy", "mplx_grid_last_error", "mplx_grid_allocate", "mplx_grid_info", "mplx_grid_clear",
     "mplx_grid_add_cloud", "mplx_grid_add_cloud_inflate", "mplx_grid_decay", "mplx_grid_clear_column", "mplx_grid_fill_column",
     "mplx_grid_fill_cell", "mplx_grid_get_map", "mplx_grid_get_cloud", "mplx_grid_to_map",
@@ -112,6 +112,10 @@ def load():
     L.mplx_result_cycles.argtypes = [P, C.c_int, C.POINTER(C.c_uint64)]
     L.mplx_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float)]
     L.mplx_version.restype = C.c_char_p
+    L.mplx_kernel_name.argtypes = [P]
+    L.mplx_kernel_name.restype = C.c_char_p
+    L.mplx_plan_epoch.argtypes = [P]
+    L.mplx_plan_epoch.restype = C.c_uint64
     G = C.c_void_p
     L.mplx_grid_create.argtypes = [C.c_int, D3, D3, C.c_float, C.POINTER(G)]
     L.mplx_grid_destroy.argtypes = [G]

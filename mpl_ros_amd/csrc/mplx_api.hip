@@ -54,9 +54,13 @@ struct mplx_ctx {
   SearchParams pools{};  // only pool pointers / sizes are used
   std::vector<void *> pool_allocs;
   std::vector<uint32_t> last_node_table;
-  // last batch
+  // last batch (the getters answer from this snapshot, not from the current configuration)
   int last_nq = 0;
   bool last_single = false;
+  int last_control = 0;
+  double last_dt = 0;
+  std::vector<double> last_U;
+  uint64_t plan_epoch = 0;  // bumped by every mplx_plan / mplx_plan_batch
   std::vector<QueryOut> last_out;
   QueryOut *d_out = nullptr;
   QueryIn *d_in = nullptr;
@@ -83,6 +87,24 @@ static int fail(mplx_ctx *c, int code, const char *fmt, ...) {
     hipError_t e__ = (call);                                                                    \
     if (e__ != hipSuccess) return fail((c), MPLX_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
   } while (0)
+
+// temporary device buffers of one entry point: freed on every exit path
+struct DevBufs {
+  std::vector<void *> v;
+  ~DevBufs() {
+    for (void *p : v) (void)hipFree(p);
+  }
+  template <typename T>
+  hipError_t alloc(T **p, size_t bytes) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e == hipSuccess) {
+      v.push_back(q);
+      *p = (T *)q;
+    }
+    return e;
+  }
+};
 
 extern "C" const char *mplx_version(void) { return "mplx 0.1 (gfx950)"; }
 extern "C" const char *mplx_last_error(const mplx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -370,16 +392,16 @@ extern "C" int mplx_map_query(mplx_ctx *c, int n, const double *pts, int32_t *ce
   double *dp = nullptr;
   int32_t *dc = nullptr;
   int8_t *ds = nullptr;
-  HIPCHK(c, hipMalloc((void **)&dp, sizeof(double) * 3 * n));
-  HIPCHK(c, hipMalloc((void **)&dc, sizeof(int32_t) * 3 * n));
-  HIPCHK(c, hipMalloc((void **)&ds, n));
+  DevBufs bufs;
+  HIPCHK(c, bufs.alloc(&dp, sizeof(double) * 3 * n));
+  HIPCHK(c, bufs.alloc(&dc, sizeof(int32_t) * 3 * n));
+  HIPCHK(c, bufs.alloc(&ds, n));
   HIPCHK(c, hipMemcpyAsync(dp, pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(map_query_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, map_dev(c), n, dp, dc, ds);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(cells, dc, sizeof(int32_t) * 3 * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(state, ds, n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(dp); (void)hipFree(dc); (void)hipFree(ds);
   return MPLX_OK;
 }
 
@@ -590,9 +612,10 @@ extern "C" int mplx_expand_batch(mplx_ctx *c, int K, const mplx_waypoint *nodes,
   double *dt = nullptr;
   SuccOut *dout = nullptr;
   const size_t no = (size_t)K * P.n_u;
-  HIPCHK(c, hipMalloc((void **)&dn, sizeof(State) * K));
-  HIPCHK(c, hipMalloc((void **)&dt, sizeof(double) * K));
-  HIPCHK(c, hipMalloc((void **)&dout, sizeof(SuccOut) * no));
+  DevBufs bufs;
+  HIPCHK(c, bufs.alloc(&dn, sizeof(State) * K));
+  HIPCHK(c, bufs.alloc(&dt, sizeof(double) * K));
+  HIPCHK(c, bufs.alloc(&dout, sizeof(SuccOut) * no));
   HIPCHK(c, hipMemcpyAsync(dn, hs.data(), sizeof(State) * K, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dt, ht.data(), sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
   const int grid = K < 4096 ? K : 4096;
@@ -607,7 +630,6 @@ extern "C" int mplx_expand_batch(mplx_ctx *c, int K, const mplx_waypoint *nodes,
   HIPCHK(c, hipMemcpyAsync(out, dout, sizeof(SuccOut) * no, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
-  (void)hipFree(dn); (void)hipFree(dt); (void)hipFree(dout);
   return MPLX_OK;
 }
 
@@ -635,10 +657,11 @@ extern "C" int mplx_heuristic_batch(mplx_ctx *c, int n, const mplx_waypoint *sta
   State *ds = nullptr;
   double *dt = nullptr, *dh = nullptr;
   int32_t *dg = nullptr;
-  HIPCHK(c, hipMalloc((void **)&ds, sizeof(State) * n));
-  HIPCHK(c, hipMalloc((void **)&dt, sizeof(double) * n));
-  HIPCHK(c, hipMalloc((void **)&dh, sizeof(double) * n));
-  HIPCHK(c, hipMalloc((void **)&dg, sizeof(int32_t) * n));
+  DevBufs bufs;
+  HIPCHK(c, bufs.alloc(&ds, sizeof(State) * n));
+  HIPCHK(c, bufs.alloc(&dt, sizeof(double) * n));
+  HIPCHK(c, bufs.alloc(&dh, sizeof(double) * n));
+  HIPCHK(c, bufs.alloc(&dg, sizeof(int32_t) * n));
   HIPCHK(c, hipMemcpyAsync(ds, hs.data(), sizeof(State) * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dt, ht.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(heuristic_kernel, dim3((n + 127) / 128), dim3(128), 0, c->stream, P, hp, n, ds, dt, dh, dg);
@@ -646,7 +669,6 @@ extern "C" int mplx_heuristic_batch(mplx_ctx *c, int n, const mplx_waypoint *sta
   HIPCHK(c, hipMemcpyAsync(h, dh, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(is_goal, dg, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(ds); (void)hipFree(dt); (void)hipFree(dh); (void)hipFree(dg);
   return MPLX_OK;
 }
 
@@ -728,7 +750,33 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   for (int i = 0; i < nq; i++) fill_result(c->last_out[i], out[i]);
   c->last_nq = nq;
   c->last_single = (nq == 1);
+  c->last_control = c->cfg.control;
+  c->last_dt = c->cfg.dt;
+  c->last_U = c->U;
+  c->plan_epoch++;
   return MPLX_OK;
+}
+
+extern "C" uint64_t mplx_plan_epoch(const mplx_ctx *c) { return c ? c->plan_epoch : 0; }
+
+extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
+  if (!c || !c->have_cfg) return "";
+  const int control = c->cfg.control, n_u = c->cfg.n_u;
+  const bool spec = (c->speculation < 0 || c->speculation > 1) && (control == CTRL_ACC || control == CTRL_JRK) && n_u <= 128;
+  static thread_local char buf[64];
+  const char *cn = control == CTRL_VEL ? "VEL" : control == CTRL_ACC ? "ACC" : control == CTRL_JRK ? "JRK" : "SNP";
+  if (!spec) {
+    snprintf(buf, sizeof(buf), "astar_kernel<%d,%s>", pick_block(n_u), cn);
+  } else {
+    int ul, k;
+    if (n_u <= 32 && c->speculation == 8) { ul = 64; k = 8; }
+    else if (n_u <= 32) { ul = 32; k = 16; }
+    else if (n_u <= 64) { ul = 64; k = 4; }
+    else if (c->speculation == 2) { ul = 128; k = 2; }
+    else { ul = 128; k = 4; }
+    snprintf(buf, sizeof(buf), "astar_spec_kernel<%d,%d,%s>", ul, k, cn);
+  }
+  return buf;
 }
 
 extern "C" int mplx_plan(mplx_ctx *c, const mplx_waypoint *start, const mplx_waypoint *goal, mplx_result *out) {
@@ -739,15 +787,15 @@ extern "C" int mplx_result_traj(mplx_ctx *c, int q, mplx_primitive *prs, mplx_wa
   if (!c || q < 0 || q >= c->last_nq) return fail(c, MPLX_ERR_ARG, "no such query");
   HIPCHK(c, hipSetDevice(c->device));
   const int len = c->last_out[q].traj_len;
-  if (c->last_out[q].status != MPLX_PLAN_OK || len <= 0) return MPLX_OK;
+  if (c->last_out[q].status != MPLX_PLAN_OK || len <= 0) return MPLX_OK;  // (MPLX_PLAN_TRAJ_TOO_LONG: cost only)
   std::vector<int32_t> tn(len + 1), ta(len);
   std::vector<double> ts((size_t)(len + 1) * 13);
   HIPCHK(c, hipMemcpyAsync(tn.data(), c->d_traj_nodes + (size_t)q * (MAX_TRAJ + 1), sizeof(int32_t) * (len + 1), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(ta.data(), c->d_traj_actions + (size_t)q * MAX_TRAJ, sizeof(int32_t) * len, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(ts.data(), c->d_traj_states + (size_t)q * (MAX_TRAJ + 1) * 13, sizeof(double) * (len + 1) * 13, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  // device order is goal -> start; emit start -> goal
-  const int control = c->cfg.control;
+  // device order is goal -> start; emit start -> goal.  Control kind, dt and U are the ones the plan ran with.
+  const int control = c->last_control;
   for (int i = 0; i <= len; i++) {
     const double *s = &ts[(size_t)(len - i) * 13];
     if (wps) {
@@ -768,8 +816,8 @@ extern "C" int mplx_result_traj(mplx_ctx *c, int q, mplx_primitive *prs, mplx_wa
       const double *s = &ts[(size_t)(len - i) * 13];
       mplx_primitive &p = prs[i];
       memset(&p, 0, sizeof(p));
-      for (int ax = 0; ax < 3; ax++) prim_build_axis(control, s[ax], s[3 + ax], s[6 + ax], s[9 + ax], c->U[3 * a + ax], p.c[ax]);
-      p.t = c->cfg.dt;
+      for (int ax = 0; ax < 3; ax++) prim_build_axis(control, s[ax], s[3 + ax], s[6 + ax], s[9 + ax], c->last_U[3 * a + ax], p.c[ax]);
+      p.t = c->last_dt;
       p.control = control;
     }
   }

@@ -261,11 +261,25 @@ extern "C" int mplx_grid_add_cloud_inflate(mplx_grid *g, int n, const double *pt
   if (n == 0) return MPLX_OK;
   GCHK(g, hipSetDevice(g->device));
   const size_t cells = grid_cells(g);
-  if (!g->first) {
-    GCHK(g, hipMalloc((void **)&g->first, sizeof(uint32_t) * cells));
-    GCHK(g, hipMemsetAsync(g->first, 0xFF, sizeof(uint32_t) * cells, g->stream));
-    GCHK(g, hipMalloc((void **)&g->keymin, sizeof(unsigned long long) * cells));
-    GCHK(g, hipMemsetAsync(g->keymin, 0xFF, sizeof(unsigned long long) * cells, g->stream));
+  // per-cell scratch (first point of a cell, winning neighbour offer): both arrays exist and hold their
+  // sentinels (all ones) between calls, or neither exists.  Any failure below drops both, so that the
+  // next call rebuilds them instead of running the kernels on half-initialised scratch.
+  auto drop_scratch = [&]() {
+    (void)hipFree(g->first);
+    (void)hipFree(g->keymin);
+    g->first = nullptr;
+    g->keymin = nullptr;
+  };
+  if (!g->first || !g->keymin) {
+    drop_scratch();
+    hipError_t es = hipMalloc((void **)&g->first, sizeof(uint32_t) * cells);
+    if (es == hipSuccess) es = hipMalloc((void **)&g->keymin, sizeof(unsigned long long) * cells);
+    if (es == hipSuccess) es = hipMemsetAsync(g->first, 0xFF, sizeof(uint32_t) * cells, g->stream);
+    if (es == hipSuccess) es = hipMemsetAsync(g->keymin, 0xFF, sizeof(unsigned long long) * cells, g->stream);
+    if (es != hipSuccess) {
+      drop_scratch();
+      return gfail(g, MPLX_ERR_HIP, "scratch allocation failed: %s", hipGetErrorString(es));
+    }
   }
   double *d = nullptr;
   int rc = grid_upload_pts(g, n, pts, &d);
@@ -310,7 +324,11 @@ extern "C" int mplx_grid_add_cloud_inflate(mplx_grid *g, int n, const double *pt
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
   }
   (void)hipFree(d); (void)hipFree(dns); (void)hipFree(okey); (void)hipFree(ocell); (void)hipFree(on);
-  if (e != hipSuccess) return gfail(g, MPLX_ERR_HIP, "%s", hipGetErrorString(e));
+  if (e != hipSuccess) {
+    (void)hipStreamSynchronize(g->stream);
+    drop_scratch();  // the sentinels may not have been restored by the apply kernel
+    return gfail(g, MPLX_ERR_HIP, "%s", hipGetErrorString(e));
+  }
   // the sequential loop's order: by (point index, neighbour index) of the flip
   std::vector<uint32_t> ord(n_out);
   for (uint32_t i = 0; i < n_out; i++) ord[i] = i;

@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         // oldest record.  Written goal -> start; the host reverses.
         uint32_t node = goal_id;
         tn[0] = (int32_t)node;
-        bool ok = true;
+        bool ok = true, too_long = false;
         while (V::pred(Q.node(node)) != NIL) {
           uint32_t best = NIL;
           double min_rhs = INFINITY, min_g = INFINITY;
@@ -1227,14 +1227,19 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
             double rhs = gp + P.ucost[er.action];
             if (rhs < min_rhs || (rhs == min_rhs && gp >= min_g)) { min_rhs = rhs; min_g = gp; best = e; }
           }
-          if (best == NIL || len >= MAX_TRAJ) { ok = false; break; }
+          if (best == NIL) { ok = false; break; }
+          if (len >= MAX_TRAJ) { too_long = true; break; }
           ta[len] = (int32_t)Q.edge(best)->action;
           node = Q.edge(best)->parent;
           len++;
           tn[len] = (int32_t)node;
           if (node == 0u) break;
         }
-        if (ok) {
+        if (too_long) {  // goal reached and cost known; the path does not fit the device-side buffer
+          cost = V::g(Q.node(goal_id));
+          status = 6;    // MPLX_PLAN_TRAJ_TOO_LONG
+          len = 0;
+        } else if (ok) {
           cost = V::g(Q.node(goal_id));
           for (int i = 0; i <= len; i++) {
             const double *st = V::state(Q.node((uint32_t)tn[i]));

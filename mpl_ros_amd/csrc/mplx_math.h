@@ -542,9 +542,11 @@ MPLX_HD double cal_heur(const HeurParams &hp, int control, const State &s) {
   const State &goal = hp.goal;
   double dp[3];
   for (int i = 0; i < 3; i++) dp[i] = goal.p[i] - s.p[i];
-  if (hp.heur_ignore_dynamics) return w * linf3(s.p, goal.p) / v_max;
+  // v_max <= 0 is the "unlimited" sentinel (the setters' default, -1): no arrival-time bound exists, so
+  // the kinematic term is dropped instead of dividing by a non-positive number
+  if (hp.heur_ignore_dynamics) return v_max > 0 ? w * linf3(s.p, goal.p) / v_max : w * linf3(s.p, goal.p);
   const double *v0 = s.v, *v1 = goal.v, *a0 = s.a, *a1 = goal.a;
-  double t_bar = linf3(s.p, goal.p) / v_max;
+  double t_bar = v_max > 0 ? linf3(s.p, goal.p) / v_max : 0.0;
   int gc = hp.goal_control;
   if (control == CTRL_JRK && gc == CTRL_JRK) {
     double a0ma1[3] = {a0[0] - a1[0], a0[1] - a1[1], a0[2] - a1[2]};
@@ -584,7 +586,7 @@ MPLX_HD double cal_heur(const HeurParams &hp, int control, const State &s) {
   } else if (control == CTRL_VEL && gc == CTRL_VEL) {
     return (w + 1) * sqrt(dot3(dp, dp));
   }
-  return w * sqrt(dot3(dp, dp)) / v_max;
+  return v_max > 0 ? w * sqrt(dot3(dp, dp)) / v_max : w * sqrt(dot3(dp, dp));
 }
 
 // get_heur: 0 when the state's key equals the goal's key

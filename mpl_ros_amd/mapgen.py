@@ -112,3 +112,22 @@ def random_queries(grid, origin, res, nq, rng, min_dist=10.0):
         if sum((s[i] - g[i]) ** 2 for i in range(3)) ** 0.5 >= min_dist:
             out.append((s, g))
     return out
+
+
+C4_SEED = 20250620
+
+
+def c4_queries(grid, origin, res, nq, rank=0, min_dist=10.0):
+    """BASELINE.md C4 query stream of `rank` (bench.py, tests/test_gpu_scale.py): nq pairs of free cell centres
+    at least min_dist apart, drawn from SplitMix64(C4_SEED + 7919 (rank + 1))."""
+    return random_queries(grid, origin, res, nq, SplitMix64(C4_SEED + 7919 * (rank + 1)), min_dist=min_dist)
+
+
+def c4_pools(control_is_jrk, nq, max_expand, single=False, per_q=0):
+    """Pool sizes (states, predecessor records, OPEN-log entries) bench.py and the scale tests use for a
+    C4 batch of nq queries (mean states per query; the pools are shared by the batch)."""
+    if not control_is_jrk:
+        per_q = per_q or 450_000
+        return dict(nodes=per_q * nq, edges=per_q * nq * 9 // 2, log=per_q * nq * 5 // 4)
+    per_q = per_q or max(1 << 16, max_expand * 24)
+    return dict(nodes=per_q * nq, edges=per_q * nq * 7 // 2, log=per_q * nq * 3 // 2)

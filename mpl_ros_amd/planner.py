@@ -34,6 +34,7 @@ class Waypoint3D:
         self.yaw = 0.0
         self.t = 0.0
         self.enable_t = False
+        self.use_yaw = False  # carried, never propagated: plan() refuses use_yaw states (no silent loss)
         self.control = control
 
     # use_pos .. use_jrk view the control bits, like the union in the reference's Waypoint
@@ -318,8 +319,19 @@ class VoxelMapPlanner:
         self._heur_ignore_dynamics, self._dirty = bool(ignore), True
 
     def setU(self, U):
+        U = np.asarray(U, dtype=np.float64)
+        if U.ndim == 2 and U.shape[1] == 4:
+            # Vec4f control inputs (x, y, z, yaw rate) of the use_yaw lattices, map_planner_node.cpp:119-139
+            raise MplxError("4-component control inputs (use_yaw) are not supported by this back-end: the yaw "
+                            "component would be dropped silently")
         self._U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, 3)
         self._dirty = True
+
+    def setYawmax(self, yaw_max):
+        """setYawmax (map_planner_node.cpp:180): yaw-constrained search is not implemented -- fail loudly
+        instead of planning a different (unconstrained) search.  A negative value means "no constraint"."""
+        if yaw_max >= 0:
+            raise MplxError("setYawmax(>= 0): yaw constraints are not supported by this back-end")
 
     def setTol(self, tol_pos, tol_vel=-1.0, tol_acc=-1.0):
         self._tol, self._dirty = (float(tol_pos), float(tol_vel), float(tol_acc)), True
@@ -347,12 +359,23 @@ class VoxelMapPlanner:
             raise MplxError("setMapUtil first")
         return self.map_util_.ctx
 
+    def _own_results(self):
+        """The device keeps the state space of the context's LAST plan only: refuse to answer from a plan
+        another planner object made on the shared context since (instead of returning its state space)."""
+        ctx = self._ctx()
+        if self._results is None or ctx.lib.mplx_plan_epoch(ctx.h) != getattr(self, "_epoch", -1):
+            raise MplxError("the results of this planner's last plan() are gone: another planner sharing the MapUtil planned since")
+        return ctx
+
     def _configure(self, control):
         if self._U is None:
             raise MplxError("setU first")
-        if not self._dirty and control == self._control:
-            return
         ctx = self._ctx()
+        # a MapUtil (= one device context) may be shared by several planner objects, like the reference's
+        # planner_ / replan_planner_ pair (map_replanner_node.cpp:415,427): re-send the set-up when another
+        # planner configured the context since
+        if not self._dirty and control == self._control and getattr(ctx, "cfg_owner", None) is self:
+            return
         cfg = _capi.Config()
         cfg.control = control
         cfg.n_u = self._U.shape[0]
@@ -364,6 +387,7 @@ class VoxelMapPlanner:
         cfg.max_expand = self._max_num
         cfg.heur_ignore_dynamics = int(self._heur_ignore_dynamics)
         ctx.check(ctx.lib.mplx_planner_config(ctx.h, C.byref(cfg)))
+        ctx.cfg_owner = self
         self._control = control
         self._dirty = False
 
@@ -371,12 +395,15 @@ class VoxelMapPlanner:
     def plan(self, start, goal):
         """bool PlannerBase::plan(start, goal)."""
         ctx = self._ctx()
+        if getattr(start, "use_yaw", False) or getattr(goal, "use_yaw", False):
+            raise MplxError("use_yaw waypoints are not supported by this back-end (yaw would be ignored)")
         self._configure(start.control)
         res = _capi.Result()
         s, g = start.to_c(), goal.to_c()
         ctx.check(ctx.lib.mplx_plan(ctx.h, C.byref(s), C.byref(g), C.byref(res)))
         self._result = res
         self._results = [res]
+        self._epoch = ctx.lib.mplx_plan_epoch(ctx.h)
         self.traj_cost_ = res.cost
         if res.status == _capi.PLAN_START_OCCUPIED:
             if self.planner_verbose_:
@@ -399,6 +426,7 @@ class VoxelMapPlanner:
         ctx.check(ctx.lib.mplx_plan_batch(ctx.h, n, S, G, R))
         self._results = [R[i] for i in range(n)]
         self._result = self._results[0]
+        self._epoch = ctx.lib.mplx_plan_epoch(ctx.h)
         return self._results
 
     def lastKernelMs(self):
@@ -406,6 +434,11 @@ class VoxelMapPlanner:
         ms = C.c_float()
         ctx.check(ctx.lib.mplx_last_kernel_ms(ctx.h, C.byref(ms)))
         return ms.value
+
+    def kernelName(self):
+        """Name of the search kernel mplx_plan / mplx_plan_batch launches for the current configuration."""
+        ctx = self._ctx()
+        return ctx.lib.mplx_kernel_name(ctx.h).decode()
 
     def queryTiming(self, q=0):
         """(begin_s, end_s, workgroup) of query q on the device clock, relative to the batch start."""
@@ -428,7 +461,7 @@ class VoxelMapPlanner:
         return self._results[q]
 
     def getTraj(self, q=0):
-        ctx = self._ctx()
+        ctx = self._own_results()
         res = self._results[q]
         n = res.traj_len if res.status == _capi.PLAN_OK else 0
         if n <= 0:
@@ -445,7 +478,7 @@ class VoxelMapPlanner:
         return tr
 
     def getExpandedIds(self, q=0):
-        ctx = self._ctx()
+        ctx = self._own_results()
         cap = int(self._results[q].n_expanded)
         ids = np.zeros(max(cap, 1), dtype=np.int32)
         n = C.c_uint32()
@@ -453,7 +486,7 @@ class VoxelMapPlanner:
         return ids[:n.value]
 
     def _nodes(self):
-        ctx = self._ctx()
+        ctx = self._own_results()
         n = int(self._result.n_nodes)
         coords = (_capi.Waypoint * max(n, 1))()
         g = np.zeros(n)
@@ -476,7 +509,7 @@ class VoxelMapPlanner:
     def getEdges(self):
         """Predecessor lists of the state space: (child, parent, action) int32 arrays, for every node in id
         order its edges in arrival order (StateSpace pred_coord / pred_action_id, poly_map_planner.h:70-86)."""
-        ctx = self._ctx()
+        ctx = self._own_results()
         n = int(self._result.n_edges)
         child = np.zeros(max(n, 1), dtype=np.int32); parent = np.zeros(max(n, 1), dtype=np.int32); action = np.zeros(max(n, 1), dtype=np.int32)
         m = C.c_uint64(0)

@@ -41,7 +41,7 @@ static double p1_a(const double *c, double t) { return c[0] / 6 * pw(t, 3) + c[1
 static double p1_j(const double *c, double t) { return c[0] / 2 * t * t + c[1] * t + c[2]; }
 
 /* ------------------------------------------------------------------ polynomial root finding
- * [DEVIATION] upstream math.h uses Cardano / Ferrari closed forms (acos, cos, cbrt) for degree 3-4
+ * [DEVIATION D1] upstream math.h uses Cardano / Ferrari closed forms (acos, cos, cbrt) for degree 3-4
  * and Eigen companion-matrix eigenvalues for degree 5-6.  Neither is bit-reproducible between a
  * host libm and device code, so degree >= 3 uses a deterministic derivative-chain isolation with
  * a safeguarded Newton/bisection iteration built from + - * / only.  Degree <= 2 keeps the
@@ -276,7 +276,7 @@ int orc_validate_primitive(const orc_primitive *pr, double mv, double ma, double
 }
 
 /* J(control) = integral over [0,t] of the squared k-th derivative, summed over axes (a9).
- * [DEVIATION] upstream expands the integral into a fixed closed form; here it is the double sum
+ * [DEVIATION D2] upstream expands the integral into a fixed closed form; here it is the double sum
  * sum_i sum_j q_i q_j t^(i+j+1)/(i+j+1) over the monomial coefficients q of the derivative, in
  * ascending (i,j) order.  Same value analytically (ACC control: u^2 t). */
 double orc_primitive_J(const orc_primitive *pr, int control) {
@@ -299,7 +299,7 @@ double orc_primitive_J(const orc_primitive *pr, int control) {
 
 /* ------------------------------------------------------------------ Waypoint key (a2) */
 /* [UNVERIFIED waypoint.h hash_value] per axis: pos/0.01, vel/0.1, acc/0.1, jrk/0.1 for the
- * enabled fields, then t/0.1 when enable_t.  [DEVIATION] nodes are identified by this integer
+ * enabled fields, then t/0.1 when enable_t.  [DEVIATION D3] nodes are identified by this integer
  * tuple itself, not by boost::hash_combine of it (upstream operator== compares hash values; the
  * tuple is the semantic intent and is free of hash collisions). */
 int orc_waypoint_key(const orc_waypoint *w, int32_t *key) {
@@ -337,9 +337,14 @@ typedef struct {
   int32_t pred_tail;
 } orc_node;
 
+typedef struct { /* successor emitted with +inf cost: hm_ entry + pred entry upstream, never relaxed */
+  int32_t parent, action;
+} orc_blocked;
+
 struct orc_planner {
   /* map (a7) */
   int8_t *map;
+  int map_owned; /* 0: adopted with orc_set_map_shared (read-only, not freed) */
   int32_t dim[3];
   double origin[3], res;
   /* config */
@@ -360,6 +365,8 @@ struct orc_planner {
   int32_t *expanded;
   int n_expanded, cap_expanded;
   int n_closed;
+  orc_blocked *blocked; /* in arrival order */
+  int n_blocked, cap_blocked;
   int32_t *traj_nodes;
   int32_t *traj_actions;
   int traj_len;
@@ -383,26 +390,41 @@ orc_planner *orc_create(void) {
 }
 static void free_search(orc_planner *p) {
   free(p->nodes); free(p->edges); free(p->table); free(p->heap); free(p->expanded);
-  free(p->traj_nodes); free(p->traj_actions);
+  free(p->traj_nodes); free(p->traj_actions); free(p->blocked);
   p->nodes = NULL; p->edges = NULL; p->table = NULL; p->heap = NULL; p->expanded = NULL;
-  p->traj_nodes = NULL; p->traj_actions = NULL;
+  p->traj_nodes = NULL; p->traj_actions = NULL; p->blocked = NULL;
+  p->n_blocked = p->cap_blocked = 0;
   p->n_nodes = p->cap_nodes = p->n_edges = p->cap_edges = p->cap_table = 0;
   p->n_heap = p->cap_heap = p->n_expanded = p->cap_expanded = p->n_closed = p->traj_len = 0;
 }
 void orc_destroy(orc_planner *p) {
   if (!p) return;
   free_search(p);
-  free(p->map);
+  if (p->map_owned) free(p->map);
   free(p->U);
   free(p);
 }
 
 /* ------------------------------------------------------------------ MapUtil (a7) */
 void orc_set_map(orc_planner *p, const int8_t *data, const int32_t dim[3], const double origin[3], double res) {
-  free(p->map);
+  if (p->map_owned) free(p->map);
   size_t n = (size_t)dim[0] * dim[1] * dim[2];
   p->map = (int8_t *)malloc(n);
+  p->map_owned = 1;
   memcpy(p->map, data, n);
+  for (int i = 0; i < 3; i++) {
+    p->dim[i] = dim[i];
+    p->origin[i] = origin[i];
+  }
+  p->res = res;
+}
+/* Adopt the caller's grid without copying it (many planner objects, one per thread, on one read-only
+ * map: the CPU baseline of bench.py).  The caller keeps it alive; free_unknown / dilate must not be
+ * called on such a planner (they would write into the shared grid). */
+void orc_set_map_shared(orc_planner *p, const int8_t *data, const int32_t dim[3], const double origin[3], double res) {
+  if (p->map_owned) free(p->map);
+  p->map = (int8_t *)data;
+  p->map_owned = 0;
   for (int i = 0; i < 3; i++) {
     p->dim[i] = dim[i];
     p->origin[i] = origin[i];
@@ -519,7 +541,7 @@ int orc_is_free_point(const orc_planner *p, const double pt[3]) {
 /* [UNVERIFIED env_map::is_free(pr); density rule IN-TREE ellipsoid_util.h:67-70]
  * max_v over axes; n = ceil(max_v * t / res); sample(n) = evaluate(i * (t/n)), i=0..n;
  * blocked if a sample is outside or occupied (>0).
- * [DEVIATION] n == 0 (stationary primitive) would give dt = t/0 = inf and evaluate(0*inf = NaN)
+ * [DEVIATION D4] n == 0 (stationary primitive) would give dt = t/0 = inf and evaluate(0*inf = NaN)
  * upstream; here it checks the single sample t = 0. */
 int orc_is_free_primitive(orc_planner *p, const orc_primitive *pr) {
   double max_v = 0;
@@ -608,9 +630,12 @@ static double cal_heur(const orc_planner *p, const orc_waypoint *s, const orc_wa
   const double w = p->cfg.w, v_max = p->cfg.v_max;
   double dp[3];
   for (int i = 0; i < 3; i++) dp[i] = goal->pos[i] - s->pos[i];
-  if (p->cfg.heur_ignore_dynamics) return w * linf3(s->pos, goal->pos) / v_max;
+  /* [DEVIATION D8 / UNVERIFIED env_base::cal_heur] v_max <= 0 means "unlimited" (the default, -1): the bound on the
+   * arrival time |dp|_inf / v_max does not exist then -- the kinematic term is dropped (upstream guards
+   * the division with `v_max_ > 0`), never divided by a non-positive number. */
+  if (p->cfg.heur_ignore_dynamics) return v_max > 0 ? w * linf3(s->pos, goal->pos) / v_max : w * linf3(s->pos, goal->pos);
   const double *v0 = s->vel, *v1 = goal->vel, *a0 = s->acc, *a1 = goal->acc;
-  double t_bar = linf3(s->pos, goal->pos) / v_max;
+  double t_bar = v_max > 0 ? linf3(s->pos, goal->pos) / v_max : 0.0;
   if (s->control == ORC_JRK && goal->control == ORC_JRK) {
     double a0ma1[3] = {a0[0] - a1[0], a0[1] - a1[1], a0[2] - a1[2]};
     double v0pv1[3] = {v0[0] + v1[0], v0[1] + v1[1], v0[2] + v1[2]};
@@ -649,7 +674,7 @@ static double cal_heur(const orc_planner *p, const orc_waypoint *s, const orc_wa
   } else if (s->control == ORC_VEL && goal->control == ORC_VEL) {
     return (w + 1) * sqrt(dot3(dp, dp));
   }
-  return w * sqrt(dot3(dp, dp)) / v_max;
+  return v_max > 0 ? w * sqrt(dot3(dp, dp)) / v_max : w * sqrt(dot3(dp, dp));
 }
 /* [UNVERIFIED env_base::get_heur] 0 when the state hashes equal to the goal */
 double orc_heuristic(const orc_planner *p, const orc_waypoint *s) {
@@ -764,7 +789,7 @@ static void edge_append(orc_planner *p, int child, int parent, int action, doubl
 /* ------------------------------------------------------------------ OPEN: indexed binary min-heap
  * [UNVERIFIED graph_search.h] upstream: boost d_ary_heap<arity 2, mutable> of (fval, node) with
  * compare_pair = { f equal ? min(g,rhs) larger loses : f larger loses }.
- * [DEVIATION] remaining ties are unspecified upstream (heap-internal); the total order here is
+ * [DEVIATION D5] remaining ties are unspecified upstream (heap-internal); the total order here is
  * (f, g, node id) ascending, node id = creation order.  Any exact min-priority structure yields
  * the same pop sequence under a strict total order. */
 static int heap_less(const orc_planner *p, int a, int b) {
@@ -911,7 +936,21 @@ int orc_plan(orc_planner *p, const orc_waypoint *start, const orc_waypoint *goal
     orc_waypoint cw = p->nodes[curr].coord; /* copy: node array may move */
     int ns = orc_get_succ(p, &cw, succ, succ_cost, succ_act);
     for (int s = 0; s < ns; s++) {
-      if (isinf(succ_cost[s])) continue;
+      if (isinf(succ_cost[s])) {
+        /* [UNVERIFIED graph_search.h] upstream creates the hm_ entry of a blocked successor too (with its
+         * heuristic) and pushes a pred entry with cost inf; the relaxation is a no-op (g + inf < g' is
+         * never true).  [DEVIATION D7] such successors are kept in a side list (parent, action) instead of
+         * the node array, so node ids stay "order of first finite arrival"; hm_.size(), getLinkedNodes and
+         * getAllPrimitives are rebuilt from the two (orc_num_states_all, orc_get_blocked_edges). */
+        if (p->n_blocked == p->cap_blocked) {
+          p->cap_blocked = p->cap_blocked ? p->cap_blocked * 2 : 1 << 14;
+          p->blocked = (orc_blocked *)realloc(p->blocked, sizeof(orc_blocked) * (size_t)p->cap_blocked);
+        }
+        p->blocked[p->n_blocked].parent = curr;
+        p->blocked[p->n_blocked].action = succ_act[s];
+        p->n_blocked++;
+        continue;
+      }
       nkey = orc_waypoint_key(&succ[s], key);
       int id = table_find(p, key, nkey);
       if (id < 0) {
@@ -927,7 +966,11 @@ int orc_plan(orc_planner *p, const orc_waypoint *start, const orc_waypoint *goal
           heap_up(p, nd->heap_pos);
           p->cnt.n_heap_decrease++;
         } else if (nd->opened && nd->closed) {
-          nd->closed = 0; /* re-open (upstream prints "ASTAR ERROR!") */
+          /* [DEVIATION D6 / UNVERIFIED] a closed node improved (possible only with an inconsistent
+           * heuristic, i.e. eps > 1): re-opened here, the textbook weighted-A* behaviour.  Upstream's
+           * branch for this case prints "ASTAR ERROR!"; whether it also re-pushes the node could not be
+           * checked (source absent).  n_reopen counts the events; it is 0 in every BASELINE config (eps = 1). */
+          nd->closed = 0;
           p->n_closed--;
           heap_push(p, id);
           p->cnt.n_reopen++;
@@ -964,6 +1007,12 @@ void orc_get_expanded(const orc_planner *p, int32_t *ids, double *pos) {
       for (int k = 0; k < 3; k++) pos[3 * i + k] = p->nodes[p->expanded[i]].coord.pos[k];
   }
 }
+/* order-dependent fold of the expansion sequence (same fold as the product's mplx_result.expand_hash) */
+uint64_t orc_expand_hash(const orc_planner *p) {
+  uint64_t h = 0;
+  for (int i = 0; i < p->n_expanded; i++) h = h * 0x100000001B3ULL + (uint64_t)((uint32_t)p->expanded[i] + 1u);
+  return h;
+}
 int orc_num_nodes(const orc_planner *p) { return p->n_nodes; }
 void orc_get_node(const orc_planner *p, int id, orc_waypoint *coord, double *g, double *h, int32_t *closed) {
   if (coord) *coord = p->nodes[id].coord;
@@ -984,6 +1033,36 @@ int orc_get_edges(const orc_planner *p, int32_t *child, int32_t *parent, int32_t
       w++;
     }
   return w;
+}
+/* pred entries with cost inf, in arrival order (expansion order of the parent, then action index) */
+int orc_num_blocked(const orc_planner *p) { return p->n_blocked; }
+void orc_get_blocked_edges(const orc_planner *p, int32_t *parent, int32_t *action) {
+  for (int i = 0; i < p->n_blocked; i++) {
+    if (parent) parent[i] = p->blocked[i].parent;
+    if (action) action[i] = p->blocked[i].action;
+  }
+}
+/* hm_.size() of upstream: states reached with finite cost + states only ever reached by blocked primitives */
+static int cmp_key13(const void *a, const void *b) { return memcmp(a, b, sizeof(int32_t) * 14); }
+int orc_num_states_all(const orc_planner *p) {
+  int32_t *keys = (int32_t *)calloc((size_t)(p->n_blocked > 0 ? p->n_blocked : 1), sizeof(int32_t) * 14);
+  int m = 0;
+  for (int i = 0; i < p->n_blocked; i++) {
+    orc_primitive pr;
+    orc_waypoint tn;
+    orc_primitive_build(&p->nodes[p->blocked[i].parent].coord, p->U + 3 * p->blocked[i].action, p->cfg.dt, &pr);
+    orc_primitive_evaluate(&pr, p->cfg.dt, &tn);
+    tn.enable_t = 0;
+    int32_t *k = keys + 14 * (size_t)m;
+    k[0] = orc_waypoint_key(&tn, k + 1);
+    if (table_find(p, k + 1, k[0]) < 0) m++; else memset(k, 0, sizeof(int32_t) * 14);
+  }
+  qsort(keys, (size_t)m, sizeof(int32_t) * 14, cmp_key13);
+  int distinct = 0;
+  for (int i = 0; i < m; i++)
+    if (i == 0 || memcmp(keys + 14 * (size_t)i, keys + 14 * (size_t)(i - 1), sizeof(int32_t) * 14) != 0) distinct++;
+  free(keys);
+  return p->n_nodes + distinct;
 }
 int orc_traj_len(const orc_planner *p) { return p->traj_len; }
 /* primitives are rebuilt from the stored parent coord + action, like upstream forward_action */

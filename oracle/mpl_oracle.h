@@ -31,6 +31,32 @@
  * against stand-ins for those three headers (oracle/ref_stubs/ + include/mpl_shim typedefs) into
  * oracle/_ref/libvoxelgrid_ref.so, and tests/test_voxel_grid.py checks the restatement -- and, on the GPU,
  * the HIP grid -- against that binary bit for bit.  For this component parity is pinned by the reference.
+ *
+ * DEVIATIONS FROM THE RECOLLECTED UPSTREAM -- the complete list, so that it can be diffed against
+ * motion_primitive_library the day its source is available.  Each is tagged [DEVIATION Dn] (or plain
+ * [DEVIATION]) at the line it applies to in mpl_oracle.c; the HIP product mirrors every one of them.
+ *   D1  polynomial roots (heuristic): upstream Cardano/Ferrari (acos, cos, cbrt) for degree 3-4 and Eigen
+ *       companion-matrix eigenvalues for 5-6; here derivative-chain isolation + safeguarded Newton/bisection
+ *       from + - * / sqrt only (bit-reproducible on host and device).  Same real roots to ~1e-15 relative.
+ *   D2  Primitive::J: upstream expands the integral into a fixed closed form; here the double sum over the
+ *       derivative's monomial coefficients in ascending (i, j) order.  Equal up to f64 rounding.
+ *   D3  node identity: the quantised integer key tuple itself, not boost::hash_combine of it (upstream
+ *       operator== compares hash values, so two states whose 64-bit hashes collide would merge upstream).
+ *   D4  is_free(pr) with n == 0 samples (stationary primitive): upstream would evaluate dt = t/0; here the
+ *       single sample t = 0 is tested.
+ *   D5  OPEN tie-breaking: upstream's d_ary_heap compares (f, then g); remaining ties are heap-internal and
+ *       unspecified.  Here the strict total order (f, g, node id), id = order of first finite arrival.
+ *   D6  closed node improved (inconsistent heuristic, eps > 1 only): re-opened.  Upstream prints
+ *       "ASTAR ERROR!"; whether it re-pushes is UNVERIFIED.  Never happens at eps = 1 (n_reopen = 0 in all
+ *       BASELINE configs).
+ *   D7  successors with cost +inf (blocked primitives): upstream gives them an hm_ entry and an inf-cost pred
+ *       entry; here they live in a side list (parent, action) and orc_num_states_all / orc_get_blocked_edges
+ *       rebuild hm_.size() / the inf-cost pred entries on request.  Expansion order, g values, trajectory and
+ *       cost are unaffected (an inf-cost edge never relaxes anything); node ids are "order of first finite
+ *       arrival".
+ *   D8  env_base::cal_heur with v_max <= 0 ("unlimited"): the |dp|_inf / v_max arrival-time bound is dropped
+ *       (t_bar = 0; heur_ignore_dynamics returns w |dp|_inf) instead of dividing by a non-positive number.
+ *       Believed to equal upstream's `v_max_ > 0` guard; UNVERIFIED.
  */
 #ifndef MPL_ORACLE_H
 #define MPL_ORACLE_H
@@ -101,6 +127,8 @@ orc_planner *orc_create(void);
 void orc_destroy(orc_planner *);
 /* copy-in map; values: free 0, occupied >0, unknown -1 */
 void orc_set_map(orc_planner *, const int8_t *data, const int32_t dim[3], const double origin[3], double res);
+/* adopt the caller's read-only grid without a copy (one map shared by many planner objects / threads) */
+void orc_set_map_shared(orc_planner *, const int8_t *data, const int32_t dim[3], const double origin[3], double res);
 void orc_free_unknown(orc_planner *);
 /* MapUtil helpers next to the search */
 void orc_map_dilate(orc_planner *, int n_offsets, const int32_t *offsets);
@@ -125,11 +153,17 @@ double orc_traj_cost(const orc_planner *);
 /* results of the last plan(): sizes then copy-out */
 int orc_num_expanded(const orc_planner *);                 /* expansion sequence length */
 void orc_get_expanded(const orc_planner *, int32_t *node_ids, double *pos /* n x 3 */);
+uint64_t orc_expand_hash(const orc_planner *);               /* fold of the expansion sequence (node ids) */
 int orc_num_nodes(const orc_planner *);
 void orc_get_node(const orc_planner *, int id, orc_waypoint *coord, double *g, double *h, int32_t *closed);
 int orc_num_closed(const orc_planner *);
 /* predecessor lists: for every node in id order its edges in arrival order; returns the number of edges */
 int orc_get_edges(const orc_planner *, int32_t *child, int32_t *parent, int32_t *action, int cap);
+/* successors emitted with +inf cost (deviation D7): count, (parent id, action) in arrival order, and the
+ * size upstream's hm_ would have (finite states + states only reached by blocked primitives) */
+int orc_num_blocked(const orc_planner *);
+void orc_get_blocked_edges(const orc_planner *, int32_t *parent, int32_t *action);
+int orc_num_states_all(const orc_planner *);
 int orc_traj_len(const orc_planner *);                      /* number of primitives */
 void orc_get_traj(const orc_planner *, orc_primitive *prs, orc_waypoint *wps /* len+1 */, int32_t *actions, int32_t *node_ids /* len+1 */);
 void orc_get_counters(const orc_planner *, orc_counters *);

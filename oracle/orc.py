@@ -52,18 +52,39 @@ def build(force=False):
 
 
 _lib = None
+_lib_path = _LIB_PATH
+
+
+def use_native():
+    """CPU-baseline timing only: build the oracle for THIS host's CPU (oracle/Makefile `native`:
+    -O3 -march=native, still -ffp-contract=off, so results stay bit-identical) and load that variant.
+    Must be called before the first lib() use; returns False (portable build kept) when that is too late
+    or gcc is missing."""
+    global _lib_path
+    if _lib is not None:
+        return _lib_path != _LIB_PATH
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cand = os.path.join(_HERE, "_native", "liborc_native.so")
+        if os.path.exists(cand):
+            _lib_path = cand
+            return True
+    except Exception:
+        pass
+    return False
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        if not os.path.exists(_lib_path):
             build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(_lib_path)
         P = C.c_void_p
         L.orc_create.restype = P
         L.orc_destroy.argtypes = [P]
         L.orc_set_map.argtypes = [P, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_double]
+        L.orc_set_map_shared.argtypes = [P, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.c_double]
         L.orc_free_unknown.argtypes = [P]
         L.orc_map_dilate.argtypes = [P, C.c_int, C.c_void_p]
         L.orc_map_get.argtypes = [P, C.c_void_p]
@@ -86,8 +107,11 @@ def lib():
         L.orc_plan.argtypes = [P, C.POINTER(Waypoint), C.POINTER(Waypoint)]
         L.orc_traj_cost.argtypes = [P]
         L.orc_traj_cost.restype = C.c_double
-        for f in ("orc_num_expanded", "orc_num_nodes", "orc_num_closed", "orc_traj_len"):
+        for f in ("orc_num_expanded", "orc_num_nodes", "orc_num_closed", "orc_traj_len", "orc_num_blocked", "orc_num_states_all"):
             getattr(L, f).argtypes = [P]
+        L.orc_get_blocked_edges.argtypes = [P, C.c_void_p, C.c_void_p]
+        L.orc_expand_hash.argtypes = [P]
+        L.orc_expand_hash.restype = C.c_uint64
         L.orc_get_expanded.argtypes = [P, C.c_void_p, C.c_void_p]
         L.orc_get_edges.argtypes = [P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_get_edges.restype = C.c_int
@@ -158,7 +182,18 @@ class Planner:
         self._shape = g.shape
         self.L.orc_set_map(self.h, g.ctypes.data, dim, ori, float(res))
 
+    def set_map_shared(self, grid, origin, res):
+        """Adopt `grid` (C-contiguous int8, shape (dz, dy, dx)) without copying: one read-only map for many
+        planner objects.  The planner keeps a reference to the array."""
+        assert grid.dtype == np.int8 and grid.flags["C_CONTIGUOUS"]
+        self._shared = grid
+        dim = (C.c_int32 * 3)(grid.shape[2], grid.shape[1], grid.shape[0])
+        ori = (C.c_double * 3)(*[float(o) for o in origin])
+        self._shape = grid.shape
+        self.L.orc_set_map_shared(self.h, grid.ctypes.data, dim, ori, float(res))
+
     def free_unknown(self):
+        assert not hasattr(self, "_shared"), "free_unknown would write into a shared map"
         self.L.orc_free_unknown(self.h)
 
     def dilate(self, offsets):
@@ -247,6 +282,9 @@ class Planner:
     def num_nodes(self):
         return self.L.orc_num_nodes(self.h)
 
+    def expand_hash(self):
+        return int(self.L.orc_expand_hash(self.h))
+
     def num_closed(self):
         return self.L.orc_num_closed(self.h)
 
@@ -256,6 +294,17 @@ class Planner:
         c = np.zeros(max(n, 1), dtype=np.int32); p = np.zeros(max(n, 1), dtype=np.int32); a = np.zeros(max(n, 1), dtype=np.int32)
         self.L.orc_get_edges(self.h, c.ctypes.data, p.ctypes.data, a.ctypes.data, n)
         return c[:n], p[:n], a[:n]
+
+    def blocked_edges(self):
+        """(parent id, action) of every successor emitted with +inf cost, in arrival order"""
+        n = self.L.orc_num_blocked(self.h)
+        p = np.zeros(max(n, 1), dtype=np.int32); a = np.zeros(max(n, 1), dtype=np.int32)
+        self.L.orc_get_blocked_edges(self.h, p.ctypes.data, a.ctypes.data)
+        return p[:n], a[:n]
+
+    def num_states_all(self):
+        """hm_.size() as upstream counts it: finite states + states only reached by blocked primitives"""
+        return self.L.orc_num_states_all(self.h)
 
     def node(self, i):
         w = Waypoint()

@@ -55,3 +55,17 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".inl")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no CPU fallback", ""), f
+
+
+def test_yaw_requests_fail_loudly():
+    """use_yaw / setYawmax / Vec4f control inputs are not implemented: they must raise, never plan a different search."""
+    import numpy as np
+    import pytest
+    from mpl_ros_amd._capi import MplxError
+    from mpl_ros_amd.planner import VoxelMapPlanner
+    pl = VoxelMapPlanner(False)
+    with pytest.raises(MplxError):
+        pl.setU(np.zeros((9, 4)))
+    with pytest.raises(MplxError):
+        pl.setYawmax(0.5)
+    pl.setYawmax(-1.0)  # "unconstrained" is what the back-end does

@@ -340,3 +340,51 @@ def test_one_context_many_configurations():
         pl.setCapacity(1, cap, cap * 4, cap * 2)
         start = ((1.05, 1.05, 1.05), (0, 0, 0), (0, 0, 0)) if control == orc.JRK else ((1.05, 1.05, 1.05), (0, 0, 0))
         util.compare_plan(P, pl, start, ((4.55, 4.05, 3.55),), control)
+
+
+@SPEC
+@pytest.mark.parametrize("hid", [False, True])
+def test_unlimited_velocity_heuristic(spec, hid):
+    """v_max = -1 (the setters' default = unlimited): the heuristic drops the arrival-time bound instead of
+    dividing by it; plans and the whole state space still match the oracle."""
+    grid, origin, res = util.small_map(48, seed=17, occupancy=0.06)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    mapgen.carve_bubble(grid, (3.55, 3.05, 2.55), origin, res, 3)
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = dict(v_max=-1.0, a_max=-1.0, max_expand=3000, heur_ignore_dynamics=hid)
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, spec=spec, **kw)
+    r, c = util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0)), ((3.55, 3.05, 2.55),), orc.ACC)
+    assert r.status == 0
+    h, _ = pl.heuristicBatch([util.gpu_wp((0.55, 0.55, 0.55)), util.gpu_wp((3.05, 3.05, 2.55))], util.gpu_wp((3.55, 3.05, 2.55)))
+    assert h[0] > h[1] > 0
+
+
+def test_two_planners_on_one_map_util_do_not_read_each_others_results():
+    """The reference shares one MapUtil between planner_ and replan_planner_ (map_replanner_node.cpp:415,427).
+    The device context keeps the LAST plan's state space: a planner whose results were overwritten refuses to
+    answer (instead of returning the other planner's state space), and re-sends its own set-up when it plans."""
+    from mpl_ros_amd._capi import MplxError
+    from mpl_ros_amd.planner import VoxelMapPlanner
+    grid, origin, res = util.small_map(48, seed=19, occupancy=0.06)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    U = mapgen.control_lattice(1.0, 1, True)
+    mu, a = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, max_expand=500)
+    b = VoxelMapPlanner(False)
+    b.setMapUtil(mu)
+    b.setVmax(1.0); b.setAmax(1.0); b.setDt(0.5); b.setU(U[:9]); b.setTol(0.5); b.setMaxNum(200)
+    b.setCapacity(1, 1 << 20, 1 << 22, 1 << 21)
+    s, g = util.gpu_wp((1.05, 1.05, 1.05)), util.gpu_wp((3.55, 3.05, 2.55))
+    a.plan(s, g)
+    ra = a.getResult().n_expanded
+    ta = a.getTraj()
+    b.plan(s, g)
+    with pytest.raises(MplxError):
+        a.getTraj()
+    with pytest.raises(MplxError):
+        a.getCloseSet()
+    assert len(b.getCloseSet()) == b.getResult().n_closed
+    a.plan(s, g)  # a's own set-up is sent again (b configured the shared context in between)
+    assert a.getResult().n_expanded == ra
+    tb = a.getTraj()
+    assert np.array_equal(ta.actions, tb.actions) and tb.segs[0].t() == 1.0 if tb.segs else True

@@ -1,0 +1,122 @@
+"""-m gpu: parity at the BASELINE.json configuration sizes, through the C-ABI.
+
+  C2  256^3 random-box map, the 8(d) query, 27-primitive ACC lattice, run to the goal: the whole plan is
+      compared (expansion order hash, states, predecessor lists, counters, path actions / node ids / waypoint
+      states, cost) -- util.compare_plan.
+  C3  512^3 map, 125-primitive JRK lattice, both sides capped at the SAME number of expansions: same fields.
+  C4  the bench's own 1024-query batch on the 512^3 map (ACC cap 2 000 000, JRK cap 20 000): a sample of
+      >= 32 queries that always contains the longest one is replayed on the CPU oracle (threads, one
+      read-only map) and compared on status, expansions, order hash, states, edges, voxel reads, cost and
+      the path's actions / node ids.
+Everything is bit-exact (integers and f64 alike)."""
+import threading
+
+import numpy as np
+import pytest
+
+from mpl_ros_amd import mapgen
+from oracle import orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def map512():
+    grid, origin, res, start, goal, _ = mapgen.benchmark_map(512)
+    return grid, origin, res, start, goal
+
+
+def test_c2_full_query_acc_256():
+    grid, origin, res, start, goal, _ = mapgen.benchmark_map(256)
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5)
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=1 << 22, max_edges=1 << 24, max_log=1 << 23, **kw)
+    r, c = util.compare_plan(P, pl, (start, (0, 0, 0)), (goal,), orc.ACC)
+    assert r.status == 0 and r.n_expanded > 10000
+    print(f"C2: expanded {r.n_expanded} states {r.n_nodes} edges {r.n_edges} cost {r.cost} kernel {pl.lastKernelMs():.1f} ms")
+
+
+@pytest.mark.parametrize("cap", [250_000])
+def test_c3_single_query_jrk_512_equal_cap(map512, cap):
+    grid, origin, res, start, goal = map512
+    U = mapgen.control_lattice(1.0, 2, True)
+    assert U.shape[0] == 125
+    kw = dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=cap)
+    P = util.make_oracle(grid, origin, res, orc.JRK, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=1 << 23, max_edges=1 << 25, max_log=1 << 24, **kw)
+    r, c = util.compare_plan(P, pl, (start, (0, 0, 0), (0, 0, 0)), (goal,), orc.JRK)
+    assert r.n_expanded == cap and r.status == 3
+    print(f"C3: expanded {r.n_expanded} states {r.n_nodes} edges {r.n_edges} voxel reads {r.voxel_reads} kernel {pl.lastKernelMs():.1f} ms")
+
+
+def _cpu_replay(grid, origin, res, control, U, kw, queries, idx, threads=16):
+    """Plan queries[i] for i in idx on the oracle; returns {i: dict of results}.  One shared read-only map."""
+    out, lock, todo = {}, threading.Lock(), list(idx)
+
+    def work():
+        P = orc.Planner()
+        P.set_map_shared(grid, origin, res)
+        P.set_config(control, U, **kw)
+        while True:
+            with lock:
+                if not todo:
+                    return
+                i = todo.pop(0)
+            s, g = queries[i]
+            P.reset_counters()
+            st = P.plan(orc.waypoint(s, control=control), orc.waypoint(g, control=control))
+            ids, _ = P.expanded()
+            c = P.counters()
+            tr = P.traj() if st == orc.OK else None
+            co, po, ao = P.edges()
+            with lock:
+                out[i] = dict(status=st, n_expanded=len(ids), hash=util.expand_hash(ids), n_nodes=P.num_nodes(), n_edges=len(co),
+                              reads=c["n_voxel_reads"], n_succ=c["n_succ"], n_fin=c["n_succ_finite"], cost=P.traj_cost,
+                              actions=None if tr is None else tr["actions"], node_ids=None if tr is None else tr["node_ids"])
+
+    ths = [threading.Thread(target=work) for _ in range(min(threads, len(todo)))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    return out
+
+
+@pytest.mark.parametrize("lattice", ["acc", "jrk"])
+def test_c4_batch_sample_matches_the_oracle(map512, lattice):
+    grid, origin, res, _, _ = map512
+    grid = np.ascontiguousarray(grid)
+    nq = 1024
+    jrk = lattice == "jrk"
+    control = orc.JRK if jrk else orc.ACC
+    U = mapgen.control_lattice(1.0, 2 if jrk else 1, True)
+    cap = 20000 if jrk else 2_000_000
+    kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5, max_expand=cap)
+    if jrk:
+        kw["j_max"] = 1.0
+    queries = mapgen.c4_queries(grid, origin, res, nq, rank=0)
+    pools = mapgen.c4_pools(jrk, nq, cap)
+    mu, pl = util.make_gpu(grid, origin, res, U, n_slots=768 if jrk else 1024, max_nodes=pools["nodes"], max_edges=pools["edges"],
+                           max_log=pools["log"], **kw)
+    R = pl.planBatch([util.gpu_wp(s, control=control) for s, g in queries], [util.gpu_wp(g, control=control) for s, g in queries])
+    assert all(r.status in (0, 1, 3) for r in R), np.bincount([r.status for r in R])
+    ne = np.array([r.n_expanded for r in R])
+    longest = int(np.argmax(ne))
+    sample = sorted(set([longest] + list(range(31)) + [int(np.argsort(ne)[len(ne) // 2])]))
+    cpu = _cpu_replay(grid, origin, res, control, U, kw, queries, sample)
+    for i in sample:
+        r, c = R[i], cpu[i]
+        assert r.status == c["status"], (i, r.status, c["status"])
+        assert r.n_expanded == c["n_expanded"] and r.expand_hash == c["hash"], i
+        assert r.n_nodes == c["n_nodes"] and r.n_edges == c["n_edges"], i
+        assert r.voxel_reads == c["reads"] and r.n_succ == c["n_succ"] and r.n_succ_finite == c["n_fin"], i
+        if c["status"] == orc.OK:
+            assert r.cost == c["cost"], i  # bit-exact f64
+            tg = pl.getTraj(i)
+            assert np.array_equal(tg.actions, c["actions"]) and np.array_equal(tg.node_ids, c["node_ids"]), i
+        else:
+            assert np.isinf(r.cost)
+    print(f"C4-{lattice}: {len(sample)} of {nq} queries replayed on the CPU (longest: query {longest}, {ne[longest]} expansions); "
+          f"batch {ne.sum()} expansions in {pl.lastKernelMs():.0f} ms")

@@ -39,29 +39,33 @@ def _worker(rank, world, port, q):
     mdist.broadcast_map(dist, map_t, meta, src=0)
     grid = map_t.numpy().reshape(n, n, n)
     origin, res = tuple(meta[3:6].tolist()), float(meta[6])
-    queries = mapgen.random_queries(grid, origin, res, 10, mapgen.SplitMix64(99), min_dist=2.0)
+    queries = mapgen.random_queries(grid, origin, res, 11, mapgen.SplitMix64(99), min_dist=2.0)
     P = orc.Planner()
     P.set_map(grid, origin, res)
     P.set_config(orc.ACC, mapgen.control_lattice(), v_max=2.0, a_max=1.0)
-    mine = mdist.shard_round_robin(len(queries), rank, world)
-    rows = []
-    for qi in mine:
-        s, g = queries[qi]
-        st = P.plan(orc.waypoint(s), orc.waypoint(g))
-        rows.append([qi, st, P.num_closed(), int(round(P.traj_cost * 1000)) if st == 0 else -1])
-    while len(rows) < (len(queries) + world - 1) // world:
-        rows.append([-1, -1, -1, -1])
-    allrows = mdist.gather_int64(dist, torch, rows)
+
+    def plan_fn(indices):  # the per-rank search: the CPU oracle here, the HIP planner in bench.py
+        rows = []
+        for qi in indices:
+            s, g = queries[qi]
+            st = P.plan(orc.waypoint(s), orc.waypoint(g))
+            ids, _ = P.expanded()
+            h = 0
+            for i in ids:
+                h = (h * 0x100000001B3 + (int(i) + 1)) & ((1 << 64) - 1)
+            rows.append(mdist.result_row(qi, st, len(ids), P.num_nodes(), P.traj_cost, h, P.traj()["n"] if st == 0 else 0))
+        return rows
+
+    out = {}
+    for mode in ("lpt", "rr"):
+        merged, t_max, per_rank = mdist.run_sharded(dist, torch, rank, world, queries, plan_fn, mode=mode)
+        assert len(per_rank) == world and t_max >= max(p[0] for p in per_rank) - 1e-12
+        assert sum(p[1] for p in per_rank) == sum(r[2] for r in merged)
+        out[mode] = merged
     dist.barrier()
     if rank == 0:
-        per_rank = [[r for r in allrows[k].tolist() if r[0] >= 0] for k in range(world)]
-        merged = mdist.merge_sharded(len(queries), world, per_rank)
-        # single-process reference
-        ref = []
-        for qi, (s, g) in enumerate(queries):
-            st = P.plan(orc.waypoint(s), orc.waypoint(g))
-            ref.append([qi, st, P.num_closed(), int(round(P.traj_cost * 1000)) if st == 0 else -1])
-        q.put((merged, ref, hash(map_t.numpy().tobytes())))
+        ref = sorted(plan_fn(range(len(queries))))  # single-process reference
+        q.put((out["lpt"], out["rr"], ref, hash(map_t.numpy().tobytes())))
     dist.destroy_process_group()
 
 
@@ -73,11 +77,27 @@ def test_two_rank_query_sharding_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    merged, ref, _ = q.get(timeout=240)
+    lpt, rr, ref, _ = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert merged == ref
+    assert lpt == ref and rr == ref  # every query planned exactly once, same rows as one process
+
+
+def test_partitions_cover_every_query_once():
+    from mpl_ros_amd import dist as mdist
+    from mpl_ros_amd import mapgen
+    rng = mapgen.SplitMix64(3)
+    queries = [((rng.uniform(), rng.uniform(), rng.uniform()), (50 * rng.uniform(), 50 * rng.uniform(), 50 * rng.uniform())) for _ in range(1024)]
+    for w in (1, 2, 4, 8):
+        for mode in ("lpt", "rr"):
+            parts = mdist.partition(queries, w, mode)
+            assert sorted(sum(parts, [])) == list(range(1024)) and max(map(len, parts)) - min(map(len, parts)) <= 1
+        d = [sum((s[i] - g[i]) ** 2 for i in range(3)) for s, g in queries]
+        tot = [sum(d[i] for i in p) for p in mdist.partition(queries, w, "lpt")]
+        assert max(tot) / min(tot) < 1.02  # the snake evens out the predictor
+        for p in mdist.partition(queries, w, "lpt"):
+            assert all(d[p[i]] >= d[p[i + 1]] for i in range(len(p) - 1))  # each rank launches longest-first
 
 
 def test_shard_and_merge_are_inverse():
