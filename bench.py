@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--max-nodes", type=int, default=0, help="mean states per query used to size the shared pools")
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="CPU-baseline sample budget of the N-thread leg (0 disables both legs)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the N-thread CPU leg (0 = all cores, at most 64)")
+    ap.add_argument("--helpers", type=int, default=-1, help="helper workgroups per leading workgroup: -1 auto (2), 0 off, 2")
+    ap.add_argument("--help-reserved", type=int, default=-1, help="workgroups that only ever help (-1 auto)")
     ap.add_argument("--dump-queries", default="", help="write per-query expansions / device timing of the last step to this JSON file")
     args = ap.parse_args()
     if args.single:
@@ -156,6 +158,7 @@ def main():
     pl.setTol(0.5)
     pl.setMaxNum(max_expand)
     pl.setCapacity(min(slots, n_local), caps["nodes"], caps["edges"], caps["log"])
+    pl.setHelpers(args.helpers, args.help_reserved)
 
     def wp(p):
         w = Waypoint3D(control)
@@ -190,13 +193,24 @@ def main():
         else:
             plan_fn(mine)
 
+    if os.environ.get("MPLX_BENCH_TRACE"):
+        import faulthandler
+        import signal
+        faulthandler.register(signal.SIGUSR1, all_threads=True)
     for _ in range(args.warmup):
         step()
+        if os.environ.get("MPLX_BENCH_TRACE"):
+            print(f"[trace] warmup step done, kernel {pl.lastKernelMs():.0f} ms", file=sys.stderr, flush=True)
     barrier()
     state["kernel_ms"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        if os.environ.get("MPLX_BENCH_TRACE"):
+            Tq = np.array([pl.queryTiming(k) for k in range(len(mine))])
+            late = np.argsort(-Tq[:, 1])[:4]
+            print(f"[trace] step done, kernel {pl.lastKernelMs():.0f} ms {pl.helperStats()} latest (q, begin, end, expansions, slot): "
+                  f"{[(int(k), round(Tq[k, 0], 2), round(Tq[k, 1], 2), int(state['results'][k].n_expanded), int(Tq[k, 2])) for k in late]}", file=sys.stderr, flush=True)
     barrier()
     elapsed = time.perf_counter() - t0
     local_s = elapsed
@@ -230,7 +244,8 @@ def main():
         T = [pl.queryTiming(k) for k in range(len(mine))]
         json.dump({"query": mine, "n_expanded": [int(r.n_expanded) for r in results], "status": [int(r.status) for r in results],
                    "t_begin": [t[0] for t in T], "t_end": [t[1] for t in T], "slot": [t[2] for t in T],
-                   "n_nodes": [int(r.n_nodes) for r in results], "kernel_ms": pl.lastKernelMs()}, open(args.dump_queries, "w"))
+                   "n_nodes": [int(r.n_nodes) for r in results], "kernel_ms": pl.lastKernelMs(),
+                   "cycles": {int(k): pl.queryCycles(int(k)) for k in np.argsort([-r.n_expanded for r in results])[:16]}}, open(args.dump_queries, "w"))
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -266,6 +281,7 @@ def main():
                 "map_dim": [n, n, n],
                 "n_primitives": int(U.shape[0]),
                 "slots_per_gpu": min(slots, n_local),
+                "helpers": {"per_leader": args.helpers, "reserved": args.help_reserved, **(pl.helperStats() if mine else {})},
                 "parallelism": f"queries sharded, {world} map replica(s), RCCL broadcast",
             },
             "expansions_per_step": tot_exp,
@@ -326,20 +342,24 @@ def main():
         dist.destroy_process_group()
 
 
-def _cpu_run(orc, grid, origin, res, control, U, kw, queries, order, budget_s, threads):
-    """`threads` host threads, one query at a time each, all on ONE read-only map (orc_set_map_shared)."""
+def _cpu_run(cfg, queries, order, budget_s, procs):
+    """`procs` worker PROCESSES (oracle/cpu_worker.py), one query at a time each, all mapping ONE read-only copy
+    of the voxel map.  A dispatcher thread per worker hands out the next query of `order` until the budget is
+    spent; queries still running then are given a grace period and dropped afterwards."""
+    import subprocess
     import threading
-    planners = []
-    for _ in range(threads):  # ctypes releases the GIL inside plan(): the threads run in parallel
-        P = orc.Planner()
-        P.set_map_shared(grid, origin, res)
-        P.set_config(control, U, **kw)
-        planners.append(P)
+    workers = []
+    for _ in range(procs):
+        w = subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), json.dumps(cfg)],
+                             stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+        workers.append(w)
+    for w in workers:
+        assert json.loads(w.stdout.readline()).get("ready")
     lock = threading.Lock()
-    state = {"next": 0, "n_exp": 0, "nq": 0, "busy": 0.0, "per_query": {}, "lat": []}
+    state = {"next": 0, "n_exp": 0, "nq": 0, "busy": 0.0, "per_query": {}, "lat": [], "last_done": 0.0}
     t_start = time.perf_counter()
 
-    def work(P):
+    def feed(w):
         while True:
             with lock:
                 k = state["next"]
@@ -348,61 +368,84 @@ def _cpu_run(orc, grid, origin, res, control, U, kw, queries, order, budget_s, t
                 state["next"] = k + 1
             i = order[k]
             s, g = queries[i]
-            P.reset_counters()
-            t0 = time.perf_counter()
-            st = P.plan(orc.waypoint(s, control=control), orc.waypoint(g, control=control))
-            dt = time.perf_counter() - t0
-            ne = P.counters()["n_expansions"]
-            actions = P.traj()["actions"] if st == orc.OK else None
+            try:
+                w.stdin.write(f"{i} {s[0]!r} {s[1]!r} {s[2]!r} {g[0]!r} {g[1]!r} {g[2]!r}\n")
+                w.stdin.flush()
+                line = w.stdout.readline()
+            except (BrokenPipeError, ValueError):
+                return
+            if not line:
+                return  # worker was stopped after the grace period
+            r = json.loads(line)
             with lock:
-                state["n_exp"] += ne
+                state["n_exp"] += r["n_expanded"]
                 state["nq"] += 1
-                state["busy"] += dt
-                state["lat"].append(dt)
-                state["per_query"][i] = (ne, P.num_nodes(), P.traj_cost, P.expand_hash(), actions)
+                state["busy"] += r["seconds"]
+                state["lat"].append(r["seconds"])
+                state["last_done"] = time.perf_counter() - t_start
+                state["per_query"][i] = (r["n_expanded"], r["n_nodes"], r["cost"], r["hash"],
+                                         None if r["actions"] is None else np.array(r["actions"], dtype=np.int32))
 
-    ths = [threading.Thread(target=work, args=(P,)) for P in planners]
+    ths = [threading.Thread(target=feed, args=(w,), daemon=True) for w in workers]
     for t in ths:
         t.start()
+    deadline = t_start + budget_s + max(6.0, 0.5 * budget_s)
     for t in ths:
-        t.join()
-    state["wall"] = time.perf_counter() - t_start
+        t.join(timeout=max(0.0, deadline - time.perf_counter()))
+    for w in workers:
+        w.kill()
+    for t in ths:
+        t.join(timeout=5.0)
+    state["wall"] = max(state["last_done"], 1e-9)
     return state
 
 
-def cpu_baseline(grid, origin, res, control, U, max_expand, queries, gpu_expansions, budget_s, threads=1):
+def cpu_baseline(grid, origin, res, control, U, max_expand, queries, gpu_expansions, budget_s, procs=1):
     """The CPU oracle (oracle/, a restatement -- kind "port") on a bounded sample of the same queries, built
     -march=native on this host when gcc is present.  Two legs, steady clock around plan() only:
-      N threads (one query at a time each; independent queries are the only parallelism the reference offers),
-      1 thread  (the reference planner's actual mode).
-    value = expansions of the N-thread sample / its wall time."""
+      N processes (one query at a time each; independent queries are the only parallelism the reference offers),
+      1 process   (the reference planner's actual mode).
+    value = expansions of the completed N-process sample / its wall time."""
+    import tempfile
     from oracle import orc
     native = orc.use_native()
-    grid = np.ascontiguousarray(grid, dtype=np.int8)
     kw = dict(dt=1.0, v_max=2.0, a_max=1.0, tol_pos=0.5, max_expand=max_expand)
     if control == orc.JRK:
         kw["j_max"] = 1.0
-    threads = max(1, min(threads, len(queries)))
-    order = list(range(len(queries)))
-    multi = _cpu_run(orc, grid, origin, res, control, U, kw, queries, order, budget_s, threads)
-    per_query = dict(multi["per_query"])
-    out = {"value": multi["n_exp"] / multi["wall"], "unit": "expansions/s", "cores": threads, "kind": "port",
-           "build": "gcc -O3 -march=native -ffp-contract=off" if native else "gcc -O3 -ffp-contract=off (portable)",
-           "value_per_core": multi["n_exp"] / max(multi["busy"], 1e-9),
-           "sample": f"first {multi['nq']} of the {len(queries)} queries of rank 0 ({multi['n_exp']} expansions, {multi['wall']:.1f} s wall, "
-                     f"{multi['busy']:.1f} core-s of plan()), one read-only map shared by the threads",
-           "plan_latency_ms": {"p50": 1e3 * float(np.percentile(multi["lat"], 50)), "max": 1e3 * float(np.max(multi["lat"])),
-                               "mean": 1e3 * multi["busy"] / max(multi["nq"], 1)}}
-    if threads > 1:
-        # 1-thread leg on queries the N-thread leg did not reach, skipping the heavy tail so the leg stays bounded
-        rest = [i for i in order if i not in per_query and gpu_expansions[i] <= 600_000]
-        single = _cpu_run(orc, grid, origin, res, control, U, kw, queries, rest, max(4.0, budget_s * 0.6), 1)
-        per_query.update(single["per_query"])
-        out["single_thread"] = {"value": single["n_exp"] / max(single["wall"], 1e-9), "cores": 1,
-                                "sample": f"{single['nq']} further queries ({single['n_exp']} expansions, {single['wall']:.1f} s)",
-                                "plan_ms_mean_per_query": 1e3 * single["busy"] / max(single["nq"], 1)}
-    out["_per_query"] = per_query
-    return out
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    map_path = os.path.join(shm, f"mplx_bench_map_{os.getpid()}.npy")
+    np.save(map_path, np.ascontiguousarray(grid, dtype=np.int8))
+    cfg = {"map": map_path, "origin": [float(o) for o in origin], "res": float(res), "control": int(control),
+           "U": np.asarray(U, dtype=np.float64).tolist(), "kw": kw, "native": bool(native)}
+    try:
+        procs = max(1, min(procs, len(queries)))
+        order = list(range(len(queries)))
+        multi = _cpu_run(cfg, queries, order, budget_s, procs)
+        per_query = dict(multi["per_query"])
+        out = {"value": multi["n_exp"] / multi["wall"], "unit": "expansions/s", "cores": procs, "kind": "port",
+               "build": "gcc -O3 -march=native -ffp-contract=off" if native else "gcc -O3 -ffp-contract=off (portable)",
+               "value_per_core": multi["n_exp"] / max(multi["busy"], 1e-9),
+               "sample": f"{multi['nq']} of the first {multi['next']} of the {len(queries)} queries of rank 0 completed within the budget "
+                         f"({multi['n_exp']} expansions, {multi['wall']:.1f} s wall, {multi['busy']:.1f} core-s of plan()); {procs} worker "
+                         f"processes, one read-only map shared through /dev/shm",
+               "plan_latency_ms": {"p50": 1e3 * float(np.percentile(multi["lat"], 50)) if multi["lat"] else None,
+                                   "max": 1e3 * float(np.max(multi["lat"])) if multi["lat"] else None,
+                                   "mean": 1e3 * multi["busy"] / max(multi["nq"], 1)}}
+        if procs > 1:
+            # 1-process leg on queries the N-process leg did not reach, skipping the heavy tail so the leg stays bounded
+            rest = [i for i in order[multi["next"]:] if gpu_expansions[i] <= 600_000]
+            single = _cpu_run(cfg, queries, rest, max(4.0, budget_s * 0.6), 1)
+            per_query.update(single["per_query"])
+            out["single_thread"] = {"value": single["n_exp"] / max(single["busy"], 1e-9), "cores": 1,
+                                    "sample": f"{single['nq']} further queries ({single['n_exp']} expansions, {single['busy']:.1f} s of plan())",
+                                    "plan_ms_mean_per_query": 1e3 * single["busy"] / max(single["nq"], 1)}
+        out["_per_query"] = per_query
+        return out
+    finally:
+        try:
+            os.remove(map_path)
+        except OSError:
+            pass
 
 
 if __name__ == "__main__":

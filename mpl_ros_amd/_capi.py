@@ -51,7 +51,7 @@ EXPORTS = [
     "mplx_ctx_create", "mplx_ctx_destroy", "mplx_last_error", "mplx_set_stream",
     "mplx_map_set", "mplx_map_set_device", "mplx_map_free_unknown", "mplx_map_get", "mplx_map_info", "mplx_map_query",
     "mplx_map_dilate", "mplx_map_cells", "mplx_map_raytrace", "mplx_map_cloud",
-    "mplx_planner_config", "mplx_set_capacity", "mplx_set_bucket_width", "mplx_set_speculation",
+    "mplx_planner_config", "mplx_set_capacity", "mplx_set_bucket_width", "mplx_set_speculation", "mplx_set_helpers", "mplx_helper_stats",
     "mplx_expand_batch", "mplx_heuristic_batch", "mplx_plan", "mplx_plan_batch",
     "mplx_result_traj", "mplx_set_record", "mplx_result_expanded", "mplx_result_nodes", "mplx_result_edges", "mplx_result_timing", "mplx_result_cycles",
     "mplx_last_kernel_ms", "mplx_version", "mplx_kernel_name", "mplx_plan_epoch",
@@ -99,6 +99,8 @@ def load():
     L.mplx_set_capacity.argtypes = [P, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]
     L.mplx_set_bucket_width.argtypes = [P, C.c_double]
     L.mplx_set_speculation.argtypes = [P, C.c_int32]
+    L.mplx_set_helpers.argtypes = [P, C.c_int32, C.c_int32, C.c_uint64]
+    L.mplx_helper_stats.argtypes = [P, C.POINTER(C.c_uint32)]
     L.mplx_expand_batch.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(Succ)]
     L.mplx_heuristic_batch.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(Waypoint), C.c_void_p, C.c_void_p]
     L.mplx_plan.argtypes = [P, C.POINTER(Waypoint), C.POINTER(Waypoint), C.POINTER(Result)]

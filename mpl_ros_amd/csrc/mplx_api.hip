@@ -43,6 +43,11 @@ struct mplx_ctx {
   double *dU = nullptr, *dUcost = nullptr;
   double bucket_width = 0;
   int speculation = -1;  // -1 auto, 0/1 off, else on
+  // helper workgroups (look-ahead expansion on idle compute units): -1 auto, 0 off, 1 / 2 helpers per leader
+  int helpers = -1;
+  int help_reserved = -1;   // workgroups that never lead (-1 auto: only for batches smaller than the machine)
+  uint64_t help_rows = 0;   // rows of the heuristic cache (0 auto)
+  int n_cus = 0;
   // capacities (shared by all queries of a batch)
   int32_t n_slots = 1;
   uint64_t cap_nodes = 1u << 20, cap_edges = 1u << 22, cap_log = 1u << 21;
@@ -71,6 +76,13 @@ struct mplx_ctx {
   uint32_t batch_rec = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0;
+  hipStream_t help_stream = nullptr;  // the helper workgroups' launch runs beside the leaders'
+  uint32_t help_epoch = 0;
+  uint32_t help_ctr_init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t help_stats[4] = {0, 0, 0, 0};
+  uint32_t help_ctr_back[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool help_stats_pending = false;  // last batch: cache rows used, queries done, helpers expired, helpers that made way
+  hipEvent_t ev_ready = nullptr, ev_hdone = nullptr;
 };
 
 static int fail(mplx_ctx *c, int code, const char *fmt, ...) {
@@ -123,6 +135,10 @@ extern "C" int mplx_ctx_create(int device, mplx_ctx **out) {
     delete c;
     return fail(nullptr, MPLX_ERR_HIP, "stream/event creation failed");
   }
+  {
+    hipDeviceProp_t prop;
+    c->n_cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
   *out = c;
   return MPLX_OK;
 }
@@ -154,6 +170,9 @@ extern "C" void mplx_ctx_destroy(mplx_ctx *c) {
   (void)hipFree(c->dUcost);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_hdone) (void)hipEventDestroy(c->ev_hdone);
+  if (c->help_stream) (void)hipStreamDestroy(c->help_stream);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -454,6 +473,27 @@ extern "C" int mplx_set_speculation(mplx_ctx *c, int32_t mode) {
   c->speculation = mode;
   return MPLX_OK;
 }
+extern "C" int mplx_set_helpers(mplx_ctx *c, int32_t per_leader, int32_t reserved, uint64_t cache_rows) {
+  if (!c || !(per_leader == -1 || per_leader == 0 || per_leader == 2)) return fail(c, MPLX_ERR_ARG, "helpers per leader: -1 (auto), 0 (off) or 2");
+  c->helpers = per_leader;
+  c->help_reserved = reserved;
+  c->help_rows = cache_rows;
+  c->pools_valid = false;  // the cache arrays are (re)sized with the pools
+  return MPLX_OK;
+}
+extern "C" int mplx_helper_stats(const mplx_ctx *cc, uint32_t stats[4]) {
+  if (!cc || !stats) return MPLX_ERR_ARG;
+  mplx_ctx *c = const_cast<mplx_ctx *>(cc);
+  if (c->help_stats_pending) {  // the read-back of the last batch completed with its stream synchronisation
+    c->help_stats[0] = c->help_ctr_back[0];
+    c->help_stats[1] = c->help_ctr_back[4];
+    c->help_stats[2] = c->help_ctr_back[2];
+    c->help_stats[3] = c->help_ctr_back[3];
+    c->help_stats_pending = false;
+  }
+  for (int i = 0; i < 4; i++) stats[i] = c->help_stats[i];
+  return MPLX_OK;
+}
 extern "C" int mplx_set_record(mplx_ctx *c, uint32_t cap) {
   if (!c) return MPLX_ERR_ARG;
   c->cap_rec = cap;
@@ -496,7 +536,7 @@ static uint64_t next_pow2(uint64_t v) {
 static int ensure_pools(mplx_ctx *c, int slots) {
   const int control = c->cfg.control;
   if (c->pools_valid && c->pool_slots >= slots && c->pool_control == control && c->pool_nodes == c->cap_nodes &&
-      c->pool_edges == c->cap_edges && c->pool_log == c->cap_log)
+      c->pool_edges == c->cap_edges && c->pool_log == c->cap_log && (c->helpers != 0) == (c->pools.boxes != nullptr))
     return MPLX_OK;
   free_pools(c);
   SearchParams &P = c->pools;
@@ -519,6 +559,21 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   PA(P.bkt_head, (size_t)slots * 2 * NB * NSUB);
   HIPCHK(c, hipMemsetAsync(P.bkt_head, 0xFF, sizeof(uint32_t) * (size_t)slots * 2 * NB * NSUB, c->stream));  // all heads NIL; queries leave them so
   PA(P.chunk_next, 4);
+  P.boxes = nullptr; P.cache_c = nullptr; P.cache_h = nullptr; P.cache_next = nullptr; P.done_word = nullptr; P.all_started = nullptr; P.cache_rows = 0;
+  if (c->helpers != 0) {  // look-ahead cache of the helper workgroups (used by the speculative kernels, lattices <= 31 inputs)
+    uint64_t rows = c->help_rows ? c->help_rows : std::max<uint64_t>((uint64_t)1 << 16, (nch << NODE_CH_LOG) / 4);
+    if (!c->help_rows && rows > ((uint64_t)48 << 20)) rows = (uint64_t)48 << 20;
+    if (rows > 0xFFFFFFF0ull) rows = 0xFFFFFFF0ull;
+    PA(P.boxes, (size_t)slots + 1024);
+    PA(P.cache_c, (size_t)(nch << NODE_CH_LOG));
+    PA(P.cache_h, (size_t)rows * CACHE_ROW_DOUBLES);
+    uint32_t *ctr = nullptr;
+    PA(ctr, 16);
+    P.cache_next = ctr;                              // [0] row counter, [2] [3] diagnostics
+    P.done_word = (unsigned long long *)(ctr + 4);   // epoch << 32 | queries done
+    P.all_started = ctr + 6;
+    P.cache_rows = (uint32_t)rows;
+  }
 #undef PA
   P.node_chunks = (uint32_t)nch;
   P.edge_chunks = (uint32_t)ech;
@@ -584,6 +639,8 @@ static void launch_expand(int control, int grid, hipStream_t s, const SearchPara
 // speculative kernels live in their own translation unit (mplx_spec_launch.hip) so the two halves of
 // the device code compile in parallel; returns false when no variant fits (control kind / lattice size)
 bool mplx_launch_spec(int speculation, int grid, hipStream_t s, const mplx::SearchParams &P);
+// helper-assisted variant (mplx_help_launch.hip): leaders on s, helper workgroups on hs
+bool mplx_launch_spec_help(int grid, hipStream_t s, int helper_grid, hipStream_t hs, const mplx::SearchParams &P);
 
 static int check_ready(mplx_ctx *c) {
   if (!c) return MPLX_ERR_ARG;
@@ -732,9 +789,59 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   HIPCHK(c, hipMemsetAsync(P.chunk_next, 0, 4 * sizeof(uint32_t), c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), c->stream));
-  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   const bool spec = c->speculation < 0 || c->speculation > 1;
-  if (!(spec && mplx_launch_spec(c->speculation, slots, c->stream, P))) {
+  // helper workgroups (a second launch beside the leaders'): look-ahead expansion on compute units that have no
+  // query to lead -- from the start when the batch is smaller than the machine (or `reserved` says so),
+  // otherwise as the leaders run out of queries
+  int grid = slots, helper_grid = 0;
+  P.help_reserved = 0;
+  P.help_max = 0;
+  const bool help = spec && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes && P.n_u <= 31 &&
+                    (P.control == CTRL_ACC || P.control == CTRL_JRK);
+  if (help) {
+    P.help_max = c->helpers < 0 ? 2 : c->helpers;
+    if (c->help_reserved > 0 && slots + c->help_reserved > c->n_cus) grid = std::max(1, c->n_cus - c->help_reserved);
+    P.help_keep = 0;
+    if (slots * (P.help_max + 1) <= c->n_cus) {  // small batch: every query gets its helpers from the start
+      helper_grid = slots * P.help_max;
+      P.help_keep = helper_grid;
+    } else {                                      // large batch: helpers arrive as leaders run out of queries
+      helper_grid = 2 * c->n_cus;
+      if (grid < slots) P.help_keep = c->n_cus - grid;  // ... plus the share reserved for them from the start
+    }
+    P.help_reserved = grid;  // number of leader boxes
+    if (!c->help_stream) {
+      HIPCHK(c, hipStreamCreateWithFlags(&c->help_stream, hipStreamNonBlocking));
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+      HIPCHK(c, hipEventCreateWithFlags(&c->ev_hdone, hipEventDisableTiming));
+    }
+    HIPCHK(c, hipMemsetAsync(P.boxes, 0, sizeof(HelpBox) * ((size_t)c->pool_slots + 1024), c->stream));
+    HIPCHK(c, hipMemsetAsync(P.cache_c, 0, sizeof(CacheRec) * ((size_t)P.node_chunks << NODE_CH_LOG), c->stream));
+    // launch epoch: every word the helpers poll is tagged with it, so nothing left over from the previous launch
+    // can be mistaken for progress of this one
+    c->help_epoch++;
+    if (c->help_epoch == 0) c->help_epoch = 1;
+    P.epoch = c->help_epoch;
+    c->help_ctr_init[0] = c->help_ctr_init[1] = c->help_ctr_init[2] = c->help_ctr_init[3] = 0;
+    const unsigned long long dw = (unsigned long long)P.epoch << 32;
+    memcpy(&c->help_ctr_init[4], &dw, 8);
+    c->help_ctr_init[6] = c->help_ctr_init[7] = 0;
+    HIPCHK(c, hipMemcpyAsync(P.cache_next, c->help_ctr_init, 8 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->help_stream, c->ev_ready, 0));
+  } else {
+    P.boxes = nullptr;
+  }
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  bool launched = false;
+  if (help) {
+    launched = mplx_launch_spec_help(grid, c->stream, helper_grid, c->help_stream, P);
+    if (launched) {
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipEventRecord(c->ev_hdone, c->help_stream));
+    }
+  }
+  if (!launched && !(spec && mplx_launch_spec(c->speculation, grid, c->stream, P))) {
     switch (pick_block(P.n_u)) {
       case 64: launch_astar<64>(P.control, slots, c->stream, P); break;
       case 128: launch_astar<128>(P.control, slots, c->stream, P); break;
@@ -743,6 +850,14 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  if (launched) {
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_hdone, 0));  // the helpers leave when the last query is done
+    HIPCHK(c, hipMemcpyAsync(c->help_ctr_back, P.cache_next, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    c->help_stats_pending = true;
+  } else {
+    memset(c->help_stats, 0, sizeof(c->help_stats));
+    c->help_stats_pending = false;
+  }
   c->last_out.resize(nq);
   HIPCHK(c, hipMemcpyAsync(c->last_out.data(), c->d_out, sizeof(QueryOut) * nq, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -774,7 +889,8 @@ extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
     else if (n_u <= 64) { ul = 64; k = 4; }
     else if (c->speculation == 2) { ul = 128; k = 2; }
     else { ul = 128; k = 4; }
-    snprintf(buf, sizeof(buf), "astar_spec_kernel<%d,%d,%s>", ul, k, cn);
+    const bool help = ul == 32 && k == 16 && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && n_u <= 31;
+    snprintf(buf, sizeof(buf), help ? "astar_spec_kernel<%d,%d,%s,help>" : "astar_spec_kernel<%d,%d,%s>", ul, k, cn);
   }
   return buf;
 }

@@ -61,6 +61,35 @@ struct QueryOut {
   uint32_t n_recorded, slot;
 };
 
+// ---- helper workgroups (look-ahead expansion of a running query on otherwise idle compute units)
+// get_succ(node) and the heuristic of its successors are pure functions of (node state, U, dt, limits,
+// map, goal): a workgroup that has no query of its own computes them AHEAD of time for the nodes at the
+// front of a running query's OPEN list and leaves the result in HBM; the leading workgroup, when it pops
+// such a node, skips the voxel sampling and the heuristic root solves and only does what depends on the
+// search state (table look-up, ordered commit).  Results are bit-identical by construction (same code,
+// same inputs); a missing or late entry only costs time.
+constexpr int WISH = 64;                       // OPEN-front entries a leader publishes per batch
+// Every word a helper polls carries the launch EPOCH in its upper half: a value left over from an earlier
+// launch (the two launches run on different streams; a stale cache line must never look like progress) is
+// recognised as such instead of being trusted.
+__host__ __device__ inline bool box_active(unsigned long long seq, uint32_t epoch) { return (uint32_t)(seq >> 32) == epoch && (uint32_t)seq != 0u; }
+constexpr uint32_t CACHE_READY = 0x80000000u;  // bit 31 of CacheRec::valid (lattices have <= 31 inputs here)
+struct alignas(64) HelpBox {   // one per workgroup slot; every word is written by ONE 8-byte agent-scope store
+  unsigned long long seq;      // epoch << 32 | n;  n = 0: no query running; 1: query running, no list yet; k + 2: list k is complete
+  unsigned long long n_expanded;  // progress of the running query (helpers prefer the longest-running leader)
+  uint32_t q;                  // query the leader is running
+  uint32_t helpers;            // bit mask of attached helpers (atomicOr / atomicAnd)
+  unsigned long long pad[5];
+  unsigned long long wish[2][WISH];  // (q << 48) | pool index of the node record, front of OPEN first; ~0: none.
+                                     // list n lives in buffer n & 1 and is announced one batch after it was written (so it is complete)
+};
+struct CacheRec {              // per node record of the pool; two self-validating 8-byte halves
+  uint32_t row_plus1, khash;   // row of cache_h (heuristics of the successors, voxel reads in slot 31); hash of the key of
+                               // the state the helper expanded -- the leader compares it with its own candidate's key
+  uint32_t valid, blocked;     // per-control-input masks (valid has CACHE_READY set)
+};
+constexpr int CACHE_ROW_DOUBLES = 32;  // slots 0..30: heuristic of the successor of input i; slot 31: voxel reads (as bits)
+
 struct SearchParams {
   // environment
   int32_t control, n_u, ns, nk;  // ns: state doubles (without t), nk: key ints
@@ -90,6 +119,18 @@ struct SearchParams {
   uint32_t *node_tables;          // nq x MAX_NODE_CH: chunk table of each query (state-space dump)
   uint32_t *edge_tables;          // nq x MAX_EDGE_CH: chunk table of the predecessor records
   int32_t *next_query;            // dynamic query counter
+  // helper workgroups (null / 0 when disabled)
+  HelpBox *boxes;                 // gridDim.x boxes
+  CacheRec *cache_c;              // one per node-pool record, zeroed per batch
+  double *cache_h;                // cache_rows x CACHE_ROW_DOUBLES
+  uint32_t cache_rows;
+  uint32_t *cache_next;           // bump counter of cache_h rows; [2], [3]: diagnostics
+  unsigned long long *done_word;  // epoch << 32 | queries finished (helpers leave when the count reaches nq)
+  uint32_t *all_started;          // = epoch once the last query of the batch has been picked up by a leader
+  uint32_t epoch;                 // launch counter of the context
+  int32_t help_reserved;          // number of leader boxes (= workgroups of the leaders' launch)
+  int32_t help_max;               // helpers per leader (1 or 2)
+  int32_t help_keep;              // helper workgroups blockIdx.x < help_keep may stay while queries are still waiting for a leader
 };
 
 // one successor record produced by the expand kernel (mirrors mplx_succ)

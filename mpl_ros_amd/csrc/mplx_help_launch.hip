@@ -1,0 +1,22 @@
+// mplx_help_launch.hip -- the helper-assisted launches: leaders that publish their OPEN front and pick up the
+// look-ahead cache (astar_spec_kernel<..., HELP = true>) plus the helper workgroups' own kernel (mplx_spec.h).
+// Third translation unit of libmplx.so (the device code builds in parallel).
+#include <hip/hip_runtime.h>
+
+#include "mplx_spec.h"
+
+using namespace mplx;
+
+// Lattices of at most 31 inputs (the masks of a cache record are one word): leaders <32 lanes x 16 units>.
+// Returns false when no helper-capable variant exists for the configuration.
+bool mplx_launch_spec_help(int grid, hipStream_t s, int helper_grid, hipStream_t hs, const SearchParams &P) {
+  if (!(P.control == CTRL_ACC || P.control == CTRL_JRK) || P.n_u > 31 || !P.boxes) return false;
+  if (P.control == CTRL_ACC) {
+    hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024, true>), dim3(grid), dim3(512), 0, s, P);
+    if (helper_grid > 0) hipLaunchKernelGGL((helper_kernel<32, 16, CTRL_ACC>), dim3(helper_grid), dim3(512), 0, hs, P);
+  } else {
+    hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_JRK, 1024, 1024, true>), dim3(grid), dim3(512), 0, s, P);
+    if (helper_grid > 0) hipLaunchKernelGGL((helper_kernel<32, 16, CTRL_JRK>), dim3(helper_grid), dim3(512), 0, hs, P);
+  }
+  return true;
+}

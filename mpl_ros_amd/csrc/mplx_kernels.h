@@ -26,6 +26,11 @@ __device__ __forceinline__ unsigned long long ld_u64(const unsigned long long *p
 __device__ __forceinline__ void st_u64(unsigned long long *p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ uint32_t ld_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// f64 through an agent-scope (sc1, write-through / L1-bypassing) 8-byte access: data another compute unit reads or wrote
+__device__ __forceinline__ double ld_f64_agent(const double *p) { return __longlong_as_double((long long)ld_u64((const unsigned long long *)p)); }
+__device__ __forceinline__ void st_f64_agent(double *p, double v) { st_u64((unsigned long long *)p, (unsigned long long)__double_as_longlong(v)); }
 __device__ __forceinline__ bool entry_less(double f1, double g1, uint32_t i1, double f2, double g2, uint32_t i2) {
   if (f1 != f2) return f1 < f2;
   if (g1 != g2) return g1 < g2;
@@ -63,6 +68,8 @@ struct Smem {
   int32_t slow[KUNITS];  // unit has more samples than the owner map covers -> generic sample loop
   uint32_t node_blk[KUNITS];  // the unit's node cell (sample 0 of every primitive): 0 free, 1 occupied, 2 outside the map
   uint32_t offs[KUNITS][BLOCK / KUNITS + 1];
+  // look-ahead cache entry of the unit's node, if a helper workgroup left one (c_row 0: none)
+  uint32_t hc_row[KUNITS], hc_valid[KUNITS], hc_blocked[KUNITS], hc_reads[KUNITS];
   uint32_t blk[BLOCK];  // first blocked sample: (i << 1) | inside
   unsigned long long dupset[KUNITS > 1 ? 2 : 2 * BLOCK];  // unused by the multi-unit kernel
   double cur[KUNITS][13];       // state of the node(s) being expanded (p,v,a,j,t)
@@ -223,11 +230,15 @@ struct NoHook {
 };
 // `after_phase1(L)` runs once the successor state and key of the lane's primitive are known (L.valid),
 // before the voxel sampling: the caller can start memory traffic that depends on the key only.
-template <int UL, int BLOCK, int CONTROL, class SM, class Hook = NoHook>
+// CACHE: units whose S.hc_row is non-zero take validity / blocked flags from the look-ahead cache entry
+// (S.hc_valid, S.hc_blocked) and skip validate_primitive and the voxel sampling altogether.
+template <int UL, int BLOCK, int CONTROL, bool CACHE = false, class SM, class Hook = NoHook>
 __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int tid, bool live_unit, LaneSucc &L, Hook after_phase1 = Hook()) {
   constexpr int NQ = nq_c(CONTROL);
   const int ku = tid / UL, lu = tid % UL;
   const double T = P.dt;
+  bool cached = false;
+  if constexpr (CACHE) cached = live_unit && S.hc_row[ku] != 0u;
 #ifdef MPLX_FINE_TIMERS
   MPLX_TIC(tf0);
 #endif
@@ -251,12 +262,19 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
     bool same = true;
 #pragma unroll
     for (int i = 0; i < key_len_c(CONTROL); i++) same = same && (L.key[i] == S.cur_key[ku][i]);
-    double max_v;
+    double max_v = 0.0;
+    bool ok;
+    if (cached) {  // decided ahead of time by a helper workgroup: nothing left to sample
+      L.valid = (S.hc_valid[ku] >> lu) & 1u;
+      L.blocked = (S.hc_blocked[ku] >> lu) & 1u;
+      ok = false;
+    } else {
 #ifdef MPLX_GENERIC_VALIDATE
-    bool ok = !same && validate_and_maxv(CONTROL, c, T, P.v_max, P.a_max, P.j_max, &max_v);
+      ok = !same && validate_and_maxv(CONTROL, c, T, P.v_max, P.a_max, P.j_max, &max_v);
 #else
-    bool ok = !same && validate_and_maxv_c<CONTROL>(c, T, P.v_max, P.a_max, P.j_max, &max_v);
+      ok = !same && validate_and_maxv_c<CONTROL>(c, T, P.v_max, P.a_max, P.j_max, &max_v);
 #endif
+    }
     if (ok) {
       int n = (int)ceil(max_v * T / P.map.res);
       my_cnt = (uint32_t)(n + 1);
@@ -281,7 +299,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
   // n_u, by a lane that has no primitive when there is one.  The load is consumed after phase 2.
   const int nl = P.n_u < UL ? P.n_u : 0;
   uint32_t node_code = 0;
-  if (live_unit && lu == nl) {
+  if (live_unit && lu == nl && !cached) {
     int32_t c[3];
     bool in = true;
 #pragma unroll
@@ -418,7 +436,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
 #endif
   if (live_unit && lu == nl) S.node_blk[ku] = node_code;
   unit_sync<UL>();
-  if (L.valid) {
+  if (L.valid && !cached) {
     uint32_t code = S.blk[tid];
     const uint32_t nb = S.node_blk[ku];
     if (nb) code = nb == 2u ? 0u : 1u;  // blocked at sample 0 (outside: no voxel read)
@@ -489,6 +507,10 @@ struct QView {
   uint32_t *bkt_head;
   __device__ __forceinline__ char *node(uint32_t i) const {
     return P.node_pool + (((size_t)S.node_tbl[i >> NODE_CH_LOG] << NODE_CH_LOG) + (i & ((1u << NODE_CH_LOG) - 1))) * rec_bytes(CONTROL);
+  }
+  // index of node i's record in the shared pool (the look-ahead cache is indexed by it)
+  __device__ __forceinline__ uint32_t node_rec(uint32_t i) const {
+    return ((uint32_t)S.node_tbl[i >> NODE_CH_LOG] << NODE_CH_LOG) + (i & ((1u << NODE_CH_LOG) - 1));
   }
   __device__ __forceinline__ EdgeRec *edge(uint32_t i) const {
     return (EdgeRec *)(P.edge_pool + (((size_t)S.edge_tbl[i >> EDGE_CH_LOG] << EDGE_CH_LOG) + (i & ((1u << EDGE_CH_LOG) - 1))) * EDGE_BYTES);

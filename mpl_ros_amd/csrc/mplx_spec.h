@@ -65,6 +65,15 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   int32_t any_shared; // some state is reached by two lanes (they only append predecessor edges unless batch_dep)
   int32_t dep_cause;  // (debug statistics) 1 shared successor, 2 candidate is a successor, 4 a sharer modifies the state
   int32_t cut_at;     // first candidate preceded by an entry pushed in this batch (K if none)
+  // helper workgroups (mplx_device.h): leader side
+  int32_t helped;               // a helper is attached to this workgroup's box (sampled every few batches)
+  unsigned long long box_seq;   // wish lists published for the running query
+  // helper side
+  int32_t help_box, help_idx, help_q, help_go;
+  unsigned long long help_seq, help_t0;
+  uint32_t n_work;
+  uint32_t work[WISH];          // pool indices of the node records to expand ahead of time
+  unsigned long long wish_l[WISH];
 #ifdef MPLX_LOOKUP_TIMERS
   unsigned long long cyc2[24];
   unsigned long long cycw[16][4];
@@ -83,7 +92,7 @@ struct LanePre {   // per-lane values of the ordered commit that do not depend o
   int cut;         // first later candidate such an entry would precede (K if none)
 };
 
-template <int UL, int K, int CONTROL, bool PAR, class SM, class V>
+template <int UL, int K, int CONTROL, bool PAR, bool HELP, class SM, class V>
 __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, int q, int kc, bool active, int my_slot, int k_stop,
                                                   const LaneSucc &L, double hspec, const LanePre &pre, uint32_t &pend_idx, uint32_t &pend_old) {
   constexpr int BLOCK = UL * K;
@@ -135,8 +144,13 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
 #pragma unroll
       for (int i = 0; i < nk; i++) kk[i] = L.key[i];
       double *st = V::state(rec);
+      if constexpr (HELP) {  // helper workgroups on other compute units read the state: agent-scope (write-through) stores
 #pragma unroll
-      for (int i = 0; i < ns; i++) st[i] = i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3];
+        for (int i = 0; i < ns; i++) st_f64_agent(&st[i], i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < ns; i++) st[i] = i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3];
+      }
       st[ns] = S.cur[kc][12] + P.dt;
       V::h(rec) = hspec;
       S.bt_id[my_slot] = id;
@@ -202,7 +216,189 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
   }
 }
 
-template <int UL, int K, int CONTROL, int BTN, int NCAP_>
+// ------------------------------------------------------------------ helper workgroups (look-ahead expansion)
+constexpr unsigned long long HELP_LIFETIME_TICKS = 800000000ull;  // 8 s of wall_clock64() (100 MHz)
+// Serve the leader of box `bi` until its query ends: every time it announces a wish list, expand the listed
+// nodes that have no cache entry yet -- get_succ (phases 1-2 of expand_unit) plus the heuristic of every
+// finite successor -- and publish {row, voxel reads, valid mask, blocked mask} in cache_c and the heuristics in
+// a row of cache_h.  Ordering: the row is written (agent scope) and drained (vmcnt 0) before the two
+// self-validating halves of the cache record; the leader reads the record first and the row after it.
+template <int UL, int K, int CONTROL, class SM>
+__device__ __noinline__ void helper_serve(const SearchParams &P, SM &S, int tid) {
+  constexpr int BLOCK = UL * K;
+  constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
+  using V = QView<BLOCK, CONTROL, SM>;
+  const int ku = tid / UL, lu = tid % UL;
+  HelpBox *const B = P.boxes + S.help_box;
+  const uint32_t q = (uint32_t)S.help_q;
+  const uint32_t epoch = P.epoch;
+  unsigned long long last_seq = ((unsigned long long)epoch << 32) | 1ull;
+  for (;;) {
+    if (tid == 0) {
+      unsigned long long seq;
+      int go = 1;
+      for (int spin = 0;; spin++) {
+        seq = ld_u64(&B->seq);
+        if (!box_active(seq, epoch) || ld_u32(&B->q) != q || ld_u32(P.cache_next) >= P.cache_rows) { go = 0; break; }
+        if (seq != last_seq) break;
+        __builtin_amdgcn_s_sleep(8);
+        // a leader that stopped announcing (no OPEN front left), or this helper's time is up: look elsewhere
+        if (spin > 200000 || wall_clock64() - S.help_t0 > HELP_LIFETIME_TICKS) { go = 0; break; }
+      }
+      S.help_go = go;
+      S.help_seq = seq;
+    }
+    __syncthreads();
+    if (!S.help_go) break;
+    last_seq = S.help_seq;
+    // ---- the announced list -> the entries that are mine and still missing
+    if (tid < WISH) {
+      const unsigned long long v = ld_u64(&B->wish[((uint32_t)last_seq - 2u) & 1u][tid]);
+      bool ok = v != ~0ull && (uint32_t)(v >> 48) == q;
+      const uint32_t rec = (uint32_t)(v & 0xFFFFFFFFFFFFull);
+      if (ok && P.help_max > 1) {
+        const uint32_t m = ld_u32(&B->helpers);
+        if (__popc(m) > 1) ok = (int)(rec & 1u) == S.help_idx;  // two helpers: split by record parity
+      }
+      if (ok) ok = (uint32_t)ld_u64((const unsigned long long *)&P.cache_c[rec]) == 0u;
+      const unsigned long long mk = __ballot(ok);
+      if (ok) S.work[__popcll(mk & ((1ull << tid) - 1ull))] = rec;
+      if (tid == 0) S.n_work = (uint32_t)__popcll(mk);
+    }
+    __syncthreads();
+    const uint32_t n_work = S.n_work;
+    for (uint32_t base = 0; base < n_work; base += K) {
+      const bool live = base + (uint32_t)ku < n_work;
+      const uint32_t rec = live ? S.work[base + ku] : 0u;
+      if (live) {
+        const double *st = V::state(P.node_pool + (size_t)rec * rec_bytes(CONTROL));
+        if (lu < ns) S.cur[ku][lu] = ld_f64_agent(&st[lu]);
+        if (lu >= ns && lu < 13) S.cur[ku][lu] = 0.0;
+      }
+      if (lu == 0) S.hc_row[ku] = 0;
+      unit_sync<UL>();
+      if (live && lu == 0) {
+        State sc;
+        for (int i = 0; i < 12; i++) ((double *)&sc)[i] = S.cur[ku][i];
+        state_key_c<CONTROL>(sc, S.cur_key[ku]);
+      }
+      unit_sync<UL>();
+      LaneSucc L;
+      expand_unit<UL, BLOCK, CONTROL>(P, S, tid, live, L);
+      const bool act = L.valid && !L.blocked;
+      double h = 0.0;
+      if (act && P.eps != 0.0) h = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
+      uint32_t treads;
+      unit_excl_scan<UL, BLOCK>(L.reads, S, tid, treads);
+      const unsigned long long bv = __ballot(L.valid), bb = __ballot(L.blocked);
+      uint32_t vmask, bmask;
+      if constexpr (UL == 32) {
+        vmask = (tid & 32) ? (uint32_t)(bv >> 32) : (uint32_t)bv;
+        bmask = (tid & 32) ? (uint32_t)(bb >> 32) : (uint32_t)bb;
+      } else {
+        vmask = (uint32_t)bv;
+        bmask = (uint32_t)bb;
+      }
+      if (live && lu == 0) {
+        const uint32_t row = atomicAdd(P.cache_next, 1u);
+        S.hc_row[ku] = row < P.cache_rows ? row + 1u : 0u;
+      }
+      unit_sync<UL>();
+      const uint32_t rp1 = live ? S.hc_row[ku] : 0u;
+      if (rp1 && lu < P.n_u) st_f64_agent(&P.cache_h[(size_t)(rp1 - 1u) * CACHE_ROW_DOUBLES + lu], h);
+      if (rp1 && lu == UL - 1) st_u64((unsigned long long *)&P.cache_h[(size_t)(rp1 - 1u) * CACHE_ROW_DOUBLES + 31], (unsigned long long)treads);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has landed before the record names it
+      unit_sync<UL>();
+      if (rp1 && lu == 0) {
+        unsigned long long *cr = (unsigned long long *)&P.cache_c[rec];
+        st_u64(cr + 1, ((unsigned long long)bmask << 32) | (unsigned long long)(vmask | CACHE_READY));
+        st_u64(cr, ((unsigned long long)(uint32_t)key_hash64(S.cur_key[ku], nk) << 32) | (unsigned long long)rp1);
+      }
+      if (lu == 0) S.hc_row[ku] = 0;
+      __syncthreads();
+    }
+  }
+}
+
+// A workgroup with no query to lead: attach to the longest-running leader that lacks a helper, serve it until
+// its query ends, repeat until every query of the batch is done.
+template <int UL, int K, int CONTROL, class SM>
+__device__ __noinline__ void helper_loop(const SearchParams &P, SM &S, int tid) {
+  constexpr int BLOCK = UL * K;
+  const int nboxes = P.help_reserved;  // number of leader boxes of the accompanying launch
+  for (;;) {
+    if (tid == 0) {
+      // leave when every query is done or the cache is full -- and, as a safety net, after a fixed lifetime: a
+      // helper may cost time, it must never be able to keep the machine from finishing
+      const bool expired = wall_clock64() - S.help_t0 > HELP_LIFETIME_TICKS;
+      if (expired) atomicAdd(P.cache_next + 2, 1u);  // (diagnostics) helpers that ran into the lifetime limit
+      const unsigned long long dw = ld_u64(P.done_word);
+      const bool done = (uint32_t)(dw >> 32) == P.epoch && (uint32_t)dw >= (uint32_t)P.nq;
+      S.flag = (expired || done || ld_u32(P.cache_next) >= P.cache_rows) ? 1 : 0;
+    }
+    __syncthreads();
+    if (S.flag) return;
+    unsigned long long best = 0;
+    int bi = -1;
+    for (int b = tid; b < nboxes; b += BLOCK) {
+      const HelpBox *B = P.boxes + b;
+      if (!box_active(ld_u64(&B->seq), P.epoch)) continue;
+      if (__popc(ld_u32(&B->helpers)) >= P.help_max) continue;
+      const unsigned long long ne = ld_u64(&B->n_expanded) + 1ull;
+      if (ne > best) { best = ne; bi = b; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned long long ob = __shfl_xor(best, d, 64);
+      const int oi = __shfl_xor(bi, d, 64);
+      if (ob > best || (ob == best && oi >= 0 && (bi < 0 || oi < bi))) { best = ob; bi = oi; }
+    }
+    if ((tid & 63) == 0) {
+      S.red_f[tid >> 6] = (double)best;  // (n_expanded < 2^53)
+      S.red_id[tid >> 6] = (uint32_t)bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double bb = 0.0;
+      int pick = -1;
+      for (int w = 0; w < BLOCK / 64; w++)
+        if ((int)S.red_id[w] >= 0 && S.red_f[w] > bb) { bb = S.red_f[w]; pick = (int)S.red_id[w]; }
+      S.help_box = -1;
+      if (pick >= 0) {
+        HelpBox *B = P.boxes + pick;
+        for (int hh = 0; hh < P.help_max; hh++) {
+          const uint32_t old = atomicOr(&B->helpers, 1u << hh);
+          if (!(old & (1u << hh))) { S.help_box = pick; S.help_idx = hh; break; }
+        }
+        if (S.help_box >= 0) {
+          const uint32_t q = ld_u32(&B->q);
+          if (q < (uint32_t)P.nq && box_active(ld_u64(&B->seq), P.epoch)) {
+            const QueryIn &in = P.queries[q];
+            S.help_q = (int)q;
+            S.hp.w = P.w; S.hp.v_max = P.v_max; S.hp.heur_ignore_dynamics = P.heur_ignore_dynamics;
+            S.hp.goal_control = in.goal_control;
+            S.hp.goal = in.goal;
+            S.hp.goal_nkey = state_key(in.goal_control, in.goal, S.hp.goal_key);
+          } else {
+            atomicAnd(&B->helpers, ~(1u << S.help_idx));
+            S.help_box = -1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (S.help_box < 0) {  // nobody to help right now: stay off the memory system for a while
+      for (int i = 0; i < 16; i++) __builtin_amdgcn_s_sleep(127);
+      __syncthreads();
+      continue;
+    }
+    helper_serve<UL, K, CONTROL>(P, S, tid);
+    if (tid == 0) atomicAnd(&(P.boxes + S.help_box)->helpers, ~(1u << S.help_idx));
+    __syncthreads();
+  }
+}
+
+template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false>
 __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
   constexpr int BLOCK = UL * K;
   using SM = SmemSpec<UL, K, CONTROL, BTN, NCAP_>;
@@ -210,11 +406,20 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
   __shared__ SM S;
   using V = QView<BLOCK, CONTROL, SM>;
   const int tid = threadIdx.x, ku = tid / UL, lu = tid % UL;
+  // HELP: this launch is accompanied by helper workgroups (helper_kernel below, a second launch): the leader
+  // publishes the front of its OPEN list and picks up the look-ahead cache entries they leave.  Compiled out
+  // of the plain variant (the kernel sits at the register limit).
+  static_assert(!HELP || UL <= 64, "per-input masks of the look-ahead cache are one word");
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   fill_uq<BLOCK, CONTROL>(P, S, tid);
   for (;;) {
-    if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
+    if (tid == 0) {
+      S.q_index = atomicAdd(P.next_query, 1);
+      if constexpr (HELP) {
+        if (S.q_index == P.nq - 1) st_u32(P.all_started, P.epoch);  // queries are picked up in order: none is left waiting
+      }
+    }
     __syncthreads();
     const int qi = S.q_index;
     if (qi >= P.nq) break;
@@ -240,6 +445,14 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       S.c_push = S.c_reopen = S.c_refill = S.c_evict = 0;
       S.c_hash = 0;
       S.cur_id = NIL;
+      S.helped = 0;
+      S.box_seq = 0;
+      if constexpr (HELP) {  // announce the query (helpers filter wish entries by q, so the order of the stores is free)
+        HelpBox *box = P.boxes + blockIdx.x;
+        st_u32(&box->q, (uint32_t)q);
+        st_u64(&box->n_expanded, 0ull);
+        st_u64(&box->seq, ((unsigned long long)P.epoch << 32) | 1ull);
+      }
       S.hp.w = P.w; S.hp.v_max = P.v_max; S.hp.heur_ignore_dynamics = P.heur_ignore_dynamics;
       S.hp.goal_control = in.goal_control;
       S.hp.goal = in.goal;
@@ -276,7 +489,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         char *rec = Q.node(0);
         for (int i = 0; i < nk; i++) V::key(rec)[i] = key[i];
         const double *src = (const double *)&in.start;
-        for (int i = 0; i < ns; i++) V::state(rec)[i] = src[i];
+        for (int i = 0; i < ns; i++) {
+          if constexpr (HELP) st_f64_agent(&V::state(rec)[i], src[i]); else V::state(rec)[i] = src[i];
+        }
         V::state(rec)[ns] = in.start_t;
         double h = P.eps == 0.0 ? 0.0 : get_heur(S.hp, CONTROL, in.start, key, nk);
         V::h(rec) = h;
@@ -340,6 +555,15 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           S.batch_dep = 0;
           S.any_shared = 0;
           S.dep_cause = 0;
+          if constexpr (HELP) {
+            HelpBox *box = P.boxes + blockIdx.x;
+            // announce the wish list written during the previous batch (complete: a __syncthreads() lies between)
+            if (S.helped && S.box_seq) {
+              st_u64(&box->n_expanded, S.c_expanded);
+              st_u64(&box->seq, ((unsigned long long)P.epoch << 32) | (S.box_seq + 1ull));
+            }
+            if ((S.cyc[7] & 7ull) == 1ull) S.helped = ld_u32(&box->helpers) != 0u;
+          }
         }
         if ((tid & 63) == 0 && tid < 192) {  // chunk capacity for everything this batch can create: one pool per wave
           const uint32_t room = (uint32_t)(K * P.n_u + K);
@@ -359,6 +583,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           S.u_succ[tid] = S.u_fin[tid] = S.u_reads[tid] = 0;
           S.u_goal[tid] = 0;
           S.u_cut[tid] = K;
+          if constexpr (HELP) S.hc_row[tid] = 0;
         }
         __syncthreads();
         MPLX_T2(S, 17, t3);
@@ -464,6 +689,16 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
           __syncthreads();
           MPLX_T2(S, 19, t3);
+          if constexpr (HELP) {
+            // wish list: the front of what is left of OPEN (sorted) = the candidates of the next batches.  Announced
+            // by the seq store at the start of the NEXT batch, so no wait for these stores is needed here.
+            if (S.helped && tid < WISH) {
+              unsigned long long v = ~0ull;
+              if ((uint32_t)tid < n - kc) v = ((unsigned long long)(uint32_t)q << 48) | (unsigned long long)Q.node_rec(S.near_id[tid]);
+              st_u64(&(P.boxes + blockIdx.x)->wish[S.box_seq & 1ull][tid], v);
+              if (tid == 0) S.box_seq++;
+            }
+          }
         }
         const int n_cand = S.n_cand;
         // ---- 2a. fetch the candidates' records; drop stale entries (improved or closed since pushed)
@@ -480,6 +715,20 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             if (lu == 0) {
               S.cand_live[ku] = 1;
               S.cand_fl[ku] = fl;
+            }
+            if constexpr (HELP) {
+              if (S.helped && lu == UL - 1) {  // did a helper expand this node ahead of time?
+                const unsigned long long *cr = (const unsigned long long *)&P.cache_c[Q.node_rec(S.cand_id[ku])];
+                const unsigned long long ca = ld_u64(cr), cb = ld_u64(cr + 1);
+                // the entry must be of THIS state: the helper's hash of the key of the state it expanded against the
+                // key in the candidate's own record (guards against anything stale on the helper's side)
+                if ((uint32_t)ca != 0u && ((uint32_t)cb & CACHE_READY) && (uint32_t)(ca >> 32) == (uint32_t)key_hash64(V::key(rec), nk)) {
+                  S.hc_row[ku] = (uint32_t)ca;
+                  S.hc_valid[ku] = (uint32_t)cb;
+                  S.hc_blocked[ku] = (uint32_t)(cb >> 32);
+                  atomicAdd(&S.cyc[9], 1ull);  // (diagnostics) candidates served from the look-ahead cache
+                }
+              }
             }
           }
         }
@@ -500,8 +749,8 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         // its voxels are sampled (a blocked successor wastes one load), consumed after the batch table is built
         unsigned long long h64 = 0, v0 = TBL_EMPTY;
         size_t pos0 = 0;
-        expand_unit<UL, BLOCK, CONTROL>(P, S, tid, live_unit, L, [&](const LaneSucc &l) {
-          if (l.valid) {
+        expand_unit<UL, BLOCK, CONTROL, HELP>(P, S, tid, live_unit, L, [&](const LaneSucc &l) {
+          if (l.valid && !l.blocked) {
             h64 = key_hash64(l.key, nk);
             pos0 = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
             v0 = ld_u64(&P.table[pos0]);
@@ -515,7 +764,10 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           if (lu == 0) {
             S.u_succ[ku] = tot & 0x3FFu;
             S.u_fin[ku] = tot >> 10;
-            S.u_reads[ku] = treads;
+            if (HELP && S.hc_row[ku] != 0u)  // voxel reads of the expansion as the helper counted them (slot 31 of its row)
+              S.u_reads[ku] = (uint32_t)ld_u64((const unsigned long long *)&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * CACHE_ROW_DOUBLES + 31]);
+            else
+              S.u_reads[ku] = treads;
           }
         }
         MPLX_TOC(S, 1, tx);
@@ -595,7 +847,14 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
               __builtin_prefetch(Q.node((uint32_t)v0), 0, 3);
             }
             MPLX_T2(S, 2, t2);
-            if (P.eps != 0.0) hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
+            if (P.eps != 0.0) {
+              // look-ahead cache hit: the heuristic of this successor is in the helper's row (written before the
+              // cache record was, read after it)
+              if (HELP && S.hc_row[ku] != 0u)
+                hspec = ld_f64_agent(&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * CACHE_ROW_DOUBLES + lu]);
+              else
+                hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
+            }
             MPLX_T2(S, 3, t2);
 #ifdef MPLX_LOOKUP_TIMERS
             atomicMax(&S.arr_heur, (unsigned long long)__builtin_readcyclecounter());
@@ -774,7 +1033,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           MPLX_T2(S, 8, t2);
           __syncthreads();  // everyone has read status / u_cut before they change
           MPLX_T2(S, 9, t2);
-          spec_commit_lanes<UL, K, CONTROL, true>(Q, S, tid, q, ku, act && mine, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
+          spec_commit_lanes<UL, K, CONTROL, true, HELP>(Q, S, tid, q, ku, act && mine, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
           if (tid == 0 && st_after >= 0) S.status = st_after;
           MPLX_T2(S, 10, t2);
         }
@@ -802,10 +1061,10 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
           if (S.cur_slot[k] != NIL) lds_barrier();  // (uniform) its closed flag must precede its own successors' relax
           if (!S.unit_seq[k]) {
-            spec_commit_lanes<UL, K, CONTROL, false>(Q, S, tid, q, k, act && ku == k, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
+            spec_commit_lanes<UL, K, CONTROL, false, HELP>(Q, S, tid, q, k, act && ku == k, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
           } else {
             for (int i = 0; i < P.n_u; i++) {
-              spec_commit_lanes<UL, K, CONTROL, false>(Q, S, tid, q, k, act && ku == k && lu == i, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
+              spec_commit_lanes<UL, K, CONTROL, false, HELP>(Q, S, tid, q, k, act && ku == k && lu == i, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
               lds_barrier();
             }
           }
@@ -880,6 +1139,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
     }
     const uint32_t goal_id = searched ? S.cur_id : NIL;
     if (searched) clear_buckets(Q, tid);
+    if constexpr (HELP) {
+      if (tid == 0) st_u64(&(P.boxes + blockIdx.x)->seq, (unsigned long long)P.epoch << 32);  // helpers of this query detach
+    }
     __syncthreads();
     // ---- recoverTraj + results (thread 0)
     if (tid == 0) {
@@ -952,8 +1214,40 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? S.node_tbl[i] : NIL;
     for (uint32_t i = tid; i < (uint32_t)MAX_EDGE_CH; i += BLOCK)
       P.edge_tables[(size_t)q * MAX_EDGE_CH + i] = i < S.edge_chunks ? S.edge_tbl[i] : NIL;
+    if constexpr (HELP) {
+      if (tid == 0) atomicAdd(P.done_word, 1ull);
+    }
     __syncthreads();
   }
+}
+
+// The helper launch: workgroups that never lead a query.  Started right after the leaders' launch on a second
+// stream; its workgroups become resident wherever a compute unit is free -- from the start when the batch is
+// smaller than the machine, otherwise as the leading workgroups run out of queries and exit.
+template <int UL, int K, int CONTROL>
+__global__ __launch_bounds__(UL *K) void helper_kernel(SearchParams P) {
+  using SM = SmemSpec<UL, K, CONTROL, 64, 64>;
+  __shared__ SM S;
+  const int tid = threadIdx.x;
+  fill_uq<UL * K, CONTROL>(P, S, tid);
+  // A helper must never keep a leader off the machine.  The two launches are dispatched concurrently, so a helper
+  // workgroup can become resident while queries are still waiting for a compute unit; unless it belongs to the
+  // share the host left free for helpers (blockIdx.x < help_keep), it leaves again when that is the case (the
+  // launch holds more workgroups than it needs: later ones arrive when the leaders run out of queries and exit).
+  if (tid == 0) {
+    S.help_t0 = wall_clock64();
+    int ok = (int)blockIdx.x < P.help_keep;
+    for (int spin = 0; spin < 128 && !ok; spin++) {
+      ok = ld_u32(P.all_started) == P.epoch;
+      if (!ok) __builtin_amdgcn_s_sleep(32);
+    }
+    if (!ok) atomicAdd(P.cache_next + 3, 1u);  // (diagnostics) helper workgroups that made way for leaders
+    S.flag = ok;
+  }
+  __syncthreads();
+  if (!S.flag) return;
+  __syncthreads();
+  helper_loop<UL, K, CONTROL>(P, S, tid);
 }
 
 }  // namespace mplx

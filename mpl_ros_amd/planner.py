@@ -350,6 +350,17 @@ class VoxelMapPlanner:
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_speculation(ctx.h, int(mode)))
 
+    def setHelpers(self, per_leader=-1, reserved=-1, cache_rows=0):
+        """Helper workgroups (look-ahead expansion on idle compute units): -1 auto, 0 off, 1 / 2 per leader."""
+        ctx = self._ctx()
+        ctx.check(ctx.lib.mplx_set_helpers(ctx.h, int(per_leader), int(reserved), int(cache_rows)))
+
+    def helperStats(self):
+        ctx = self._ctx()
+        st = (C.c_uint32 * 4)()
+        ctx.check(ctx.lib.mplx_helper_stats(ctx.h, st))
+        return dict(zip(("cache_rows_used", "queries_done", "helpers_expired", "helpers_made_way"), [int(x) for x in st]))
+
     def setRecord(self, cap):
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_record(ctx.h, int(cap)))
@@ -451,7 +462,7 @@ class VoxelMapPlanner:
         ctx = self._ctx()
         cyc = (C.c_uint64 * 10)()
         ctx.check(ctx.lib.mplx_result_cycles(ctx.h, q, cyc))
-        return dict(zip(("pop", "expand", "lookup", "evict", "refill", "activate", "commit", "batches", "dep_batches"), [int(x) for x in cyc[:9]]))
+        return dict(zip(("pop", "expand", "lookup", "evict", "refill", "activate", "commit", "batches", "dep_batches", "cache_hits"), [int(x) for x in cyc[:10]]))
 
     # ---- results
     def getTrajCost(self):

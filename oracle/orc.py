@@ -186,7 +186,7 @@ class Planner:
         """Adopt `grid` (C-contiguous int8, shape (dz, dy, dx)) without copying: one read-only map for many
         planner objects.  The planner keeps a reference to the array."""
         assert grid.dtype == np.int8 and grid.flags["C_CONTIGUOUS"]
-        self._shared = grid
+        self._shared = grid  # (may be a read-only memory map)
         dim = (C.c_int32 * 3)(grid.shape[2], grid.shape[1], grid.shape[0])
         ori = (C.c_double * 3)(*[float(o) for o in origin])
         self._shape = grid.shape
