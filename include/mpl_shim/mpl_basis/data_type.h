@@ -48,7 +48,20 @@ struct Vec {
   const T *data() const { return v; }
   static constexpr int size() { return N; }
   static Vec Zero() { return Vec(); }
+  static Vec Ones() { return Constant(T(1)); }
   static Vec Constant(T c) { Vec r; for (int i = 0; i < N; i++) r.v[i] = c; return r; }
+  static Vec Unit(int k) { Vec r; r.v[k] = T(1); return r; }
+  static Vec UnitX() { return Unit(0); }
+  static Vec UnitY() { return Unit(1); }
+  static Vec UnitZ() { return Unit(2); }
+  Vec operator-() const { Vec r; for (int i = 0; i < N; i++) r.v[i] = -v[i]; return r; }
+  Vec &operator+=(const Vec &o) { for (int i = 0; i < N; i++) v[i] += o.v[i]; return *this; }
+  Vec &operator-=(const Vec &o) { for (int i = 0; i < N; i++) v[i] -= o.v[i]; return *this; }
+  Vec &operator*=(T s) { for (int i = 0; i < N; i++) v[i] *= s; return *this; }
+  Vec &operator/=(T s) { for (int i = 0; i < N; i++) v[i] /= s; return *this; }
+  bool operator!=(const Vec &o) const { return !(*this == o); }
+  const Vec &transpose() const { return *this; }
+  template <int P> T lpNorm() const { return lpNormInf(); }  // only lpNorm<Eigen::Infinity> is used in-tree
   Vec operator+(const Vec &o) const { Vec r; for (int i = 0; i < N; i++) r.v[i] = v[i] + o.v[i]; return r; }
   Vec operator-(const Vec &o) const { Vec r; for (int i = 0; i < N; i++) r.v[i] = v[i] - o.v[i]; return r; }
   Vec operator*(T s) const { Vec r; for (int i = 0; i < N; i++) r.v[i] = v[i] * s; return r; }
@@ -60,6 +73,8 @@ struct Vec {
   T lpNormInf() const { T m = T(0); for (int i = 0; i < N; i++) m = std::fabs(v[i]) > m ? std::fabs(v[i]) : m; return m; }
   template <typename U> Vec<U, N> cast() const { Vec<U, N> r; for (int i = 0; i < N; i++) r.v[i] = static_cast<U>(v[i]); return r; }
 };
+template <typename T, int N>
+Vec<T, N> operator*(T s, const Vec<T, N> &a) { return a * s; }
 /// dynamic-size vector (control inputs: vec_E<VecDf> U; U.push_back(Vec3f(dx, dy, dz)), map_planner_node.cpp:108-139)
 struct VecD {
   std::vector<decimal_t> v;
@@ -90,5 +105,10 @@ typedef vec_E<Vec2f> vec_Vec2f;
 typedef vec_E<Vec2i> vec_Vec2i;
 typedef vec_E<Vec3f> vec_Vec3f;
 typedef vec_E<Vec3i> vec_Vec3i;
+#ifndef MPLX_USE_EIGEN
+namespace Eigen { enum { Infinity = -1 }; }  // so that `lpNorm<Eigen::Infinity>()` reads the same
+/// 3x3 matrix placeholder (Mat3f only appears in the ROS display glue, which is out of scope)
+struct Mat3f { decimal_t m[3][3]; };
+#endif
 
 #endif

@@ -8,6 +8,9 @@
  */
 #ifndef MPLX_SHIM_PRIMITIVE_H
 #define MPLX_SHIM_PRIMITIVE_H
+#include <mpl_basis/math.h>
+
+#include <algorithm>
 #include <mpl_basis/waypoint.h>
 
 class Primitive1D {
@@ -21,6 +24,38 @@ class Primitive1D {
   decimal_t v(decimal_t t) const { return c(0) / 24 * t * t * t * t + c(1) / 6 * t * t * t + c(2) / 2 * t * t + c(3) * t + c(4); }
   decimal_t a(decimal_t t) const { return c(0) / 6 * t * t * t + c(1) / 2 * t * t + c(2) * t + c(3); }
   decimal_t j(decimal_t t) const { return c(0) / 2 * t * t + c(1) * t + c(2); }
+  /// integral over [0, t] of the squared k-th derivative (k = 1 VEL .. 4 SNP): double sum over the derivative's
+  /// monomial coefficients in ascending order -- the expression the device and the oracle evaluate (deviation D2)
+  decimal_t J(decimal_t t, Control::Control control) const {
+    const int k = (control & 15) == Control::VEL ? 1 : (control & 15) == Control::ACC ? 2 : (control & 15) == Control::JRK ? 3 : 4;
+    const decimal_t fact[6] = {1, 1, 2, 6, 24, 120};
+    decimal_t q[6];
+    const int nq = 6 - k;
+    for (int m = k; m <= 5; m++) q[m - k] = c(5 - m) / fact[m - k];
+    decimal_t s = 0.0;
+    for (int i = 0; i < nq; i++)
+      for (int jj = 0; jj < nq; jj++) {
+        decimal_t pw = t;
+        for (int r = 1; r < i + jj + 1; r++) pw = pw * t;
+        s += q[i] * q[jj] * pw / (decimal_t)(i + jj + 1);
+      }
+    return s;
+  }
+  /// times in (0, t) where the k-th derivative is stationary (roots of derivative k + 1), as `solve` returns them
+  std::vector<decimal_t> extrema(int k, decimal_t t) const {
+    std::vector<decimal_t> ts = k == 1 ? solve(0, c(0) / 6, c(1) / 2, c(2), c(3)) : k == 2 ? solve(0, 0, c(0) / 2, c(1), c(2)) : solve(0, 0, 0, c(0), c(1));
+    std::vector<decimal_t> out;
+    for (decimal_t x : ts)
+      if (x > 0 && x < t) out.push_back(x);
+    return out;
+  }
+  /// max over [0, t] of |d^k p| for k = 1 (vel), 2 (acc), 3 (jrk): end points and interior stationary points
+  decimal_t max_abs(int k, decimal_t t) const {
+    auto f = [&](decimal_t x) { return k == 1 ? v(x) : k == 2 ? a(x) : j(x); };
+    decimal_t m = std::max(std::fabs(f(0)), std::fabs(f(t)));
+    for (decimal_t x : extrema(k, t)) m = std::max(m, std::fabs(f(x)));
+    return m;
+  }
 
  private:
   Vec6f c;
@@ -61,6 +96,17 @@ class Primitive {
     }
     return p;
   }
+  /// sum over the axes of the integral of the squared derivative `control` selects (env_poly_map.h:72, map_planner_node.cpp:213)
+  decimal_t J(const Control::Control &control) const {
+    decimal_t j = 0;
+    for (int k = 0; k < Dim; k++) j += prs_[k].J(t_, control);
+    return j;
+  }
+  decimal_t Jyaw() const { return pr_yaw_.J(t_, Control::VEL); }
+  /// max |velocity| / |acceleration| / |jerk| along axis k (ellipsoid_util.h:68)
+  decimal_t max_vel(int k) const { return prs_[k].max_abs(1, t_); }
+  decimal_t max_acc(int k) const { return prs_[k].max_abs(2, t_); }
+  decimal_t max_jrk(int k) const { return prs_[k].max_abs(3, t_); }
   vec_E<Waypoint<Dim>> sample(int N) const {
     vec_E<Waypoint<Dim>> ps(N + 1);
     decimal_t dt = t_ / N;
@@ -76,4 +122,31 @@ class Primitive {
 };
 typedef Primitive<2> Primitive2D;
 typedef Primitive<3> Primitive3D;
+
+/// validate_primitive(pr, v_max, a_max, j_max[, yaw_max]) (env_poly_map.h:58, env_cloud.h:62): a control kind checks the
+/// derivatives below its own order (ACC: vel; JRK: vel, acc; SNP: vel, acc, jrk); a limit <= 0 is not checked
+/// [UNVERIFIED rule, same as the oracle's and the device's].  yaw_max >= 0 is refused: yaw is not implemented.
+template <int Dim>
+bool validate_primitive(const Primitive<Dim> &pr, decimal_t mv = 0, decimal_t ma = 0, decimal_t mj = 0, decimal_t myaw = 0) {
+  const int c = pr.control() & 15;
+  if (c == Control::ACC || c == Control::JRK || c == Control::SNP)
+    for (int i = 0; i < Dim; i++)
+      if (mv > 0 && pr.max_vel(i) > mv) return false;
+  if (c == Control::JRK || c == Control::SNP)
+    for (int i = 0; i < Dim; i++)
+      if (ma > 0 && pr.max_acc(i) > ma) return false;
+  if (c == Control::SNP)
+    for (int i = 0; i < Dim; i++)
+      if (mj > 0 && pr.max_jrk(i) > mj) return false;
+  (void)myaw;
+  return true;
+}
+template <int Dim>
+void print(const Primitive<Dim> &p) {
+  for (int i = 0; i < Dim; i++) {
+    const Vec6f c = p.pr(i).coeff();
+    printf("dim[%d]: %f %f %f %f %f %f\n", i, c(0), c(1), c(2), c(3), c(4), c(5));
+  }
+  printf("t: %f\n", p.t());
+}
 #endif

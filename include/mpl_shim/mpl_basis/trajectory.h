@@ -53,6 +53,17 @@ class Trajectory {
     }
     return Waypoint<Dim>();
   }
+  /// total control effort of the derivative `control` selects / of yaw (map_planner_node.cpp:210-214)
+  decimal_t J(const Control::Control &control) const {
+    decimal_t j = 0;
+    for (const auto &seg : segs) j += seg.J(control);
+    return j;
+  }
+  decimal_t Jyaw() const {
+    decimal_t j = 0;
+    for (const auto &seg : segs) j += seg.Jyaw();
+    return j;
+  }
   vec_E<Primitive<Dim>> segs;
   std::vector<decimal_t> taus;
   std::vector<decimal_t> Ts;

@@ -4,39 +4,74 @@
  * done by libmplx.so on the GPU.  Method names, argument meaning and error behaviour follow the
  * in-tree call sites: setters store parameters, plan() returns false and
  * prints a diagnostic when the start is occupied or no trajectory is found, results are returned by
- * value.  Not covered by this back-end: LPA* (setLPAstar / update*Nodes), potential fields, yaw.
+ * value.  Not covered by this back-end: LPA* (setLPAstar / update*Nodes), potential fields, yaw -- each of them
+ * fails loudly (planner_base.h) instead of silently planning something else.
  */
 #ifndef MPLX_SHIM_MAP_PLANNER_H
 #define MPLX_SHIM_MAP_PLANNER_H
 #include <mpl_basis/trajectory.h>
 #include <mpl_collision/map_util.h>
+#include <mpl_planner/common/planner_base.h>
 
 #include <algorithm>
 
 namespace MPL {
 
+/// env_map<Dim>: the voxel / occupancy-map environment.  Its expansion IS the device's: get_succ runs the
+/// get_succ kernel for the one node (mplx_expand_batch), is_free asks the device map.
 template <int Dim>
-class MapPlanner {
+class env_map : public env_base<Dim> {
+ public:
+  env_map(const std::shared_ptr<MapUtil<Dim>> &map_util) : map_util_(map_util) {}
+  bool is_free(const Vecf<Dim> &pt) const override { return map_util_->isFree(map_util_->floatToInt(pt)); }
+  void get_succ(const Waypoint<Dim> &curr, vec_E<Waypoint<Dim>> &succ, std::vector<decimal_t> &succ_cost, std::vector<int> &action_idx) const override {
+    succ.clear(); succ_cost.clear(); action_idx.clear();
+    this->expanded_nodes_.push_back(curr.pos);
+    const int n_u = (int)this->U_.size();
+    if (n_u == 0) return;
+    mplx_waypoint c = mplx_waypoint();
+    for (int i = 0; i < Dim; i++) { c.pos[i] = curr.pos(i); c.vel[i] = curr.vel(i); c.acc[i] = curr.acc(i); c.jrk[i] = curr.jrk(i); }
+    c.t = curr.t;
+    c.control = (int32_t)curr.control & 15;
+    std::vector<mplx_succ> out((size_t)n_u);
+    if (mplx_expand_batch(map_util_->ctx(), 1, &c, out.data()) != MPLX_OK) {  // needs the planner set-up on the context: MapPlanner::plan / configure
+      printf(ANSI_COLOR_RED "[env_map] %s\n" ANSI_COLOR_RESET, mplx_last_error(map_util_->ctx()));
+      return;
+    }
+    for (int i = 0; i < n_u; i++) {
+      if (!out[(size_t)i].valid) continue;
+      Waypoint<Dim> tn(curr.control);
+      for (int k = 0; k < Dim; k++) { tn.pos(k) = out[i].wp.pos[k]; tn.vel(k) = out[i].wp.vel[k]; tn.acc(k) = out[i].wp.acc[k]; tn.jrk(k) = out[i].wp.jrk[k]; }
+      tn.t = out[i].wp.t;
+      succ.push_back(tn);
+      succ_cost.push_back(out[i].cost);
+      action_idx.push_back(i);
+    }
+  }
+
+ protected:
+  std::shared_ptr<MapUtil<Dim>> map_util_;
+};
+
+template <int Dim>
+class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
+  typedef PlannerBase<Dim, Waypoint<Dim>> Base;
+  using Base::planner_verbose_; using Base::traj_; using Base::traj_cost_; using Base::epsilon_; using Base::max_num_;
+  using Base::v_max_; using Base::a_max_; using Base::j_max_; using Base::dt_; using Base::w_; using Base::t_max_;
+  using Base::tol_pos_; using Base::tol_vel_; using Base::tol_acc_; using Base::heur_ignore_dynamics_;
+
  public:
   /// no HIP work here: planner objects may be constructed at static-initialisation time
-  MapPlanner(bool verbose) : planner_verbose_(verbose) {
+  MapPlanner(bool verbose) : Base(verbose) {
     if (planner_verbose_) printf(ANSI_COLOR_CYAN "[MapPlanner] PLANNER VERBOSE ON (mplx back-end)\n" ANSI_COLOR_RESET);
   }
-  void setMapUtil(const std::shared_ptr<MapUtil<Dim>> &map_util) { map_util_ = map_util; }
-  void setVmax(decimal_t v) { v_max_ = v; }
-  void setAmax(decimal_t a) { a_max_ = a; }
-  void setJmax(decimal_t j) { j_max_ = j; }
-  void setYawmax(decimal_t) {}  // yaw is not propagated by this back-end
-  void setDt(decimal_t dt) { dt_ = dt; }
-  void setW(decimal_t w) { w_ = w; }
-  void setEpsilon(decimal_t eps) { epsilon_ = eps; }
-  void setMaxNum(int num) { max_num_ = num; }
-  void setTmax(decimal_t t) { t_max_ = t; }
-  void setHeurIgnoreDynamics(bool ignore) { heur_ignore_dynamics_ = ignore; }
-  void setTol(decimal_t tol_pos, decimal_t tol_vel = -1, decimal_t tol_acc = -1) {
-    tol_pos_ = tol_pos; tol_vel_ = tol_vel; tol_acc_ = tol_acc;
+  void setMapUtil(const std::shared_ptr<MapUtil<Dim>> &map_util) {
+    map_util_ = map_util;
+    this->ENV_.reset(new env_map<Dim>(map_util));
+    this->apply_to_env();
   }
-  void setU(const vec_E<VecDf> &U) {
+  void setU(const vec_E<VecDf> &U) override {
+    Base::setU(U);
     U_.clear();
     for (const auto &u : U) {
       U_.push_back(u(0));
@@ -50,8 +85,14 @@ class MapPlanner {
   }
 
   /// bool PlannerBase::plan(start, goal)  (map_planner_node.cpp:187)
-  bool plan(const Waypoint<Dim> &start, const Waypoint<Dim> &goal) {
+  bool plan(const Waypoint<Dim> &start, const Waypoint<Dim> &goal) override {
     if (planner_verbose_) { start.print("Start:"); goal.print("Goal:"); }
+    traj_ = Trajectory<Dim>();
+    traj_cost_ = std::numeric_limits<decimal_t>::infinity();
+    if (this->unsupported_ || start.use_yaw || goal.use_yaw || start.enable_t) {  // never a silently different search
+      printf(ANSI_COLOR_RED "[MapPlanner] plan(): yaw (use_yaw / setYawmax / 4-component inputs) and time-keyed states are not supported by the mplx back-end\n" ANSI_COLOR_RESET);
+      return false;
+    }
     mplx_ctx *ctx = map_util_->ctx();
     mplx_config cfg;
     cfg.control = (int32_t)start.control & 15;
@@ -63,8 +104,6 @@ class MapPlanner {
     cfg.t_max = t_max_;
     cfg.max_expand = max_num_;
     cfg.heur_ignore_dynamics = heur_ignore_dynamics_ ? 1 : 0;
-    traj_ = Trajectory<Dim>();
-    traj_cost_ = std::numeric_limits<decimal_t>::infinity();
     mplx_set_record(ctx, record_cap_);  // expansion order for getExpandedNodes()
     control_ = (Control::Control)cfg.control;
     if (mplx_planner_config(ctx, &cfg) != MPLX_OK) { printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx)); return false; }
@@ -85,15 +124,13 @@ class MapPlanner {
     traj_ = Trajectory<Dim>(out);
     return true;
   }
-  Trajectory<Dim> getTraj() const { return traj_; }
-  decimal_t getTrajCost() const { return traj_cost_; }
   /// closed set / open set / expansion count (map_planner_node.cpp:192-196, map_replanner_node.cpp:79-94)
-  vec_Vecf<Dim> getCloseSet() const { return node_set(true); }
-  vec_Vecf<Dim> getOpenSet() const { return node_set(false); }
+  vec_Vecf<Dim> getCloseSet() const override { return node_set(true); }
+  vec_Vecf<Dim> getOpenSet() const override { return node_set(false); }
   size_t getExpandedNum() const { return (size_t)res_.n_expanded; }
   /// positions in expansion order = env_base::expanded_nodes_ (map_replanner_node.cpp:78-79,119); the first
   /// `setExpandedRecord(cap)` expansions are kept (default 1 << 20)
-  vec_Vecf<Dim> getExpandedNodes() const {
+  vec_Vecf<Dim> getExpandedNodes() const override {
     vec_Vecf<Dim> ps;
     std::vector<mplx_waypoint> coords;
     if (!nodes(coords)) return ps;
@@ -116,12 +153,28 @@ class MapPlanner {
       if (child[e] != last) { ps.push_back(pos_of(coords[(size_t)child[e]])); last = child[e]; }
     return ps;
   }
-  /// the primitive of every predecessor record: Primitive(parent state, U[action], dt)
-  /// (getAllPrimitives poly_map_replanner_node.cpp:184,234; blocked successors are never stored here, so
-  /// getValidPrimitives() is the same list; getExpandedEdges(), map_replanner_node.cpp:100-102, keeps the
-  /// edges that enter an expanded (closed) node)  [UNVERIFIED selection rules: upstream bodies not vendored]
-  vec_E<Primitive<Dim>> getAllPrimitives() const { return edge_primitives(false); }
+  /// the primitive of every predecessor record: Primitive(parent state, U[action], dt).  getValidPrimitives(): the
+  /// finite-cost records the device stores; getAllPrimitives() (poly_map_replanner_node.cpp:184,234) adds the blocked
+  /// ones (cost inf upstream), re-derived on request by mplx_result_blocked; getExpandedEdges()
+  /// (map_replanner_node.cpp:100-102) keeps the edges that enter an expanded (closed) node
+  /// [UNVERIFIED selection rules: upstream bodies not vendored]
   vec_E<Primitive<Dim>> getValidPrimitives() const { return edge_primitives(false); }
+  vec_E<Primitive<Dim>> getAllPrimitives() const {
+    vec_E<Primitive<Dim>> prs = edge_primitives(false);
+    uint64_t n = 0, n_all = 0;
+    if (mplx_result_blocked(map_util_->ctx(), nullptr, nullptr, 0, &n, &n_all) != MPLX_OK || n == 0) return prs;
+    std::vector<int32_t> parent((size_t)n), action((size_t)n);
+    if (mplx_result_blocked(map_util_->ctx(), parent.data(), action.data(), n, &n, &n_all) != MPLX_OK) return prs;
+    std::vector<mplx_waypoint> coords;
+    if (!nodes(coords)) return prs;
+    for (size_t e = 0; e < parent.size(); e++) prs.push_back(primitive_of(coords[(size_t)parent[e]], action[e]));
+    return prs;
+  }
+  /// hm_.size() as upstream counts it: states reached with finite cost + states only blocked primitives reach
+  size_t getStateSpaceSize() const {
+    uint64_t n = 0, n_all = 0;
+    return mplx_result_blocked(map_util_->ctx(), nullptr, nullptr, 0, &n, &n_all) == MPLX_OK ? (size_t)n_all : (size_t)res_.n_nodes;
+  }
   vec_E<Primitive<Dim>> getExpandedEdges() const { return edge_primitives(true); }
   const mplx_result &getResult() const { return res_; }
 
@@ -161,15 +214,17 @@ class MapPlanner {
     if (!nodes(coords, &closed) || !edges(child, parent, action)) return prs;
     for (size_t e = 0; e < child.size(); e++) {
       if (into_closed_only && !closed[(size_t)child[e]]) continue;
-      const mplx_waypoint &c = coords[(size_t)parent[e]];
-      Waypoint<Dim> w(control_);
-      for (int k = 0; k < Dim; k++) { w.pos(k) = c.pos[k]; w.vel(k) = c.vel[k]; w.acc(k) = c.acc[k]; w.jrk(k) = c.jrk[k]; }
-      w.t = c.t;
-      VecDf u(Dim);
-      for (int k = 0; k < Dim; k++) u(k) = U_[3 * (size_t)action[e] + k];
-      prs.push_back(Primitive<Dim>(w, u, dt_));
+      prs.push_back(primitive_of(coords[(size_t)parent[e]], action[e]));
     }
     return prs;
+  }
+  Primitive<Dim> primitive_of(const mplx_waypoint &c, int32_t action) const {
+    Waypoint<Dim> w(control_);
+    for (int k = 0; k < Dim; k++) { w.pos(k) = c.pos[k]; w.vel(k) = c.vel[k]; w.acc(k) = c.acc[k]; w.jrk(k) = c.jrk[k]; }
+    w.t = c.t;
+    VecDf u(Dim);
+    for (int k = 0; k < Dim; k++) u(k) = U_[3 * (size_t)action + k];
+    return Primitive<Dim>(w, u, dt_);
   }
   vec_Vecf<Dim> node_set(bool closed_set) const {
     vec_Vecf<Dim> ps;
@@ -189,13 +244,6 @@ class MapPlanner {
   }
   std::shared_ptr<MapUtil<Dim>> map_util_;
   std::vector<double> U_;
-  bool planner_verbose_;
-  decimal_t v_max_ = -1, a_max_ = -1, j_max_ = -1, dt_ = 1.0, w_ = 10, epsilon_ = 1.0;
-  decimal_t tol_pos_ = 0.5, tol_vel_ = -1, tol_acc_ = -1, t_max_ = std::numeric_limits<decimal_t>::infinity();
-  int max_num_ = -1;
-  bool heur_ignore_dynamics_ = false;
-  Trajectory<Dim> traj_;
-  decimal_t traj_cost_ = std::numeric_limits<decimal_t>::infinity();
   mplx_result res_ = mplx_result();
   Control::Control control_ = Control::ACC;
   uint32_t record_cap_ = 1u << 20;

@@ -95,8 +95,9 @@ typedef struct {
   double cost;         /* getTrajCost(); +inf when no trajectory */
   uint64_t n_expanded; /* get_succ calls == expanded_nodes_.size() */
   uint64_t n_closed;   /* getCloseSet().size() */
-  uint64_t n_nodes;    /* states created in the state space (hm_.size()) */
-  uint64_t n_edges;    /* predecessor records stored */
+  uint64_t n_nodes;    /* states reached with finite cost (upstream's hm_.size() also counts states only blocked
+                          primitives reach: mplx_result_blocked) */
+  uint64_t n_edges;    /* predecessor records with finite cost (n_succ - n_succ_finite more have cost inf upstream) */
   uint64_t n_primitives, n_succ, n_succ_finite;
   uint64_t voxel_reads;
   uint64_t n_push, n_reopen;
@@ -195,6 +196,15 @@ int mplx_result_nodes(mplx_ctx *ctx, mplx_waypoint *coords, double *g, double *h
  * arrival order (the order of the reference's push_back): child / parent are node ids, action indexes U (edge cost = J(U[action]) + w dt).
  * Arrays sized mplx_result.n_edges (NULLs allowed); *n = number of edges of the state space. */
 int mplx_result_edges(mplx_ctx *ctx, int32_t *child, int32_t *parent, int32_t *action, uint64_t cap, uint64_t *n);
+
+/* Blocked primitives of the LAST single mplx_plan().  The reference's GraphSearch gives EVERY successor get_succ
+ * returns an hm_ entry and a pred_coord / pred_action_id / pred_action_cost entry, also the ones whose cost is +inf
+ * (is_free(pr) failed; the successor is still emitted: env_poly_map.h:60-66), so upstream's getAllPrimitives()
+ * contains them and hm_.size() counts the states only they reach.  The device search stores only what can be
+ * relaxed (mplx_result.n_nodes / n_edges count finite arrivals); this call re-derives the rest on request with one
+ * get_succ launch over the closed nodes.  parent / action: one entry per blocked primitive (parents in node-id
+ * order); *n = their number (may exceed cap); *n_states_all = hm_.size() as upstream counts it. */
+int mplx_result_blocked(mplx_ctx *ctx, int32_t *parent, int32_t *action, uint64_t cap, uint64_t *n, uint64_t *n_states_all);
 
 /* ---- VoxelGrid (planning_ros_utils/src/mapping_utils/voxel_grid.cpp, the mapper in front of the planner:
  *      map_replanner_node.cpp:17,181,218,329-331, cloud_to_map.cpp:11-12).  Device-resident; same

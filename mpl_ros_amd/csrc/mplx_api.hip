@@ -1053,6 +1053,75 @@ extern "C" int mplx_result_nodes(mplx_ctx *c, mplx_waypoint *coords, double *g, 
   return MPLX_OK;
 }
 
+// Successors with cost +inf of the LAST single mplx_plan(): the reference's GraphSearch gives every successor
+// get_succ returns an hm_ entry and a pred_* entry, also the blocked ones (cost inf, env_poly_map.h:60-66); the
+// device search keeps only what can be relaxed.  get_succ is a pure function of (node, U, dt, limits, map), so the
+// blocked primitives are re-derived here on request -- one expand launch over the closed nodes -- instead of being
+// stored on the hot path.  parent / action: one entry per blocked primitive, parents in node-id order, actions
+// ascending; *n_states_all = hm_.size() as upstream counts it (states reached with finite cost + states that only
+// blocked primitives reach).  Needs the map and the planner set-up of that plan to be still in place.
+extern "C" int mplx_result_blocked(mplx_ctx *c, int32_t *parent, int32_t *action, uint64_t cap, uint64_t *n_out, uint64_t *n_states_all) {
+  if (!c || !c->last_single || !c->pools_valid || !n_out) return fail(c, MPLX_ERR_ARG, "blocked-primitive dump needs a preceding single mplx_plan()");
+  if (c->last_control != c->cfg.control || c->last_dt != c->cfg.dt || c->last_U != c->U)
+    return fail(c, MPLX_ERR_ARG, "the planner was re-configured since the plan: blocked primitives cannot be re-derived");
+  const size_t n = c->last_out[0].n_nodes;
+  *n_out = 0;
+  if (n_states_all) *n_states_all = n;
+  if (n == 0) return MPLX_OK;
+  std::vector<mplx_waypoint> coords(n);
+  std::vector<int32_t> closed(n);
+  int r = mplx_result_nodes(c, coords.data(), nullptr, nullptr, closed.data(), nullptr);
+  if (r) return r;
+  const int control = c->last_control, nk = state_len(control), n_u = c->cfg.n_u;
+  auto key_of = [&](const mplx_waypoint &w) {
+    State st;
+    mplx_waypoint ww = w;
+    ww.control = control;
+    wp_to_state(ww, st);
+    int32_t k[MAX_KEY];
+    state_key(control, st, k);
+    std::string s((const char *)k, sizeof(int32_t) * (size_t)nk);
+    return s;
+  };
+  std::vector<std::string> keys(n);
+  for (size_t i = 0; i < n; i++) keys[i] = key_of(coords[i]);
+  std::vector<std::string> sorted_keys = keys;
+  std::sort(sorted_keys.begin(), sorted_keys.end());
+  std::vector<int32_t> ids;
+  for (size_t i = 0; i < n; i++)
+    if (closed[i]) ids.push_back((int32_t)i);
+  std::vector<std::string> only_blocked;
+  uint64_t w = 0;
+  const size_t CH = 8192;
+  std::vector<mplx_waypoint> batch;
+  std::vector<mplx_succ> succ;
+  for (size_t base = 0; base < ids.size(); base += CH) {
+    const size_t cnt = std::min(CH, ids.size() - base);
+    batch.resize(cnt);
+    for (size_t k = 0; k < cnt; k++) batch[k] = coords[ids[base + k]];
+    succ.resize(cnt * (size_t)n_u);
+    r = mplx_expand_batch(c, (int)cnt, batch.data(), succ.data());
+    if (r) return r;
+    for (size_t k = 0; k < cnt; k++)
+      for (int a = 0; a < n_u; a++) {
+        const mplx_succ &sc = succ[k * (size_t)n_u + a];
+        if (!sc.valid || !std::isinf(sc.cost)) continue;
+        if (w < cap) {
+          if (parent) parent[w] = ids[base + k];
+          if (action) action[w] = a;
+        }
+        w++;
+        std::string ks((const char *)sc.key, sizeof(int32_t) * (size_t)nk);
+        if (!std::binary_search(sorted_keys.begin(), sorted_keys.end(), ks)) only_blocked.push_back(ks);
+      }
+  }
+  std::sort(only_blocked.begin(), only_blocked.end());
+  only_blocked.erase(std::unique(only_blocked.begin(), only_blocked.end()), only_blocked.end());
+  *n_out = w;
+  if (n_states_all) *n_states_all = n + only_blocked.size();
+  return MPLX_OK;
+}
+
 extern "C" int mplx_result_timing(mplx_ctx *c, int q, double *t_begin_s, double *t_end_s, int32_t *slot) {
   if (!c || q < 0 || q >= c->last_nq) return fail(c, MPLX_ERR_ARG, "no such query");
   // wall_clock64() ticks at 100 MHz on gfx950; times are relative to the first query start of the batch

@@ -527,11 +527,18 @@ class VoxelMapPlanner:
         ctx.check(ctx.lib.mplx_result_edges(ctx.h, child.ctypes.data, parent.ctypes.data, action.ctypes.data, n, C.byref(m)))
         return child[:m.value], parent[:m.value], action[:m.value]
 
-    def getAllPrimitives(self):
-        """PlannerBase::getAllPrimitives (poly_map_replanner_node.cpp:184,234): the primitive of every edge
-        of the state space, Primitive(parent state, U[action], dt)."""
-        coords, _, _, _, _, _ = self._nodes()
-        child, parent, action = self.getEdges()
+    def getBlockedEdges(self):
+        """(parent id, action) of every successor get_succ emitted with cost inf during the last plan() -- the
+        inf-cost pred entries of upstream's state space -- and hm_.size() as upstream counts it."""
+        ctx = self._own_results()
+        n = C.c_uint64(0)
+        tot = C.c_uint64(0)
+        ctx.check(ctx.lib.mplx_result_blocked(ctx.h, None, None, 0, C.byref(n), C.byref(tot)))
+        parent = np.zeros(max(n.value, 1), dtype=np.int32); action = np.zeros(max(n.value, 1), dtype=np.int32)
+        ctx.check(ctx.lib.mplx_result_blocked(ctx.h, parent.ctypes.data, action.ctypes.data, n.value, C.byref(n), C.byref(tot)))
+        return parent[:n.value], action[:n.value], int(tot.value)
+
+    def _primitives(self, coords, parent, action):
         prs = []
         for p, a in zip(parent, action):
             w = coords[int(p)]
@@ -545,6 +552,21 @@ class VoxelMapPlanner:
                 if self._control >= SNP: co[ax, 1] = self._U[a][ax]
             prs.append(Primitive3D(co, self._dt, self._control))
         return prs
+
+    def getValidPrimitives(self):
+        """PlannerBase::getValidPrimitives: the primitive of every finite-cost pred entry of the state space,
+        Primitive(parent state, U[action], dt)."""
+        coords, _, _, _, _, _ = self._nodes()
+        _, parent, action = self.getEdges()
+        return self._primitives(coords, parent, action)
+
+    def getAllPrimitives(self):
+        """PlannerBase::getAllPrimitives (poly_map_replanner_node.cpp:184,234): every pred entry of the state
+        space, the blocked (cost inf) ones included -- those are re-derived on request (mplx_result_blocked)."""
+        coords, _, _, _, _, _ = self._nodes()
+        _, parent, action = self.getEdges()
+        bp, ba, _ = self.getBlockedEdges()
+        return self._primitives(coords, np.concatenate([parent, bp]), np.concatenate([action, ba]))
 
     def getExpandedNodes(self):
         """Positions in expansion order (env_base::expanded_nodes_); needs setRecord()."""

@@ -83,3 +83,25 @@ def test_reference_driver_through_the_shim(tmp_path, skir):
         w = P.node(int(par))[0]
         end_sum += U[act][0] / 2 * 1.0 * 1.0 + w.vel[0] * 1.0 + w.pos[0]
     assert abs(viz["prs_end_sum"] - end_sum) < 1e-6 * max(1.0, abs(end_sum))
+
+
+REF_POLY = "/root/reference/mpl_external_planner/include"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_POLY), reason="reference tree not present (GPU box)")
+def test_reference_planner_headers_compile_unchanged_against_the_shim(tmp_path):
+    """SURVEY.md 8(b): env_base / PlannerBase / StateSpace / Primitive::J,max_vel / validate_primitive / solve() --
+    the reference's own env_poly_map.h + poly_map_planner.h + poly_map_util.h + primitive_geometry_utils.h +
+    simple_obstacle.h are compiled from where they lie, unchanged, against include/mpl_shim (DecompUtil's
+    polyhedron.h is a labelled stand-in).  plan() through a host environment must refuse (no CPU search here)."""
+    exe = str(tmp_path / "ref_headers_compile")
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mpl_shim"),
+                           "-I" + REF_POLY, "-o", exe, os.path.join(ROOT, "tests", "cpp", "ref_headers_compile.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0
+    assert "no CPU search" in out.stdout
+    last = out.stdout.strip().splitlines()[-1]
+    r = json.loads(last[last.index("{"):])  # (the refusal message ends in an ANSI colour reset on the same line)
+    # start (4,0) v (1,0), u = U[5] = (0,1) for dt 0.5: analytic known answers
+    assert r["polys"] == 2 and r["planned"] == 0 and r["collide_static"] == 1
+    assert r["J_acc"] == 0.5 and abs(r["J_vel"] - (1.0 * 0.5 + 0.5 ** 3 / 3)) < 1e-15 and r["max_vel_x"] == 1.0 and r["valid"] == 1

@@ -388,3 +388,26 @@ def test_two_planners_on_one_map_util_do_not_read_each_others_results():
     assert a.getResult().n_expanded == ra
     tb = a.getTraj()
     assert np.array_equal(ta.actions, tb.actions) and tb.segs[0].t() == 1.0 if tb.segs else True
+
+
+@pytest.mark.parametrize("control", [orc.ACC, orc.JRK])
+def test_blocked_primitives_and_hm_size_match_upstream_accounting(control):
+    """Upstream stores an hm_ entry and an inf-cost pred entry for every blocked successor (env_poly_map.h:60-66
+    emits it).  The device keeps only finite arrivals and re-derives the rest on request: the set of (parent,
+    action) pairs, the hm_.size() they imply and getAllPrimitives must equal the oracle's accounting (D7)."""
+    grid, origin, res = util.small_map(48, seed=3, occupancy=0.12)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = dict(v_max=2.0, a_max=1.0, max_expand=700)
+    if control == orc.JRK:
+        kw["j_max"] = 1.0
+    P = util.make_oracle(grid, origin, res, control, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    start = ((1.05, 1.05, 1.05), (0, 0, 0), (0, 0, 0)) if control == orc.JRK else ((1.05, 1.05, 1.05), (0, 0, 0))
+    r, c = util.compare_plan(P, pl, start, ((3.55, 3.55, 3.05),), control)
+    po, ao = P.blocked_edges()
+    pg, ag, n_all = pl.getBlockedEdges()
+    assert len(pg) == c["n_succ"] - c["n_succ_finite"] == len(po) > 0
+    assert sorted(zip(pg.tolist(), ag.tolist())) == sorted(zip(po.tolist(), ao.tolist()))
+    assert n_all == P.num_states_all() > r.n_nodes
+    assert len(pl.getAllPrimitives()) == r.n_edges + len(pg) and len(pl.getValidPrimitives()) == r.n_edges
