@@ -232,6 +232,36 @@ int mplx_grid_get_cloud(mplx_grid *g, double *pts, uint64_t cap, uint64_t *n);  
  * map_replanner_node.cpp:186-188,224-226, without the host round trip) */
 int mplx_grid_to_map(mplx_grid *g, int inflated, mplx_ctx *ctx);
 
+/* ---- moving-obstacle environment: env_poly_map / PolyMapUtil / collide() of
+ *      mpl_external_planner/include/mpl_external_planner/poly_map_planner/ (env_poly_map.h:45-73, poly_map_util.h:72-109,
+ *      primitive_geometry_utils.h:5-173, simple_obstacle.h), 2-D like the multi-robot node.  One object holds several
+ *      WORLDS -- what one robot's planner sees: bounding box, start time, static / linear / nonlinear obstacles -- so
+ *      that the 16 planners of a decentralised tick (robot_team.hpp:33-66) run in one launch.  VEL / ACC control. ---- */
+typedef struct mplx_poly mplx_poly;
+typedef struct {
+  double state[9];     /* tn: pos2 vel2 acc2 jrk2, t = curr.t + dt (enable_t, env_poly_map.h:63-64) */
+  double cost;         /* calculate_intrinsic_cost(pr) = J(control) + 0.001 J(VEL) + w dt, or +inf when isFree(pr, t) fails */
+  int32_t action;      /* index into U */
+  int32_t valid;       /* 0: skipped (end point outside the bounding box, or validate_primitive failed) */
+} mplx_poly_succ;
+int mplx_poly_create(int device, mplx_poly **out);
+void mplx_poly_destroy(mplx_poly *p);
+const char *mplx_poly_last_error(const mplx_poly *p);
+/* planner set-up: control kind (MPLX_VEL / MPLX_ACC), control inputs U (n_u x 2), dt, limits, time weight w */
+int mplx_poly_config(mplx_poly *p, int32_t control, int32_t n_u, const double *U, double dt, double v_max, double a_max, double j_max, double w);
+/* (re)build the worlds: begin(n), set_world + add_* per world, commit() uploads them */
+int mplx_poly_begin(mplx_poly *p, int32_t n_worlds);
+int mplx_poly_set_world(mplx_poly *p, int32_t world, const double ori[2], const double dim[2], double start_t); /* setMap + setStartTime, poly_map_planner.h:30-36 */
+/* hp: n_hp x {px, py, nx, ny} = Hyperplane2D(p, n) of the obstacle's Polyhedron2D; pt: representative point */
+int mplx_poly_add_static(mplx_poly *p, int32_t world, int32_t n_hp, const double *hp, const double pt[2]);                            /* PolyhedronObstacle */
+int mplx_poly_add_linear(mplx_poly *p, int32_t world, int32_t n_hp, const double *hp, const double pt[2], const double v[2], double cov_v); /* PolyhedronLinearObstacle */
+/* segs: n_seg x {cx[6], cy[6], T} primitives of the obstacle's trajectory; start_t, disappear_front/back: simple_obstacle.h:122-160 */
+int mplx_poly_add_nonlinear(mplx_poly *p, int32_t world, int32_t n_hp, const double *hp, int32_t n_seg, const double *segs, double start_t, int32_t dis_front, int32_t dis_back);
+int mplx_poly_commit(mplx_poly *p);
+/* env_poly_map::get_succ for K nodes in one launch; node k (state: pos2 vel2 acc2 jrk2 t) lives in world world_of[k].
+ * out: K x n_u records, record [k * n_u + i] belongs to control input i */
+int mplx_poly_get_succ_batch(mplx_poly *p, int32_t K, const int32_t *world_of, const double *states, mplx_poly_succ *out);
+
 /* ---- measurement ---- */
 /* device-clock begin / end (seconds since the first query of the batch started) and workgroup of query q */
 int mplx_result_timing(mplx_ctx *ctx, int q, double *t_begin_s, double *t_end_s, int32_t *slot);

@@ -58,7 +58,13 @@ EXPORTS = [
     "mplx_grid_create", "mplx_grid_destroy", "mplx_grid_last_error", "mplx_grid_allocate", "mplx_grid_info", "mplx_grid_clear",
     "mplx_grid_add_cloud", "mplx_grid_add_cloud_inflate", "mplx_grid_decay", "mplx_grid_clear_column", "mplx_grid_fill_column",
     "mplx_grid_fill_cell", "mplx_grid_get_map", "mplx_grid_get_cloud", "mplx_grid_to_map",
+    "mplx_poly_create", "mplx_poly_destroy", "mplx_poly_last_error", "mplx_poly_config", "mplx_poly_begin", "mplx_poly_set_world",
+    "mplx_poly_add_static", "mplx_poly_add_linear", "mplx_poly_add_nonlinear", "mplx_poly_commit", "mplx_poly_get_succ_batch",
 ]
+
+
+class PolySucc(C.Structure):
+    _fields_ = [("state", C.c_double * 9), ("cost", C.c_double), ("action", C.c_int32), ("valid", C.c_int32)]
 
 _lib = None
 
@@ -137,5 +143,19 @@ def load():
     L.mplx_grid_get_map.argtypes = [G, C.c_int, C.c_void_p]
     L.mplx_grid_get_cloud.argtypes = [G, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.mplx_grid_to_map.argtypes = [G, C.c_int, P]
+    D2 = C.POINTER(C.c_double)
+    L.mplx_poly_create.argtypes = [C.c_int, C.POINTER(P)]
+    L.mplx_poly_destroy.argtypes = [P]
+    L.mplx_poly_destroy.restype = None
+    L.mplx_poly_last_error.argtypes = [P]
+    L.mplx_poly_last_error.restype = C.c_char_p
+    L.mplx_poly_config.argtypes = [P, C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.mplx_poly_begin.argtypes = [P, C.c_int32]
+    L.mplx_poly_set_world.argtypes = [P, C.c_int32, D2, D2, C.c_double]
+    L.mplx_poly_add_static.argtypes = [P, C.c_int32, C.c_int32, C.c_void_p, D2]
+    L.mplx_poly_add_linear.argtypes = [P, C.c_int32, C.c_int32, C.c_void_p, D2, D2, C.c_double]
+    L.mplx_poly_add_nonlinear.argtypes = [P, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_int32, C.c_int32]
+    L.mplx_poly_commit.argtypes = [P]
+    L.mplx_poly_get_succ_batch.argtypes = [P, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(PolySucc)]
     _lib = L
     return L

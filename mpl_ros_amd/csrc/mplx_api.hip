@@ -16,6 +16,7 @@
 
 #define MPLX_UTILITY_KERNELS
 #include "mplx_kernels.h"
+#include "mplx_poly_dev.h"
 
 using namespace mplx;
 
@@ -1146,3 +1147,4 @@ extern "C" int mplx_last_kernel_ms(const mplx_ctx *c, float *ms) {
   return MPLX_OK;
 }
 #include "mplx_grid.inl"
+#include "mplx_poly.inl"

@@ -1,0 +1,287 @@
+// mplx_poly.inl -- host side + kernels of the moving-obstacle (PolyMap) environment (C-ABI mplx_poly_*, include/mplx.h).
+// Included by mplx_api.hip.  Device arithmetic: mplx_poly_dev.h.
+
+namespace mplx {
+
+// One successor of env_poly_map::get_succ (mirrors mplx_poly_succ)
+struct PolySuccOut {
+  double state[9];  // pos2 vel2 acc2 jrk2 t
+  double cost;      // intrinsic cost, or +inf when PolyMapUtil::isFree(pr, t) fails
+  int32_t action, valid;
+};
+
+// env_poly_map::get_succ for K nodes: one workgroup per node.  Lane i < n_u builds primitive i (end state, bounding
+// box, validate_primitive, intrinsic cost); then the (primitive, obstacle) pairs are spread over the lanes -- every
+// pair is one collide() -- and the start-point test isFree(start.pos, t) over the obstacles; results are OR-ed in LDS.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void poly_get_succ_kernel(PolyDev D, int K, const int32_t *world_of, const double *states, PolySuccOut *out, int32_t *flags) {
+  __shared__ double cs[POLY_MAX_U][2][6];
+  __shared__ int32_t valid[POLY_MAX_U], hit[POLY_MAX_U];
+  __shared__ int32_t start_hit, unsupported;
+  const int tid = threadIdx.x;
+  for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    const double *st = states + 9 * (size_t)k;
+    const PolyWorld W = D.worlds[world_of[k]];
+    const double T = D.dt, t_rel = st[8] - W.start_t;
+    if (tid == 0) { start_hit = 0; unsupported = 0; }
+    if (tid < D.n_u) {
+      const double pos[2] = {st[0], st[1]}, vel[2] = {st[2], st[3]}, u[2] = {D.U[2 * tid], D.U[2 * tid + 1]};
+      double c[2][6];
+      poly_prim_build(D.control, pos, vel, u, c);
+      for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 6; j++) cs[tid][i][j] = c[i][j];
+      const double ex = pp_p(c[0], T), ey = pp_p(c[1], T);
+      valid[tid] = (poly_inside(W.bbox, 4, ex, ey) && poly_validate(D.control, c, T, D.v_max)) ? 1 : 0;
+      hit[tid] = 0;
+    }
+    __syncthreads();
+    // isFree(start.pos, t): start = pr.evaluate(0) = the node position for every primitive
+    for (int j = tid; j < W.n_obs; j += BLOCK)
+      if (obs_point_hits(D, D.obs[W.obs_off + j], pp_p(cs[0][0], 0.0), pp_p(cs[0][1], 0.0), t_rel)) start_hit = 1;
+    const int pairs = D.n_u * W.n_obs;
+    for (int e = tid; e < pairs; e += BLOCK) {
+      const int i = e / W.n_obs, j = e % W.n_obs;
+      if (!valid[i]) continue;
+      double c[2][6];
+      for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 6; b++) c[a][b] = cs[i][a][b];
+      const int r = obs_prim_hits(D, c, T, D.obs[W.obs_off + j], t_rel);
+      if (r < 0) unsupported = 1;
+      if (r > 0) hit[i] = 1;
+    }
+    __syncthreads();
+    if (tid < D.n_u) {
+      PolySuccOut &o = out[(size_t)k * D.n_u + tid];
+      double c[2][6];
+      for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 6; b++) c[a][b] = cs[tid][a][b];
+      o.state[0] = pp_p(c[0], T); o.state[1] = pp_p(c[1], T);
+      o.state[2] = pp_v(c[0], T); o.state[3] = pp_v(c[1], T);
+      o.state[4] = pp_a(c[0], T); o.state[5] = pp_a(c[1], T);
+      o.state[6] = pp_j(c[0], T); o.state[7] = pp_j(c[1], T);
+      o.state[8] = st[8] + D.dt;
+      o.action = tid;
+      o.valid = valid[tid];
+      o.cost = (start_hit || hit[tid]) ? INFINITY : poly_intrinsic_cost(D.control, c, T, D.w, D.dt);
+    }
+    if (tid == 0 && unsupported) atomicOr(flags, 1);
+    __syncthreads();
+  }
+}
+
+}  // namespace mplx
+
+struct mplx_poly {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // configuration
+  bool have_cfg = false;
+  int control = 0, n_u = 0;
+  double dt = 1, v_max = -1, a_max = -1, j_max = -1, w = 10;
+  std::vector<double> U;
+  // worlds being assembled on the host
+  std::vector<mplx::PolyHP> hps;
+  std::vector<mplx::PolySeg> segs;
+  std::vector<mplx::PolyObs> obs;       // grouped by world at commit
+  std::vector<int> obs_world;
+  std::vector<mplx::PolyWorld> worlds;
+  bool committed = false;
+  // device copies
+  mplx::PolyHP *d_hps = nullptr;
+  mplx::PolySeg *d_segs = nullptr;
+  mplx::PolyObs *d_obs = nullptr;
+  mplx::PolyWorld *d_worlds = nullptr;
+  double *d_U = nullptr;
+};
+
+static int pfail(mplx_poly *p, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (p) p->err = buf; else g_create_error = buf;
+  return code;
+}
+#define PCHK(p, call)                                                                           \
+  do {                                                                                          \
+    hipError_t e__ = (call);                                                                    \
+    if (e__ != hipSuccess) return pfail((p), MPLX_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
+  } while (0)
+
+extern "C" int mplx_poly_create(int device, mplx_poly **out) {
+  if (!out) return pfail(nullptr, MPLX_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return pfail(nullptr, MPLX_ERR_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+  if (device < 0 || device >= n) return pfail(nullptr, MPLX_ERR_ARG, "device %d out of range", device);
+  mplx_poly *p = new mplx_poly();
+  p->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&p->stream) != hipSuccess) {
+    delete p;
+    return pfail(nullptr, MPLX_ERR_HIP, "stream creation failed");
+  }
+  *out = p;
+  return MPLX_OK;
+}
+static void poly_free_dev(mplx_poly *p) {
+  (void)hipFree(p->d_hps); (void)hipFree(p->d_segs); (void)hipFree(p->d_obs); (void)hipFree(p->d_worlds);
+  p->d_hps = nullptr; p->d_segs = nullptr; p->d_obs = nullptr; p->d_worlds = nullptr;
+  p->committed = false;
+}
+extern "C" void mplx_poly_destroy(mplx_poly *p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  (void)hipStreamSynchronize(p->stream);
+  poly_free_dev(p);
+  (void)hipFree(p->d_U);
+  (void)hipStreamDestroy(p->stream);
+  delete p;
+}
+extern "C" const char *mplx_poly_last_error(const mplx_poly *p) { return p ? p->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int mplx_poly_config(mplx_poly *p, int32_t control, int32_t n_u, const double *U, double dt, double v_max, double a_max, double j_max, double w) {
+  if (!p || !U) return pfail(p, MPLX_ERR_ARG, "null argument");
+  if (!(control == CTRL_VEL || control == CTRL_ACC)) return pfail(p, MPLX_ERR_ARG, "the moving-obstacle environment supports VEL / ACC control (hyperplane equations up to degree 2), got %d", control);
+  if (n_u <= 0 || n_u > POLY_MAX_U) return pfail(p, MPLX_ERR_ARG, "n_u must be in [1,%d]", POLY_MAX_U);
+  if (!(dt > 0)) return pfail(p, MPLX_ERR_ARG, "dt must be > 0");
+  PCHK(p, hipSetDevice(p->device));
+  p->control = control; p->n_u = n_u; p->dt = dt; p->v_max = v_max; p->a_max = a_max; p->j_max = j_max; p->w = w;
+  p->U.assign(U, U + 2 * (size_t)n_u);
+  (void)hipFree(p->d_U);
+  p->d_U = nullptr;
+  PCHK(p, hipMalloc((void **)&p->d_U, sizeof(double) * 2 * (size_t)n_u));
+  PCHK(p, hipMemcpyAsync(p->d_U, p->U.data(), sizeof(double) * 2 * (size_t)n_u, hipMemcpyHostToDevice, p->stream));
+  PCHK(p, hipStreamSynchronize(p->stream));
+  p->have_cfg = true;
+  return MPLX_OK;
+}
+
+extern "C" int mplx_poly_begin(mplx_poly *p, int32_t n_worlds) {
+  if (!p || n_worlds <= 0) return pfail(p, MPLX_ERR_ARG, "bad argument");
+  p->hps.clear(); p->segs.clear(); p->obs.clear(); p->obs_world.clear();
+  p->worlds.assign((size_t)n_worlds, mplx::PolyWorld());
+  p->committed = false;
+  return MPLX_OK;
+}
+// PolyMapUtil::setBoundingBox (poly_map_util.h:40-50) + setStartTime (:19)
+extern "C" int mplx_poly_set_world(mplx_poly *p, int32_t world, const double ori[2], const double dim[2], double start_t) {
+  if (!p || world < 0 || world >= (int)p->worlds.size() || !ori || !dim) return pfail(p, MPLX_ERR_ARG, "bad argument");
+  mplx::PolyWorld &W = p->worlds[(size_t)world];
+  W.start_t = start_t;
+  W.bbox[0] = mplx::PolyHP{ori[0] + 0.0, ori[1] + dim[1] / 2, -1.0, -0.0};
+  W.bbox[1] = mplx::PolyHP{ori[0] + dim[0] / 2, ori[1] + 0.0, -0.0, -1.0};
+  W.bbox[2] = mplx::PolyHP{(ori[0] + dim[0]) - 0.0, (ori[1] + dim[1]) - dim[1] / 2, 1.0, 0.0};
+  W.bbox[3] = mplx::PolyHP{(ori[0] + dim[0]) - dim[0] / 2, (ori[1] + dim[1]) - 0.0, 0.0, 1.0};
+  return MPLX_OK;
+}
+static int poly_add(mplx_poly *p, int32_t world, int kind, int n_hp, const double *hp, mplx::PolyObs &o) {
+  if (!p || world < 0 || world >= (int)p->worlds.size() || n_hp <= 0 || !hp) return pfail(p, MPLX_ERR_ARG, "bad argument");
+  o.kind = kind;
+  o.hp_off = (int32_t)p->hps.size();
+  o.n_hp = n_hp;
+  for (int i = 0; i < n_hp; i++) p->hps.push_back(mplx::PolyHP{hp[4 * i], hp[4 * i + 1], hp[4 * i + 2], hp[4 * i + 3]});
+  p->obs.push_back(o);
+  p->obs_world.push_back(world);
+  p->committed = false;
+  return MPLX_OK;
+}
+extern "C" int mplx_poly_add_static(mplx_poly *p, int32_t world, int32_t n_hp, const double *hp, const double pt[2]) {
+  mplx::PolyObs o = mplx::PolyObs();
+  if (pt) { o.p[0] = pt[0]; o.p[1] = pt[1]; }
+  return poly_add(p, world, 0, n_hp, hp, o);
+}
+extern "C" int mplx_poly_add_linear(mplx_poly *p, int32_t world, int32_t n_hp, const double *hp, const double pt[2], const double v[2], double cov_v) {
+  if (!pt || !v) return pfail(p, MPLX_ERR_ARG, "null argument");
+  mplx::PolyObs o = mplx::PolyObs();
+  o.p[0] = pt[0]; o.p[1] = pt[1]; o.v[0] = v[0]; o.v[1] = v[1]; o.cov_v = cov_v;
+  return poly_add(p, world, 1, n_hp, hp, o);
+}
+extern "C" int mplx_poly_add_nonlinear(mplx_poly *p, int32_t world, int32_t n_hp, const double *hp, int32_t n_seg, const double *segs, double start_t, int32_t dis_front, int32_t dis_back) {
+  if (!p || n_seg < 0 || (n_seg > 0 && !segs)) return pfail(p, MPLX_ERR_ARG, "bad argument");
+  mplx::PolyObs o = mplx::PolyObs();
+  o.seg_off = (int32_t)p->segs.size();
+  o.n_seg = n_seg;
+  double total = 0.0;
+  for (int i = 0; i < n_seg; i++) {
+    mplx::PolySeg s;
+    for (int k = 0; k < 6; k++) { s.c[0][k] = segs[13 * i + k]; s.c[1][k] = segs[13 * i + 6 + k]; }
+    for (int ax = 0; ax < 2; ax++)
+      if (s.c[ax][0] != 0 || s.c[ax][1] != 0 || s.c[ax][2] != 0) return pfail(p, MPLX_ERR_ARG, "obstacle trajectories must be VEL / ACC primitives (c0 = c1 = c2 = 0)");
+    s.T = segs[13 * i + 12];
+    total = s.T + total;  // Trajectory: taus.push_back(pr.t() + taus.back())
+    p->segs.push_back(s);
+  }
+  o.total_t = total;
+  o.start_t = start_t;
+  o.dis_front = dis_front ? 1 : 0;
+  o.dis_back = dis_back ? 1 : 0;
+  // representative point p_ = traj.evaluate(start_t).pos (simple_obstacle.h:126); not used by the collision tests
+  return poly_add(p, world, 2, n_hp, hp, o);
+}
+extern "C" int mplx_poly_commit(mplx_poly *p) {
+  if (!p || p->worlds.empty()) return pfail(p, MPLX_ERR_ARG, "mplx_poly_begin first");
+  PCHK(p, hipSetDevice(p->device));
+  // group the obstacles by world, keeping the order they were added in (static, linear, nonlinear as the caller adds them)
+  std::vector<mplx::PolyObs> grouped;
+  for (size_t w = 0; w < p->worlds.size(); w++) {
+    p->worlds[w].obs_off = (int32_t)grouped.size();
+    for (size_t i = 0; i < p->obs.size(); i++)
+      if (p->obs_world[i] == (int)w) grouped.push_back(p->obs[i]);
+    p->worlds[w].n_obs = (int32_t)grouped.size() - p->worlds[w].obs_off;
+  }
+  poly_free_dev(p);
+  auto up = [&](auto **d, const auto &v) -> hipError_t {
+    using T = typename std::remove_reference<decltype(v)>::type::value_type;
+    const size_t bytes = sizeof(T) * std::max<size_t>(v.size(), 1);
+    hipError_t e = hipMalloc((void **)d, bytes);
+    if (e == hipSuccess && !v.empty()) e = hipMemcpyAsync(*d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice, p->stream);
+    return e;
+  };
+  PCHK(p, up(&p->d_hps, p->hps));
+  PCHK(p, up(&p->d_segs, p->segs));
+  PCHK(p, up(&p->d_obs, grouped));
+  PCHK(p, up(&p->d_worlds, p->worlds));
+  PCHK(p, hipStreamSynchronize(p->stream));
+  p->committed = true;
+  return MPLX_OK;
+}
+static mplx::PolyDev poly_dev(const mplx_poly *p) {
+  mplx::PolyDev D;
+  D.hps = p->d_hps; D.segs = p->d_segs; D.obs = p->d_obs; D.worlds = p->d_worlds;
+  D.control = p->control; D.n_u = p->n_u; D.U = p->d_U;
+  D.dt = p->dt; D.v_max = p->v_max; D.a_max = p->a_max; D.j_max = p->j_max; D.w = p->w;
+  return D;
+}
+static_assert(sizeof(mplx::PolySuccOut) == sizeof(mplx_poly_succ), "PolySuccOut must mirror mplx_poly_succ");
+
+extern "C" int mplx_poly_get_succ_batch(mplx_poly *p, int32_t K, const int32_t *world_of, const double *states, mplx_poly_succ *out) {
+  if (!p || K <= 0 || !world_of || !states || !out) return pfail(p, MPLX_ERR_ARG, "bad argument");
+  if (!p->have_cfg) return pfail(p, MPLX_ERR_ARG, "mplx_poly_config first");
+  if (!p->committed) return pfail(p, MPLX_ERR_ARG, "mplx_poly_commit first");
+  for (int k = 0; k < K; k++)
+    if (world_of[k] < 0 || world_of[k] >= (int)p->worlds.size()) return pfail(p, MPLX_ERR_ARG, "world index out of range");
+  PCHK(p, hipSetDevice(p->device));
+  DevBufs bufs;
+  int32_t *dw = nullptr, *dflags = nullptr;
+  double *ds = nullptr;
+  mplx::PolySuccOut *dout = nullptr;
+  const size_t no = (size_t)K * p->n_u;
+  PCHK(p, bufs.alloc(&dw, sizeof(int32_t) * K));
+  PCHK(p, bufs.alloc(&ds, sizeof(double) * 9 * K));
+  PCHK(p, bufs.alloc(&dout, sizeof(mplx::PolySuccOut) * no));
+  PCHK(p, bufs.alloc(&dflags, sizeof(int32_t)));
+  PCHK(p, hipMemcpyAsync(dw, world_of, sizeof(int32_t) * K, hipMemcpyHostToDevice, p->stream));
+  PCHK(p, hipMemcpyAsync(ds, states, sizeof(double) * 9 * K, hipMemcpyHostToDevice, p->stream));
+  PCHK(p, hipMemsetAsync(dflags, 0, sizeof(int32_t), p->stream));
+  hipLaunchKernelGGL((mplx::poly_get_succ_kernel<256>), dim3(K < 4096 ? K : 4096), dim3(256), 0, p->stream, poly_dev(p), K, dw, ds, dout, dflags);
+  PCHK(p, hipGetLastError());
+  int32_t flags = 0;
+  PCHK(p, hipMemcpyAsync(out, dout, sizeof(mplx::PolySuccOut) * no, hipMemcpyDeviceToHost, p->stream));
+  PCHK(p, hipMemcpyAsync(&flags, dflags, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
+  PCHK(p, hipStreamSynchronize(p->stream));
+  if (flags & 1) return pfail(p, MPLX_ERR_ARG, "a hyperplane equation of degree > 2 was met (JRK / SNP trajectories are not supported by the moving-obstacle environment)");
+  return MPLX_OK;
+}

@@ -1,0 +1,96 @@
+"""Host mirror of the reference's moving-obstacle (PolyMap) planner interface over the C-ABI (mplx_poly_*).
+
+Names follow mpl_external_planner/include/mpl_external_planner/poly_map_planner/ (poly_map_planner.h:18-60,
+simple_obstacle.h): a `PolyWorld` is what ONE PolyMapPlanner2D sees -- setMap(ori, dim), setStartTime,
+setStaticObstacles / setLinearObstacles / setNonlinearObstacles -- and a `PolyTeam` holds the worlds of all robots of
+a decentralised tick (robot_team.hpp:33-66) so that their expansions run in one launch.  No compute happens here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import MplxError
+
+VEL, ACC = _capi.VEL, _capi.ACC
+
+
+def rectangle(hx, hy=None):
+    """Polyhedron2D of an axis-aligned box with half sizes (hx, hy) around the origin, hyperplanes in the order of
+    multi_robot_node.cpp:65-69: rows {px, py, nx, ny}."""
+    hy = hx if hy is None else hy
+    return np.array([[-hx, 0, -1, -0.0], [hx, 0, 1, 0], [0, -hy, -0.0, -1], [0, hy, 0, 1]], dtype=np.float64)
+
+
+class StaticObstacle:          # PolyhedronObstacle2D(poly, p)
+    def __init__(self, poly, p):
+        self.poly, self.p = np.ascontiguousarray(poly, dtype=np.float64).reshape(-1, 4), np.array(p, dtype=np.float64)
+
+
+class LinearObstacle:          # PolyhedronLinearObstacle2D(poly, p, v) + set_cov_v
+    def __init__(self, poly, p, v, cov_v=0.0):
+        self.poly, self.p, self.v, self.cov_v = np.ascontiguousarray(poly, dtype=np.float64).reshape(-1, 4), np.array(p, float), np.array(v, float), float(cov_v)
+
+
+class NonlinearObstacle:       # PolyhedronNonlinearObstacle2D(poly, traj, t) + disappear_front_/back_
+    def __init__(self, poly, segs, start_t, disappear_front=False, disappear_back=False):
+        """segs: rows {cx[6], cy[6], T} -- the primitives of the obstacle's trajectory"""
+        self.poly = np.ascontiguousarray(poly, dtype=np.float64).reshape(-1, 4)
+        self.segs = np.ascontiguousarray(segs, dtype=np.float64).reshape(-1, 13)
+        self.start_t, self.disappear_front, self.disappear_back = float(start_t), bool(disappear_front), bool(disappear_back)
+
+
+class PolyWorld:
+    def __init__(self, ori, dim, start_t=0.0):
+        self.ori, self.dim, self.start_t = np.array(ori, float), np.array(dim, float), float(start_t)
+        self.static, self.linear, self.nonlinear = [], [], []
+
+
+class PolyTeam:
+    """The worlds of several planners on the device + the shared planner set-up (setVmax/setAmax/setDt/setU/setW)."""
+
+    def __init__(self, device=0):
+        self.lib = _capi.load()
+        self.h = C.c_void_p()
+        code = self.lib.mplx_poly_create(device, C.byref(self.h))
+        if code != _capi.OK:
+            raise MplxError(self.lib.mplx_poly_last_error(None).decode())
+        self.n_u = 0
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.mplx_poly_destroy(self.h)
+        except Exception:
+            pass
+
+    def check(self, code):
+        if code != _capi.OK:
+            raise MplxError(self.lib.mplx_poly_last_error(self.h).decode())
+
+    def configure(self, control, U, dt, v_max=-1.0, a_max=-1.0, j_max=-1.0, w=10.0):
+        U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, 2)
+        self.n_u = U.shape[0]
+        self.check(self.lib.mplx_poly_config(self.h, int(control), self.n_u, U.ctypes.data, float(dt), float(v_max), float(a_max), float(j_max), float(w)))
+
+    def set_worlds(self, worlds):
+        self.check(self.lib.mplx_poly_begin(self.h, len(worlds)))
+        D2 = C.c_double * 2
+        for i, W in enumerate(worlds):
+            self.check(self.lib.mplx_poly_set_world(self.h, i, D2(*W.ori), D2(*W.dim), W.start_t))
+            for o in W.static:
+                self.check(self.lib.mplx_poly_add_static(self.h, i, len(o.poly), o.poly.ctypes.data, D2(*o.p)))
+            for o in W.linear:
+                self.check(self.lib.mplx_poly_add_linear(self.h, i, len(o.poly), o.poly.ctypes.data, D2(*o.p), D2(*o.v), o.cov_v))
+            for o in W.nonlinear:
+                self.check(self.lib.mplx_poly_add_nonlinear(self.h, i, len(o.poly), o.poly.ctypes.data, len(o.segs), o.segs.ctypes.data,
+                                                            o.start_t, int(o.disappear_front), int(o.disappear_back)))
+        self.check(self.lib.mplx_poly_commit(self.h))
+
+    def get_succ_batch(self, world_of, states):
+        """env_poly_map::get_succ for K nodes: states K x 9 (pos2 vel2 acc2 jrk2 t); returns K x n_u records."""
+        w = np.ascontiguousarray(world_of, dtype=np.int32)
+        s = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 9)
+        out = (_capi.PolySucc * (len(w) * self.n_u))()
+        self.check(self.lib.mplx_poly_get_succ_batch(self.h, len(w), w.ctypes.data, s.ctypes.data, out))
+        return out

@@ -1,0 +1,226 @@
+// oracle/_ref/libpolymap_ref.so -- the reference's OWN moving-obstacle environment, compiled from where it lies.
+//
+// TEST INFRASTRUCTURE ONLY (see oracle/mpl_oracle.h).  The PolyMap planner is the one search environment whose
+// arithmetic is vendored in the reference tree:
+//   mpl_external_planner/include/mpl_external_planner/poly_map_planner/env_poly_map.h      (get_succ, intrinsic cost)
+//   .../poly_map_planner/poly_map_util.h                                                   (isInside, isFree(pt,t), isFree(pr,t))
+//   .../poly_map_planner/primitive_geometry_utils.h                                        (the three collide())
+//   .../poly_map_planner/simple_obstacle.h                                                 (static / linear / nonlinear obstacles)
+// This file only wraps them in a C interface; `make -C oracle ref` compiles it against those headers (never copied)
+// and against stand-ins for what they include from un-vendored submodules: mpl_basis / mpl_planner (include/mpl_shim)
+// and DecompUtil's polyhedron.h (include/mpl_shim/decomp_geometry, labelled UNVERIFIED).  2-D, like the
+// multi-robot configuration (multi_robot_node.cpp).  A best-first search over this environment is added below so
+// that whole plans can be checked too: GraphSearch itself is NOT vendored, so that loop is the same restatement
+// as oracle/mpl_oracle.c's orc_plan (same order, same tie-breaking), only templated over the reference's get_succ.
+#include <mpl_external_planner/poly_map_planner/poly_map_planner.h>
+
+#include <cstring>
+#include <map>
+#include <queue>
+
+namespace {
+struct Ref {
+  std::shared_ptr<PolyMapUtil<2>> map_util;
+  std::shared_ptr<MPL::env_poly_map<2>> env;
+  vec_E<PolyhedronObstacle2D> st;
+  vec_E<PolyhedronLinearObstacle2D> lin;
+  vec_E<PolyhedronNonlinearObstacle2D> nl;
+};
+Polyhedron2D poly_of(int n_hp, const double *hp) {
+  Polyhedron2D p;
+  for (int i = 0; i < n_hp; i++) p.add(Hyperplane2D(Vec2f(hp[4 * i], hp[4 * i + 1]), Vec2f(hp[4 * i + 2], hp[4 * i + 3])));
+  return p;
+}
+Waypoint2D wp_of(const double *s /* pos2 vel2 acc2 jrk2 t */, int control) {
+  Waypoint2D w((Control::Control)control);
+  w.pos = Vec2f(s[0], s[1]); w.vel = Vec2f(s[2], s[3]); w.acc = Vec2f(s[4], s[5]); w.jrk = Vec2f(s[6], s[7]);
+  w.t = s[8];
+  return w;
+}
+void wp_to(const Waypoint2D &w, double *s) {
+  s[0] = w.pos(0); s[1] = w.pos(1); s[2] = w.vel(0); s[3] = w.vel(1); s[4] = w.acc(0); s[5] = w.acc(1); s[6] = w.jrk(0); s[7] = w.jrk(1);
+  s[8] = w.t;
+}
+void sync(Ref *r) {
+  r->map_util->setStaticObstacle(r->st);
+  r->map_util->setLinearObstacle(r->lin);
+  r->map_util->setNonlinearObstacle(r->nl);
+}
+}  // namespace
+
+extern "C" {
+void *refpoly_create(double ox, double oy, double dx, double dy) {
+  Ref *r = new Ref();
+  r->map_util.reset(new PolyMapUtil<2>());
+  r->map_util->setBoundingBox(Vec2f(ox, oy), Vec2f(dx, dy));
+  r->env.reset(new MPL::env_poly_map<2>(r->map_util));
+  return r;
+}
+void refpoly_destroy(void *h) { delete (Ref *)h; }
+void refpoly_set_start_time(void *h, double t) { ((Ref *)h)->map_util->setStartTime(t); }
+void refpoly_clear_obstacles(void *h) { Ref *r = (Ref *)h; r->st.clear(); r->lin.clear(); r->nl.clear(); sync(r); }
+// hp: n_hp x {px, py, nx, ny}
+void refpoly_add_static(void *h, int n_hp, const double *hp, double px, double py) {
+  Ref *r = (Ref *)h;
+  r->st.push_back(PolyhedronObstacle2D(poly_of(n_hp, hp), Vec2f(px, py)));
+  sync(r);
+}
+void refpoly_add_linear(void *h, int n_hp, const double *hp, double px, double py, double vx, double vy, double cov_v) {
+  Ref *r = (Ref *)h;
+  PolyhedronLinearObstacle2D o(poly_of(n_hp, hp), Vec2f(px, py), Vec2f(vx, vy));
+  o.set_cov_v(cov_v);
+  r->lin.push_back(o);
+  sync(r);
+}
+// segs: n_seg x {cx[6], cy[6], T}; the obstacle follows that trajectory from its local time start_t on
+void refpoly_add_nonlinear(void *h, int n_hp, const double *hp, int n_seg, const double *segs, int control, double start_t, int dis_front, int dis_back) {
+  Ref *r = (Ref *)h;
+  vec_E<Primitive2D> prs;
+  for (int i = 0; i < n_seg; i++) {
+    vec_E<Vec6f> cs(2);
+    for (int k = 0; k < 6; k++) { cs[0](k) = segs[13 * i + k]; cs[1](k) = segs[13 * i + 6 + k]; }
+    prs.push_back(Primitive2D(cs, segs[13 * i + 12], (Control::Control)control));
+  }
+  PolyhedronNonlinearObstacle2D o(poly_of(n_hp, hp), Trajectory2D(prs), start_t);
+  o.disappear_front_ = dis_front != 0;
+  o.disappear_back_ = dis_back != 0;
+  r->nl.push_back(o);
+  sync(r);
+}
+void refpoly_set_env(void *h, int n_u, const double *U, double dt, double v_max, double a_max, double j_max, double w) {
+  Ref *r = (Ref *)h;
+  vec_E<VecDf> Us;
+  for (int i = 0; i < n_u; i++) Us.push_back(Vec2f(U[2 * i], U[2 * i + 1]));
+  r->env->set_u(Us);
+  r->env->set_dt(dt); r->env->set_v_max(v_max); r->env->set_a_max(a_max); r->env->set_j_max(j_max); r->env->set_w(w);
+}
+int refpoly_is_inside(void *h, double x, double y) { return ((Ref *)h)->map_util->isInside(Vec2f(x, y)) ? 1 : 0; }
+int refpoly_is_free_point(void *h, double x, double y, double t) { return ((Ref *)h)->map_util->isFree(Vec2f(x, y), t) ? 1 : 0; }
+// env_poly_map::get_succ: state = pos2 vel2 acc2 jrk2 t; out arrays sized n_u (succ: n x 9); returns the number emitted
+int refpoly_get_succ(void *h, const double *state, int control, double *succ, double *cost, int *action) {
+  Ref *r = (Ref *)h;
+  vec_E<Waypoint2D> s;
+  std::vector<decimal_t> c;
+  std::vector<int> a;
+  r->env->get_succ(wp_of(state, control), s, c, a);
+  for (size_t i = 0; i < s.size(); i++) { wp_to(s[i], succ + 9 * i); cost[i] = c[i]; action[i] = a[i]; }
+  return (int)s.size();
+}
+
+// ---- best-first search over the reference environment (GraphSearch::Astar restated, see the header comment).
+// Total order of OPEN: (f, g, creation id); goal test after the expansion; max_expand then empty-OPEN.
+// heur: w * |dp|_inf / v_max (heur_ignore_dynamics form; v_max <= 0: w * |dp|_inf) -- the time-keyed PolyMap states
+// use the distance bound (the dynamics-aware closed forms are pinned elsewhere), is_goal: |dp|_inf <= tol_pos.
+struct PNode { Waypoint2D coord; double g, h; int closed, opened; std::vector<int> pred, pact; std::vector<double> pcost; };
+static std::vector<int> g_exp, g_traj_nodes, g_traj_act;
+static std::vector<PNode> g_nodes;
+static double g_cost;
+int refpoly_plan(void *h, const double *start, const double *goal, int control, double eps, double tol_pos, int max_expand, int heur_mode) {
+  Ref *r = (Ref *)h;
+  g_nodes.clear(); g_exp.clear(); g_traj_nodes.clear(); g_traj_act.clear();
+  g_cost = std::numeric_limits<double>::infinity();
+  Waypoint2D s = wp_of(start, control), g = wp_of(goal, control);
+  s.enable_t = true;  // env_poly_map keys its successors with time (env_poly_map.h:64)
+  if (!r->map_util->isFree(s.pos, s.t)) return 2;
+  const double v_max = r->env->v_max_, w = r->env->w_;
+  auto heur = [&](const Waypoint2D &x) {
+    const double d = std::max(std::fabs(x.pos(0) - g.pos(0)), std::fabs(x.pos(1) - g.pos(1)));
+    (void)heur_mode;
+    return v_max > 0 ? w * d / v_max : w * d;
+  };
+  auto is_goal = [&](const Waypoint2D &x) { return std::max(std::fabs(x.pos(0) - g.pos(0)), std::fabs(x.pos(1) - g.pos(1))) <= tol_pos; };
+  if (is_goal(s)) { g_cost = 0; return 0; }
+  std::map<std::vector<int>, int> table;
+  auto less = [&](int a, int b) {  // a after b in the queue?
+    const double fa = g_nodes[a].g + eps * g_nodes[a].h, fb = g_nodes[b].g + eps * g_nodes[b].h;
+    if (fa != fb) return fa > fb;
+    if (g_nodes[a].g != g_nodes[b].g) return g_nodes[a].g > g_nodes[b].g;
+    return a > b;
+  };
+  // lazy-deletion heap keyed by (f, g, id) snapshots: stale entries are skipped at pop time
+  struct E { double f, g; int id; };
+  auto ecmp = [](const E &a, const E &b) { if (a.f != b.f) return a.f > b.f; if (a.g != b.g) return a.g > b.g; return a.id > b.id; };
+  std::priority_queue<E, std::vector<E>, decltype(ecmp)> open(ecmp);
+  (void)less;
+  g_nodes.push_back(PNode{s, 0.0, eps == 0 ? 0.0 : heur(s), 0, 1, {}, {}, {}});
+  table[s.key()] = 0;
+  open.push(E{eps * g_nodes[0].h, 0.0, 0});
+  int status = 0, curr = -1, it = 0;
+  vec_E<Waypoint2D> succ;
+  std::vector<decimal_t> cost;
+  std::vector<int> act;
+  for (;;) {
+    for (;;) {  // pop the smallest live entry
+      if (open.empty()) { curr = -1; break; }
+      const E e = open.top();
+      open.pop();
+      if (g_nodes[e.id].closed || g_nodes[e.id].g != e.g) continue;
+      curr = e.id;
+      break;
+    }
+    if (curr < 0) { status = 1; break; }
+    it++;
+    g_nodes[curr].closed = 1;
+    g_exp.push_back(curr);
+    const Waypoint2D cw = g_nodes[curr].coord;
+    r->env->get_succ(cw, succ, cost, act);
+    for (size_t k = 0; k < succ.size(); k++) {
+      if (std::isinf(cost[k])) continue;  // (deviation D7 of oracle/mpl_oracle.h: blocked successors are not materialised)
+      Waypoint2D tn = succ[k];
+      tn.control = cw.control;
+      const auto key = tn.key();
+      int id;
+      auto f = table.find(key);
+      if (f == table.end()) {
+        id = (int)g_nodes.size();
+        g_nodes.push_back(PNode{tn, std::numeric_limits<double>::infinity(), eps == 0 ? 0.0 : heur(tn), 0, 0, {}, {}, {}});
+        table[key] = id;
+      } else {
+        id = f->second;
+      }
+      g_nodes[id].pred.push_back(curr); g_nodes[id].pact.push_back(act[k]); g_nodes[id].pcost.push_back(cost[k]);
+      const double tg = g_nodes[curr].g + cost[k];
+      if (tg < g_nodes[id].g) {
+        g_nodes[id].g = tg;
+        g_nodes[id].closed = 0;  // (re-open: deviation D6)
+        g_nodes[id].opened = 1;
+        open.push(E{tg + eps * g_nodes[id].h, tg, id});
+      }
+    }
+    if (is_goal(g_nodes[curr].coord)) break;
+    if (max_expand > 0 && it >= max_expand) { status = 3; break; }
+  }
+  if (status != 0) return status;
+  // recoverTraj: minimise g(pred) + cost, ties -> larger g(pred), then the oldest record
+  int node = curr;
+  g_traj_nodes.push_back(node);
+  while (!g_nodes[node].pred.empty()) {
+    int best = -1;
+    double min_rhs = std::numeric_limits<double>::infinity(), min_g = std::numeric_limits<double>::infinity();
+    for (size_t e = 0; e < g_nodes[node].pred.size(); e++) {
+      const double gp = g_nodes[g_nodes[node].pred[e]].g, rhs = gp + g_nodes[node].pcost[e];
+      if (min_rhs > rhs) { min_rhs = rhs; min_g = gp; best = (int)e; }
+      else if (min_rhs == rhs && min_g < gp) { min_g = gp; best = (int)e; }
+    }
+    if (best < 0) return 1;
+    g_traj_act.push_back(g_nodes[node].pact[best]);
+    node = g_nodes[node].pred[best];
+    g_traj_nodes.push_back(node);
+    if (node == 0) break;
+  }
+  g_cost = g_nodes[curr].g;
+  return 0;
+}
+int refpoly_num_expanded() { return (int)g_exp.size(); }
+int refpoly_num_nodes() { return (int)g_nodes.size(); }
+double refpoly_traj_cost() { return g_cost; }
+int refpoly_traj_len() { return (int)g_traj_act.size(); }
+// expansion order (node ids), path (goal -> start order reversed to start -> goal), node states
+void refpoly_get_expanded(int *ids) { for (size_t i = 0; i < g_exp.size(); i++) ids[i] = g_exp[i]; }
+void refpoly_get_traj(int *node_ids, int *actions) {
+  const size_t n = g_traj_act.size();
+  for (size_t i = 0; i <= n && !g_traj_nodes.empty(); i++) node_ids[i] = g_traj_nodes[n - i];
+  for (size_t i = 0; i < n; i++) actions[i] = g_traj_act[n - 1 - i];
+}
+void refpoly_get_node(int id, double *state, double *g, double *hh) { wp_to(g_nodes[id].coord, state); *g = g_nodes[id].g; *hh = g_nodes[id].h; }
+}

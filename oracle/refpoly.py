@@ -1,0 +1,91 @@
+"""ctypes binding of oracle/_ref/libpolymap_ref.so: the reference's own env_poly_map / PolyMapUtil / collide()
+compiled from where they lie (oracle/ref_stubs/poly_map_ref_api.cpp, `make -C oracle ref`).
+TEST INFRASTRUCTURE ONLY -- see oracle/mpl_oracle.h."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_ref", "libpolymap_ref.so")
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(LIB_PATH)
+        P, D = C.c_void_p, C.c_double
+        L.refpoly_create.restype = P
+        L.refpoly_create.argtypes = [D, D, D, D]
+        L.refpoly_destroy.argtypes = [P]
+        L.refpoly_set_start_time.argtypes = [P, D]
+        L.refpoly_clear_obstacles.argtypes = [P]
+        L.refpoly_add_static.argtypes = [P, C.c_int, C.c_void_p, D, D]
+        L.refpoly_add_linear.argtypes = [P, C.c_int, C.c_void_p, D, D, D, D, D]
+        L.refpoly_add_nonlinear.argtypes = [P, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, D, C.c_int, C.c_int]
+        L.refpoly_set_env.argtypes = [P, C.c_int, C.c_void_p, D, D, D, D, D]
+        L.refpoly_is_inside.argtypes = [P, D, D]
+        L.refpoly_is_free_point.argtypes = [P, D, D, D]
+        L.refpoly_get_succ.argtypes = [P, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.refpoly_plan.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int, D, D, C.c_int, C.c_int]
+        L.refpoly_traj_cost.restype = D
+        L.refpoly_get_expanded.argtypes = [C.c_void_p]
+        L.refpoly_get_traj.argtypes = [C.c_void_p, C.c_void_p]
+        L.refpoly_get_node.argtypes = [C.c_int, C.c_void_p, C.POINTER(D), C.POINTER(D)]
+        _lib = L
+    return _lib
+
+
+class RefWorld:
+    """One reference PolyMapUtil<2> + env_poly_map<2>, filled from a mpl_ros_amd.poly_map.PolyWorld."""
+
+    def __init__(self, world, control, U, dt, v_max=-1.0, a_max=-1.0, j_max=-1.0, w=10.0):
+        L = lib()
+        self.L, self.control = L, int(control)
+        self.h = L.refpoly_create(float(world.ori[0]), float(world.ori[1]), float(world.dim[0]), float(world.dim[1]))
+        L.refpoly_set_start_time(self.h, world.start_t)
+        for o in world.static:
+            L.refpoly_add_static(self.h, len(o.poly), o.poly.ctypes.data, float(o.p[0]), float(o.p[1]))
+        for o in world.linear:
+            L.refpoly_add_linear(self.h, len(o.poly), o.poly.ctypes.data, float(o.p[0]), float(o.p[1]), float(o.v[0]), float(o.v[1]), o.cov_v)
+        for o in world.nonlinear:
+            L.refpoly_add_nonlinear(self.h, len(o.poly), o.poly.ctypes.data, len(o.segs), o.segs.ctypes.data, self.control, o.start_t,
+                                    int(o.disappear_front), int(o.disappear_back))
+        self.U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, 2)
+        L.refpoly_set_env(self.h, len(self.U), self.U.ctypes.data, float(dt), float(v_max), float(a_max), float(j_max), float(w))
+
+    def __del__(self):
+        try:
+            self.L.refpoly_destroy(self.h)
+        except Exception:
+            pass
+
+    def get_succ(self, state):
+        s = np.ascontiguousarray(state, dtype=np.float64)
+        n = len(self.U)
+        succ = np.zeros((n, 9)); cost = np.zeros(n); act = np.zeros(n, dtype=np.int32)
+        k = self.L.refpoly_get_succ(self.h, s.ctypes.data, self.control, succ.ctypes.data, cost.ctypes.data, act.ctypes.data)
+        return succ[:k], cost[:k], act[:k]
+
+    def plan(self, start, goal, eps=1.0, tol_pos=0.5, max_expand=-1):
+        s = np.ascontiguousarray(start, dtype=np.float64); g = np.ascontiguousarray(goal, dtype=np.float64)
+        st = self.L.refpoly_plan(self.h, s.ctypes.data, g.ctypes.data, self.control, float(eps), float(tol_pos), int(max_expand), 0)
+        ne, nl = self.L.refpoly_num_expanded(), self.L.refpoly_traj_len()
+        ids = np.zeros(max(ne, 1), dtype=np.int32)
+        self.L.refpoly_get_expanded(ids.ctypes.data)
+        tn = np.zeros(nl + 1, dtype=np.int32); ta = np.zeros(max(nl, 1), dtype=np.int32)
+        if st == 0 and nl:
+            self.L.refpoly_get_traj(tn.ctypes.data, ta.ctypes.data)
+        return dict(status=st, expanded=ids[:ne], n_nodes=self.L.refpoly_num_nodes(), cost=self.L.refpoly_traj_cost(), actions=ta[:nl], node_ids=tn[:nl + 1] if nl else tn[:0])
+
+    def node(self, i):
+        s = np.zeros(9); g = C.c_double(); h = C.c_double()
+        self.L.refpoly_get_node(int(i), s.ctypes.data, C.byref(g), C.byref(h))
+        return s, g.value, h.value

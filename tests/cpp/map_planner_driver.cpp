@@ -85,6 +85,12 @@ int main(int argc, char **argv) {
 
   bool valid = planner_ptr->plan(start, goal);
   auto traj = planner_ptr->getTraj();
+  // map_planner_node.cpp:210-214, verbatim
+  printf(
+      "Raw traj -- J(VEL): %f, J(ACC): %f, J(JRK): %f, J(SNP): %f, J(YAW): "
+      "%f, total time: %f\n",
+      traj.J(Control::VEL), traj.J(Control::ACC), traj.J(Control::JRK),
+      traj.J(Control::SNP), traj.Jyaw(), traj.getTotalTime());
   // the replanner's visualisation getters (map_replanner_node.cpp:78-102)
   const size_t n_expanded_nodes = planner_ptr->getExpandedNodes().size(), n_linked = planner_ptr->getLinkedNodes().size();
   const auto all_prs = planner_ptr->getAllPrimitives();

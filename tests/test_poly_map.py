@@ -1,0 +1,156 @@
+"""Moving-obstacle (PolyMap) environment, SURVEY.md 8 f1 / BASELINE config 5.
+
+The checker here is the REFERENCE ITSELF: oracle/_ref/libpolymap_ref.so is the reference's env_poly_map.h +
+poly_map_util.h + primitive_geometry_utils.h + simple_obstacle.h compiled from where they lie (the un-vendored
+basis classes and DecompUtil's polyhedron come from include/mpl_shim).  -m gpu: the HIP kernels
+(mplx_poly_get_succ_batch) against it, bit-exact, on random worlds and on the Team2 layout of robot_team.hpp."""
+import numpy as np
+import pytest
+
+from mpl_ros_amd import poly_map as pm
+from oracle import refpoly
+
+needs_ref = pytest.mark.skipif(not refpoly.available(), reason="oracle/_ref/libpolymap_ref.so not built (make -C oracle ref)")
+
+U9 = np.array([(dx, dy) for dx in (-1.0, 0.0, 1.0) for dy in (-1.0, 0.0, 1.0)])  # multi_robot_node.cpp:56-59, u = 1, num = 1
+
+
+def acc_segs(p0, v0, us, dt):
+    """Trajectory of ACC primitives from (p0, v0) under the inputs `us`: rows {cx[6], cy[6], T}."""
+    p, v = np.array(p0, float), np.array(v0, float)
+    rows = []
+    for u in us:
+        u = np.array(u, float)
+        rows.append([0, 0, 0, u[0], v[0], p[0], 0, 0, 0, u[1], v[1], p[1], dt])
+        p = u / 2 * dt * dt + v * dt + p
+        v = u * dt + v
+    return np.array(rows)
+
+
+def random_world(rng, n_static=2, n_linear=2, n_nonlinear=3, dt=0.5):
+    W = pm.PolyWorld((0.0, -5.0), (10.0, 10.0), start_t=float(rng.choice([0.0, 0.5, 1.25])))
+    for _ in range(n_static):
+        W.static.append(pm.StaticObstacle(pm.rectangle(float(rng.uniform(0.3, 1.0)), float(rng.uniform(0.3, 1.0))), rng.uniform((1, -4), (9, 4))))
+    for _ in range(n_linear):
+        W.linear.append(pm.LinearObstacle(pm.rectangle(0.5), rng.uniform((1, -4), (9, 4)), rng.uniform(-1, 1, 2), cov_v=float(rng.choice([0.0, 0.1]))))
+    for _ in range(n_nonlinear):
+        n = int(rng.integers(1, 7))
+        us = U9[rng.integers(0, 9, n)]
+        segs = acc_segs(rng.uniform((1, -4), (9, 4)), np.round(rng.uniform(-1, 1, 2), 1), us, dt)
+        W.nonlinear.append(pm.NonlinearObstacle(pm.rectangle(0.5), segs, start_t=float(rng.choice([0.0, 0.3, -0.5, 2.0])),
+                                                disappear_front=bool(rng.integers(0, 2)), disappear_back=bool(rng.integers(0, 2))))
+    return W
+
+
+def random_states(rng, n, dt=0.5):
+    s = np.zeros((n, 9))
+    s[:, 0:2] = np.round(rng.uniform((0.2, -4.8), (9.8, 4.8), (n, 2)), 2)
+    s[:, 2:4] = np.round(rng.uniform(-2, 2, (n, 2)), 1)
+    s[:, 8] = rng.integers(0, 8, n) * dt
+    s[: n // 8, 0:2] = np.round(s[: n // 8, 0:2])  # lattice points: hyperplane-boundary cases
+    return s
+
+
+@needs_ref
+def test_reference_environment_known_answers():
+    """The compiled reference on hand-checkable cases (pins the stand-ins it was compiled against)."""
+    W = pm.PolyWorld((0.0, -5.0), (10.0, 10.0))
+    W.static.append(pm.StaticObstacle(pm.rectangle(1.0), (5.0, 0.0)))  # box [4,6] x [-1,1]
+    R = refpoly.RefWorld(W, pm.ACC, U9, dt=1.0, v_max=2.0, a_max=1.0, w=10.0)
+    succ, cost, act = R.get_succ([2.0, 0.0, 1.0, 0.0, 0, 0, 0, 0, 0.0])  # moving +x at 1 m/s towards the box
+    by_act = dict(zip(act.tolist(), zip(succ, cost)))
+    # u = (0, 0): ends at x = 3 (free, cost J_acc 0 + 0.001 * J_vel 1 + w dt 10); u = (1, 0): ends at 3.5, free
+    assert by_act[4][0][0] == 3.0 and by_act[4][1] == 0.0 + 0.001 * 1.0 + 10.0
+    assert np.isfinite(by_act[7][1])
+    s2, c2, a2 = R.get_succ([3.5, 0.0, 1.0, 0.0, 0, 0, 0, 0, 0.0])  # 0.5 m before the box: every primitive enters it
+    assert np.isinf(dict(zip(a2.tolist(), c2))[4]) and np.isinf(dict(zip(a2.tolist(), c2))[7])
+    s3, c3, a3 = R.get_succ([0.2, 0.0, -1.0, 0.0, 0, 0, 0, 0, 0.0])  # leaves the bounding box for u_x <= 0
+    assert 4 not in a3.tolist() and 1 not in a3.tolist()
+    assert len(R.get_succ([9.0, 4.0, 2.0, 0.0, 0, 0, 0, 0, 0.0])[2]) < 9  # v_max: u_x = 1 would exceed 2 m/s
+
+
+def _compare_get_succ(team, worlds, refs, world_of, states, n_u):
+    out = team.get_succ_batch(world_of, states)
+    n_inf = n_fin = 0
+    for k, (w, s) in enumerate(zip(world_of, states)):
+        succ, cost, act = refs[w].get_succ(s)
+        got = [out[k * n_u + i] for i in range(n_u)]
+        gv = [g for g in got if g.valid]
+        assert [g.action for g in gv] == act.tolist(), (k, w)
+        for g, so, co in zip(gv, succ, cost):
+            assert np.array_equal(np.array(g.state[:]), so), (k, g.action)        # bit-exact f64
+            assert g.cost == co or (np.isinf(g.cost) and np.isinf(co)), (k, g.action, g.cost, co)
+            n_inf += int(np.isinf(co)); n_fin += int(np.isfinite(co))
+    return n_fin, n_inf
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("seed", range(4))
+def test_get_succ_matches_the_compiled_reference_on_random_worlds(seed):
+    rng = np.random.default_rng(100 + seed)
+    dt = 0.5
+    worlds = [random_world(rng, dt=dt) for _ in range(6)]
+    team = pm.PolyTeam()
+    kw = dict(dt=dt, v_max=2.0, a_max=1.0, w=10.0)
+    team.configure(pm.ACC, U9, **kw)
+    team.set_worlds(worlds)
+    refs = [refpoly.RefWorld(W, pm.ACC, U9, **kw) for W in worlds]
+    K = 600
+    world_of = rng.integers(0, len(worlds), K)
+    states = random_states(rng, K, dt)
+    n_fin, n_inf = _compare_get_succ(team, worlds, refs, world_of, states, 9)
+    assert n_fin > 500 and n_inf > 300  # both outcomes are exercised
+
+
+def team2_worlds(t_now, trajs, traj_t, dt, traj_time=0.0):
+    """HomogeneousRobotTeam::set_obs (robot_team.hpp:33-51) for Team2: robot i sees the static box and the other
+    robots as nonlinear obstacles following their current trajectories (robot.hpp:156-170)."""
+    rec = pm.rectangle(0.5)
+    box = np.array([[4, 0, -1, -0.0], [6, 0, 1, 0], [5, -1, -0.0, -1], [5, 1, 0, 1]], dtype=np.float64)  # robot_team.hpp:383-388
+    worlds = []
+    for i in range(len(trajs)):
+        W = pm.PolyWorld((0.0, -5.0), (10.0, 10.0))
+        W.static.append(pm.StaticObstacle(box, (0.0, 0.0)))
+        for j in range(len(trajs)):
+            if j == i:
+                continue
+            segs, dis = trajs[j], False
+            if traj_time > 0 and len(segs) * dt > traj_time:
+                segs, dis = segs[: int(round(traj_time / dt))], True
+            W.nonlinear.append(pm.NonlinearObstacle(rec, segs, start_t=t_now - traj_t[j], disappear_back=dis))
+        worlds.append(W)
+    return worlds
+
+
+TEAM2 = [((0, -5), (10, 5)), ((0, -2.5), (10, 2.5)), ((0, 0), (10, 0)), ((0, 2.5), (10, -2.5)), ((0, 5), (10, -5)), ((2.5, 5), (7.5, -5)),
+         ((5, 5), (5, -5)), ((7.5, 5), (2.5, -5)), ((10, 5), (0, -5)), ((10, 2.5), (0, -2.5)), ((10, 0), (0, 0)), ((10, -2.5), (0, 2.5)),
+         ((10, -5), (0, 5)), ((7.5, -5), (2.5, 5)), ((5, -5), (5, 5)), ((2.5, -5), (7.5, 5))]  # robot_team.hpp:275-353
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_team2_tick_get_succ_matches_the_compiled_reference():
+    """BASELINE config 5 at the expansion level: 16 robots of Team2, each seeing the 15 others as nonlinear obstacles
+    (straight-line stand-in trajectories towards their goals) + the static box, dt 0.5, v_max 2, a_max 1."""
+    dt = 0.5
+    rng = np.random.default_rng(7)
+    trajs, traj_t = [], []
+    for s, g in TEAM2:  # a plausible current trajectory of every robot: accelerate towards its goal, then coast
+        d = np.sign(np.array(g, float) - np.array(s, float))
+        trajs.append(acc_segs(s, (0, 0), [d, d, 0 * d, 0 * d, 0 * d, 0 * d, -d, -d], dt))
+        traj_t.append(0.01 * len(traj_t))
+    worlds = team2_worlds(1.0, trajs, traj_t, dt, traj_time=4.0)
+    team = pm.PolyTeam()
+    kw = dict(dt=dt, v_max=2.0, a_max=1.0, w=10.0)
+    team.configure(pm.ACC, U9, **kw)
+    team.set_worlds(worlds)
+    refs = [refpoly.RefWorld(W, pm.ACC, U9, **kw) for W in worlds]
+    K = 16 * 40
+    world_of = np.repeat(np.arange(16), 40)
+    states = random_states(rng, K, dt)
+    for r in range(16):  # include each robot's own replanning start: traj.evaluate(dt)
+        seg = trajs[r][1]
+        states[r * 40] = [seg[5], seg[11], seg[4], seg[10], 0, 0, 0, 0, dt]
+    n_fin, n_inf = _compare_get_succ(team, worlds, refs, world_of, states, 9)
+    assert n_fin > 1000 and n_inf > 100
