@@ -261,6 +261,18 @@ int mplx_poly_commit(mplx_poly *p);
 /* env_poly_map::get_succ for K nodes in one launch; node k (state: pos2 vel2 acc2 jrk2 t) lives in world world_of[k].
  * out: K x n_u records, record [k * n_u + i] belongs to control input i */
 int mplx_poly_get_succ_batch(mplx_poly *p, int32_t K, const int32_t *world_of, const double *states, mplx_poly_succ *out);
+/* PlannerBase::plan through env_poly_map for n queries in ONE launch, one workgroup per query (the planners of a
+ * decentralised tick, robot.hpp:92-133): query k plans in world world_of[k] from starts[k] (pos2 vel2 acc2 jrk2 t) to
+ * goals[k] (pos2 vel2 ...).  States are keyed with their time (enable_t, env_poly_map.h:63-64).  setEpsilon / setTol /
+ * setMaxNum / setHeurIgnoreDynamics are the eps / tol_* / max_expand / heur_ignore_dynamics arguments.  ACC control. */
+int mplx_poly_set_capacity(mplx_poly *p, int32_t n_slots, uint64_t total_nodes, uint64_t total_edges, uint64_t total_open_log);
+int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *world_of, const double *starts, const double *goals, double eps, double tol_pos,
+                         double tol_vel, int32_t max_expand, int32_t heur_ignore_dynamics, mplx_result *out);
+/* trajectory of query q of the last batch: actions[traj_len], node_ids[traj_len + 1], states (traj_len + 1) x 9; NULLs allowed */
+int mplx_poly_result_traj(mplx_poly *p, int32_t q, int32_t *actions, int32_t *node_ids, double *states);
+int mplx_poly_set_record(mplx_poly *p, uint32_t cap_per_query);
+int mplx_poly_result_expanded(mplx_poly *p, int32_t q, uint32_t cap, int32_t *ids, uint32_t *n);
+int mplx_poly_last_kernel_ms(const mplx_poly *p, float *ms);
 
 /* ---- measurement ---- */
 /* device-clock begin / end (seconds since the first query of the batch started) and workgroup of query q */

@@ -59,7 +59,8 @@ EXPORTS = [
     "mplx_grid_add_cloud", "mplx_grid_add_cloud_inflate", "mplx_grid_decay", "mplx_grid_clear_column", "mplx_grid_fill_column",
     "mplx_grid_fill_cell", "mplx_grid_get_map", "mplx_grid_get_cloud", "mplx_grid_to_map",
     "mplx_poly_create", "mplx_poly_destroy", "mplx_poly_last_error", "mplx_poly_config", "mplx_poly_begin", "mplx_poly_set_world",
-    "mplx_poly_add_static", "mplx_poly_add_linear", "mplx_poly_add_nonlinear", "mplx_poly_commit", "mplx_poly_get_succ_batch",
+    "mplx_poly_add_static", "mplx_poly_add_linear", "mplx_poly_add_nonlinear", "mplx_poly_commit", "mplx_poly_get_succ_batch", "mplx_poly_set_capacity", "mplx_poly_plan_batch", "mplx_poly_result_traj",
+    "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms",
 ]
 
 
@@ -157,5 +158,11 @@ def load():
     L.mplx_poly_add_nonlinear.argtypes = [P, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_double, C.c_int32, C.c_int32]
     L.mplx_poly_commit.argtypes = [P]
     L.mplx_poly_get_succ_batch.argtypes = [P, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(PolySucc)]
+    L.mplx_poly_set_capacity.argtypes = [P, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.mplx_poly_plan_batch.argtypes = [P, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, C.POINTER(Result)]
+    L.mplx_poly_result_traj.argtypes = [P, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mplx_poly_set_record.argtypes = [P, C.c_uint32]
+    L.mplx_poly_result_expanded.argtypes = [P, C.c_int32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+    L.mplx_poly_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float)]
     _lib = L
     return L

@@ -1147,4 +1147,5 @@ extern "C" int mplx_last_kernel_ms(const mplx_ctx *c, float *ms) {
   return MPLX_OK;
 }
 #include "mplx_grid.inl"
+#include "mplx_poly_search.h"
 #include "mplx_poly.inl"

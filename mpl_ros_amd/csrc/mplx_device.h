@@ -12,6 +12,7 @@
 // bump-allocated from the pools and never returned within a batch.
 #pragma once
 #include "mplx_math.h"
+#include "mplx_poly_dev.h"
 
 namespace mplx {
 
@@ -131,6 +132,9 @@ struct SearchParams {
   int32_t help_reserved;          // number of leader boxes (= workgroups of the leaders' launch)
   int32_t help_max;               // helpers per leader (1 or 2)
   int32_t help_keep;              // helper workgroups blockIdx.x < help_keep may stay while queries are still waiting for a leader
+  // moving-obstacle environment (astar_poly_kernel): the worlds and the world of each query
+  PolyDev poly;
+  const int32_t *poly_world;
 };
 
 // one successor record produced by the expand kernel (mirrors mplx_succ)

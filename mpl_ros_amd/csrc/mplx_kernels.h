@@ -859,12 +859,14 @@ __device__ __forceinline__ void open_push(const QView<BLOCK, CONTROL, SM> &Q, ui
 // `act`: this lane commits a finite-cost successor.  With all keys distinct the lanes commit in
 // parallel; node / edge / log ids come from prefix sums in lane order, so they equal the ids a
 // sequential loop over the control inputs would assign.
-template <int BLOCK, int CONTROL, class SM>
-__device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64) {
+// NK: key ints (key_len_c(CONTROL), + 1 when the state's time is part of the key); lane_cost: cost of this lane's
+// primitive (the voxel environment's cost depends on the control input only: P.ucost[tid]).
+template <int BLOCK, int CONTROL, class SM, int NK = key_len_c(CONTROL)>
+__device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64, double lane_cost) {
   using V = QView<BLOCK, CONTROL, SM>;
   const SearchParams &P = Q.P;
   SM &S = Q.S;
-  constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
+  constexpr int nk = NK, ns = key_len_c(CONTROL);
   int role = 0;  // 1 found, 2 creator
   uint32_t id = NIL;
   size_t tslot = 0;
@@ -949,7 +951,7 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
     e->next = old_pred;
     e->action = (uint32_t)tid;
     V::pred(rec) = base_edges + (sc >> 12);
-    tg = S.cur_g + P.ucost[tid];
+    tg = S.cur_g + lane_cost;
     improved = tg < old_g;
     if (improved) {
       if (fl & FLAG_CLOSED) {  // re-open
@@ -979,11 +981,11 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
 
 // ------------------------------------------------------------------ pop the minimum valid OPEN entry
 // On success S.cur_id / S.cur_g / S.cur / S.cur_key describe the node to expand and it is closed.
-template <int BLOCK, int CONTROL, class SM>
+template <int BLOCK, int CONTROL, class SM, int NK = key_len_c(CONTROL)>
 __device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL, SM> &Q, int tid) {
   using V = QView<BLOCK, CONTROL, SM>;
   SM &S = Q.S;
-  constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
+  constexpr int nk = NK, ns = key_len_c(CONTROL);
   for (;;) {
     if (S.n_near == 0) {
       __syncthreads();
@@ -1199,10 +1201,10 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         }
         __syncthreads();
         if (!S.flag) {
-          commit_parallel(Q, tid, q, act, L, h64);
+          commit_parallel(Q, tid, q, act, L, h64, act ? P.ucost[tid] : 0.0);
         } else {
           // rare: two control inputs reach the same key -> commit one successor at a time, in order
-          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel(Q, tid, q, act && tid == i, L, h64);
+          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel(Q, tid, q, act && tid == i, L, h64, act ? P.ucost[tid] : 0.0);
         }
         __syncthreads();
         MPLX_TOC(S, 2, tc);

@@ -93,6 +93,10 @@ struct mplx_poly {
   mplx::PolyObs *d_obs = nullptr;
   mplx::PolyWorld *d_worlds = nullptr;
   double *d_U = nullptr;
+  // search: pools, batch buffers and result getters of an internal planner context
+  mplx_ctx *ctx = nullptr;
+  int32_t *d_world_of = nullptr;
+  int world_cap = 0;
 };
 
 static int pfail(mplx_poly *p, int code, const char *fmt, ...) {
@@ -119,9 +123,10 @@ extern "C" int mplx_poly_create(int device, mplx_poly **out) {
   if (device < 0 || device >= n) return pfail(nullptr, MPLX_ERR_ARG, "device %d out of range", device);
   mplx_poly *p = new mplx_poly();
   p->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&p->stream) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&p->stream) != hipSuccess || mplx_ctx_create(device, &p->ctx) != MPLX_OK) {
+    if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
-    return pfail(nullptr, MPLX_ERR_HIP, "stream creation failed");
+    return pfail(nullptr, MPLX_ERR_HIP, "stream / context creation failed");
   }
   *out = p;
   return MPLX_OK;
@@ -137,6 +142,8 @@ extern "C" void mplx_poly_destroy(mplx_poly *p) {
   (void)hipStreamSynchronize(p->stream);
   poly_free_dev(p);
   (void)hipFree(p->d_U);
+  (void)hipFree(p->d_world_of);
+  mplx_ctx_destroy(p->ctx);
   (void)hipStreamDestroy(p->stream);
   delete p;
 }
@@ -285,3 +292,127 @@ extern "C" int mplx_poly_get_succ_batch(mplx_poly *p, int32_t K, const int32_t *
   if (flags & 1) return pfail(p, MPLX_ERR_ARG, "a hyperplane equation of degree > 2 was met (JRK / SNP trajectories are not supported by the moving-obstacle environment)");
   return MPLX_OK;
 }
+
+// ---- PlannerBase::plan through env_poly_map for n queries in one launch (one workgroup per query): the 16 planners of
+// a decentralised tick (robot.hpp:92-133, robot_team.hpp:60-66).  Query k plans in world world_of[k] from starts[k]
+// (pos2 vel2 acc2 jrk2 t) to goals[k] (same layout; goals carry position and velocity).
+extern "C" int mplx_poly_set_capacity(mplx_poly *p, int32_t n_slots, uint64_t total_nodes, uint64_t total_edges, uint64_t total_open_log) {
+  if (!p) return MPLX_ERR_ARG;
+  return mplx_set_capacity(p->ctx, n_slots, total_nodes, total_edges, total_open_log);
+}
+extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *world_of, const double *starts, const double *goals, double eps, double tol_pos,
+                                    double tol_vel, int32_t max_expand, int32_t heur_ignore_dynamics, mplx_result *out) {
+  if (!p || n <= 0 || !world_of || !starts || !goals || !out) return pfail(p, MPLX_ERR_ARG, "bad argument");
+  if (!p->have_cfg) return pfail(p, MPLX_ERR_ARG, "mplx_poly_config first");
+  if (!p->committed) return pfail(p, MPLX_ERR_ARG, "mplx_poly_commit first");
+  if (p->control != CTRL_ACC) return pfail(p, MPLX_ERR_ARG, "the moving-obstacle search is built for ACC control (the multi-robot configuration)");
+  for (int k = 0; k < n; k++)
+    if (world_of[k] < 0 || world_of[k] >= (int)p->worlds.size()) return pfail(p, MPLX_ERR_ARG, "world index out of range");
+  mplx_ctx *c = p->ctx;
+  PCHK(p, hipSetDevice(p->device));
+  // the internal context carries the record layout (ACC) and the pools; its own voxel set-up stays unused
+  c->cfg = mplx_config();
+  c->cfg.control = CTRL_ACC;
+  c->cfg.n_u = p->n_u;
+  c->cfg.dt = p->dt; c->cfg.v_max = p->v_max; c->cfg.a_max = p->a_max; c->cfg.j_max = p->j_max;
+  c->cfg.w = p->w; c->cfg.eps = eps;
+  c->cfg.tol_pos = tol_pos; c->cfg.tol_vel = tol_vel; c->cfg.tol_acc = -1.0;
+  c->cfg.t_max = INFINITY;
+  c->cfg.max_expand = max_expand;
+  c->cfg.heur_ignore_dynamics = heur_ignore_dynamics;
+  c->U.assign(3 * (size_t)p->n_u, 0.0);
+  for (int i = 0; i < p->n_u; i++) { c->U[3 * i] = p->U[2 * i]; c->U[3 * i + 1] = p->U[2 * i + 1]; }
+  c->cfg.U = c->U.data();
+  c->have_cfg = true;
+  const int helpers_saved = c->helpers;
+  c->helpers = 0;  // (no look-ahead cache arrays for this kernel)
+  const int slots = n < c->n_slots ? n : c->n_slots;
+  int r = ensure_pools(c, slots);
+  c->helpers = helpers_saved;
+  if (r != MPLX_OK) return pfail(p, r, "%s", c->err.c_str());
+  if ((r = ensure_batch(c, n)) != MPLX_OK) return pfail(p, r, "%s", c->err.c_str());
+  if (p->world_cap < n) {
+    (void)hipFree(p->d_world_of);
+    p->d_world_of = nullptr;
+    PCHK(p, hipMalloc((void **)&p->d_world_of, sizeof(int32_t) * (size_t)n));
+    p->world_cap = n;
+  }
+  std::vector<QueryIn> in((size_t)n);
+  std::vector<int32_t> order((size_t)n);
+  for (int k = 0; k < n; k++) {
+    const double *s = starts + 9 * (size_t)k, *g = goals + 9 * (size_t)k;
+    QueryIn &q = in[(size_t)k];
+    memset(&q, 0, sizeof(q));
+    q.start.p[0] = s[0]; q.start.p[1] = s[1]; q.start.v[0] = s[2]; q.start.v[1] = s[3];
+    q.goal.p[0] = g[0]; q.goal.p[1] = g[1]; q.goal.v[0] = g[2]; q.goal.v[1] = g[3];
+    q.start_t = s[8];
+    q.goal_control = CTRL_ACC;
+    order[(size_t)k] = k;
+  }
+  SearchParams P = c->pools;
+  fill_params(c, P);
+  P.boxes = nullptr;
+  P.cap_rec = c->cap_rec;
+  P.nq = n;
+  P.queries = c->d_in;
+  P.order = c->d_order;
+  P.out = c->d_out;
+  P.traj_nodes = c->d_traj_nodes; P.traj_actions = c->d_traj_actions; P.traj_states = c->d_traj_states;
+  P.rec_ids = c->cap_rec ? c->d_rec : nullptr;
+  P.node_tables = c->d_node_tables;
+  P.edge_tables = c->d_edge_tables;
+  P.next_query = c->d_next;
+  P.poly = poly_dev(p);
+  P.poly_world = p->d_world_of;
+  hipStream_t st = c->stream;
+  PCHK(p, hipMemcpyAsync(p->d_world_of, world_of, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  PCHK(p, hipMemcpyAsync(c->d_order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
+  PCHK(p, hipMemsetAsync(P.table, 0xFF, (size_t)(P.table_mask + 1) * sizeof(unsigned long long), st));
+  PCHK(p, hipMemsetAsync(P.chunk_next, 0, 4 * sizeof(uint32_t), st));
+  PCHK(p, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * (size_t)n, hipMemcpyHostToDevice, st));
+  PCHK(p, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), st));
+  PCHK(p, hipEventRecord(c->ev0, st));
+  hipLaunchKernelGGL((mplx::astar_poly_kernel<256>), dim3(slots), dim3(256), 0, st, P);
+  PCHK(p, hipGetLastError());
+  PCHK(p, hipEventRecord(c->ev1, st));
+  c->last_out.resize((size_t)n);
+  PCHK(p, hipMemcpyAsync(c->last_out.data(), c->d_out, sizeof(QueryOut) * (size_t)n, hipMemcpyDeviceToHost, st));
+  PCHK(p, hipStreamSynchronize(st));
+  PCHK(p, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+  for (int k = 0; k < n; k++) fill_result(c->last_out[(size_t)k], out[k]);
+  c->last_nq = n;
+  c->last_single = (n == 1);
+  c->last_control = CTRL_ACC;
+  c->last_dt = p->dt;
+  c->last_U = c->U;
+  c->plan_epoch++;
+  for (int k = 0; k < n; k++)
+    if (out[k].status == MPLX_PLAN_INTERNAL) return pfail(p, MPLX_ERR_ARG, "a hyperplane equation of degree > 2 was met (JRK / SNP trajectories are not supported)");
+  return MPLX_OK;
+}
+// trajectory of query q of the last mplx_poly_plan_batch: actions[traj_len], node_ids[traj_len + 1], states (traj_len + 1) x 9
+extern "C" int mplx_poly_result_traj(mplx_poly *p, int32_t q, int32_t *actions, int32_t *node_ids, double *states) {
+  if (!p) return MPLX_ERR_ARG;
+  mplx_ctx *c = p->ctx;
+  if (q < 0 || q >= c->last_nq) return pfail(p, MPLX_ERR_ARG, "no such query");
+  const int len = c->last_out[(size_t)q].traj_len;
+  if (c->last_out[(size_t)q].status != MPLX_PLAN_OK || len <= 0) return MPLX_OK;
+  std::vector<mplx_waypoint> wps((size_t)len + 1);
+  int r = mplx_result_traj(c, q, nullptr, wps.data(), actions, node_ids);
+  if (r) return pfail(p, r, "%s", c->err.c_str());
+  if (states)
+    for (int i = 0; i <= len; i++) {
+      double *s = states + 9 * (size_t)i;
+      s[0] = wps[(size_t)i].pos[0]; s[1] = wps[(size_t)i].pos[1]; s[2] = wps[(size_t)i].vel[0]; s[3] = wps[(size_t)i].vel[1];
+      s[4] = s[5] = s[6] = s[7] = 0.0;
+      s[8] = wps[(size_t)i].t;
+    }
+  return MPLX_OK;
+}
+extern "C" int mplx_poly_last_kernel_ms(const mplx_poly *p, float *ms) { return p ? mplx_last_kernel_ms(p->ctx, ms) : MPLX_ERR_ARG; }
+extern "C" int mplx_poly_result_expanded(mplx_poly *p, int32_t q, uint32_t cap, int32_t *ids, uint32_t *n) {
+  if (!p) return MPLX_ERR_ARG;
+  int r = mplx_result_expanded(p->ctx, q, cap, ids, n);
+  return r ? pfail(p, r, "%s", p->ctx->err.c_str()) : MPLX_OK;
+}
+extern "C" int mplx_poly_set_record(mplx_poly *p, uint32_t cap) { return p ? mplx_set_record(p->ctx, cap) : MPLX_ERR_ARG; }

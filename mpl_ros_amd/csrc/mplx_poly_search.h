@@ -1,0 +1,286 @@
+// mplx_poly_search.h -- astar_poly_kernel: GraphSearch::Astar over the moving-obstacle environment (env_poly_map),
+// one workgroup per query, device resident like astar_kernel (mplx_kernels.h) whose OPEN structure, state-space
+// pools, hash table, commit and recoverTraj it shares.  What differs from the voxel environment:
+//   * get_succ is env_poly_map::get_succ (mplx_poly_dev.h): lane i < n_u builds primitive i, the (primitive,
+//     obstacle) pairs are spread over the lanes, one collide() each;
+//   * successors carry time: tn.t = curr.t + dt and enable_t (env_poly_map.h:63-64), so the state key has one more
+//     integer, round(t / 0.1), and a state revisited at another time is another node;
+//   * the edge cost depends on the state (J(control) + 0.001 J(VEL) + w dt, env_poly_map.h:71-73), so it travels
+//     with the lane and recoverTraj recomputes it from the parent state;
+//   * PlannerBase::plan's start test is ENV_->is_free(start.pos) = inside the bounding box (env_poly_map.h:33).
+// States are stored in the 3-D record layout with z = 0 (like the occupancy-map planner).
+#pragma once
+#include "mplx_kernels.h"
+
+namespace mplx {
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
+  constexpr int CONTROL = CTRL_ACC;
+  constexpr int ns = key_len_c(CONTROL), NK = ns + 1;
+  __shared__ Smem<BLOCK> S;
+  __shared__ double pcs[POLY_MAX_U][2][6];
+  __shared__ int32_t pvalid[POLY_MAX_U], phit[POLY_MAX_U];
+  __shared__ int32_t pstart_hit, punsupported;
+  using V = QView<BLOCK, CONTROL>;
+  const int tid = threadIdx.x;
+  const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
+  const PolyDev &D = P.poly;
+  for (;;) {
+    if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
+    __syncthreads();
+    const int qi = S.q_index;
+    if (qi >= P.nq) break;
+    const int q = P.order[qi];
+    const QueryIn &in = P.queries[q];
+    const PolyWorld W = D.worlds[P.poly_world[q]];
+    const unsigned long long t_begin = wall_clock64();
+    for (int i = tid; i < 2 * NB; i += BLOCK) S.cnt[0][i] = 0;
+    if (tid == 0) {
+      S.n_near = 0; S.n_nodes = 0; S.n_edges = 0; S.n_log = 0;
+      S.reserve = (uint32_t)P.n_u;
+      S.node_chunks = S.edge_chunks = S.open_chunks = 0;
+      S.cur1 = 0; S.cur0 = 0; S.lo1 = 0.0; S.ts_f = INFINITY; S.ts_g = INFINITY; S.ts_id = 0xFFFFFFFFu;
+      S.status = -1;
+      for (int i = 0; i < 10; i++) S.cyc[i] = 0;
+      S.c_expanded = S.c_closed = S.c_prims = S.c_succ = S.c_succ_finite = S.c_reads = 0;
+      S.c_push = S.c_reopen = S.c_refill = S.c_evict = 0;
+      S.c_hash = 0;
+      punsupported = 0;
+      S.hp.w = P.w; S.hp.v_max = P.v_max; S.hp.heur_ignore_dynamics = P.heur_ignore_dynamics;
+      S.hp.goal_control = in.goal_control;
+      S.hp.goal = in.goal;
+      S.hp.goal_nkey = state_key(in.goal_control, in.goal, S.hp.goal_key);
+      double cost0 = INFINITY;
+      if (!poly_inside(W.bbox, 4, in.start.p[0], in.start.p[1]))
+        S.status = 2;  // ENV_->is_free(start.pos) failed
+      else if (in.start_t >= P.t_max || is_goal_state(in.start, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) {
+        S.status = 0;
+        cost0 = 0.0;
+      }
+      S.tmp_d0 = cost0;
+      if (S.status < 0) {
+        bool ok = ensure_chunks(S.node_tbl, S.node_chunks, 1, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks) &&
+                  ensure_chunks(S.open_tbl, S.open_chunks, 1, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
+        if (!ok) S.status = 4;
+      }
+    }
+    __syncthreads();
+    uint32_t goal_id = NIL;
+    if (S.status < 0) {
+      if (tid == 0) {  // start node (id 0); its key carries the start time
+        int32_t key[MAX_KEY];
+        state_key_c<CONTROL>(in.start, key);
+        key[ns] = (int32_t)round(in.start_t / 0.1);
+        char *rec = Q.node(0);
+        for (int i = 0; i < NK; i++) V::key(rec)[i] = key[i];
+        const double *src = (const double *)&in.start;
+        for (int i = 0; i < ns; i++) V::state(rec)[i] = src[i];
+        V::state(rec)[ns] = in.start_t;
+        double h = P.eps == 0.0 ? 0.0 : get_heur(S.hp, CONTROL, in.start, key, NK);
+        V::h(rec) = h;
+        V::g(rec) = 0.0;
+        V::flags(rec) = FLAG_OPENED;
+        V::pred(rec) = NIL;
+        const unsigned long long h64 = key_hash64(key, NK);
+        const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
+        size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
+        for (;;) {
+          unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, tagq | 0ull);
+          if (old == TBL_EMPTY) break;
+          pos = (pos + 1) & (size_t)P.table_mask;
+        }
+        S.n_nodes = 1;
+        S.f_base = 0.0 + P.eps * h;
+        S.lo1 = S.f_base;
+        S.n_log = 1;
+        S.c_push = 1;
+      }
+      __syncthreads();
+      if (tid == 0) open_push(Q, 0u, S.f_base, 0.0, 0u);
+      __syncthreads();
+      for (;;) {
+        while (S.n_near + S.reserve > (uint32_t)NC) {
+          evict_half(Q, tid);
+          __syncthreads();
+        }
+        const bool popped = pop_min<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid);
+        if (!popped) {
+          if (tid == 0) S.status = 1;
+          __syncthreads();
+          break;
+        }
+        const uint32_t cur = S.cur_id;
+        if (tid == 0) {
+          S.c_expanded++;
+          S.c_closed++;
+          S.c_hash = S.c_hash * 0x100000001B3ull + (unsigned long long)(cur + 1u);
+          if (P.rec_ids && S.c_expanded <= P.cap_rec) P.rec_ids[(size_t)q * P.cap_rec + (S.c_expanded - 1)] = (int32_t)cur;
+          S.flag = 0;
+          pstart_hit = 0;
+        }
+        // ---- env_poly_map::get_succ(curr): S.cur[0] = pos3 vel3 ... , S.cur[0][12] = curr.t
+        const double T = P.dt, cur_t = S.cur[0][12], t_rel = cur_t - W.start_t;
+        LaneSucc L;
+        L.valid = false; L.blocked = false; L.reads = 0;
+        double lane_cost = 0.0;
+        if (tid < P.n_u) {
+          const double pos[2] = {S.cur[0][0], S.cur[0][1]}, vel[2] = {S.cur[0][3], S.cur[0][4]}, u[2] = {D.U[2 * tid], D.U[2 * tid + 1]};
+          double c[2][6];
+          poly_prim_build(CONTROL, pos, vel, u, c);
+          for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 6; j++) pcs[tid][i][j] = c[i][j];
+          L.tn.p[0] = pp_p(c[0], T); L.tn.p[1] = pp_p(c[1], T); L.tn.p[2] = 0.0;
+          L.tn.v[0] = pp_v(c[0], T); L.tn.v[1] = pp_v(c[1], T); L.tn.v[2] = 0.0;
+          for (int k = 0; k < 3; k++) { L.tn.a[k] = 0.0; L.tn.j[k] = 0.0; }
+          pvalid[tid] = (poly_inside(W.bbox, 4, L.tn.p[0], L.tn.p[1]) && poly_validate(CONTROL, c, T, P.v_max)) ? 1 : 0;
+          phit[tid] = 0;
+          lane_cost = poly_intrinsic_cost(CONTROL, c, T, P.w, P.dt);
+          state_key_c<CONTROL>(L.tn, L.key);
+          L.key[ns] = (int32_t)round((cur_t + P.dt) / 0.1);
+        }
+        __syncthreads();
+        for (int j = tid; j < W.n_obs; j += BLOCK)
+          if (obs_point_hits(D, D.obs[W.obs_off + j], pp_p(pcs[0][0], 0.0), pp_p(pcs[0][1], 0.0), t_rel)) pstart_hit = 1;
+        const int pairs = P.n_u * W.n_obs;
+        for (int e = tid; e < pairs; e += BLOCK) {
+          const int i = e / W.n_obs, j = e % W.n_obs;
+          if (!pvalid[i]) continue;
+          double c[2][6];
+          for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 6; b++) c[a][b] = pcs[i][a][b];
+          const int r = obs_prim_hits(D, c, T, D.obs[W.obs_off + j], t_rel);
+          if (r < 0) punsupported = 1;
+          if (r > 0) phit[i] = 1;
+        }
+        __syncthreads();
+        if (tid < P.n_u) {
+          L.valid = pvalid[tid] != 0;
+          L.blocked = L.valid && (pstart_hit || phit[tid]);
+        }
+        const bool act = L.valid && !L.blocked;
+        {
+          uint32_t tot;
+          block_excl_scan<BLOCK>((L.valid ? 1u : 0u) | (act ? 1u << 10 : 0u), S, tid, tot);
+          if (tid == 0) {
+            S.c_prims += (unsigned long long)P.n_u;
+            S.c_succ += tot & 0x3FFu;
+            S.c_succ_finite += tot >> 10;
+            if (punsupported) S.status = 5;
+          }
+        }
+        unsigned long long h64 = 0;
+        S.dupset[tid] = 0;
+        S.dupset[tid + BLOCK] = 0;
+        __syncthreads();
+        if (S.status >= 0) break;
+        if (act) {
+          h64 = key_hash64(L.key, NK);
+          const unsigned long long hv = h64 | 1ull;
+          uint32_t sl = (uint32_t)(h64 >> 7) & (2 * BLOCK - 1);
+          for (;;) {
+            unsigned long long old = atomicCAS(&S.dupset[sl], 0ull, hv);
+            if (old == 0ull) break;
+            if (old == hv) { S.flag = 1; break; }
+            sl = (sl + 1) & (2 * BLOCK - 1);
+          }
+        }
+        __syncthreads();
+        if (!S.flag) {
+          commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid, q, act, L, h64, lane_cost);
+        } else {
+          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid, q, act && tid == i, L, h64, lane_cost);
+        }
+        __syncthreads();
+        if (S.status >= 0) break;
+        if (tid == 0) {
+          State s;
+          for (int i = 0; i < 12; i++) ((double *)&s)[i] = S.cur[0][i];
+          if (S.cur[0][12] >= P.t_max || is_goal_state(s, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc))
+            S.status = 0;
+          else if (P.max_expand > 0 && S.c_expanded >= (unsigned long long)P.max_expand)
+            S.status = 3;
+        }
+        __syncthreads();
+        if (S.status >= 0) break;
+      }
+      goal_id = S.cur_id;
+      clear_buckets(Q, tid);
+    }
+    __syncthreads();
+    if (tid == 0) {  // recoverTraj + results
+      QueryOut &o = P.out[q];
+      int32_t *tn = P.traj_nodes + (size_t)q * (MAX_TRAJ + 1);
+      int32_t *ta = P.traj_actions + (size_t)q * MAX_TRAJ;
+      double *ts = P.traj_states + (size_t)q * (MAX_TRAJ + 1) * 13;
+      int status = S.status;
+      double cost = INFINITY;
+      int len = 0;
+      auto edge_cost = [&](uint32_t parent, uint32_t action) {  // calculate_intrinsic_cost of Primitive(parent, U[action], dt)
+        const double *st = V::state(Q.node(parent));
+        const double pos[2] = {st[0], st[1]}, vel[2] = {st[3], st[4]}, u[2] = {D.U[2 * action], D.U[2 * action + 1]};
+        double c[2][6];
+        poly_prim_build(CONTROL, pos, vel, u, c);
+        return poly_intrinsic_cost(CONTROL, c, P.dt, P.w, P.dt);
+      };
+      if (status == 0 && goal_id == NIL) {
+        cost = S.tmp_d0;
+      } else if (status == 0) {
+        uint32_t node = goal_id;
+        tn[0] = (int32_t)node;
+        bool ok = true, too_long = false;
+        while (V::pred(Q.node(node)) != NIL) {
+          uint32_t best = NIL;
+          double min_rhs = INFINITY, min_g = INFINITY;
+          for (uint32_t e = V::pred(Q.node(node)); e != NIL; e = Q.edge(e)->next) {
+            const EdgeRec er = *Q.edge(e);
+            double gp = V::g(Q.node(er.parent));
+            double rhs = gp + edge_cost(er.parent, er.action);
+            if (rhs < min_rhs || (rhs == min_rhs && gp >= min_g)) { min_rhs = rhs; min_g = gp; best = e; }
+          }
+          if (best == NIL) { ok = false; break; }
+          if (len >= MAX_TRAJ) { too_long = true; break; }
+          ta[len] = (int32_t)Q.edge(best)->action;
+          node = Q.edge(best)->parent;
+          len++;
+          tn[len] = (int32_t)node;
+          if (node == 0u) break;
+        }
+        if (too_long) {
+          cost = V::g(Q.node(goal_id));
+          status = 6;
+          len = 0;
+        } else if (ok) {
+          cost = V::g(Q.node(goal_id));
+          for (int i = 0; i <= len; i++) {
+            const double *st = V::state(Q.node((uint32_t)tn[i]));
+            for (int k = 0; k < 12; k++) ts[i * 13 + k] = k < ns ? st[k] : 0.0;
+            ts[i * 13 + 12] = st[ns];
+          }
+        } else {
+          status = 1;
+          len = 0;
+        }
+      }
+      o.status = status;
+      o.traj_len = len;
+      o.cost = cost;
+      o.n_expanded = S.c_expanded; o.n_closed = S.c_closed; o.n_nodes = S.n_nodes; o.n_edges = S.n_edges;
+      o.n_primitives = S.c_prims; o.n_succ = S.c_succ; o.n_succ_finite = S.c_succ_finite; o.voxel_reads = 0;
+      o.n_push = S.c_push; o.n_reopen = S.c_reopen; o.n_refill = S.c_refill; o.n_evict = S.c_evict;
+      o.expand_hash = S.c_hash;
+      o.n_recorded = (uint32_t)(S.c_expanded < P.cap_rec ? S.c_expanded : P.cap_rec);
+      o.slot = blockIdx.x;
+      o.t_begin = t_begin;
+      o.t_end = wall_clock64();
+      for (int i = 0; i < 10; i++) o.cyc[i] = S.cyc[i];
+    }
+    for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)
+      P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? S.node_tbl[i] : NIL;
+    for (uint32_t i = tid; i < (uint32_t)MAX_EDGE_CH; i += BLOCK)
+      P.edge_tables[(size_t)q * MAX_EDGE_CH + i] = i < S.edge_chunks ? S.edge_tbl[i] : NIL;
+    __syncthreads();
+  }
+}
+
+}  // namespace mplx

@@ -94,3 +94,40 @@ class PolyTeam:
         out = (_capi.PolySucc * (len(w) * self.n_u))()
         self.check(self.lib.mplx_poly_get_succ_batch(self.h, len(w), w.ctypes.data, s.ctypes.data, out))
         return out
+
+    def set_capacity(self, n_slots, nodes, edges, open_log):
+        self.check(self.lib.mplx_poly_set_capacity(self.h, int(n_slots), int(nodes), int(edges), int(open_log)))
+
+    def set_record(self, cap):
+        self.check(self.lib.mplx_poly_set_record(self.h, int(cap)))
+
+    def plan_batch(self, world_of, starts, goals, eps=1.0, tol_pos=0.5, tol_vel=-1.0, max_expand=-1, heur_ignore_dynamics=True):
+        """PlannerBase::plan for one query per entry, all in one launch; starts / goals: n x 9 (pos2 vel2 acc2 jrk2 t)."""
+        w = np.ascontiguousarray(world_of, dtype=np.int32)
+        s = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 9)
+        g = np.ascontiguousarray(goals, dtype=np.float64).reshape(-1, 9)
+        R = (_capi.Result * len(w))()
+        self.check(self.lib.mplx_poly_plan_batch(self.h, len(w), w.ctypes.data, s.ctypes.data, g.ctypes.data, float(eps), float(tol_pos), float(tol_vel),
+                                                 int(max_expand), int(bool(heur_ignore_dynamics)), R))
+        self._results = [R[i] for i in range(len(w))]
+        return self._results
+
+    def traj(self, q):
+        r = self._results[q]
+        n = r.traj_len if r.status == _capi.PLAN_OK else 0
+        act = np.zeros(max(n, 1), dtype=np.int32); ids = np.zeros(n + 1, dtype=np.int32); st = np.zeros((n + 1, 9))
+        if n:
+            self.check(self.lib.mplx_poly_result_traj(self.h, q, act.ctypes.data, ids.ctypes.data, st.ctypes.data))
+        return act[:n], ids[:n + 1] if n else ids[:0], st[:n + 1] if n else st[:0]
+
+    def expanded_ids(self, q):
+        cap = int(self._results[q].n_expanded)
+        ids = np.zeros(max(cap, 1), dtype=np.int32)
+        n = C.c_uint32()
+        self.check(self.lib.mplx_poly_result_expanded(self.h, q, cap, ids.ctypes.data, C.byref(n)))
+        return ids[:n.value]
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self.check(self.lib.mplx_poly_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value

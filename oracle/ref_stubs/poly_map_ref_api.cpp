@@ -121,7 +121,7 @@ int refpoly_plan(void *h, const double *start, const double *goal, int control, 
   g_cost = std::numeric_limits<double>::infinity();
   Waypoint2D s = wp_of(start, control), g = wp_of(goal, control);
   s.enable_t = true;  // env_poly_map keys its successors with time (env_poly_map.h:64)
-  if (!r->map_util->isFree(s.pos, s.t)) return 2;
+  if (!r->env->is_free(s.pos)) return 2;  // PlannerBase::plan: ENV_->is_free(start.pos) = inside the bounding box (env_poly_map.h:33)
   const double v_max = r->env->v_max_, w = r->env->w_;
   auto heur = [&](const Waypoint2D &x) {
     const double d = std::max(std::fabs(x.pos(0) - g.pos(0)), std::fabs(x.pos(1) - g.pos(1)));

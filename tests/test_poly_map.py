@@ -154,3 +154,84 @@ def test_team2_tick_get_succ_matches_the_compiled_reference():
         states[r * 40] = [seg[5], seg[11], seg[4], seg[10], 0, 0, 0, 0, dt]
     n_fin, n_inf = _compare_get_succ(team, worlds, refs, world_of, states, 9)
     assert n_fin > 1000 and n_inf > 100
+
+
+def _team2_tick(dt=0.5, t_now=1.0, traj_time=4.0):
+    trajs, traj_t = [], []
+    for s, g in TEAM2:
+        d = np.sign(np.array(g, float) - np.array(s, float))
+        trajs.append(acc_segs(s, (0, 0), [d, d, 0 * d, 0 * d, 0 * d, 0 * d, -d, -d], dt))
+        traj_t.append(0.01 * len(traj_t))
+    worlds = team2_worlds(t_now, trajs, traj_t, dt, traj_time=traj_time)
+    starts, goals = np.zeros((16, 9)), np.zeros((16, 9))
+    for r, (s, g) in enumerate(TEAM2):  # Robot::plan: start_ = traj_.evaluate(dt_) (robot.hpp:97), goal = the robot's goal
+        seg = trajs[r][1]
+        starts[r] = [seg[5], seg[11], seg[4], seg[10], 0, 0, 0, 0, dt]
+        goals[r, 0:2] = g
+    return worlds, starts, goals
+
+
+def _compare_plans(team, refs, world_of, starts, goals, **kw):
+    team.set_record(1 << 16)
+    R = team.plan_batch(world_of, starts, goals, **kw)
+    n_ok = 0
+    for k, w in enumerate(world_of):
+        ref = refs[w].plan(starts[k], goals[k], eps=kw.get("eps", 1.0), tol_pos=kw.get("tol_pos", 0.5), max_expand=kw.get("max_expand", -1))
+        r = R[k]
+        assert r.status == ref["status"], (k, r.status, ref["status"])
+        assert r.n_expanded == len(ref["expanded"]) and r.n_nodes == ref["n_nodes"], (k, r.n_expanded, len(ref["expanded"]), r.n_nodes, ref["n_nodes"])
+        assert np.array_equal(team.expanded_ids(k), ref["expanded"]), k  # same nodes in the same order
+        if ref["status"] == 0:
+            n_ok += 1
+            assert r.cost == ref["cost"], (k, r.cost, ref["cost"])  # bit-exact f64
+            act, ids, st = team.traj(k)
+            assert np.array_equal(act, ref["actions"]) and np.array_equal(ids, ref["node_ids"]), k
+            for i, nid in enumerate(ids):  # waypoint states: position, velocity and time of every node of the path
+                s, _, _ = refs[w].node(int(nid))
+                assert np.array_equal(st[i][[0, 1, 2, 3, 8]], s[[0, 1, 2, 3, 8]]), (k, i)
+        else:
+            assert np.isinf(r.cost)
+    return R, n_ok
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("seed", range(3))
+def test_plans_match_a_search_over_the_compiled_reference_environment(seed):
+    """Whole plans: the device A* over the moving-obstacle environment against a best-first search (the restated
+    GraphSearch loop) that expands through the REFERENCE's env_poly_map::get_succ -- expansion order, states created,
+    cost, path actions / node ids / waypoint states, bit-exact."""
+    rng = np.random.default_rng(300 + seed)
+    dt = 0.5
+    worlds = [random_world(rng, dt=dt) for _ in range(8)]
+    team = pm.PolyTeam()
+    kw = dict(dt=dt, v_max=2.0, a_max=1.0, w=10.0)
+    team.configure(pm.ACC, U9, **kw)
+    team.set_worlds(worlds)
+    team.set_capacity(16, 1 << 20, 1 << 22, 1 << 21)
+    refs = [refpoly.RefWorld(W, pm.ACC, U9, **kw) for W in worlds]
+    n = 12
+    world_of = rng.integers(0, len(worlds), n)
+    starts, goals = np.zeros((n, 9)), np.zeros((n, 9))
+    starts[:, 0:2] = np.round(rng.uniform((0.5, -4.5), (3.0, 4.5), (n, 2)), 1)
+    starts[:, 8] = rng.integers(0, 3, n) * dt
+    goals[:, 0:2] = np.round(rng.uniform((7.0, -4.5), (9.5, 4.5), (n, 2)), 1)
+    R, n_ok = _compare_plans(team, refs, world_of, starts, goals, max_expand=4000)
+    assert n_ok >= 4
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_team2_tick_plans_match():
+    """BASELINE config 5: one decentralised tick of Team2 -- 16 robots replanning at once against each other's
+    trajectories (4 s horizon) and the static box, one launch, against the search over the compiled reference env."""
+    worlds, starts, goals = _team2_tick()
+    team = pm.PolyTeam()
+    kw = dict(dt=0.5, v_max=2.0, a_max=1.0, w=10.0)
+    team.configure(pm.ACC, U9, **kw)
+    team.set_worlds(worlds)
+    team.set_capacity(16, 1 << 21, 1 << 23, 1 << 22)
+    refs = [refpoly.RefWorld(W, pm.ACC, U9, **kw) for W in worlds]
+    R, n_ok = _compare_plans(team, refs, np.arange(16), starts, goals, max_expand=20000)
+    print("Team2 tick:", [(r.status, int(r.n_expanded)) for r in R], "kernel ms", team.last_kernel_ms())
+    assert n_ok >= 12
