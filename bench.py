@@ -67,10 +67,15 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the N-thread CPU leg (0 = all cores, at most 64)")
     ap.add_argument("--helpers", type=int, default=-1, help="helper workgroups per leading workgroup: -1 auto (2), 0 off, 2")
     ap.add_argument("--help-reserved", type=int, default=-1, help="workgroups that only ever help (-1 auto)")
+    ap.add_argument("--config", choices=["c4", "c5"], default="c4",
+                    help="c4 (default): the query batch on the voxel map; c5: BASELINE config 5 -- one decentralised replanning tick of 16 robots "
+                         "(Team2) through the moving-obstacle planner, batched in one launch")
     ap.add_argument("--dump-queries", default="", help="write per-query expansions / device timing of the last step to this JSON file")
     args = ap.parse_args()
     if args.single:
         args.queries = 1
+    if args.config == "c5":
+        return bench_c5(args)
 
     import torch
     import torch.distributed as dist
@@ -342,6 +347,77 @@ def main():
         dist.destroy_process_group()
 
 
+def bench_c5(args):
+    """BASELINE config 5: 16-robot decentralised replanning at a fixed 4 s horizon on PolyMapPlanner2D-style moving
+    obstacles, one tick (all 16 robots replan) per step, batched in one launch on 1 GPU.  The CPU baseline is the search
+    through the REFERENCE's own env_poly_map compiled from where it lies (oracle/_ref/libpolymap_ref.so), one robot
+    after the other on one core, like the reference's update_decentralized (robot_team.hpp:60-66)."""
+    import torch
+    from mpl_ros_amd import poly_map as pm
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    worlds, starts, goals = pm.team2_tick(dt=0.5, t_now=1.0, traj_time=4.0)
+    max_expand = args.max_expand if args.max_expand > 0 else 20000
+    kw = dict(dt=0.5, v_max=2.0, a_max=1.0, w=10.0)
+    team = pm.PolyTeam()
+    team.configure(pm.ACC, pm.U9, **kw)
+    team.set_worlds(worlds)
+    team.set_capacity(16, 1 << 21, 1 << 23, 1 << 22)
+    world_of = np.arange(16)
+    pkw = dict(eps=1.0, tol_pos=0.5, max_expand=max_expand, heur_ignore_dynamics=True)
+    for _ in range(args.warmup):
+        team.plan_batch(world_of, starts, goals, **pkw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        team.set_worlds(worlds)  # a tick re-uploads every robot's obstacle set (the trajectories changed)
+        R = team.plan_batch(world_of, starts, goals, **pkw)
+        kernel_ms += team.last_kernel_ms()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_exp = sum(r.n_expanded for r in R)
+    nsf = sum(r.n_succ_finite for r in R)
+    n_prims = sum(r.n_succ for r in R)
+    # algorithmic bytes per expansion: S_in + obstacle data read by the collision tests of the valid primitives
+    # (15 trajectories x (104 B record + 4 hyperplanes x 32 B + 8 segments x 104 B) + the box) + N_succ (S_out + S_probe)
+    obs_bytes = sum(104 + 32 * len(o.poly) + 104 * len(o.segs) for o in worlds[0].nonlinear) + 104 + 32 * 4
+    alg = n_exp * (48 + 16) + n_prims * obs_bytes + nsf * ((48 + 16) + (2 * 7 * 4 + 8))
+    k_ms = kernel_ms / args.steps
+    out = {"metric": "node_expansions_per_s", "value": n_exp * args.steps / elapsed, "unit": "expansions/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "C5: one decentralised replanning tick of the 16 robots of Team2 (robot_team.hpp:275-353), each against the 15 others' "
+                                  "trajectories (4 s horizon) + the static box, moving-obstacle planner (env_poly_map), 9-primitive acc lattice, dt 0.5 "
+                                  f"v_max 2 a_max 1 tol 0.5, distance heuristic, max_expand {max_expand}; all 16 searches in one launch",
+                      "robots": 16, "n_primitives": 9},
+           "expansions_per_step": n_exp, "plan_status_counts": {str(k): int(v) for k, v in enumerate(np.bincount([r.status for r in R], minlength=7))},
+           "tick_ms": 1e3 * elapsed / args.steps,
+           "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "astar_poly_kernel<256>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
+                        "note": "16 workgroups (one per robot): the obstacle data stays in L2 and the expansion is f64 root solving; latency bound"}}
+    if args.cpu_seconds > 0:
+        from oracle import refpoly
+        if refpoly.available():
+            t0 = time.perf_counter()
+            n_cpu, bad = 0, 0
+            for r in range(16):
+                ref = refpoly.RefWorld(worlds[r], pm.ACC, pm.U9, **kw).plan(starts[r], goals[r], eps=1.0, tol_pos=0.5, max_expand=max_expand)
+                n_cpu += len(ref["expanded"])
+                act, ids, _ = team.traj(r)
+                ok = ref["status"] == R[r].status and len(ref["expanded"]) == R[r].n_expanded and ref["n_nodes"] == R[r].n_nodes
+                ok = ok and (ref["cost"] == R[r].cost or (np.isinf(ref["cost"]) and np.isinf(R[r].cost)))
+                ok = ok and (ref["status"] != 0 or (np.array_equal(act, ref["actions"]) and np.array_equal(ids, ref["node_ids"])))
+                bad += 0 if ok else 1
+            cpu_s = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n_cpu / cpu_s, "unit": "expansions/s", "cores": 1, "kind": "reference",
+                                   "sample": f"the same tick, the 16 robots one after the other ({n_cpu} expansions, {cpu_s:.1f} s): the reference's env_poly_map "
+                                             "compiled from its own headers, driven by the restated best-first loop (GraphSearch is not vendored)",
+                                   "tick_ms": 1e3 * cpu_s}
+            out["parity_sample"] = {"queries": 16, "mismatches": bad, "checked": "status, n_expanded, n_nodes, cost (bit-exact f64), actions, node ids"}
+    print(json.dumps(out), flush=True)
+
+
 def _cpu_run(cfg, queries, order, budget_s, procs):
     """`procs` worker PROCESSES (oracle/cpu_worker.py), one query at a time each, all mapping ONE read-only copy
     of the voxel map.  A dispatcher thread per worker hands out the next query of `order` until the budget is
@@ -349,8 +425,14 @@ def _cpu_run(cfg, queries, order, budget_s, procs):
     import subprocess
     import threading
     workers = []
-    for _ in range(procs):
-        w = subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), json.dumps(cfg)],
+    ncpu = os.cpu_count() or 1
+    for k in range(procs):
+        # pin worker k to its own physical core, every other core when there are enough of them (fewer workers per
+        # shared L3); logical CPUs [0, ncpu / 2) are taken to be the first hardware thread of each core
+        phys = max(ncpu // 2, 1)
+        stride = 2 if procs * 2 <= phys else 1
+        cfg_k = dict(cfg, cpu=(k * stride) % phys if procs > 1 else None)
+        w = subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), json.dumps(cfg_k)],
                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
         workers.append(w)
     for w in workers:

@@ -46,6 +46,59 @@ class PolyWorld:
         self.static, self.linear, self.nonlinear = [], [], []
 
 
+U9 = np.array([(dx, dy) for dx in (-1.0, 0.0, 1.0) for dy in (-1.0, 0.0, 1.0)])  # multi_robot_node.cpp:56-59 with u = 1, num = 1
+
+# Team2 (robot_team.hpp:275-353): start / goal of the 16 robots on the border of the 10 m x 10 m map
+TEAM2 = [((0, -5), (10, 5)), ((0, -2.5), (10, 2.5)), ((0, 0), (10, 0)), ((0, 2.5), (10, -2.5)), ((0, 5), (10, -5)), ((2.5, 5), (7.5, -5)),
+         ((5, 5), (5, -5)), ((7.5, 5), (2.5, -5)), ((10, 5), (0, -5)), ((10, 2.5), (0, -2.5)), ((10, 0), (0, 0)), ((10, -2.5), (0, 2.5)),
+         ((10, -5), (0, 5)), ((7.5, -5), (2.5, 5)), ((5, -5), (5, 5)), ((2.5, -5), (7.5, 5))]
+
+
+def acc_segs(p0, v0, us, dt):
+    """Trajectory of ACC primitives from (p0, v0) under the inputs `us`: rows {cx[6], cy[6], T}."""
+    p, v = np.array(p0, float), np.array(v0, float)
+    rows = []
+    for u in us:
+        u = np.array(u, float)
+        rows.append([0, 0, 0, u[0], v[0], p[0], 0, 0, 0, u[1], v[1], p[1], dt])
+        p = u / 2 * dt * dt + v * dt + p
+        v = u * dt + v
+    return np.array(rows)
+
+
+def team2_tick(dt=0.5, t_now=1.0, traj_time=4.0):
+    """One decentralised replanning tick of Team2 (BASELINE config 5): HomogeneousRobotTeam::set_obs
+    (robot_team.hpp:33-51) gives robot i the static box (robot_team.hpp:383-388) and the 15 other robots as
+    nonlinear obstacles following their current trajectories, truncated to `traj_time` (robot.hpp:156-170); every
+    robot then plans from traj.evaluate(dt) to its goal (robot.hpp:92-133).  The robots' current trajectories are
+    synthetic stand-ins (accelerate towards the goal, coast, brake).  Returns (worlds, starts, goals)."""
+    rec = rectangle(0.5)
+    box = np.array([[4, 0, -1, -0.0], [6, 0, 1, 0], [5, -1, -0.0, -1], [5, 1, 0, 1]], dtype=np.float64)
+    trajs, traj_t = [], []
+    for s, g in TEAM2:
+        d = np.sign(np.array(g, float) - np.array(s, float))
+        trajs.append(acc_segs(s, (0, 0), [d, d, 0 * d, 0 * d, 0 * d, 0 * d, -d, -d], dt))
+        traj_t.append(0.01 * len(traj_t))
+    worlds = []
+    for i in range(16):
+        W = PolyWorld((0.0, -5.0), (10.0, 10.0))
+        W.static.append(StaticObstacle(box, (0.0, 0.0)))
+        for j in range(16):
+            if j == i:
+                continue
+            segs, dis = trajs[j], False
+            if traj_time > 0 and len(segs) * dt > traj_time:
+                segs, dis = segs[: int(round(traj_time / dt))], True
+            W.nonlinear.append(NonlinearObstacle(rec, segs, start_t=t_now - traj_t[j], disappear_back=dis))
+        worlds.append(W)
+    starts, goals = np.zeros((16, 9)), np.zeros((16, 9))
+    for r, (s, g) in enumerate(TEAM2):
+        seg = trajs[r][1]
+        starts[r] = [seg[5], seg[11], seg[4], seg[10], 0, 0, 0, 0, dt]
+        goals[r, 0:2] = g
+    return worlds, starts, goals
+
+
 class PolyTeam:
     """The worlds of several planners on the device + the shared planner set-up (setVmax/setAmax/setDt/setU/setW)."""
 

@@ -19,6 +19,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     cfg = json.loads(sys.argv[1])
+    if cfg.get("cpu") is not None:  # one worker per physical core, spread over the sockets
+        try:
+            os.sched_setaffinity(0, {int(cfg["cpu"])})
+        except OSError:
+            pass
     from oracle import orc
     if cfg.get("native"):
         orc.use_native()

@@ -77,12 +77,13 @@ def test_reference_driver_through_the_shim(tmp_path, skir):
     assert r["grid_occ"] == int((G.get_map() > 0).sum()) == r["grid_cloud2"]
     # visualisation getters: expansion record, linked nodes, one primitive per predecessor record
     co, po, ao = P.edges()
-    assert viz["expanded_nodes"] == len(P.expanded()[0]) and viz["all_primitives"] == len(co) and viz["linked"] == len(set(co.tolist()))
+    bp, ba = P.blocked_edges()  # getAllPrimitives() = the finite pred entries + the blocked (cost inf) ones, like upstream's hm_
+    assert viz["expanded_nodes"] == len(P.expanded()[0]) and viz["all_primitives"] == len(co) + len(bp) and viz["linked"] == len(set(co.tolist()))
     closed = [P.node(int(i))[3] for i in range(P.num_nodes())]
     assert viz["expanded_edges"] == sum(1 for ch in co if closed[int(ch)])
     U = mapgen.control_lattice(1.0, 1, True)
     end_sum = 0.0
-    for par, act in zip(po, ao):  # end point x of Primitive(parent, U[action], dt = 1): p + v + u / 2, summed in the same order
+    for par, act in zip(list(po) + list(bp), list(ao) + list(ba)):  # end point x of Primitive(parent, U[action], dt = 1): p + v + u / 2
         w = P.node(int(par))[0]
         end_sum += U[act][0] / 2 * 1.0 * 1.0 + w.vel[0] * 1.0 + w.pos[0]
     assert abs(viz["prs_end_sum"] - end_sum) < 1e-6 * max(1.0, abs(end_sum))

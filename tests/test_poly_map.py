@@ -12,19 +12,7 @@ from oracle import refpoly
 
 needs_ref = pytest.mark.skipif(not refpoly.available(), reason="oracle/_ref/libpolymap_ref.so not built (make -C oracle ref)")
 
-U9 = np.array([(dx, dy) for dx in (-1.0, 0.0, 1.0) for dy in (-1.0, 0.0, 1.0)])  # multi_robot_node.cpp:56-59, u = 1, num = 1
-
-
-def acc_segs(p0, v0, us, dt):
-    """Trajectory of ACC primitives from (p0, v0) under the inputs `us`: rows {cx[6], cy[6], T}."""
-    p, v = np.array(p0, float), np.array(v0, float)
-    rows = []
-    for u in us:
-        u = np.array(u, float)
-        rows.append([0, 0, 0, u[0], v[0], p[0], 0, 0, 0, u[1], v[1], p[1], dt])
-        p = u / 2 * dt * dt + v * dt + p
-        v = u * dt + v
-    return np.array(rows)
+U9, acc_segs = pm.U9, pm.acc_segs
 
 
 def random_world(rng, n_static=2, n_linear=2, n_nonlinear=3, dt=0.5):
@@ -103,29 +91,7 @@ def test_get_succ_matches_the_compiled_reference_on_random_worlds(seed):
     assert n_fin > 500 and n_inf > 300  # both outcomes are exercised
 
 
-def team2_worlds(t_now, trajs, traj_t, dt, traj_time=0.0):
-    """HomogeneousRobotTeam::set_obs (robot_team.hpp:33-51) for Team2: robot i sees the static box and the other
-    robots as nonlinear obstacles following their current trajectories (robot.hpp:156-170)."""
-    rec = pm.rectangle(0.5)
-    box = np.array([[4, 0, -1, -0.0], [6, 0, 1, 0], [5, -1, -0.0, -1], [5, 1, 0, 1]], dtype=np.float64)  # robot_team.hpp:383-388
-    worlds = []
-    for i in range(len(trajs)):
-        W = pm.PolyWorld((0.0, -5.0), (10.0, 10.0))
-        W.static.append(pm.StaticObstacle(box, (0.0, 0.0)))
-        for j in range(len(trajs)):
-            if j == i:
-                continue
-            segs, dis = trajs[j], False
-            if traj_time > 0 and len(segs) * dt > traj_time:
-                segs, dis = segs[: int(round(traj_time / dt))], True
-            W.nonlinear.append(pm.NonlinearObstacle(rec, segs, start_t=t_now - traj_t[j], disappear_back=dis))
-        worlds.append(W)
-    return worlds
-
-
-TEAM2 = [((0, -5), (10, 5)), ((0, -2.5), (10, 2.5)), ((0, 0), (10, 0)), ((0, 2.5), (10, -2.5)), ((0, 5), (10, -5)), ((2.5, 5), (7.5, -5)),
-         ((5, 5), (5, -5)), ((7.5, 5), (2.5, -5)), ((10, 5), (0, -5)), ((10, 2.5), (0, -2.5)), ((10, 0), (0, 0)), ((10, -2.5), (0, 2.5)),
-         ((10, -5), (0, 5)), ((7.5, -5), (2.5, 5)), ((5, -5), (5, 5)), ((2.5, -5), (7.5, 5))]  # robot_team.hpp:275-353
+TEAM2 = pm.TEAM2
 
 
 @pytest.mark.gpu
@@ -135,12 +101,7 @@ def test_team2_tick_get_succ_matches_the_compiled_reference():
     (straight-line stand-in trajectories towards their goals) + the static box, dt 0.5, v_max 2, a_max 1."""
     dt = 0.5
     rng = np.random.default_rng(7)
-    trajs, traj_t = [], []
-    for s, g in TEAM2:  # a plausible current trajectory of every robot: accelerate towards its goal, then coast
-        d = np.sign(np.array(g, float) - np.array(s, float))
-        trajs.append(acc_segs(s, (0, 0), [d, d, 0 * d, 0 * d, 0 * d, 0 * d, -d, -d], dt))
-        traj_t.append(0.01 * len(traj_t))
-    worlds = team2_worlds(1.0, trajs, traj_t, dt, traj_time=4.0)
+    worlds, starts_t, _ = pm.team2_tick(dt=dt, t_now=1.0, traj_time=4.0)
     team = pm.PolyTeam()
     kw = dict(dt=dt, v_max=2.0, a_max=1.0, w=10.0)
     team.configure(pm.ACC, U9, **kw)
@@ -150,25 +111,9 @@ def test_team2_tick_get_succ_matches_the_compiled_reference():
     world_of = np.repeat(np.arange(16), 40)
     states = random_states(rng, K, dt)
     for r in range(16):  # include each robot's own replanning start: traj.evaluate(dt)
-        seg = trajs[r][1]
-        states[r * 40] = [seg[5], seg[11], seg[4], seg[10], 0, 0, 0, 0, dt]
+        states[r * 40] = starts_t[r]
     n_fin, n_inf = _compare_get_succ(team, worlds, refs, world_of, states, 9)
     assert n_fin > 1000 and n_inf > 100
-
-
-def _team2_tick(dt=0.5, t_now=1.0, traj_time=4.0):
-    trajs, traj_t = [], []
-    for s, g in TEAM2:
-        d = np.sign(np.array(g, float) - np.array(s, float))
-        trajs.append(acc_segs(s, (0, 0), [d, d, 0 * d, 0 * d, 0 * d, 0 * d, -d, -d], dt))
-        traj_t.append(0.01 * len(traj_t))
-    worlds = team2_worlds(t_now, trajs, traj_t, dt, traj_time=traj_time)
-    starts, goals = np.zeros((16, 9)), np.zeros((16, 9))
-    for r, (s, g) in enumerate(TEAM2):  # Robot::plan: start_ = traj_.evaluate(dt_) (robot.hpp:97), goal = the robot's goal
-        seg = trajs[r][1]
-        starts[r] = [seg[5], seg[11], seg[4], seg[10], 0, 0, 0, 0, dt]
-        goals[r, 0:2] = g
-    return worlds, starts, goals
 
 
 def _compare_plans(team, refs, world_of, starts, goals, **kw):
@@ -225,7 +170,7 @@ def test_plans_match_a_search_over_the_compiled_reference_environment(seed):
 def test_team2_tick_plans_match():
     """BASELINE config 5: one decentralised tick of Team2 -- 16 robots replanning at once against each other's
     trajectories (4 s horizon) and the static box, one launch, against the search over the compiled reference env."""
-    worlds, starts, goals = _team2_tick()
+    worlds, starts, goals = pm.team2_tick()
     team = pm.PolyTeam()
     kw = dict(dt=0.5, v_max=2.0, a_max=1.0, w=10.0)
     team.configure(pm.ACC, U9, **kw)
