@@ -8,6 +8,15 @@
 #define MPLX_SHIM_TRAJECTORY_H
 #include <mpl_basis/primitive.h>
 
+/// one sample of a trajectory: what TrajectoryExtractor turns into a TrajectoryCommand message
+/// (planning_ros_utils/src/planning_utils/trajectory_extractor.hpp:13-30 reads pos, vel, acc, jrk, yaw, yaw_dot, t)
+template <int Dim>
+struct Command {
+  Vecf<Dim> pos, vel, acc, jrk;
+  decimal_t yaw{0}, yaw_dot{0};
+  decimal_t t{0};
+};
+
 template <int Dim>
 class Trajectory {
  public:
@@ -52,6 +61,21 @@ class Trajectory {
       }
     }
     return Waypoint<Dim>();
+  }
+  /// N + 1 equally spaced samples over the whole trajectory (trajectory_extractor.hpp:9-10: N = ceil(total / dt))
+  vec_E<Command<Dim>> sample(int N) const {
+    vec_E<Command<Dim>> ps;
+    if (segs.empty() || N <= 0) return ps;
+    const decimal_t dt = total_t_ / N;
+    for (int i = 0; i <= N; i++) {
+      const Waypoint<Dim> w = evaluate(i * dt);
+      Command<Dim> c;
+      c.pos = w.pos; c.vel = w.vel; c.acc = w.acc; c.jrk = w.jrk;
+      c.yaw = w.yaw;
+      c.t = i * dt;
+      ps.push_back(c);
+    }
+    return ps;
   }
   /// total control effort of the derivative `control` selects / of yaw (map_planner_node.cpp:210-214)
   decimal_t J(const Control::Control &control) const {

@@ -7,6 +7,7 @@
 // expected to REFUSE (host environment, no CPU search in this back-end).
 #include <mpl_external_planner/poly_map_planner/poly_map_planner.h>
 
+#include <cmath>
 #include <cstdio>
 
 int main() {
@@ -48,6 +49,9 @@ int main() {
   Primitive2D pr(start, U[5], 0.5);
   const bool hit = collide(pr, st[0]);
   const Trajectory2D traj(vec_E<Primitive2D>(1, pr));
+  // TrajectoryExtractor's sampling (trajectory_extractor.hpp:8-10): N = ceil(total / dt) -> N + 1 commands
+  const auto cmds = traj.sample((int)std::ceil(traj.getTotalTime() / 0.1));
+  printf("{\"cmds\": %zu, \"cmd_last_y\": %.17g, \"cmd_last_t\": %.17g}\n", cmds.size(), cmds.back().pos(1), cmds.back().t);
   printf("{\"polys\": %zu, \"planned\": %d, \"collide_static\": %d, \"J_acc\": %.17g, \"J_vel\": %.17g, \"max_vel_x\": %.17g, \"valid\": %d}\n",
          polys.size(), planned ? 1 : 0, hit ? 1 : 0, traj.J(Control::ACC), traj.J(Control::VEL), pr.max_vel(0),
          validate_primitive(pr, 2.0, 1.0, -1.0) ? 1 : 0);

@@ -105,7 +105,10 @@ def test_reference_planner_headers_compile_unchanged_against_the_shim(tmp_path):
     assert out.returncode == 0
     assert "no CPU search" in out.stdout
     last = out.stdout.strip().splitlines()[-1]
-    r = json.loads(last[last.index("{"):])  # (the refusal message ends in an ANSI colour reset on the same line)
+    r = json.loads(last[last.index("{"):])  # (the refusal message ends in an ANSI colour reset before the next line's text)
     # start (4,0) v (1,0), u = U[5] = (0,1) for dt 0.5: analytic known answers
     assert r["polys"] == 2 and r["planned"] == 0 and r["collide_static"] == 1
+    cml = out.stdout.strip().splitlines()[-2]
+    cm = json.loads(cml[cml.index("{"):])
+    assert cm["cmds"] == 6 and cm["cmd_last_t"] == 0.5 and cm["cmd_last_y"] == 0.5 * 0.25 / 1  # y(t) = u t^2 / 2 at t = 0.5
     assert r["J_acc"] == 0.5 and abs(r["J_vel"] - (1.0 * 0.5 + 0.5 ** 3 / 3)) < 1e-15 and r["max_vel_x"] == 1.0 and r["valid"] == 1
