@@ -87,10 +87,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # (dry runs of the multi-rank path on a one-GPU box: MPLX_BENCH_SHARE_GPU=1 puts every rank on device 0 and
+    #  MPLX_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device; small collectives then run on the host)
+    backend = os.environ.get("MPLX_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("MPLX_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mpl_ros_amd import dist as mdist
     from mpl_ros_amd import mapgen
@@ -121,7 +129,7 @@ def main():
     if grid is None:
         grid = map_t.cpu().numpy().reshape(n, n, n)  # host copy only to draw free query cells
 
-    mu = VoxelMapUtil(local_rank)
+    mu = VoxelMapUtil(dev_index)
     mu.setMapDevice(map_t.data_ptr(), origin, (n, n, n), res)
 
     # ---- the query stream and this rank's share of it
@@ -194,7 +202,7 @@ def main():
     def step():
         if sharded:  # the function tests/test_multiproc_gloo.py drives with gloo: partition -> plan -> gather -> merge
             state["merged"], _, state["per_rank"] = mdist.run_sharded(dist, torch, rank, world, queries, plan_fn, mode=args.shard,
-                                                                      device=dev, sync=torch.cuda.synchronize)
+                                                                      device=coll_dev, sync=torch.cuda.synchronize)
         else:
             plan_fn(mine)
 
@@ -228,14 +236,14 @@ def main():
     lat = np.array([pl.queryTiming(k)[1] - pl.queryTiming(k)[0] for k in range(len(mine))]) if mine else np.zeros(0)
     per_rank = [[local_s, float(n_exp), float(len(mine))]]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([n_exp, reads, nsf] + status.tolist(), dtype=torch.int64, device=dev)
+        c = torch.tensor([n_exp, reads, nsf] + status.tolist(), dtype=torch.int64, device=coll_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         tot_exp = int(c[0].item())
         tot_status = c[3:].tolist()
-        st = torch.tensor([local_s, float(n_exp), float(len(mine))], dtype=torch.float64, device=dev)
+        st = torch.tensor([local_s, float(n_exp), float(len(mine))], dtype=torch.float64, device=coll_dev)
         sts = [torch.empty_like(st) for _ in range(world)]
         dist.all_gather(sts, st)
         per_rank = [s.cpu().tolist() for s in sts]
@@ -298,7 +306,7 @@ def main():
             "plan_latency_ms": {"p50": float(np.percentile(lat, 50)) * 1e3, "p90": float(np.percentile(lat, 90)) * 1e3,
                                 "p99": float(np.percentile(lat, 99)) * 1e3, "max": float(lat.max()) * 1e3, "mean": float(lat.mean()) * 1e3},
             "map_setup_s": {"generate": round(t_gen, 3), "rccl_broadcast": round(t_bcast, 4)},
-            "per_rank": [{"rank": r, "seconds": round(p[0], 4), "expansions_per_step": int(p[1]), "queries": int(p[2])} for r, p in enumerate(per_rank)],
+            "per_rank": [{"rank": r, "seconds_per_step": round(p[0] / args.steps, 4), "expansions_per_step": int(p[1]), "queries": int(p[2])} for r, p in enumerate(per_rank)],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": pl.kernelName(), "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
