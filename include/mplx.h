@@ -158,11 +158,12 @@ int mplx_set_speculation(mplx_ctx *ctx, int32_t mode);
  * per_leader: -1 auto (2), 0 off, 2.  reserved: compute units kept free of leading workgroups for helpers from the
  * start of a batch that is larger than the machine (-1 / 0: none -- helpers then arrive as queries finish; a batch
  * smaller than the machine always gets 2 helpers per query from the start).  cache_rows: rows of the heuristic
- * cache (0 auto).  Used by the speculative kernels for lattices of at most 31 inputs.  A helper workgroup leaves
- * after a fixed lifetime (8 s) whatever happens: it can cost time, it cannot keep a batch from finishing. */
+ * cache (0 auto).  Used by the speculative kernels for lattices of at most 31 inputs and for the 65..128-input jerk
+ * lattices.  A helper workgroup leaves the launch when it has found nobody to help for 8 s or when the leader it
+ * serves completes no batch for 2 s: it can cost time, it cannot keep a batch from finishing. */
 int mplx_set_helpers(mplx_ctx *ctx, int32_t per_leader, int32_t reserved, uint64_t cache_rows);
-/* last batch: [0] heuristic-cache rows used, [1] queries finished, [2] helper workgroups that hit their lifetime
- * limit (0 in a healthy run), [3] helper workgroups that left again to make way for leading workgroups */
+/* last batch: [0] heuristic-cache rows used, [1] queries finished, [2] helper workgroups that hit a safety
+ * limit (idle 8 s / stalled leader 2 s; 0 in a healthy run), [3] helper workgroups that left again to make way for leading workgroups */
 int mplx_helper_stats(const mplx_ctx *ctx, uint32_t stats[4]);
 /* f-width of one coarse OPEN bucket (0 = default 8*w*dt); the fine level divides it by 1024 */
 int mplx_set_bucket_width(mplx_ctx *ctx, double width);

@@ -49,6 +49,7 @@ struct mplx_ctx {
   int help_reserved = -1;   // workgroups that never lead (-1 auto: only for batches smaller than the machine)
   uint64_t help_rows = 0;   // rows of the heuristic cache (0 auto)
   int n_cus = 0;
+  int pool_help_lanes = 0;  // unit width the heuristic-cache rows were sized for
   // capacities (shared by all queries of a batch)
   int32_t n_slots = 1;
   uint64_t cap_nodes = 1u << 20, cap_edges = 1u << 22, cap_log = 1u << 21;
@@ -537,7 +538,8 @@ static uint64_t next_pow2(uint64_t v) {
 static int ensure_pools(mplx_ctx *c, int slots) {
   const int control = c->cfg.control;
   if (c->pools_valid && c->pool_slots >= slots && c->pool_control == control && c->pool_nodes == c->cap_nodes &&
-      c->pool_edges == c->cap_edges && c->pool_log == c->cap_log && (c->helpers != 0) == (c->pools.boxes != nullptr))
+      c->pool_edges == c->cap_edges && c->pool_log == c->cap_log && (c->helpers != 0) == (c->pools.boxes != nullptr) &&
+      (c->helpers == 0 || c->pool_help_lanes == (c->cfg.n_u <= 31 ? 32 : 128)))
     return MPLX_OK;
   free_pools(c);
   SearchParams &P = c->pools;
@@ -562,12 +564,17 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   PA(P.chunk_next, 4);
   P.boxes = nullptr; P.cache_c = nullptr; P.cache_h = nullptr; P.cache_next = nullptr; P.done_word = nullptr; P.all_started = nullptr; P.cache_rows = 0;
   if (c->helpers != 0) {  // look-ahead cache of the helper workgroups (used by the speculative kernels, lattices <= 31 inputs)
+    // rows of the heuristic cache: a quarter of the state capacity (a node is expanded ahead of time at most once),
+    // at most 12 GiB unless the caller says otherwise; the row size follows the lattice (cache_row_doubles)
+    const int unit_lanes = c->cfg.n_u <= 31 ? 32 : 128;
+    const uint64_t row_bytes = (uint64_t)cache_row_doubles(unit_lanes) * sizeof(double);
     uint64_t rows = c->help_rows ? c->help_rows : std::max<uint64_t>((uint64_t)1 << 16, (nch << NODE_CH_LOG) / 4);
-    if (!c->help_rows && rows > ((uint64_t)48 << 20)) rows = (uint64_t)48 << 20;
+    if (!c->help_rows && rows * row_bytes > ((uint64_t)12 << 30)) rows = ((uint64_t)12 << 30) / row_bytes;
     if (rows > 0xFFFFFFF0ull) rows = 0xFFFFFFF0ull;
     PA(P.boxes, (size_t)slots + 1024);
     PA(P.cache_c, (size_t)(nch << NODE_CH_LOG));
-    PA(P.cache_h, (size_t)rows * CACHE_ROW_DOUBLES);
+    PA(P.cache_h, (size_t)rows * cache_row_doubles(unit_lanes));
+    c->pool_help_lanes = unit_lanes;
     uint32_t *ctr = nullptr;
     PA(ctr, 16);
     P.cache_next = ctr;                              // [0] row counter, [2] [3] diagnostics
@@ -797,8 +804,8 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   int grid = slots, helper_grid = 0;
   P.help_reserved = 0;
   P.help_max = 0;
-  const bool help = spec && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes && P.n_u <= 31 &&
-                    (P.control == CTRL_ACC || P.control == CTRL_JRK);
+  const bool help = spec && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
+                    ((P.n_u <= 31 && (P.control == CTRL_ACC || P.control == CTRL_JRK)) || (P.control == CTRL_JRK && P.n_u > 64 && P.n_u <= 128));
   if (help) {
     P.help_max = c->helpers < 0 ? 2 : c->helpers;
     if (c->help_reserved > 0 && slots + c->help_reserved > c->n_cus) grid = std::max(1, c->n_cus - c->help_reserved);
@@ -890,7 +897,8 @@ extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
     else if (n_u <= 64) { ul = 64; k = 4; }
     else if (c->speculation == 2) { ul = 128; k = 2; }
     else { ul = 128; k = 4; }
-    const bool help = ul == 32 && k == 16 && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && n_u <= 31;
+    const bool help = (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 &&
+                      ((ul == 32 && k == 16 && n_u <= 31) || (ul == 128 && k == 4 && control == CTRL_JRK && n_u > 64));
     snprintf(buf, sizeof(buf), help ? "astar_spec_kernel<%d,%d,%s,help>" : "astar_spec_kernel<%d,%d,%s>", ul, k, cn);
   }
   return buf;

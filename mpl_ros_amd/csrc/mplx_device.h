@@ -89,7 +89,13 @@ struct CacheRec {              // per node record of the pool; two self-validati
                                // the state the helper expanded -- the leader compares it with its own candidate's key
   uint32_t valid, blocked;     // per-control-input masks (valid has CACHE_READY set)
 };
-constexpr int CACHE_ROW_DOUBLES = 32;  // slots 0..30: heuristic of the successor of input i; slot 31: voxel reads (as bits)
+// Row of cache_h.  Lattices of at most 31 inputs (units of <= 64 lanes): 32 doubles -- slots 0..30 the heuristic of
+// the successor of input i, slot 31 the voxel reads (as bits); the masks live in the cache record.  Larger lattices
+// (units of 128 lanes, <= 128 inputs): 136 doubles -- [0..3] eight 32-bit mask words (valid x 4, blocked x 4), [4] the
+// voxel reads, [8..135] the heuristics; the record's second half then only carries CACHE_READY.
+constexpr int cache_row_doubles(int unit_lanes) { return unit_lanes <= 64 ? 32 : 136; }
+constexpr int cache_h_slot(int unit_lanes, int lu) { return unit_lanes <= 64 ? lu : 8 + lu; }
+constexpr int cache_reads_slot(int unit_lanes) { return unit_lanes <= 64 ? 31 : 4; }
 
 struct SearchParams {
   // environment
@@ -123,7 +129,7 @@ struct SearchParams {
   // helper workgroups (null / 0 when disabled)
   HelpBox *boxes;                 // gridDim.x boxes
   CacheRec *cache_c;              // one per node-pool record, zeroed per batch
-  double *cache_h;                // cache_rows x CACHE_ROW_DOUBLES
+  double *cache_h;                // cache_rows x cache_row_doubles(unit lanes)
   uint32_t cache_rows;
   uint32_t *cache_next;           // bump counter of cache_h rows; [2], [3]: diagnostics
   unsigned long long *done_word;  // epoch << 32 | queries finished (helpers leave when the count reaches nq)

@@ -7,10 +7,17 @@
 
 using namespace mplx;
 
-// Lattices of at most 31 inputs (the masks of a cache record are one word): leaders <32 lanes x 16 units>.
+// Lattices of at most 31 inputs (the masks of a cache record are one word): leaders <32 lanes x 16 units>; the
+// 125-input jerk lattice of BASELINE config 3 (65..128 inputs, JRK): leaders <128 lanes x 4 units>, masks in the row.
 // Returns false when no helper-capable variant exists for the configuration.
 bool mplx_launch_spec_help(int grid, hipStream_t s, int helper_grid, hipStream_t hs, const SearchParams &P) {
-  if (!(P.control == CTRL_ACC || P.control == CTRL_JRK) || P.n_u > 31 || !P.boxes) return false;
+  if (!(P.control == CTRL_ACC || P.control == CTRL_JRK) || !P.boxes) return false;
+  if (P.control == CTRL_JRK && P.n_u > 64 && P.n_u <= 128) {
+    hipLaunchKernelGGL((astar_spec_kernel<128, 4, CTRL_JRK, 1024, 1024, true>), dim3(grid), dim3(512), 0, s, P);
+    if (helper_grid > 0) hipLaunchKernelGGL((helper_kernel<128, 4, CTRL_JRK>), dim3(helper_grid), dim3(512), 0, hs, P);
+    return true;
+  }
+  if (P.n_u > 31) return false;
   if (P.control == CTRL_ACC) {
     hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024, true>), dim3(grid), dim3(512), 0, s, P);
     if (helper_grid > 0) hipLaunchKernelGGL((helper_kernel<32, 16, CTRL_ACC>), dim3(helper_grid), dim3(512), 0, hs, P);

@@ -265,8 +265,14 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
     double max_v = 0.0;
     bool ok;
     if (cached) {  // decided ahead of time by a helper workgroup: nothing left to sample
-      L.valid = (S.hc_valid[ku] >> lu) & 1u;
-      L.blocked = (S.hc_blocked[ku] >> lu) & 1u;
+      if constexpr (UL <= 64) {
+        L.valid = (S.hc_valid[ku] >> lu) & 1u;
+        L.blocked = (S.hc_blocked[ku] >> lu) & 1u;
+      } else {  // large lattice: the mask words are at the head of the helper's row
+        const uint32_t *rw = (const uint32_t *)(P.cache_h + (size_t)(S.hc_row[ku] - 1u) * cache_row_doubles(UL));
+        L.valid = (ld_u32(rw + (lu >> 5)) >> (lu & 31)) & 1u;
+        L.blocked = (ld_u32(rw + 4 + (lu >> 5)) >> (lu & 31)) & 1u;
+      }
       ok = false;
     } else {
 #ifdef MPLX_GENERIC_VALIDATE

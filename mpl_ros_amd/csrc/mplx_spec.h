@@ -69,7 +69,7 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   int32_t helped;               // a helper is attached to this workgroup's box (sampled every few batches)
   unsigned long long box_seq;   // wish lists published for the running query
   // helper side
-  int32_t help_box, help_idx, help_q, help_go;
+  int32_t help_box, help_idx, help_q, help_go, help_quit;
   unsigned long long help_seq, help_t0;
   uint32_t n_work;
   uint32_t work[WISH];          // pool indices of the node records to expand ahead of time
@@ -217,7 +217,11 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
 }
 
 // ------------------------------------------------------------------ helper workgroups (look-ahead expansion)
-constexpr unsigned long long HELP_LIFETIME_TICKS = 800000000ull;  // 8 s of wall_clock64() (100 MHz)
+// Safety net (wall_clock64() ticks, 100 MHz): a helper may cost time, it must never be able to keep a batch from
+// finishing.  It leaves the launch for good when it has found nobody to help for HELP_IDLE_TICKS, or when the leader
+// it serves has not completed a batch for HELP_STALL_TICKS (a healthy leader completes thousands per second).
+constexpr unsigned long long HELP_IDLE_TICKS = 800000000ull;   // 8 s
+constexpr unsigned long long HELP_STALL_TICKS = 200000000ull;  // 2 s
 // Serve the leader of box `bi` until its query ends: every time it announces a wish list, expand the listed
 // nodes that have no cache entry yet -- get_succ (phases 1-2 of expand_unit) plus the heuristic of every
 // finite successor -- and publish {row, voxel reads, valid mask, blocked mask} in cache_c and the heuristics in
@@ -233,6 +237,7 @@ __device__ __noinline__ void helper_serve(const SearchParams &P, SM &S, int tid)
   const uint32_t q = (uint32_t)S.help_q;
   const uint32_t epoch = P.epoch;
   unsigned long long last_seq = ((unsigned long long)epoch << 32) | 1ull;
+  unsigned long long t_progress = wall_clock64();  // (thread 0) when the leader last announced a new list
   for (;;) {
     if (tid == 0) {
       unsigned long long seq;
@@ -240,10 +245,13 @@ __device__ __noinline__ void helper_serve(const SearchParams &P, SM &S, int tid)
       for (int spin = 0;; spin++) {
         seq = ld_u64(&B->seq);
         if (!box_active(seq, epoch) || ld_u32(&B->q) != q || ld_u32(P.cache_next) >= P.cache_rows) { go = 0; break; }
-        if (seq != last_seq) break;
+        if (seq != last_seq) { t_progress = wall_clock64(); break; }
         __builtin_amdgcn_s_sleep(8);
-        // a leader that stopped announcing (no OPEN front left), or this helper's time is up: look elsewhere
-        if (spin > 200000 || wall_clock64() - S.help_t0 > HELP_LIFETIME_TICKS) { go = 0; break; }
+        if (wall_clock64() - t_progress > HELP_STALL_TICKS) {  // the leader makes no progress: leave the launch
+          S.help_quit = 1;
+          go = 0;
+          break;
+        }
       }
       S.help_go = go;
       S.help_seq = seq;
@@ -291,11 +299,11 @@ __device__ __noinline__ void helper_serve(const SearchParams &P, SM &S, int tid)
       uint32_t treads;
       unit_excl_scan<UL, BLOCK>(L.reads, S, tid, treads);
       const unsigned long long bv = __ballot(L.valid), bb = __ballot(L.blocked);
-      uint32_t vmask, bmask;
+      uint32_t vmask = 0, bmask = 0;
       if constexpr (UL == 32) {
         vmask = (tid & 32) ? (uint32_t)(bv >> 32) : (uint32_t)bv;
         bmask = (tid & 32) ? (uint32_t)(bb >> 32) : (uint32_t)bb;
-      } else {
+      } else if constexpr (UL == 64) {
         vmask = (uint32_t)bv;
         bmask = (uint32_t)bb;
       }
@@ -305,8 +313,16 @@ __device__ __noinline__ void helper_serve(const SearchParams &P, SM &S, int tid)
       }
       unit_sync<UL>();
       const uint32_t rp1 = live ? S.hc_row[ku] : 0u;
-      if (rp1 && lu < P.n_u) st_f64_agent(&P.cache_h[(size_t)(rp1 - 1u) * CACHE_ROW_DOUBLES + lu], h);
-      if (rp1 && lu == UL - 1) st_u64((unsigned long long *)&P.cache_h[(size_t)(rp1 - 1u) * CACHE_ROW_DOUBLES + 31], (unsigned long long)treads);
+      if (rp1 && lu < P.n_u) st_f64_agent(&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_h_slot(UL, lu)], h);
+      if (rp1 && lu == UL - 1) st_u64((unsigned long long *)&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)], (unsigned long long)treads);
+      if constexpr (UL > 64) {  // large lattice: every wave of the unit leaves its two words of each mask in the row
+        if (rp1 && (tid & 63) == 0) {
+          uint32_t *rw = (uint32_t *)(P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL));
+          const int w2 = 2 * (lu >> 6);
+          st_u32(rw + w2, (uint32_t)bv); st_u32(rw + w2 + 1, (uint32_t)(bv >> 32));
+          st_u32(rw + 4 + w2, (uint32_t)bb); st_u32(rw + 4 + w2 + 1, (uint32_t)(bb >> 32));
+        }
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has landed before the record names it
       unit_sync<UL>();
       if (rp1 && lu == 0) {
@@ -328,9 +344,9 @@ __device__ __noinline__ void helper_loop(const SearchParams &P, SM &S, int tid) 
   const int nboxes = P.help_reserved;  // number of leader boxes of the accompanying launch
   for (;;) {
     if (tid == 0) {
-      // leave when every query is done or the cache is full -- and, as a safety net, after a fixed lifetime: a
-      // helper may cost time, it must never be able to keep the machine from finishing
-      const bool expired = wall_clock64() - S.help_t0 > HELP_LIFETIME_TICKS;
+      // leave when every query is done or the cache is full -- and, as a safety net, when there has been nobody to
+      // help for a long time or the leader just served stopped making progress (helper_serve sets help_quit)
+      const bool expired = S.help_quit || wall_clock64() - S.help_t0 > HELP_IDLE_TICKS;
       if (expired) atomicAdd(P.cache_next + 2, 1u);  // (diagnostics) helpers that ran into the lifetime limit
       const unsigned long long dw = ld_u64(P.done_word);
       const bool done = (uint32_t)(dw >> 32) == P.epoch && (uint32_t)dw >= (uint32_t)P.nq;
@@ -393,7 +409,10 @@ __device__ __noinline__ void helper_loop(const SearchParams &P, SM &S, int tid) 
       continue;
     }
     helper_serve<UL, K, CONTROL>(P, S, tid);
-    if (tid == 0) atomicAnd(&(P.boxes + S.help_box)->helpers, ~(1u << S.help_idx));
+    if (tid == 0) {
+      atomicAnd(&(P.boxes + S.help_box)->helpers, ~(1u << S.help_idx));
+      S.help_t0 = wall_clock64();  // the idle clock restarts after useful work
+    }
     __syncthreads();
   }
 }
@@ -409,7 +428,6 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
   // HELP: this launch is accompanied by helper workgroups (helper_kernel below, a second launch): the leader
   // publishes the front of its OPEN list and picks up the look-ahead cache entries they leave.  Compiled out
   // of the plain variant (the kernel sits at the register limit).
-  static_assert(!HELP || UL <= 64, "per-input masks of the look-ahead cache are one word");
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   fill_uq<BLOCK, CONTROL>(P, S, tid);
@@ -765,7 +783,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             S.u_succ[ku] = tot & 0x3FFu;
             S.u_fin[ku] = tot >> 10;
             if (HELP && S.hc_row[ku] != 0u)  // voxel reads of the expansion as the helper counted them (slot 31 of its row)
-              S.u_reads[ku] = (uint32_t)ld_u64((const unsigned long long *)&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * CACHE_ROW_DOUBLES + 31]);
+              S.u_reads[ku] = (uint32_t)ld_u64((const unsigned long long *)&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)]);
             else
               S.u_reads[ku] = treads;
           }
@@ -851,7 +869,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
               // look-ahead cache hit: the heuristic of this successor is in the helper's row (written before the
               // cache record was, read after it)
               if (HELP && S.hc_row[ku] != 0u)
-                hspec = ld_f64_agent(&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * CACHE_ROW_DOUBLES + lu]);
+                hspec = ld_f64_agent(&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * cache_row_doubles(UL) + cache_h_slot(UL, lu)]);
               else
                 hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
             }
@@ -1236,6 +1254,7 @@ __global__ __launch_bounds__(UL *K) void helper_kernel(SearchParams P) {
   // launch holds more workgroups than it needs: later ones arrive when the leaders run out of queries and exit).
   if (tid == 0) {
     S.help_t0 = wall_clock64();
+    S.help_quit = 0;
     int ok = (int)blockIdx.x < P.help_keep;
     for (int spin = 0; spin < 128 && !ok; spin++) {
       ok = ld_u32(P.all_started) == P.epoch;
