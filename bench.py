@@ -213,7 +213,14 @@ def main():
     for _ in range(args.warmup):
         step()
         if os.environ.get("MPLX_BENCH_TRACE"):
-            print(f"[trace] warmup step done, kernel {pl.lastKernelMs():.0f} ms", file=sys.stderr, flush=True)
+            Tq = np.array([pl.queryTiming(k) for k in range(len(mine))])
+            late = np.argsort(-Tq[:, 1])[:3]
+            print(f"[trace] warmup step done, kernel {pl.lastKernelMs():.0f} ms {pl.helperStats()} last start {Tq[:, 0].max():.2f} s; running at 2 s / 4 s / 6 s: "
+                  f"{int(((Tq[:, 0] <= 2) & (Tq[:, 1] > 2)).sum())} / {int(((Tq[:, 0] <= 4) & (Tq[:, 1] > 4)).sum())} / {int(((Tq[:, 0] <= 6) & (Tq[:, 1] > 6)).sum())}; latest "
+                  f"{[(int(k), round(float(Tq[k, 0]), 2), round(float(Tq[k, 1]), 2), int(state['results'][k].n_expanded), int(Tq[k, 2])) for k in late]}", file=sys.stderr, flush=True)
+            if pl.lastKernelMs() > 5000:  # a stalled launch: where did the latest queries spend their cycles (Gcycles per phase)
+                for k in late:
+                    print(f"[trace]   q {int(k)} Gcycles {({n: round(v / 1e9, 2) for n, v in pl.queryCycles(int(k)).items()})}", file=sys.stderr, flush=True)
     barrier()
     state["kernel_ms"] = 0.0
     t0 = time.perf_counter()

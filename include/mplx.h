@@ -152,18 +152,20 @@ int mplx_set_capacity(mplx_ctx *ctx, int32_t n_slots, uint64_t total_nodes, uint
 /* speculative multi-node expansion (results are identical either way): -1 auto (on when
  * n_u <= 128), 0 = sequential kernel (one node per iteration), 2 = on */
 int mplx_set_speculation(mplx_ctx *ctx, int32_t mode);
-/* Helper workgroups: compute units without a query of their own expand the front of a running query's OPEN list
+/* Helper workgroups: a workgroup with no query (left) to lead expands the front of a running query's OPEN list
  * ahead of time (get_succ and successor heuristics are pure functions of the node, the map and the goal) and
- * leave the result in HBM for the workgroup that leads the query.  Results are identical with or without them.
- * per_leader: -1 auto (2), 0 off, 2.  reserved: compute units kept free of leading workgroups for helpers from the
- * start of a batch that is larger than the machine (-1 / 0: none -- helpers then arrive as queries finish; a batch
- * smaller than the machine always gets 2 helpers per query from the start).  cache_rows: rows of the heuristic
- * cache (0 auto).  Used by the speculative kernels for lattices of at most 31 inputs and for the 65..128-input jerk
- * lattices.  A helper workgroup leaves the launch when it has found nobody to help for 8 s or when the leader it
- * serves completes no batch for 2 s: it can cost time, it cannot keep a batch from finishing. */
+ * leaves the result in HBM for the workgroup that leads the query.  Results are identical with or without them.
+ * One launch, at most one workgroup per compute unit: in a batch larger than the machine the leading workgroups
+ * turn into helpers as they run out of queries; a batch smaller than the machine is launched with extra
+ * workgroups that help from the start (up to per_leader for every query).
+ * per_leader: -1 auto (2), 0 off, 2.  reserved: workgroups that never lead, for a batch larger than the machine
+ * (-1 / 0: none).  cache_rows: rows of the heuristic cache (0 auto).  Used by the speculative kernels for lattices
+ * of at most 31 inputs and for the 65..128-input jerk lattices.  The leader never waits for a helper; a helper
+ * leaves when every query is done, when it finds every running leader served, or when the leader it serves
+ * stops completing batches. */
 int mplx_set_helpers(mplx_ctx *ctx, int32_t per_leader, int32_t reserved, uint64_t cache_rows);
-/* last batch: [0] heuristic-cache rows used, [1] queries finished, [2] helper workgroups that hit a safety
- * limit (idle 8 s / stalled leader 2 s; 0 in a healthy run), [3] helper workgroups that left again to make way for leading workgroups */
+/* last batch: [0] heuristic-cache rows used, [1] queries finished, [2] helpers that gave up on a leader that
+ * completed no batch for ~1 s of polling (0 in a healthy run), [3] helpers that left because every running leader was served */
 int mplx_helper_stats(const mplx_ctx *ctx, uint32_t stats[4]);
 /* f-width of one coarse OPEN bucket (0 = default 8*w*dt); the fine level divides it by 1024 */
 int mplx_set_bucket_width(mplx_ctx *ctx, double width);

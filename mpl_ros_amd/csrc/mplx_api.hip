@@ -78,13 +78,12 @@ struct mplx_ctx {
   uint32_t batch_rec = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float last_ms = 0;
-  hipStream_t help_stream = nullptr;  // the helper workgroups' launch runs beside the leaders'
   uint32_t help_epoch = 0;
-  uint32_t help_ctr_init[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long help_done_init = 0;
+  HelpBox *dbg_boxes = nullptr;
   uint32_t help_stats[4] = {0, 0, 0, 0};
-  uint32_t help_ctr_back[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  bool help_stats_pending = false;  // last batch: cache rows used, queries done, helpers expired, helpers that made way
-  hipEvent_t ev_ready = nullptr, ev_hdone = nullptr;
+  uint32_t help_ctr_back[HELP_CTR_WORDS] = {};
+  bool help_stats_pending = false;  // last batch: cache rows used, queries done, helpers that gave up on a stopped leader, helpers that found every leader served
 };
 
 static int fail(mplx_ctx *c, int code, const char *fmt, ...) {
@@ -172,9 +171,6 @@ extern "C" void mplx_ctx_destroy(mplx_ctx *c) {
   (void)hipFree(c->dUcost);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
-  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-  if (c->ev_hdone) (void)hipEventDestroy(c->ev_hdone);
-  if (c->help_stream) (void)hipStreamDestroy(c->help_stream);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -488,10 +484,27 @@ extern "C" int mplx_helper_stats(const mplx_ctx *cc, uint32_t stats[4]) {
   mplx_ctx *c = const_cast<mplx_ctx *>(cc);
   if (c->help_stats_pending) {  // the read-back of the last batch completed with its stream synchronisation
     c->help_stats[0] = c->help_ctr_back[0];
-    c->help_stats[1] = c->help_ctr_back[4];
+    c->help_stats[1] = c->help_ctr_back[32];
     c->help_stats[2] = c->help_ctr_back[2];
     c->help_stats[3] = c->help_ctr_back[3];
     c->help_stats_pending = false;
+#ifdef MPLX_HELP_DEBUG
+    {
+      fprintf(stderr, "[help debug] stall quits by (helper XCD row, leader XCD column) | attachments:\n");
+      for (int r = 0; r < 8; r++) {
+        for (int k = 0; k < 8; k++) fprintf(stderr, "%4u", c->help_ctr_back[128 + r * 8 + k]);
+        fprintf(stderr, "   |");
+        for (int k = 0; k < 8; k++) fprintf(stderr, "%5u", c->help_ctr_back[192 + r * 8 + k]);
+        fprintf(stderr, "\n");
+      }
+      std::vector<HelpBox> hb(c->pool_slots);
+      if (c->dbg_boxes && hipMemcpy(hb.data(), c->dbg_boxes, sizeof(HelpBox) * hb.size(), hipMemcpyDeviceToHost) == hipSuccess)
+        for (size_t i = 0; i < hb.size(); i++)
+          if (hb[i].pad1[0] > 1000000ull)
+            fprintf(stderr, "[help debug] slot %zu (XCD %u): longest batch %.1f ms at %.1f ms into query %llu (batch %llu), helped %llu\n", i, hb[i].pad0 - 1u,
+                    hb[i].pad1[0] * 1e-5, (hb[i].pad1[1] >> 1) * 1e-5, hb[i].pad1[2], hb[i].pad1[3], hb[i].pad1[1] & 1ull);
+    }
+#endif
   }
   for (int i = 0; i < 4; i++) stats[i] = c->help_stats[i];
   return MPLX_OK;
@@ -562,7 +575,7 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   PA(P.bkt_head, (size_t)slots * 2 * NB * NSUB);
   HIPCHK(c, hipMemsetAsync(P.bkt_head, 0xFF, sizeof(uint32_t) * (size_t)slots * 2 * NB * NSUB, c->stream));  // all heads NIL; queries leave them so
   PA(P.chunk_next, 4);
-  P.boxes = nullptr; P.cache_c = nullptr; P.cache_h = nullptr; P.cache_next = nullptr; P.done_word = nullptr; P.all_started = nullptr; P.cache_rows = 0;
+  P.boxes = nullptr; P.cache_c = nullptr; P.cache_h = nullptr; P.cache_next = nullptr; P.done_word = nullptr; P.cache_rows = 0;
   if (c->helpers != 0) {  // look-ahead cache of the helper workgroups (used by the speculative kernels, lattices <= 31 inputs)
     // rows of the heuristic cache: a quarter of the state capacity (a node is expanded ahead of time at most once),
     // at most 12 GiB unless the caller says otherwise; the row size follows the lattice (cache_row_doubles)
@@ -576,10 +589,9 @@ static int ensure_pools(mplx_ctx *c, int slots) {
     PA(P.cache_h, (size_t)rows * cache_row_doubles(unit_lanes));
     c->pool_help_lanes = unit_lanes;
     uint32_t *ctr = nullptr;
-    PA(ctr, 16);
+    PA(ctr, HELP_CTR_WORDS);                         // one 128-byte line per polled word
     P.cache_next = ctr;                              // [0] row counter, [2] [3] diagnostics
-    P.done_word = (unsigned long long *)(ctr + 4);   // epoch << 32 | queries done
-    P.all_started = ctr + 6;
+    P.done_word = (unsigned long long *)(ctr + 32);  // epoch << 32 | queries done
     P.cache_rows = (uint32_t)rows;
   }
 #undef PA
@@ -648,7 +660,7 @@ static void launch_expand(int control, int grid, hipStream_t s, const SearchPara
 // the device code compile in parallel; returns false when no variant fits (control kind / lattice size)
 bool mplx_launch_spec(int speculation, int grid, hipStream_t s, const mplx::SearchParams &P);
 // helper-assisted variant (mplx_help_launch.hip): leaders on s, helper workgroups on hs
-bool mplx_launch_spec_help(int grid, hipStream_t s, int helper_grid, hipStream_t hs, const mplx::SearchParams &P);
+bool mplx_launch_spec_help(int grid, hipStream_t s, const mplx::SearchParams &P);
 
 static int check_ready(mplx_ctx *c) {
   if (!c) return MPLX_ERR_ARG;
@@ -798,56 +810,42 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   HIPCHK(c, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), c->stream));
   const bool spec = c->speculation < 0 || c->speculation > 1;
-  // helper workgroups (a second launch beside the leaders'): look-ahead expansion on compute units that have no
-  // query to lead -- from the start when the batch is smaller than the machine (or `reserved` says so),
-  // otherwise as the leaders run out of queries
-  int grid = slots, helper_grid = 0;
-  P.help_reserved = 0;
+  // Helper workgroups: a workgroup with no query (left) to lead expands the front of a running leader's OPEN list ahead
+  // of time.  The launch holds one workgroup per compute unit at most, so all of them are resident together: for a
+  // batch smaller than the machine the extra workgroups (blockIdx.x >= help_lead) help from the start; in a large
+  // batch the leaders turn into helpers as they run out of queries.
+  int grid = slots;
+  P.help_lead = slots;
   P.help_max = 0;
   const bool help = spec && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
                     ((P.n_u <= 31 && (P.control == CTRL_ACC || P.control == CTRL_JRK)) || (P.control == CTRL_JRK && P.n_u > 64 && P.n_u <= 128));
   if (help) {
     P.help_max = c->helpers < 0 ? 2 : c->helpers;
-    if (c->help_reserved > 0 && slots + c->help_reserved > c->n_cus) grid = std::max(1, c->n_cus - c->help_reserved);
-    P.help_keep = 0;
-    if (slots * (P.help_max + 1) <= c->n_cus) {  // small batch: every query gets its helpers from the start
-      helper_grid = slots * P.help_max;
-      P.help_keep = helper_grid;
-    } else {                                      // large batch: helpers arrive as leaders run out of queries
-      helper_grid = 2 * c->n_cus;
-      if (grid < slots) P.help_keep = c->n_cus - grid;  // ... plus the share reserved for them from the start
-    }
-    P.help_reserved = grid;  // number of leader boxes
-    if (!c->help_stream) {
-      HIPCHK(c, hipStreamCreateWithFlags(&c->help_stream, hipStreamNonBlocking));
-      HIPCHK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
-      HIPCHK(c, hipEventCreateWithFlags(&c->ev_hdone, hipEventDisableTiming));
-    }
+    P.help_lead = std::min(slots, c->n_cus);  // (one workgroup of these kernels fills a compute unit: more would only wait)
+    if (c->help_reserved > 0 && slots + c->help_reserved > c->n_cus) P.help_lead = std::max(1, c->n_cus - c->help_reserved);  // a share that never leads
+    grid = std::max(P.help_lead, std::min(P.help_lead * (P.help_max + 1), c->n_cus));
     HIPCHK(c, hipMemsetAsync(P.boxes, 0, sizeof(HelpBox) * ((size_t)c->pool_slots + 1024), c->stream));
+    c->dbg_boxes = P.boxes;
     HIPCHK(c, hipMemsetAsync(P.cache_c, 0, sizeof(CacheRec) * ((size_t)P.node_chunks << NODE_CH_LOG), c->stream));
     // launch epoch: every word the helpers poll is tagged with it, so nothing left over from the previous launch
     // can be mistaken for progress of this one
     c->help_epoch++;
     if (c->help_epoch == 0) c->help_epoch = 1;
     P.epoch = c->help_epoch;
-    c->help_ctr_init[0] = c->help_ctr_init[1] = c->help_ctr_init[2] = c->help_ctr_init[3] = 0;
-    const unsigned long long dw = (unsigned long long)P.epoch << 32;
-    memcpy(&c->help_ctr_init[4], &dw, 8);
-    c->help_ctr_init[6] = c->help_ctr_init[7] = 0;
-    HIPCHK(c, hipMemcpyAsync(P.cache_next, c->help_ctr_init, 8 * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(c->ev_ready, c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->help_stream, c->ev_ready, 0));
+    c->help_done_init = (unsigned long long)P.epoch << 32;
+    HIPCHK(c, hipMemsetAsync(P.cache_next, 0, HELP_CTR_WORDS * sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemcpyAsync(P.done_word, &c->help_done_init, 8, hipMemcpyHostToDevice, c->stream));
   } else {
     P.boxes = nullptr;
   }
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   bool launched = false;
   if (help) {
-    launched = mplx_launch_spec_help(grid, c->stream, helper_grid, c->help_stream, P);
-    if (launched) {
-      HIPCHK(c, hipGetLastError());
-      HIPCHK(c, hipEventRecord(c->ev_hdone, c->help_stream));
-    }
+    launched = mplx_launch_spec_help(grid, c->stream, P);
+  }
+  if (!launched) {
+    grid = slots;
+    P.help_lead = slots;
   }
   if (!launched && !(spec && mplx_launch_spec(c->speculation, grid, c->stream, P))) {
     switch (pick_block(P.n_u)) {
@@ -859,8 +857,7 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   if (launched) {
-    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_hdone, 0));  // the helpers leave when the last query is done
-    HIPCHK(c, hipMemcpyAsync(c->help_ctr_back, P.cache_next, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->help_ctr_back, P.cache_next, HELP_CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     c->help_stats_pending = true;
   } else {
     memset(c->help_stats, 0, sizeof(c->help_stats));

@@ -75,12 +75,17 @@ constexpr int WISH = 64;                       // OPEN-front entries a leader pu
 // recognised as such instead of being trusted.
 __host__ __device__ inline bool box_active(unsigned long long seq, uint32_t epoch) { return (uint32_t)(seq >> 32) == epoch && (uint32_t)seq != 0u; }
 constexpr uint32_t CACHE_READY = 0x80000000u;  // bit 31 of CacheRec::valid (lattices have <= 31 inputs here)
+constexpr int HELP_CTR_WORDS = 320;  // counters of the helper protocol: [0,32) rows + diagnostics, [32,64) done word, [128,320) debug
 struct alignas(64) HelpBox {   // one per workgroup slot; every word is written by ONE 8-byte agent-scope store
+  // line 0: written by the leader, polled by its helpers
   unsigned long long seq;      // epoch << 32 | n;  n = 0: no query running; 1: query running, no list yet; k + 2: list k is complete
   unsigned long long n_expanded;  // progress of the running query (helpers prefer the longest-running leader)
   uint32_t q;                  // query the leader is running
+  uint32_t pad0;
+  unsigned long long pad1[5];
+  // line 1: written by helpers (atomics), read by the leader every few batches -- kept off the line the leader stores to
   uint32_t helpers;            // bit mask of attached helpers (atomicOr / atomicAnd)
-  unsigned long long pad[5];
+  uint32_t pad2[15];
   unsigned long long wish[2][WISH];  // (q << 48) | pool index of the node record, front of OPEN first; ~0: none.
                                      // list n lives in buffer n & 1 and is announced one batch after it was written (so it is complete)
 };
@@ -133,11 +138,9 @@ struct SearchParams {
   uint32_t cache_rows;
   uint32_t *cache_next;           // bump counter of cache_h rows; [2], [3]: diagnostics
   unsigned long long *done_word;  // epoch << 32 | queries finished (helpers leave when the count reaches nq)
-  uint32_t *all_started;          // = epoch once the last query of the batch has been picked up by a leader
   uint32_t epoch;                 // launch counter of the context
-  int32_t help_reserved;          // number of leader boxes (= workgroups of the leaders' launch)
+  int32_t help_lead;              // workgroups blockIdx.x < help_lead lead queries (and own the boxes [0, help_lead)); the others only help
   int32_t help_max;               // helpers per leader (1 or 2)
-  int32_t help_keep;              // helper workgroups blockIdx.x < help_keep may stay while queries are still waiting for a leader
   // moving-obstacle environment (astar_poly_kernel): the worlds and the world of each query
   PolyDev poly;
   const int32_t *poly_world;

@@ -70,7 +70,11 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   unsigned long long box_seq;   // wish lists published for the running query
   // helper side
   int32_t help_box, help_idx, help_q, help_go, help_quit;
-  unsigned long long help_seq, help_t0;
+#ifdef MPLX_HELP_DEBUG
+  unsigned long long dbg_t, dbg_gap, dbg_when;
+#endif
+  unsigned long long help_seq;
+  int32_t help_idle;
   uint32_t n_work;
   uint32_t work[WISH];          // pool indices of the node records to expand ahead of time
   unsigned long long wish_l[WISH];
@@ -217,18 +221,33 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
 }
 
 // ------------------------------------------------------------------ helper workgroups (look-ahead expansion)
-// Safety net (wall_clock64() ticks, 100 MHz): a helper may cost time, it must never be able to keep a batch from
-// finishing.  It leaves the launch for good when it has found nobody to help for HELP_IDLE_TICKS, or when the leader
-// it serves has not completed a batch for HELP_STALL_TICKS (a healthy leader completes thousands per second).
-constexpr unsigned long long HELP_IDLE_TICKS = 800000000ull;   // 8 s
-constexpr unsigned long long HELP_STALL_TICKS = 200000000ull;  // 2 s
+// A workgroup that has no query left to lead turns into a helper (the tail of astar_spec_kernel<..., HELP>): there is
+// no second launch and nothing waiting for a compute unit, so whatever takes the launch's waves off the machine and
+// puts them back (the driver evicts and restores a process's queues around memory-management events) finds room
+// for all of them again.  [An earlier version ran the helpers as a second launch on a second stream, more workgroups
+// than compute units, waiting to be dispatched as leaders exited: after an eviction the waiting ones took the
+// leaders' compute units and the leaders stayed off the machine until those helpers gave up -- seconds.]
+// A helper leaves when every query is done or the cache is full; when it has found nobody to help HELP_IDLE_ROUNDS
+// times in a row (leaders that want help are there from the start: a helper that finds every leader served is
+// surplus); or -- a safety net, the leader never waits for a helper -- when the leader it serves has not completed a
+// batch for HELP_STALL_POLLS polls.  Both limits count the helper's own iterations, not wall-clock time: time spent
+// off the machine is not progress missed.
+constexpr int HELP_IDLE_ROUNDS = 1000;     // x ~54 us
+constexpr int HELP_STALL_POLLS = 100000;   // x >= 3.4 us (13.6 us after the first few)
+#ifdef MPLX_HELP_DEBUG
+__device__ __forceinline__ uint32_t dbg_xcc() {
+  uint32_t x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 15u;
+}
+#endif
 // Serve the leader of box `bi` until its query ends: every time it announces a wish list, expand the listed
 // nodes that have no cache entry yet -- get_succ (phases 1-2 of expand_unit) plus the heuristic of every
 // finite successor -- and publish {row, voxel reads, valid mask, blocked mask} in cache_c and the heuristics in
 // a row of cache_h.  Ordering: the row is written (agent scope) and drained (vmcnt 0) before the two
 // self-validating halves of the cache record; the leader reads the record first and the row after it.
 template <int UL, int K, int CONTROL, class SM>
-__device__ __noinline__ void helper_serve(const SearchParams &P, SM &S, int tid) {
+__device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int tid) {
   constexpr int BLOCK = UL * K;
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   using V = QView<BLOCK, CONTROL, SM>;
@@ -237,7 +256,6 @@ __device__ __noinline__ void helper_serve(const SearchParams &P, SM &S, int tid)
   const uint32_t q = (uint32_t)S.help_q;
   const uint32_t epoch = P.epoch;
   unsigned long long last_seq = ((unsigned long long)epoch << 32) | 1ull;
-  unsigned long long t_progress = wall_clock64();  // (thread 0) when the leader last announced a new list
   for (;;) {
     if (tid == 0) {
       unsigned long long seq;
@@ -245,11 +263,15 @@ __device__ __noinline__ void helper_serve(const SearchParams &P, SM &S, int tid)
       for (int spin = 0;; spin++) {
         seq = ld_u64(&B->seq);
         if (!box_active(seq, epoch) || ld_u32(&B->q) != q || ld_u32(P.cache_next) >= P.cache_rows) { go = 0; break; }
-        if (seq != last_seq) { t_progress = wall_clock64(); break; }
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t_progress > HELP_STALL_TICKS) {  // the leader makes no progress: leave the launch
+        if (seq != last_seq) break;
+        // poll gently: every few microseconds (a leader's batch takes ~25)
+        for (int z = 0; z < (spin < 8 ? 1 : 4); z++) __builtin_amdgcn_s_sleep(127);
+        if (spin > HELP_STALL_POLLS) {  // the leader makes no progress: leave the launch
           S.help_quit = 1;
           go = 0;
+#ifdef MPLX_HELP_DEBUG
+          atomicAdd(P.cache_next + 128 + (dbg_xcc() & 7u) * 8u + ((ld_u32(&B->pad0) - 1u) & 7u), 1u);
+#endif
           break;
         }
       }
@@ -339,15 +361,16 @@ __device__ __noinline__ void helper_serve(const SearchParams &P, SM &S, int tid)
 // A workgroup with no query to lead: attach to the longest-running leader that lacks a helper, serve it until
 // its query ends, repeat until every query of the batch is done.
 template <int UL, int K, int CONTROL, class SM>
-__device__ __noinline__ void helper_loop(const SearchParams &P, SM &S, int tid) {
+__device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int tid) {
   constexpr int BLOCK = UL * K;
-  const int nboxes = P.help_reserved;  // number of leader boxes of the accompanying launch
+  const int nboxes = P.help_lead;  // boxes of the workgroups that lead queries
   for (;;) {
     if (tid == 0) {
-      // leave when every query is done or the cache is full -- and, as a safety net, when there has been nobody to
-      // help for a long time or the leader just served stopped making progress (helper_serve sets help_quit)
-      const bool expired = S.help_quit || wall_clock64() - S.help_t0 > HELP_IDLE_TICKS;
-      if (expired) atomicAdd(P.cache_next + 2, 1u);  // (diagnostics) helpers that ran into the lifetime limit
+      // leave when every query is done or the cache is full, when there has been nobody to help for a while, or
+      // when the leader just served stopped making progress (helper_serve sets help_quit)
+      const bool expired = S.help_quit || S.help_idle > HELP_IDLE_ROUNDS;
+      if (S.help_quit) atomicAdd(P.cache_next + 2, 1u);  // (diagnostics) helpers that left a leader that had stopped
+      else if (expired) atomicAdd(P.cache_next + 3, 1u);  // (diagnostics) helpers that found every leader served
       const unsigned long long dw = ld_u64(P.done_word);
       const bool done = (uint32_t)(dw >> 32) == P.epoch && (uint32_t)dw >= (uint32_t)P.nq;
       S.flag = (expired || done || ld_u32(P.cache_next) >= P.cache_rows) ? 1 : 0;
@@ -389,6 +412,9 @@ __device__ __noinline__ void helper_loop(const SearchParams &P, SM &S, int tid) 
         if (S.help_box >= 0) {
           const uint32_t q = ld_u32(&B->q);
           if (q < (uint32_t)P.nq && box_active(ld_u64(&B->seq), P.epoch)) {
+#ifdef MPLX_HELP_DEBUG
+            atomicAdd(P.cache_next + 192 + (dbg_xcc() & 7u) * 8u + ((ld_u32(&B->pad0) - 1u) & 7u), 1u);
+#endif
             const QueryIn &in = P.queries[q];
             S.help_q = (int)q;
             S.hp.w = P.w; S.hp.v_max = P.v_max; S.hp.heur_ignore_dynamics = P.heur_ignore_dynamics;
@@ -404,6 +430,7 @@ __device__ __noinline__ void helper_loop(const SearchParams &P, SM &S, int tid) 
     }
     __syncthreads();
     if (S.help_box < 0) {  // nobody to help right now: stay off the memory system for a while
+      if (tid == 0) S.help_idle++;
       for (int i = 0; i < 16; i++) __builtin_amdgcn_s_sleep(127);
       __syncthreads();
       continue;
@@ -411,7 +438,7 @@ __device__ __noinline__ void helper_loop(const SearchParams &P, SM &S, int tid) 
     helper_serve<UL, K, CONTROL>(P, S, tid);
     if (tid == 0) {
       atomicAnd(&(P.boxes + S.help_box)->helpers, ~(1u << S.help_idx));
-      S.help_t0 = wall_clock64();  // the idle clock restarts after useful work
+      S.help_idle = 0;  // the idle count restarts after useful work
     }
     __syncthreads();
   }
@@ -425,18 +452,16 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
   __shared__ SM S;
   using V = QView<BLOCK, CONTROL, SM>;
   const int tid = threadIdx.x, ku = tid / UL, lu = tid % UL;
-  // HELP: this launch is accompanied by helper workgroups (helper_kernel below, a second launch): the leader
-  // publishes the front of its OPEN list and picks up the look-ahead cache entries they leave.  Compiled out
-  // of the plain variant (the kernel sits at the register limit).
+  // HELP: workgroups with no query left to lead turn into helpers (helper_loop above); a leader publishes the front
+  // of its OPEN list and picks up the look-ahead cache entries they leave.  Compiled out of the plain variant (the
+  // kernel sits at the register limit).
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   fill_uq<BLOCK, CONTROL>(P, S, tid);
   for (;;) {
     if (tid == 0) {
-      S.q_index = atomicAdd(P.next_query, 1);
-      if constexpr (HELP) {
-        if (S.q_index == P.nq - 1) st_u32(P.all_started, P.epoch);  // queries are picked up in order: none is left waiting
-      }
+      if (HELP && (int)blockIdx.x >= P.help_lead) S.q_index = P.nq;  // a workgroup launched to help only (batch smaller than the machine)
+      else S.q_index = atomicAdd(P.next_query, 1);
     }
     __syncthreads();
     const int qi = S.q_index;
@@ -468,6 +493,12 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       if constexpr (HELP) {  // announce the query (helpers filter wish entries by q, so the order of the stores is free)
         HelpBox *box = P.boxes + blockIdx.x;
         st_u32(&box->q, (uint32_t)q);
+#ifdef MPLX_HELP_DEBUG
+        st_u32(&box->pad0, dbg_xcc() + 1u);
+        S.dbg_t = wall_clock64();
+        S.dbg_gap = 0;
+        S.dbg_when = 0;
+#endif
         st_u64(&box->n_expanded, 0ull);
         st_u64(&box->seq, ((unsigned long long)P.epoch << 32) | 1ull);
       }
@@ -543,7 +574,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           MPLX_TOC(S, 3, te);
         }
         MPLX_TIC(tp);
-        unsigned long long t3 = __builtin_readcyclecounter();
+        [[maybe_unused]] unsigned long long t3 = __builtin_readcyclecounter();
         if (S.n_near == 0) {
           __syncthreads();
           if (!refill(Q, tid)) {
@@ -575,6 +606,16 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           S.dep_cause = 0;
           if constexpr (HELP) {
             HelpBox *box = P.boxes + blockIdx.x;
+#ifdef MPLX_HELP_DEBUG
+            {  // longest time between two batch starts of this slot, when (since the query began), of which query, helped or not
+              const unsigned long long now = wall_clock64(), gap = now - S.dbg_t;
+              S.dbg_t = now;
+              if (gap > S.dbg_gap) { S.dbg_gap = gap; S.dbg_when = ((now - t_begin) << 1) | (S.helped ? 1ull : 0ull); }
+              if (gap > 1000000ull) {  // > 10 ms: leave a record right away
+                if (gap > box->pad1[0]) { box->pad1[0] = gap; box->pad1[1] = S.dbg_when; box->pad1[2] = (unsigned long long)q; box->pad1[3] = S.cyc[7]; }
+              }
+            }
+#endif
             // announce the wish list written during the previous batch (complete: a __syncthreads() lies between)
             if (S.helped && S.box_seq) {
               st_u64(&box->n_expanded, S.c_expanded);
@@ -605,6 +646,31 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         }
         __syncthreads();
         MPLX_T2(S, 17, t3);
+        // Look-ahead cache records of the LIKELY candidates, issued before the ranking so that their (agent-scope,
+        // always-missing) loads overlap it: the head of the sorted prefix is almost always what the ranking selects
+        // (fresh pushes rarely enter the top K); a candidate that turns out different is looked up in 2a as before.
+        // The same goes for the candidates' node records: unit ku fetches the record of the ku-th entry of the
+        // sorted prefix now and keeps it in registers across the ranking (nothing is committed in between).
+        [[maybe_unused]] unsigned long long pf_a = 0, pf_b = 0;
+        uint32_t pf_id = NIL;
+        double pf_g = 0.0, pf_s = 0.0;
+        uint32_t pf_fl = 0;
+        int32_t pf_k = 0;
+        if ((uint32_t)ku < S.n_sorted && S.n_sorted <= S.n_near) {
+          pf_id = S.near_id[ku];
+          char *prec = Q.node(pf_id);
+          pf_g = V::g(prec);
+          pf_fl = V::flags(prec);
+          if (lu <= ns) pf_s = V::state(prec)[lu];
+          if (lu < nk) pf_k = V::key(prec)[lu];
+          if constexpr (HELP) {
+            if (S.helped && lu == UL - 1) {
+              const unsigned long long *cr = (const unsigned long long *)&P.cache_c[Q.node_rec(pf_id)];
+              pf_a = ld_u64(cr);
+              pf_b = ld_u64(cr + 1);
+            }
+          }
+        }
         {
           // rank every near entry among all of them (strict total order -> unique ranks): ranks
           // 0..K-1 are the candidates in pop order, the others move to position rank-K (which also
@@ -721,32 +787,35 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         const int n_cand = S.n_cand;
         // ---- 2a. fetch the candidates' records; drop stale entries (improved or closed since pushed)
         bool live_unit = false;
+        [[maybe_unused]] unsigned long long hc_a = 0, hc_b = 0;
         if (ku < n_cand) {
-          char *rec = Q.node(S.cand_id[ku]);
-          const double rg = V::g(rec);
-          const uint32_t fl = V::flags(rec);
+          const uint32_t cid = S.cand_id[ku];
+          double rg = pf_g, sval = pf_s;
+          uint32_t fl = pf_fl;
+          int32_t kval = pf_k;
+          hc_a = pf_a; hc_b = pf_b;
+          if (cid != pf_id) {  // (uniform per unit) not the prefetched entry: fetch it now
+            char *rec = Q.node(cid);
+            rg = V::g(rec);
+            fl = V::flags(rec);
+            if (lu <= ns) sval = V::state(rec)[lu];
+            if (lu < nk) kval = V::key(rec)[lu];
+            if constexpr (HELP) {
+              if (S.helped && lu == UL - 1) {
+                const unsigned long long *cr = (const unsigned long long *)&P.cache_c[Q.node_rec(cid)];
+                hc_a = ld_u64(cr);
+                hc_b = ld_u64(cr + 1);
+              }
+            }
+          }
           live_unit = __double_as_longlong(rg) == __double_as_longlong(S.cand_g[ku]) && !(fl & FLAG_CLOSED);
           if (live_unit) {
-            if (lu <= ns) S.cur[ku][lu < ns ? lu : 12] = V::state(rec)[lu];
+            if (lu <= ns) S.cur[ku][lu < ns ? lu : 12] = sval;
             if (lu >= ns && lu < 12) S.cur[ku][lu] = 0.0;
-            if (lu < nk) S.cur_key[ku][lu] = V::key(rec)[lu];
+            if (lu < nk) S.cur_key[ku][lu] = kval;
             if (lu == 0) {
               S.cand_live[ku] = 1;
               S.cand_fl[ku] = fl;
-            }
-            if constexpr (HELP) {
-              if (S.helped && lu == UL - 1) {  // did a helper expand this node ahead of time?
-                const unsigned long long *cr = (const unsigned long long *)&P.cache_c[Q.node_rec(S.cand_id[ku])];
-                const unsigned long long ca = ld_u64(cr), cb = ld_u64(cr + 1);
-                // the entry must be of THIS state: the helper's hash of the key of the state it expanded against the
-                // key in the candidate's own record (guards against anything stale on the helper's side)
-                if ((uint32_t)ca != 0u && ((uint32_t)cb & CACHE_READY) && (uint32_t)(ca >> 32) == (uint32_t)key_hash64(V::key(rec), nk)) {
-                  S.hc_row[ku] = (uint32_t)ca;
-                  S.hc_valid[ku] = (uint32_t)cb;
-                  S.hc_blocked[ku] = (uint32_t)(cb >> 32);
-                  atomicAdd(&S.cyc[9], 1ull);  // (diagnostics) candidates served from the look-ahead cache
-                }
-              }
             }
           }
         }
@@ -756,6 +825,17 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           State sgoal;
           for (int i = 0; i < 12; i++) ((double *)&sgoal)[i] = S.cur[ku][i];
           S.u_goal[ku] = (S.cur[ku][12] >= P.t_max || is_goal_state(sgoal, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) ? 1 : 0;
+        }
+        if constexpr (HELP) {
+          // did a helper expand this node ahead of time?  The entry must be of THIS state: the helper's hash of the
+          // key of the state it expanded against the candidate's own key (guards against anything stale on its side)
+          if (live_unit && S.helped && lu == UL - 1 && (uint32_t)hc_a != 0u && ((uint32_t)hc_b & CACHE_READY) &&
+              (uint32_t)(hc_a >> 32) == (uint32_t)key_hash64(S.cur_key[ku], nk)) {
+            S.hc_row[ku] = (uint32_t)hc_a;
+            S.hc_valid[ku] = (uint32_t)hc_b;
+            S.hc_blocked[ku] = (uint32_t)(hc_b >> 32);
+            atomicAdd(&S.cyc[9], 1ull);  // (diagnostics) candidates served from the look-ahead cache
+          }
         }
         unit_sync<UL>();
         MPLX_T2(S, 21, t3);
@@ -792,7 +872,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         // ---- 2c. batch table: one entry per distinct successor key; its leader looks the key up in
         //          the state space (or claims a slot) and computes the heuristic of a new state
         MPLX_TIC(tc);
-        unsigned long long t2 = __builtin_readcyclecounter();
+        [[maybe_unused]] unsigned long long t2 = __builtin_readcyclecounter();
         int my_slot = 0;
         for (int i = tid; i < BT; i += BLOCK) {
           S.bt_hash[i] = 0ull;
@@ -1237,36 +1317,16 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
     }
     __syncthreads();
   }
-}
-
-// The helper launch: workgroups that never lead a query.  Started right after the leaders' launch on a second
-// stream; its workgroups become resident wherever a compute unit is free -- from the start when the batch is
-// smaller than the machine, otherwise as the leading workgroups run out of queries and exit.
-template <int UL, int K, int CONTROL>
-__global__ __launch_bounds__(UL *K) void helper_kernel(SearchParams P) {
-  using SM = SmemSpec<UL, K, CONTROL, 64, 64>;
-  __shared__ SM S;
-  const int tid = threadIdx.x;
-  fill_uq<UL * K, CONTROL>(P, S, tid);
-  // A helper must never keep a leader off the machine.  The two launches are dispatched concurrently, so a helper
-  // workgroup can become resident while queries are still waiting for a compute unit; unless it belongs to the
-  // share the host left free for helpers (blockIdx.x < help_keep), it leaves again when that is the case (the
-  // launch holds more workgroups than it needs: later ones arrive when the leaders run out of queries and exit).
-  if (tid == 0) {
-    S.help_t0 = wall_clock64();
-    S.help_quit = 0;
-    int ok = (int)blockIdx.x < P.help_keep;
-    for (int spin = 0; spin < 128 && !ok; spin++) {
-      ok = ld_u32(P.all_started) == P.epoch;
-      if (!ok) __builtin_amdgcn_s_sleep(32);
+  if constexpr (HELP) {  // no query left to lead: help the leaders that are still running
+    if (P.help_max > 0) {
+      if (tid == 0) {
+        S.help_idle = 0;
+        S.help_quit = 0;
+      }
+      __syncthreads();
+      helper_loop<UL, K, CONTROL>(P, S, tid);
     }
-    if (!ok) atomicAdd(P.cache_next + 3, 1u);  // (diagnostics) helper workgroups that made way for leaders
-    S.flag = ok;
   }
-  __syncthreads();
-  if (!S.flag) return;
-  __syncthreads();
-  helper_loop<UL, K, CONTROL>(P, S, tid);
 }
 
 }  // namespace mplx

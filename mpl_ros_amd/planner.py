@@ -359,7 +359,7 @@ class VoxelMapPlanner:
         ctx = self._ctx()
         st = (C.c_uint32 * 4)()
         ctx.check(ctx.lib.mplx_helper_stats(ctx.h, st))
-        return dict(zip(("cache_rows_used", "queries_done", "helpers_expired", "helpers_made_way"), [int(x) for x in st]))
+        return dict(zip(("cache_rows_used", "queries_done", "helpers_gave_up", "helpers_surplus"), [int(x) for x in st]))
 
     def setRecord(self, cap):
         ctx = self._ctx()

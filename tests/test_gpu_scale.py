@@ -9,6 +9,7 @@
       read-only map) and compared on status, expansions, order hash, states, edges, voxel reads, cost and
       the path's actions / node ids.
 Everything is bit-exact (integers and f64 alike)."""
+import gc
 import threading
 
 import numpy as np
@@ -120,3 +121,46 @@ def test_c4_batch_sample_matches_the_oracle(map512, lattice):
             assert np.isinf(r.cost)
     print(f"C4-{lattice}: {len(sample)} of {nq} queries replayed on the CPU (longest: query {longest}, {ne[longest]} expansions); "
           f"batch {ne.sum()} expansions in {pl.lastKernelMs():.0f} ms")
+
+
+@pytest.mark.parametrize("nq", [1, 40, 600])
+def test_helpers_leave_every_result_unchanged(nq):
+    """Helper workgroups (mplx_set_helpers): a batch smaller than the machine gets extra workgroups that help from the
+    start, a larger one has its leaders turn into helpers as the queries run out; off / on / a reserved share must give
+    identical plans -- counters, expansion-order hash, cost, path -- and the first few are replayed on the CPU oracle."""
+    grid, origin, res, start, goal, _ = mapgen.benchmark_map(128)
+    grid = np.ascontiguousarray(grid)
+    U = mapgen.control_lattice(1.0, 1, True)
+    cap = 20000
+    kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5, max_expand=cap)
+    queries = mapgen.c4_queries(grid, origin, res, nq, rank=3, min_dist=6.0)
+    pools = mapgen.c4_pools(False, nq, cap, per_q=200_000 if nq == 1 else 100_000)
+    S = [util.gpu_wp(s, control=orc.ACC) for s, g in queries]
+    G = [util.gpu_wp(g, control=orc.ACC) for s, g in queries]
+    runs = {}
+    gc.collect()
+    for name, (per, reserved) in {"off": (0, -1), "on": (2, -1), "reserved": (2, 64)}.items():
+        mu, pl = util.make_gpu(grid, origin, res, U, n_slots=min(nq, 1024), max_nodes=pools["nodes"], max_edges=pools["edges"], max_log=pools["log"], **kw)
+        pl.setHelpers(per, reserved)
+        R = pl.planBatch(S, G)
+        runs[name] = [(r.status, r.n_expanded, r.expand_hash, r.n_nodes, r.n_edges, r.voxel_reads, r.n_succ, r.n_succ_finite, r.cost,
+                       tuple(pl.getTraj(i).actions.tolist()) if r.status == 0 else None) for i, r in enumerate(R)]
+        st = pl.helperStats()
+        assert st["helpers_gave_up"] == 0
+        if per:
+            assert st["queries_done"] == nq
+        hits = sum(pl.queryCycles(i)["cache_hits"] for i in range(nq))
+        print(f"helpers {name}: batch of {nq}, {sum(r.n_expanded for r in R)} expansions, kernel {pl.lastKernelMs():.1f} ms, cache hits {hits}, {st}")
+        if name == "off":
+            assert hits == 0
+        del mu, pl, R
+        gc.collect()  # (the context and its pools go with the planner)
+    assert runs["on"] == runs["off"] and runs["reserved"] == runs["off"]
+    sample = list(range(min(nq, 4)))
+    cpu = _cpu_replay(grid, origin, res, orc.ACC, U, kw, queries, sample)
+    for i in sample:
+        st, ne, hh, nn, ned, reads, nsucc, nfin, cost, acts = runs["on"][i]
+        c = cpu[i]
+        assert (st, ne, hh, nn, ned, reads, nsucc, nfin) == (c["status"], c["n_expanded"], c["hash"], c["n_nodes"], c["n_edges"], c["reads"], c["n_succ"], c["n_fin"]), i
+        if st == 0:
+            assert cost == c["cost"] and acts == tuple(np.asarray(c["actions"]).tolist())

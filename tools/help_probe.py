@@ -20,7 +20,7 @@ for it in range(iters):
     times.append(pl.lastKernelMs())
     ne = sum(r.n_expanded for r in R)
     st = pl.helperStats()
-    if iters <= 3 or times[-1] > 3 * np.median(times) or st["helpers_expired"]:
+    if iters <= 3 or times[-1] > 3 * np.median(times) or st["helpers_gave_up"]:
         hits = sum(pl.queryCycles(k)["cache_hits"] for k in range(nq))
         T = np.array([pl.queryTiming(k) for k in range(nq)])
         late = np.argsort(-T[:, 1])[:3]
