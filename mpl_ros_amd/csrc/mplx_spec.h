@@ -59,8 +59,8 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   int32_t u_cut[K];   // first later candidate preceded by an entry unit k pushes (K if none)
   uint32_t n_sorted;  // near_[0, n_sorted) is in ascending order (left so by the previous selection)
   // the entries appended since, sorted (selection scratch)
-  double app_f[128], app_g[128];
-  uint32_t app_id[128], app_rank[128];
+  double app_f[256], app_g[256];
+  uint32_t app_id[256], app_rank[256];
   int32_t batch_dep;  // units interact through a state one of them MODIFIES -> ordered, unit-by-unit commit
   int32_t any_shared; // some state is reached by two lanes (they only append predecessor edges unless batch_dep)
   int32_t dep_cause;  // (debug statistics) 1 shared successor, 2 candidate is a successor, 4 a sharer modifies the state
@@ -82,6 +82,7 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   unsigned long long cyc2[24];
   unsigned long long cycw[16][4];
   unsigned long long arr_max, arr_heur, sum_heur, sum_arr;
+  unsigned long long dbg_n, dbg_na, dbg_slow, dbg_n256, dbg_pulls;
 #endif
 };
 
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       for (int i = 0; i < 24; i++) S.cyc2[i] = 0;
       for (int i = 0; i < 64; i++) (&S.cycw[0][0])[i] = 0;
       S.arr_max = 0; S.arr_heur = 0; S.sum_heur = 0; S.sum_arr = 0;
+      S.dbg_n = S.dbg_na = S.dbg_slow = S.dbg_n256 = S.dbg_pulls = 0;
 #endif
       S.c_expanded = S.c_closed = S.c_prims = S.c_succ = S.c_succ_finite = S.c_reads = 0;
       S.c_push = S.c_reopen = S.c_refill = S.c_evict = 0;
@@ -690,22 +692,16 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             ex[r] = v ? S.near_idx[i] : NIL;
             rk[r] = 0;
           }
-          // near_[0, ns) is sorted (previous selection), near_[ns, n) are the entries appended since:
-          // rank = (#sorted entries before me: my index, or a binary search) + (#appended entries before me)
+          // near_[0, ns) is sorted (previous selection), near_[ns, n) are the entries appended since
           const uint32_t ns_ = S.n_sorted <= n ? S.n_sorted : 0u;
           const uint32_t na = n - ns_;
-          auto rank_in_prefix = [&](int r) {  // number of sorted entries that precede entry r of this thread
-            uint32_t lo = 0, hi = ns_;
-            while (lo < hi) {
-              const uint32_t mid = (lo + hi) >> 1;
-              if (entry_less(S.near_f[mid], S.near_g[mid], S.near_id[mid], ef[r], eg[r], ei[r])) lo = mid + 1; else hi = mid;
-            }
-            return lo;
-          };
-          if (na <= 128u) {  // (uniform) the usual case: a few dozen entries pushed by the previous batch
+#ifdef MPLX_LOOKUP_TIMERS
+          if (tid == 0) { S.dbg_n += n; S.dbg_na += na; S.dbg_slow += na > 256u; S.dbg_n256 += n > 256u; }
+#endif
+          if (na <= 256u) {  // (uniform) the usual case: the entries pushed by the previous batch (a deep query: 100-200)
             // sort the appended entries among themselves (all pairs, G threads per entry), then every
             // entry finds the number of appended entries before it with a binary search
-            const uint32_t G = na <= 64u ? BLOCK / 64 : BLOCK / 128;
+            const uint32_t G = na <= 64u ? BLOCK / 64 : na <= 128u ? BLOCK / 128 : BLOCK / 256;
             const uint32_t a = (uint32_t)tid / G, part = (uint32_t)tid % G;
             uint32_t cnt = 0;
             double af = 0.0, ag = 0.0;
@@ -722,37 +718,77 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
               S.app_f[cnt] = af; S.app_g[cnt] = ag; S.app_id[cnt] = ai;
               S.app_rank[a] = cnt;
             }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < PERT; r++) {
+            lds_barrier();  // (LDS only: the record loads issued above stay in flight across the whole ranking)
+            // one binary search per entry, in the OTHER sorted sequence (a prefix entry among the appended ones, an
+            // appended entry in the prefix), all in the same loop: the lanes of a wave hold both kinds, and two
+            // separate loops would run one after the other; the entries of a thread are independent chains
+            static_assert(PERT <= 2, "the merged search below handles two entries per thread");
+            struct Search { const double *f, *g; const uint32_t *id; uint32_t lo, hi; };
+            auto begin = [&](int r) {
               const uint32_t i = tid + r * BLOCK;
-              if (i < ns_) {
-                uint32_t lo = 0, hi = na;  // appended entries that precede mine
-                while (lo < hi) {
-                  const uint32_t mid = (lo + hi) >> 1;
-                  if (entry_less(S.app_f[mid], S.app_g[mid], S.app_id[mid], ef[r], eg[r], ei[r])) lo = mid + 1; else hi = mid;
-                }
-                rk[r] = i + lo;
-              } else if (i < n) {
-                rk[r] = rank_in_prefix(r) + S.app_rank[i - ns_];
+              const bool app = i >= ns_;
+              return Search{app ? S.near_f : S.app_f, app ? S.near_g : S.app_g, app ? S.near_id : S.app_id, 0u, i < n ? (app ? ns_ : na) : 0u};
+            };
+            auto advance = [&](Search &b, double mf, double mg, uint32_t mi) {
+              if (b.lo < b.hi) {
+                const uint32_t mid = (b.lo + b.hi) >> 1;
+                if (entry_less(b.f[mid], b.g[mid], b.id[mid], mf, mg, mi)) b.lo = mid + 1; else b.hi = mid;
               }
+            };
+            Search b0 = begin(0), b1 = begin(PERT - 1);
+            if (PERT == 1) b1.hi = 0;
+            while (__any(b0.lo < b0.hi || b1.lo < b1.hi)) {
+              advance(b0, ef[0], eg[0], ei[0]);
+              if constexpr (PERT > 1) advance(b1, ef[PERT - 1], eg[PERT - 1], ei[PERT - 1]);
+            }
+            {
+              const uint32_t i = tid;
+              if (i < ns_) rk[0] = i + b0.lo; else if (i < n) rk[0] = b0.lo + S.app_rank[i - ns_];
+            }
+            if constexpr (PERT > 1) {
+              const uint32_t i = tid + (PERT - 1) * BLOCK;
+              if (i < ns_) rk[PERT - 1] = i + b1.lo; else if (i < n) rk[PERT - 1] = b1.lo + S.app_rank[i - ns_];
             }
           } else {
+            // the near set was refilled from a far bucket (hundreds of unsorted entries, one batch in twenty): sort all
+            // of it in place with a bitonic network, one compare-exchange per thread and stage.  Stages whose pairs
+            // lie within 64 consecutive entries involve 32 consecutive threads -- one wave, whose LDS operations
+            // execute in order -- so only the wider stages need a workgroup barrier (10 of the 55 for 1024 entries).
+            // [ranking every entry against all others took ~150 k cycles here: 15 % of a deep query's time]
+            static_assert(SM::NCAP <= 2 * BLOCK, "one compare-exchange per thread");
+            uint32_t np2 = 512;
+            while (np2 < n) np2 <<= 1;
+            for (uint32_t i = n + tid; i < np2; i += BLOCK) {  // padding sorts last
+              S.near_f[i] = INFINITY; S.near_g[i] = INFINITY; S.near_id[i] = 0xFFFFFFFFu; S.near_idx[i] = NIL;
+            }
+            lds_barrier();
+            for (uint32_t k = 2; k <= np2; k <<= 1) {
+              for (uint32_t jj = k >> 1; jj > 0; jj >>= 1) {
+                const uint32_t t = (uint32_t)tid;
+                if (t < (np2 >> 1)) {
+                  const uint32_t a = ((t & ~(jj - 1u)) << 1) | (t & (jj - 1u)), b = a | jj;
+                  const double fa = S.near_f[a], ga = S.near_g[a], fb = S.near_f[b], gb = S.near_g[b];
+                  const uint32_t ia = S.near_id[a], ib = S.near_id[b];
+                  const bool b_first = entry_less(fb, gb, ib, fa, ga, ia);
+                  if (((a & k) == 0u) == b_first) {  // ascending run and b precedes a, or descending run and a precedes b
+                    const uint32_t xa = S.near_idx[a], xb = S.near_idx[b];
+                    S.near_f[a] = fb; S.near_g[a] = gb; S.near_id[a] = ib; S.near_idx[a] = xb;
+                    S.near_f[b] = fa; S.near_g[b] = ga; S.near_id[b] = ia; S.near_idx[b] = xa;
+                  }
+                }
+                const uint32_t next = jj > 1u ? (jj >> 1) : k;  // stride of the stage that follows
+                if (jj > 32u || next > 32u) lds_barrier(); else unit_sync<64>();
+              }
+            }
+            lds_barrier();
 #pragma unroll
             for (int r = 0; r < PERT; r++) {
               const uint32_t i = tid + r * BLOCK;
-              if (i < ns_) rk[r] = i; else if (i < n) rk[r] = rank_in_prefix(r);
-            }
-            for (uint32_t j = ns_; j < n; j++) {
-              const double f = S.near_f[j], g = S.near_g[j];
-              const uint32_t id = S.near_id[j];
-#pragma unroll
-              for (int r = 0; r < PERT; r++)
-                if (entry_less(f, g, id, ef[r], eg[r], ei[r])) rk[r]++;
+              if (i < n) { ef[r] = S.near_f[i]; eg[r] = S.near_g[i]; ei[r] = S.near_id[i]; ex[r] = S.near_idx[i]; rk[r] = i; }
             }
           }
           MPLX_T2(S, 15, t3);
-          __syncthreads();
+          lds_barrier();
           MPLX_T2(S, 18, t3);
 #pragma unroll
           for (int r = 0; r < PERT; r++) {
@@ -771,7 +807,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             S.n_near = n - kc;
             S.n_sorted = n - kc;
           }
-          __syncthreads();
+          lds_barrier();
           MPLX_T2(S, 19, t3);
           if constexpr (HELP) {
             // wish list: the front of what is left of OPEN (sorted) = the candidates of the next batches.  Announced
@@ -1305,6 +1341,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       printf("cyc2 q%d batches %llu:", q, S.cyc[7]);
       for (int i = 0; i < 24; i++) printf(" %llu", S.cyc2[i] / (S.cyc[7] ? S.cyc[7] : 1ull));
       printf("\n  max-over-lanes: heuristic done %llu, barrier arrival %llu\n", S.sum_heur / S.cyc[7], S.sum_arr / S.cyc[7]);
+      printf("  ranking: mean near size %.1f, mean appended %.1f, batches on the all-pairs path %llu, batches with near > 256: %llu, of %llu\n", (double)S.dbg_n / S.cyc[7], (double)S.dbg_na / S.cyc[7], S.dbg_slow, S.dbg_n256, S.cyc[7]);
       for (int j = 0; j < 4; j++) { printf("  per-wave %d:", j); for (int w = 0; w < BLOCK / 64; w++) printf(" %llu", S.cycw[w][j] / (S.cyc[7] ? S.cyc[7] : 1ull)); printf("\n"); }
 #endif
     }

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Builds a diagnostic variant of libmplx.so into build_tmp/ (git-ignored; travels with gpurun snapshots).
+# usage: tools/build_variant.sh timers|helpdbg      -> build_tmp/libmplx_<variant>.so   (use with MPLX_LIB=...)
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+V=${1:-timers}
+case $V in
+  timers) DEF=-DMPLX_LOOKUP_TIMERS ;;
+  helpdbg) DEF=-DMPLX_HELP_DEBUG ;;
+  *) echo "unknown variant $V"; exit 2 ;;
+esac
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function $DEF"
+S=$ROOT/mpl_ros_amd/csrc
+O=$ROOT/build_tmp
+mkdir -p $O
+/opt/rocm/bin/hipcc $F -c -o $O/v_api.o $S/mplx_api.hip &
+/opt/rocm/bin/hipcc $F -c -o $O/v_spec.o $S/mplx_spec_launch.hip &
+/opt/rocm/bin/hipcc $F -c -o $O/v_help.o $S/mplx_help_launch.hip &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libmplx_$V.so $O/v_api.o $O/v_spec.o $O/v_help.o
+rm -f $O/v_*.o
+ls -la $O/libmplx_$V.so
