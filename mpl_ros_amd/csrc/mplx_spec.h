@@ -567,7 +567,15 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       if (tid == 0) open_push(Q, 0u, S.f_base, 0.0, 0u);
       __syncthreads();
       // ---- main loop: one batch of up to K expansions per iteration
+      // far-bucket link whose atomicExch (an HBM round trip) is still in flight: open(pend_idx)->next = pend_old is
+      // stored at the top of the NEXT iteration -- nothing walks a far list before that -- so the round trip
+      // overlaps the end-of-batch bookkeeping instead of being waited for
+      uint32_t pend_idx = NIL, pend_old = NIL;
       for (;;) {
+        if (pend_idx != NIL) {
+          Q.open(pend_idx)->next = pend_old;
+          pend_idx = NIL;
+        }
         while (S.n_near + S.reserve > (uint32_t)SM::NCAP) {
           MPLX_TIC(te);
           evict_half(Q, tid);
@@ -1115,7 +1123,6 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
 #endif
         int k_stop = n_cand, n_commit = 0;
         const unsigned long long expanded0 = S.c_expanded;
-        uint32_t pend_idx = NIL, pend_old = NIL;  // far-bucket link whose atomicExch is still in flight
         const bool parallel_commit = !S.batch_dep;
         MPLX_T2(S, 7, t2);
         if (parallel_commit) {
@@ -1206,7 +1213,6 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           if (S.status >= 0) { k_stop = k + 1; break; }
         }
         MPLX_T2(S, 11, t2);
-        if (pend_idx != NIL) Q.open(pend_idx)->next = pend_old;
         if (!parallel_commit) {
           lds_barrier();
           // write the batch table back: one store per field and state, whatever number of units touched it
@@ -1245,12 +1251,23 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             const uint32_t pos = S.n_near + (uint32_t)__popcll(mb & below);
             S.near_f[pos] = S.cand_f[l]; S.near_g[pos] = S.cand_g[l]; S.near_id[pos] = cur; S.near_idx[pos] = S.cand_idx[l];
           }
-          unsigned long long hh = S.c_hash;
+          // running hash of the expansion order, h <- h P + (id + 1) per committed unit in order (mod 2^64), unrolled
+          // algebraically: h P^n + sum_k (id_k + 1) P^(number of committed units after k); each lane forms its own
+          // term (square-and-multiply on the bits of the exponent), a butterfly adds them up
+          static_assert(K <= 16, "exponents below 16");
+          auto pow_p = [](uint32_t e) {
+            unsigned long long r = 1ull;
+            if (e & 1u) r *= 0x100000001B3ull;
+            if (e & 2u) r *= 0x366000002E329ull;
+            if (e & 4u) r *= 0x9FFAAC085635BC91ull;
+            if (e & 8u) r *= 0x1EFAC7090AEF4A21ull;
+            if (e & 16u) r *= 0x4EFE15C813151841ull;
+            return r;
+          };
+          unsigned long long term = done ? (unsigned long long)(cur + 1u) * pow_p((uint32_t)__popcll((m >> l) >> 1)) : 0ull;
 #pragma unroll
-          for (int k = 0; k < K; k++) {  // the running hash of the expansion order is a serial chain
-            const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)cur, k);
-            if ((m >> k) & 1ull) hh = hh * 0x100000001B3ull + (unsigned long long)(ck + 1u);
-          }
+          for (int d = 1; d < K; d <<= 1) term += __shfl_xor(term, d, 64);  // (lanes >= K hold 0; every lane < K ends up with the sum)
+          const unsigned long long hh = S.c_hash * pow_p((uint32_t)__popcll(m)) + term;
           if (m && l == 63 - __clzll((long long)m)) S.cur_id = cur;
           if (l == 0) {
             const unsigned long long ncm = (unsigned long long)__popcll(m);
