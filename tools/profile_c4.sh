@@ -18,4 +18,4 @@ timeout 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU -d "
 cd - > /dev/null
 python profiles/summarize_rocprof.py "$OUT" > "$OUT/summary.txt" 2>&1
 find "$OUT" -name "*.db" -delete   # the databases are large; the summary is what is kept
-tail -3 "$OUT"/bench_*.log | cut -c1-300
+for f in "$OUT"/bench_*.log; do tail -n 2 "$f" | cut -c1-300; done
