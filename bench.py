@@ -305,6 +305,9 @@ def main():
                 "parallelism": f"queries sharded, {world} map replica(s), RCCL broadcast",
             },
             "expansions_per_step": tot_exp,
+            # what rank 0's searches did in the last step (the HBM traffic accounted by structure)
+            "search_counters_rank0": {k: int(sum(getattr(r, k) for r in results)) for k in
+                                      ("n_expanded", "n_nodes", "n_edges", "n_succ", "n_succ_finite", "voxel_reads", "n_push", "n_reopen", "n_refill", "n_evict")},
             "plan_status_counts": {"ok": tot_status[0], "no_path": tot_status[1], "start_occupied": tot_status[2],
                                    "max_expand": tot_status[3], "pool_full": tot_status[4], "internal": tot_status[5],
                                    "traj_too_long": tot_status[6]},

@@ -158,8 +158,10 @@ int mplx_set_speculation(mplx_ctx *ctx, int32_t mode);
  * One launch, at most one workgroup per compute unit: in a batch larger than the machine the leading workgroups
  * turn into helpers as they run out of queries; a batch smaller than the machine is launched with extra
  * workgroups that help from the start (up to per_leader for every query).
- * per_leader: -1 auto (2), 0 off, 2.  reserved: workgroups that never lead, for a batch larger than the machine
- * (-1 / 0: none).  cache_rows: rows of the heuristic cache (0 auto).  Used by the speculative kernels for lattices
+ * per_leader: -1 auto (2), 0 off, 2.  reserved: workgroups that never lead, for a batch larger than the machine:
+ * they help, from the start, the queries predicted longest (earliest in the launch order = longest straight-line
+ * distance); 0 none, -1 auto (one eighth of the compute units when the batch holds at least twice as many queries
+ * as the machine has compute units).  cache_rows: rows of the heuristic cache (0 auto).  Used by the speculative kernels for lattices
  * of at most 31 inputs and for the 65..128-input jerk lattices.  The leader never waits for a helper; a helper
  * leaves when every query is done, when it finds every running leader served, or when the leader it serves
  * stops completing batches. */

@@ -46,7 +46,7 @@ struct mplx_ctx {
   int speculation = -1;  // -1 auto, 0/1 off, else on
   // helper workgroups (look-ahead expansion on idle compute units): -1 auto, 0 off, 1 / 2 helpers per leader
   int helpers = -1;
-  int help_reserved = -1;   // workgroups that never lead (-1 auto: only for batches smaller than the machine)
+  int help_reserved = -1;   // workgroups that never lead in a batch larger than the machine (-1 auto: n_cus / 8 when nq >= 2 n_cus; 0 none)
   uint64_t help_rows = 0;   // rows of the heuristic cache (0 auto)
   int n_cus = 0;
   int pool_help_lanes = 0;  // unit width the heuristic-cache rows were sized for
@@ -501,7 +501,7 @@ extern "C" int mplx_helper_stats(const mplx_ctx *cc, uint32_t stats[4]) {
       if (c->dbg_boxes && hipMemcpy(hb.data(), c->dbg_boxes, sizeof(HelpBox) * hb.size(), hipMemcpyDeviceToHost) == hipSuccess)
         for (size_t i = 0; i < hb.size(); i++)
           if (hb[i].pad1[0] > 1000000ull)
-            fprintf(stderr, "[help debug] slot %zu (XCD %u): longest batch %.1f ms at %.1f ms into query %llu (batch %llu), helped %llu\n", i, hb[i].pad0 - 1u,
+            fprintf(stderr, "[help debug] slot %zu (XCD %u): longest batch %.1f ms at %.1f ms into query %llu (batch %llu), helped %llu\n", i, (uint32_t)hb[i].pad1[4] - 1u,
                     hb[i].pad1[0] * 1e-5, (hb[i].pad1[1] >> 1) * 1e-5, hb[i].pad1[2], hb[i].pad1[3], hb[i].pad1[1] & 1ull);
     }
 #endif
@@ -822,7 +822,11 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   if (help) {
     P.help_max = c->helpers < 0 ? 2 : c->helpers;
     P.help_lead = std::min(slots, c->n_cus);  // (one workgroup of these kernels fills a compute unit: more would only wait)
-    if (c->help_reserved > 0 && slots + c->help_reserved > c->n_cus) P.help_lead = std::max(1, c->n_cus - c->help_reserved);  // a share that never leads
+    // a share of the machine that never leads: its workgroups help, from the start, the queries predicted longest
+    // (the launch order is longest straight-line distance first; a batch lasts as long as its longest query).
+    // auto: one eighth of the compute units when the batch is at least twice the machine
+    const int reserved = c->help_reserved >= 0 ? c->help_reserved : (nq >= 2 * c->n_cus ? c->n_cus / 8 : 0);
+    if (reserved > 0 && slots + reserved > c->n_cus) P.help_lead = std::max(1, c->n_cus - reserved);
     grid = std::max(P.help_lead, std::min(P.help_lead * (P.help_max + 1), c->n_cus));
     HIPCHK(c, hipMemsetAsync(P.boxes, 0, sizeof(HelpBox) * ((size_t)c->pool_slots + 1024), c->stream));
     c->dbg_boxes = P.boxes;

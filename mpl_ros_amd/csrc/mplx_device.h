@@ -81,8 +81,8 @@ struct alignas(64) HelpBox {   // one per workgroup slot; every word is written 
   unsigned long long seq;      // epoch << 32 | n;  n = 0: no query running; 1: query running, no list yet; k + 2: list k is complete
   unsigned long long n_expanded;  // progress of the running query (helpers prefer the longest-running leader)
   uint32_t q;                  // query the leader is running
-  uint32_t pad0;
-  unsigned long long pad1[5];
+  uint32_t rank;               // position of that query in the launch order (longest predicted first)
+  unsigned long long pad1[5];  // (pad1[0..4]: diagnostics of the -DMPLX_HELP_DEBUG build)
   // line 1: written by helpers (atomics), read by the leader every few batches -- kept off the line the leader stores to
   uint32_t helpers;            // bit mask of attached helpers (atomicOr / atomicAnd)
   uint32_t pad2[15];

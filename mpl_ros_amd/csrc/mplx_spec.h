@@ -271,7 +271,7 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
           S.help_quit = 1;
           go = 0;
 #ifdef MPLX_HELP_DEBUG
-          atomicAdd(P.cache_next + 128 + (dbg_xcc() & 7u) * 8u + ((ld_u32(&B->pad0) - 1u) & 7u), 1u);
+          atomicAdd(P.cache_next + 128 + (dbg_xcc() & 7u) * 8u + (((uint32_t)B->pad1[4] - 1u) & 7u), 1u);
 #endif
           break;
         }
@@ -378,14 +378,17 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
     }
     __syncthreads();
     if (S.flag) return;
-    unsigned long long best = 0;
+    // whom to help: the leader that has been expanding the longest (in steps of 65 536 expansions, ~0.1 s); among
+    // those -- at the start of a batch: everybody -- the query predicted longest (earliest in the launch order)
+    unsigned long long best = 0;  // ((steps + 1) << 20) | (2^20 - 1 - min(rank, 2^20 - 1)) < 2^53
     int bi = -1;
     for (int b = tid; b < nboxes; b += BLOCK) {
       const HelpBox *B = P.boxes + b;
       if (!box_active(ld_u64(&B->seq), P.epoch)) continue;
       if (__popc(ld_u32(&B->helpers)) >= P.help_max) continue;
-      const unsigned long long ne = ld_u64(&B->n_expanded) + 1ull;
-      if (ne > best) { best = ne; bi = b; }
+      const uint32_t rk = ld_u32(&B->rank);
+      const unsigned long long key = (((ld_u64(&B->n_expanded) >> 16) + 1ull) << 20) | (unsigned long long)(0xFFFFFu - (rk < 0xFFFFFu ? rk : 0xFFFFFu));
+      if (key > best) { best = key; bi = b; }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -394,7 +397,7 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
       if (ob > best || (ob == best && oi >= 0 && (bi < 0 || oi < bi))) { best = ob; bi = oi; }
     }
     if ((tid & 63) == 0) {
-      S.red_f[tid >> 6] = (double)best;  // (n_expanded < 2^53)
+      S.red_f[tid >> 6] = (double)best;  // (exact: the key is below 2^53)
       S.red_id[tid >> 6] = (uint32_t)bi;
     }
     __syncthreads();
@@ -414,7 +417,7 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
           const uint32_t q = ld_u32(&B->q);
           if (q < (uint32_t)P.nq && box_active(ld_u64(&B->seq), P.epoch)) {
 #ifdef MPLX_HELP_DEBUG
-            atomicAdd(P.cache_next + 192 + (dbg_xcc() & 7u) * 8u + ((ld_u32(&B->pad0) - 1u) & 7u), 1u);
+            atomicAdd(P.cache_next + 192 + (dbg_xcc() & 7u) * 8u + (((uint32_t)B->pad1[4] - 1u) & 7u), 1u);
 #endif
             const QueryIn &in = P.queries[q];
             S.help_q = (int)q;
@@ -495,8 +498,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       if constexpr (HELP) {  // announce the query (helpers filter wish entries by q, so the order of the stores is free)
         HelpBox *box = P.boxes + blockIdx.x;
         st_u32(&box->q, (uint32_t)q);
+        st_u32(&box->rank, (uint32_t)qi);
 #ifdef MPLX_HELP_DEBUG
-        st_u32(&box->pad0, dbg_xcc() + 1u);
+        box->pad1[4] = dbg_xcc() + 1u;
         S.dbg_t = wall_clock64();
         S.dbg_gap = 0;
         S.dbg_when = 0;
