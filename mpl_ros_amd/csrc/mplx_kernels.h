@@ -37,6 +37,58 @@ __device__ __forceinline__ bool entry_less(double f1, double g1, uint32_t i1, do
   return i1 < i2;
 }
 
+// ---- cross-lane prefix operations on the VALU's DPP path (row shifts and row broadcasts: a few cycles per step)
+// instead of ds_bpermute (__shfl_up: an LDS-crossbar round trip per step, ~30 dependent ones per batch of the
+// search).  Every lane of the wave must be active.  WIDTH = 16, 32 or 64 consecutive lanes per segment.
+// [row_shr:n = 0x110 + n, row_bcast:15 = 0x142 (into rows 1 and 3), row_bcast:31 = 0x143 (into rows 2 and 3): the
+//  scan LLVM's own atomic optimiser emits for gfx9]
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xf, false);
+}
+template <int WIDTH>
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
+  static_assert(WIDTH == 16 || WIDTH == 32 || WIDTH == 64, "segment of 16, 32 or 64 lanes");
+  x += dpp_u32<0x111, 0xf>(0u, x);
+  x += dpp_u32<0x112, 0xf>(0u, x);
+  x += dpp_u32<0x114, 0xf>(0u, x);
+  x += dpp_u32<0x118, 0xf>(0u, x);
+  if constexpr (WIDTH >= 32) x += dpp_u32<0x142, 0xa>(0u, x);
+  if constexpr (WIDTH >= 64) x += dpp_u32<0x143, 0xc>(0u, x);
+  return x;
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long x) {  // source lane's value, 0 where there is none
+  const uint32_t lo = dpp_u32<CTRL, 0xf>(0u, (uint32_t)x), hi = dpp_u32<CTRL, 0xf>(0u, (uint32_t)(x >> 32));
+  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+__device__ __forceinline__ unsigned long long row_incl_sum64(unsigned long long x) {  // rows of 16 lanes, mod 2^64
+  x += dpp_u64<0x111>(x);
+  x += dpp_u64<0x112>(x);
+  x += dpp_u64<0x114>(x);
+  x += dpp_u64<0x118>(x);
+  return x;
+}
+__device__ __forceinline__ int row_incl_min(int x, int identity) {  // rows of 16 lanes
+  int y;
+  y = (int)dpp_u32<0x111, 0xf>((uint32_t)identity, (uint32_t)x); x = y < x ? y : x;
+  y = (int)dpp_u32<0x112, 0xf>((uint32_t)identity, (uint32_t)x); x = y < x ? y : x;
+  y = (int)dpp_u32<0x114, 0xf>((uint32_t)identity, (uint32_t)x); x = y < x ? y : x;
+  y = (int)dpp_u32<0x118, 0xf>((uint32_t)identity, (uint32_t)x); x = y < x ? y : x;
+  return x;
+}
+// value held by the last lane of my segment (uniform per segment)
+template <int WIDTH>
+__device__ __forceinline__ uint32_t segment_last(uint32_t x, int lane) {
+  if constexpr (WIDTH == 64) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+  } else {
+    static_assert(WIDTH == 32, "two segments per wave");
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)x, 31), b = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+    return (lane & 32) ? b : a;
+  }
+}
+
 struct alignas(8) OpenRec {  // OPEN-log record (OPEN_BYTES)
   double f, g;
   uint32_t id, next;
@@ -104,14 +156,9 @@ struct Smem {
 template <int BLOCK, class SM>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, SM &S, int tid, uint32_t &total) {
   const int lane = tid & 63, wave = tid >> 6;
-  uint32_t x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t y = __shfl_up(x, d, 64);
-    if (lane >= d) x += y;
-  }
+  const uint32_t x = wave_incl_sum<64>(v);
   if constexpr (BLOCK == 64) {
-    total = __shfl(x, 63, 64);
+    total = segment_last<64>(x, lane);
     return x - v;
   } else {
     if (lane == 63) S.wsum[wave] = x;
@@ -167,25 +214,14 @@ __device__ __forceinline__ uint32_t unit_excl_scan(uint32_t v, SM &S, int tid, u
     return block_excl_scan<BLOCK>(v, S, tid, total);
   } else {
     if constexpr (UL < 64) {  // several units per wave: segmented scan, no barrier
-      const int ls = tid % UL;
-      uint32_t x = v;
-#pragma unroll
-      for (int d = 1; d < UL; d <<= 1) {
-        uint32_t y = __shfl_up(x, d, UL);
-        if (ls >= d) x += y;
-      }
-      total = __shfl(x, UL - 1, UL);
+      const uint32_t x = wave_incl_sum<UL>(v);
+      total = segment_last<UL>(x, tid & 63);
       return x - v;
     }
     const int lane = tid & 63, wave = tid >> 6;
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t y = __shfl_up(x, d, 64);
-      if (lane >= d) x += y;
-    }
+    const uint32_t x = wave_incl_sum<64>(v);
     if constexpr (UL == 64) {
-      total = __shfl(x, 63, 64);
+      total = segment_last<64>(x, lane);
       return x - v;
     } else {
       if (lane == 63) S.wsum[wave] = x;

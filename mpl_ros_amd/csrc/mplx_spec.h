@@ -723,9 +723,12 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
               for (uint32_t j = part; j < na; j += G)
                 if (entry_less(S.near_f[ns_ + j], S.near_g[ns_ + j], S.near_id[ns_ + j], af, ag, ai)) cnt++;
             }
-#pragma unroll
-            for (int d = 1; d < BLOCK / 64; d <<= 1)
-              if ((uint32_t)d < G) cnt += __shfl_xor(cnt, d, 64);
+            // the G consecutive lanes of an entry add up their counts; lane `part == 0` (the only one that uses it) ends
+            // up with the total (row_shl:n = 0x100 + n: lane i receives lane i + n of its row of 16, or nothing)
+            if (G > 1u) cnt += dpp_u32<0x101, 0xf>(0u, cnt);
+            if (G > 2u) cnt += dpp_u32<0x102, 0xf>(0u, cnt);
+            if (G > 4u) cnt += dpp_u32<0x104, 0xf>(0u, cnt);
+            static_assert(BLOCK / 64 <= 8, "at most 8 lanes per appended entry");
             if (a < na && part == 0) {
               S.app_f[cnt] = af; S.app_g[cnt] = ag; S.app_id[cnt] = ai;
               S.app_rank[a] = cnt;
@@ -1141,14 +1144,8 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             const bool lvk = inb && S.cand_live[inb ? l : 0] != 0;
             const int uck = lvk ? S.u_cut[l] : K;
             const bool ugk = lvk && S.u_goal[l] != 0;
-            int c = uck;  // inclusive prefix minimum of the cut points of the live units
-#pragma unroll
-            for (int d = 1; d < K; d <<= 1) {
-              const int y = __shfl_up(c, d, 64);
-              if (l >= d) c = y < c ? y : c;
-            }
-            int cex = __shfl_up(c, 1, 64);  // cut point set by the units before mine
-            if (l == 0) cex = K;
+            const int c = row_incl_min(uck, K);  // inclusive prefix minimum of the cut points of the live units
+            const int cex = (int)dpp_u32<0x111, 0xf>((uint32_t)K, (uint32_t)c);  // cut point set by the units before mine (lane 0: none)
             const unsigned long long livem = __ballot(lvk);
             const unsigned long long le = ~0ull >> (63 - l);
             const int cnt = __popcll(livem & le);  // live units up to and including mine
@@ -1240,13 +1237,10 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           const unsigned long long m = __ballot(done), mb = __ballot(back);
           const unsigned long long below = (1ull << l) - 1ull;
           const unsigned long long ne0 = S.c_expanded;
-          uint32_t su = done ? S.u_succ[l] : 0u, fi = done ? S.u_fin[l] : 0u, rd = done ? S.u_reads[l] : 0u;
-#pragma unroll
-          for (int d = 1; d < K; d <<= 1) {
-            su += __shfl_xor(su, d, 64);
-            fi += __shfl_xor(fi, d, 64);
-            rd += __shfl_xor(rd, d, 64);
-          }
+          // (lanes >= K hold 0: the sums over the first row of 16 lanes are the totals)
+          const uint32_t su = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_sum<16>(done ? S.u_succ[l] : 0u), 15);
+          const uint32_t fi = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_sum<16>(done ? S.u_fin[l] : 0u), 15);
+          const uint32_t rd = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_sum<16>(done ? S.u_reads[l] : 0u), 15);
           if (done && P.rec_ids) {
             const unsigned long long at = ne0 + (unsigned long long)__popcll(m & below);
             if (at < P.cap_rec) P.rec_ids[(size_t)q * P.cap_rec + at] = (int32_t)cur;
@@ -1257,7 +1251,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
           // running hash of the expansion order, h <- h P + (id + 1) per committed unit in order (mod 2^64), unrolled
           // algebraically: h P^n + sum_k (id_k + 1) P^(number of committed units after k); each lane forms its own
-          // term (square-and-multiply on the bits of the exponent), a butterfly adds them up
+          // term (square-and-multiply on the bits of the exponent), a row scan adds them up
           static_assert(K <= 16, "exponents below 16");
           auto pow_p = [](uint32_t e) {
             unsigned long long r = 1ull;
@@ -1268,10 +1262,10 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             if (e & 16u) r *= 0x4EFE15C813151841ull;
             return r;
           };
-          unsigned long long term = done ? (unsigned long long)(cur + 1u) * pow_p((uint32_t)__popcll((m >> l) >> 1)) : 0ull;
-#pragma unroll
-          for (int d = 1; d < K; d <<= 1) term += __shfl_xor(term, d, 64);  // (lanes >= K hold 0; every lane < K ends up with the sum)
-          const unsigned long long hh = S.c_hash * pow_p((uint32_t)__popcll(m)) + term;
+          const unsigned long long term = row_incl_sum64(done ? (unsigned long long)(cur + 1u) * pow_p((uint32_t)__popcll((m >> l) >> 1)) : 0ull);
+          const unsigned long long terms = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(term >> 32), 15) << 32) |
+                                           (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)term, 15);
+          const unsigned long long hh = S.c_hash * pow_p((uint32_t)__popcll(m)) + terms;
           if (m && l == 63 - __clzll((long long)m)) S.cur_id = cur;
           if (l == 0) {
             const unsigned long long ncm = (unsigned long long)__popcll(m);
