@@ -59,6 +59,7 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   int32_t u_cut[K];   // first later candidate preceded by an entry unit k pushes (K if none)
   uint32_t n_sorted;  // near_[0, n_sorted) is in ascending order (left so by the previous selection)
   // the entries appended since, sorted (selection scratch)
+  unsigned long long hpow[17];  // powers of the expansion-hash multiplier (0x100000001B3^e mod 2^64), filled once per workgroup
   double app_f[256], app_g[256];
   uint32_t app_id[256], app_rank[256];
   int32_t batch_dep;  // units interact through a state one of them MODIFIES -> ordered, unit-by-unit commit
@@ -462,6 +463,10 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   fill_uq<BLOCK, CONTROL>(P, S, tid);
+  if (tid == 0) {
+    unsigned long long pw = 1ull;
+    for (int e = 0; e < 17; e++) { S.hpow[e] = pw; pw *= 0x100000001B3ull; }
+  }
   for (;;) {
     if (tid == 0) {
       if (HELP && (int)blockIdx.x >= P.help_lead) S.q_index = P.nq;  // a workgroup launched to help only (batch smaller than the machine)
@@ -1251,21 +1256,12 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
           // running hash of the expansion order, h <- h P + (id + 1) per committed unit in order (mod 2^64), unrolled
           // algebraically: h P^n + sum_k (id_k + 1) P^(number of committed units after k); each lane forms its own
-          // term (square-and-multiply on the bits of the exponent), a row scan adds them up
-          static_assert(K <= 16, "exponents below 16");
-          auto pow_p = [](uint32_t e) {
-            unsigned long long r = 1ull;
-            if (e & 1u) r *= 0x100000001B3ull;
-            if (e & 2u) r *= 0x366000002E329ull;
-            if (e & 4u) r *= 0x9FFAAC085635BC91ull;
-            if (e & 8u) r *= 0x1EFAC7090AEF4A21ull;
-            if (e & 16u) r *= 0x4EFE15C813151841ull;
-            return r;
-          };
-          const unsigned long long term = row_incl_sum64(done ? (unsigned long long)(cur + 1u) * pow_p((uint32_t)__popcll((m >> l) >> 1)) : 0ull);
+          // term (powers from a table in LDS), a row scan adds them up
+          static_assert(K <= 16, "exponents up to 16: S.hpow");
+          const unsigned long long term = row_incl_sum64(done ? (unsigned long long)(cur + 1u) * S.hpow[__popcll((m >> l) >> 1) & 31] : 0ull);
           const unsigned long long terms = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(term >> 32), 15) << 32) |
                                            (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)term, 15);
-          const unsigned long long hh = S.c_hash * pow_p((uint32_t)__popcll(m)) + terms;
+          const unsigned long long hh = S.c_hash * S.hpow[__popcll(m) & 31] + terms;
           if (m && l == 63 - __clzll((long long)m)) S.cur_id = cur;
           if (l == 0) {
             const unsigned long long ncm = (unsigned long long)__popcll(m);
