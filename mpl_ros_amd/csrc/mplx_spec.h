@@ -205,8 +205,8 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
         uint32_t pos = atomicAdd(&S.n_near, 1u);
         S.near_f[pos] = pf; S.near_g[pos] = tg; S.near_id[pos] = id; S.near_idx[pos] = idx;
       } else {
-        atomicAdd(&S.cnt[0][code], 1u);
-        pend_old = atomicExch(&Q.bkt_head[(size_t)code * NSUB + (idx & (NSUB - 1))], idx);
+        const uint32_t c = atomicAdd(&S.cnt[0][code], 1u);  // (sub-list by the bucket's running count: see far_link)
+        pend_old = atomicExch(&Q.bkt_head[(size_t)code * NSUB + (c & (NSUB - 1))], idx);
         pend_idx = idx;
       }
       if (!PAR && pre.cut < K) atomicMin(&S.cut_at, pre.cut);  // this entry precedes a later candidate: cut there
