@@ -26,6 +26,12 @@ __device__ __forceinline__ unsigned long long ld_u64(const unsigned long long *p
 __device__ __forceinline__ void st_u64(unsigned long long *p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// state-table probe: workgroup scope = past the compute unit's L1, but free to hit in the XCD's L2.  Safe for a table
+// shared by queries on other XCDs: a slot of this query is only ever written by this workgroup; a stale EMPTY is caught
+// by the claiming compare-and-swap (executed at the memory side), a stale foreign entry just moves the probe on.
+__device__ __forceinline__ unsigned long long ld_u64_probe(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // f64 through an agent-scope (sc1, write-through / L1-bypassing) 8-byte access: data another compute unit reads or wrote

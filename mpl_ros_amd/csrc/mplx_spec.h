@@ -907,7 +907,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           if (l.valid && !l.blocked) {
             h64 = key_hash64(l.key, nk);
             pos0 = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
-            v0 = ld_u64(&P.table[pos0]);
+            v0 = ld_u64_probe(&P.table[pos0]);
           }
         });
         const bool act = L.valid && !L.blocked;
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
 #endif
             bool first = true;
             for (;;) {
-              unsigned long long v = first ? v0 : ld_u64(&P.table[pos]);
+              unsigned long long v = first ? v0 : ld_u64_probe(&P.table[pos]);
               if (v == TBL_EMPTY) {
                 unsigned long long old = (first && did_cas0) ? cas0 : atomicCAS(&P.table[pos], TBL_EMPTY, claim);
                 first = false;
