@@ -161,7 +161,8 @@ int mplx_set_speculation(mplx_ctx *ctx, int32_t mode);
  * per_leader: -1 auto (2), 0 off, 2.  reserved: workgroups that never lead, for a batch larger than the machine:
  * they help, from the start, the queries predicted longest (earliest in the launch order = longest straight-line
  * distance); 0 none, -1 auto (one eighth of the compute units when the batch holds at least twice as many queries
- * as the machine has compute units).  cache_rows: rows of the heuristic cache (0 auto).  Used by the speculative kernels for lattices
+ * as the machine has compute units and max_expand is 0 or at least 200 000, i.e. one query can outlast the rest).
+ * cache_rows: rows of the heuristic cache (0 auto).  Used by the speculative kernels for lattices
  * of at most 31 inputs and for the 65..128-input jerk lattices.  The leader never waits for a helper; a helper
  * leaves when every query is done, when it finds every running leader served, or when the leader it serves
  * stops completing batches. */
