@@ -11,6 +11,7 @@ Every call that computes goes through libmplx.so (HIP, gfx950).  Nothing here ev
 primitives, touches voxels or searches on the CPU.
 """
 import ctypes as C
+import sys
 import math
 
 import numpy as np
@@ -332,6 +333,51 @@ class VoxelMapPlanner:
         instead of planning a different (unconstrained) search.  A negative value means "no constraint"."""
         if yaw_max >= 0:
             raise MplxError("setYawmax(>= 0): yaw constraints are not supported by this back-end")
+
+    # ---- reference API that this back-end does not cover (SURVEY.md 8f rows 2, 3)
+    def setLPAstar(self, use_lpastar):
+        """setLPAstar (map_replanner_node.cpp:425,437), as include/mpl_shim's PlannerBase treats it: LPA* would reuse and
+        repair the previous state space; here every plan() is a fresh A* on the current map -- the same optimal cost, no
+        reuse -- and asking for LPA* says so on stderr."""
+        self._use_lpastar = bool(use_lpastar)
+        if use_lpastar:
+            print("\x1b[31m[VoxelMapPlanner] setLPAstar(True): incremental replanning is not implemented by the mplx back-end; "
+                  "every plan() is a fresh A*\x1b[0m", file=sys.stderr)
+
+    def updateBlockedNodes(self, blocked_pns):   # map_replanner_node.cpp:190
+        """Map edits reach the planner through setMap / mplx_map_set_device; a fresh A* needs no list of changed cells."""
+        return False
+
+    def updateClearedNodes(self, cleared_pns):   # map_replanner_node.cpp:228
+        return False
+
+    def getSubStateSpace(self, time_step):       # map_replanner_node.cpp:246 (prunes the tree LPA* would reuse)
+        return None
+
+    def _unsupported(self, what):
+        raise MplxError(f"{what}: not supported by this back-end")
+
+    # (these change the cost function, i.e. the plan: refused, never ignored)
+    def setSearchRadius(self, radius):           # distance_map_planner_node.cpp:185
+        self._unsupported("setSearchRadius (search region)")
+
+    def setSearchRegion(self, path, dense=False):
+        self._unsupported("setSearchRegion (search region)")
+
+    def setPotentialRadius(self, radius):        # distance_map_planner_node.cpp:186
+        self._unsupported("setPotentialRadius (potential-field cost)")
+
+    def setPotentialWeight(self, w):             # distance_map_planner_node.cpp:187
+        self._unsupported("setPotentialWeight (potential-field cost)")
+
+    def setGradientWeight(self, w):              # distance_map_planner_node.cpp:188
+        self._unsupported("setGradientWeight (potential-field cost)")
+
+    def updatePotentialMap(self, pos, range_=None):
+        self._unsupported("updatePotentialMap (potential-field cost)")
+
+    def getPotentialCloud(self, h_max=1.0):      # distance_map_planner_node.cpp:231
+        self._unsupported("getPotentialCloud (potential-field cost)")
 
     def setTol(self, tol_pos, tol_vel=-1.0, tol_acc=-1.0):
         self._tol, self._dirty = (float(tol_pos), float(tol_vel), float(tol_acc)), True

@@ -69,3 +69,20 @@ def test_yaw_requests_fail_loudly():
     with pytest.raises(MplxError):
         pl.setYawmax(0.5)
     pl.setYawmax(-1.0)  # "unconstrained" is what the back-end does
+
+
+def test_uncovered_reference_api_fails_loudly():
+    """SURVEY.md 8(f) rows 2 and 3 are not covered.  LPA* replanning degrades to a fresh A* per plan() (same optimal cost)
+    and says so; potential-field / search-region cost would change the plan, so those setters raise."""
+    import pytest
+    from mpl_ros_amd._capi import MplxError
+    from mpl_ros_amd.planner import VoxelMapPlanner
+    pl = VoxelMapPlanner(False)
+    pl.setLPAstar(False)  # the default
+    pl.setLPAstar(True)   # says "every plan() is a fresh A*" on stderr, like the C++ shim; same optimal cost, no reuse
+    assert pl.updateBlockedNodes([]) is False and pl.updateClearedNodes([]) is False and pl.getSubStateSpace(1) is None
+    for call in (lambda: pl.setSearchRadius([0.5, 0.5, 0.5]), lambda: pl.setSearchRegion([]),
+                 lambda: pl.setPotentialRadius([1, 1, 1]), lambda: pl.setPotentialWeight(0.1), lambda: pl.setGradientWeight(0.0),
+                 lambda: pl.updatePotentialMap([0, 0, 0]), lambda: pl.getPotentialCloud()):
+        with pytest.raises(MplxError):
+            call()
