@@ -90,7 +90,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     traj_ = Trajectory<Dim>();
     traj_cost_ = std::numeric_limits<decimal_t>::infinity();
     if (this->unsupported_ || start.use_yaw || goal.use_yaw || start.enable_t) {  // never a silently different search
-      printf(ANSI_COLOR_RED "[MapPlanner] plan(): yaw (use_yaw / setYawmax / 4-component inputs) and time-keyed states are not supported by the mplx back-end\n" ANSI_COLOR_RESET);
+      printf(ANSI_COLOR_RED "[MapPlanner] plan() refused: yaw (use_yaw / setYawmax / 4-component inputs), time-keyed states, search regions and potential-field cost are not supported by the mplx back-end\n" ANSI_COLOR_RESET);
       return false;
     }
     mplx_ctx *ctx = map_util_->ctx();
@@ -141,6 +141,17 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     return ps;
   }
   void setExpandedRecord(uint32_t cap) { record_cap_ = cap; }
+  /// Search-region and potential-field cost (distance_map_planner_node.cpp:185-193,218-231) change the cost function,
+  /// i.e. the plan: not implemented by the mplx back-end, so a request makes plan() fail instead of planning without it.
+  void setSearchRadius(const Vecf<Dim> &) { refuse("setSearchRadius"); }
+  void setSearchRegion(const vec_Vecf<Dim> &, bool = false) { refuse("setSearchRegion"); }
+  void setPotentialRadius(const Vecf<Dim> &) { refuse("setPotentialRadius"); }
+  void setPotentialMapRange(const Vecf<Dim> &) { refuse("setPotentialMapRange"); }
+  void setPotentialWeight(decimal_t) { refuse("setPotentialWeight"); }
+  void setGradientWeight(decimal_t) { refuse("setGradientWeight"); }
+  void updatePotentialMap(const Vecf<Dim> &) { refuse("updatePotentialMap"); }
+  vec_Vec3f getPotentialCloud(decimal_t = 1.0) { refuse("getPotentialCloud"); return vec_Vec3f(); }
+  vec_Vecf<Dim> getSearchRegion() { refuse("getSearchRegion"); return vec_Vecf<Dim>(); }
   /// nodes that are linked into the graph, i.e. have at least one predecessor record (map_replanner_node.cpp:94)
   /// [UNVERIFIED: the upstream body is not vendored; node-id order here, hash-map order upstream]
   vec_Vecf<Dim> getLinkedNodes() const {
@@ -247,6 +258,10 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   mplx_result res_ = mplx_result();
   Control::Control control_ = Control::ACC;
   uint32_t record_cap_ = 1u << 20;
+  void refuse(const char *what) {
+    printf(ANSI_COLOR_RED "[MapPlanner] %s: not supported by the mplx back-end; plan() will fail\n" ANSI_COLOR_RESET, what);
+    this->unsupported_ = true;
+  }
 };
 
 typedef MapPlanner<2> OccMapPlanner;

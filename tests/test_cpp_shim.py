@@ -89,6 +89,17 @@ def test_reference_driver_through_the_shim(tmp_path, skir):
     assert abs(viz["prs_end_sum"] - end_sum) < 1e-6 * max(1.0, abs(end_sum))
 
 
+def test_shim_refuses_cost_changing_requests(tmp_path):
+    """Search-region / potential-field setters exist on the shim's MapPlanner and make plan() refuse (they would change the
+    plan); setLPAstar(true) only announces that every plan() is a fresh A*.  plan() fails before it reaches the device."""
+    exe = str(tmp_path / "shim_refusals")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mpl_shim"),
+                           "-o", exe, os.path.join(ROOT, "tests", "cpp", "shim_refusals.cpp"), os.path.join(LIBDIR, "libmplx.so"), "-Wl,-rpath," + LIBDIR])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "planned 0" in out.stdout
+    assert "fresh A*" in out.stdout and out.stdout.count("plan() will fail") == 4 and "plan() refused" in out.stdout
+
+
 REF_POLY = "/root/reference/mpl_external_planner/include"
 
 
