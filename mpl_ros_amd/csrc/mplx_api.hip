@@ -536,7 +536,11 @@ template <typename T>
 static int pool_alloc(mplx_ctx *c, T **p, size_t count) {
   void *v = nullptr;
   hipError_t e = hipMalloc(&v, count * sizeof(T));
-  if (e != hipSuccess) return fail(c, MPLX_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+  if (e != hipSuccess) {
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    return fail(c, MPLX_ERR_HIP, "hipMalloc(%zu bytes) failed: %s (device memory: %zu of %zu bytes free)", count * sizeof(T), hipGetErrorString(e), free_b, total_b);
+  }
   c->pool_allocs.push_back(v);
   *p = (T *)v;
   return MPLX_OK;

@@ -12,6 +12,7 @@ primitives, touches voxels or searches on the CPU.
 """
 import ctypes as C
 import sys
+import weakref
 import math
 
 import numpy as np
@@ -431,7 +432,8 @@ class VoxelMapPlanner:
         # a MapUtil (= one device context) may be shared by several planner objects, like the reference's
         # planner_ / replan_planner_ pair (map_replanner_node.cpp:415,427): re-send the set-up when another
         # planner configured the context since
-        if not self._dirty and control == self._control and getattr(ctx, "cfg_owner", None) is self:
+        owner = getattr(ctx, "cfg_owner", None)  # (a weak reference: the context must not keep its planners -- and through
+        if not self._dirty and control == self._control and owner is not None and owner() is self:  # them itself -- alive)
             return
         cfg = _capi.Config()
         cfg.control = control
@@ -444,7 +446,7 @@ class VoxelMapPlanner:
         cfg.max_expand = self._max_num
         cfg.heur_ignore_dynamics = int(self._heur_ignore_dynamics)
         ctx.check(ctx.lib.mplx_planner_config(ctx.h, C.byref(cfg)))
-        ctx.cfg_owner = self
+        ctx.cfg_owner = weakref.ref(self)
         self._control = control
         self._dirty = False
 

@@ -17,3 +17,12 @@ def skir():
     import numpy as np
     d = np.load(os.path.join(ROOT, "tests", "golden", "skir_map.npz"))
     return d["grid"], d["origin"], float(d["res"])
+
+
+@pytest.fixture(autouse=True)
+def _release_device_contexts():
+    """Device contexts own tens of GB of HBM in the scale tests; whatever a test leaves in a reference cycle is
+    collected before the next test allocates."""
+    yield
+    import gc
+    gc.collect()
