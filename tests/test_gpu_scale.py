@@ -134,7 +134,7 @@ def test_helpers_leave_every_result_unchanged(nq):
     cap = 20000
     kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5, max_expand=cap)
     queries = mapgen.c4_queries(grid, origin, res, nq, rank=3, min_dist=6.0)
-    pools = mapgen.c4_pools(False, nq, cap, per_q=200_000 if nq == 1 else 40_000 if nq == 40 else 25_000)  # (the 600 queries create 1.5 M states in all)
+    pools = mapgen.c4_pools(False, nq, cap, per_q=200_000 if nq == 1 else 100_000)  # (every query takes at least one 32 768-state chunk of the shared pool)
     S = [util.gpu_wp(s, control=orc.ACC) for s, g in queries]
     G = [util.gpu_wp(g, control=orc.ACC) for s, g in queries]
     runs = {}
