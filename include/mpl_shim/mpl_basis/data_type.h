@@ -72,6 +72,12 @@ struct Vec {
   T prod() const { T s = T(1); for (int i = 0; i < N; i++) s *= v[i]; return s; }
   T lpNormInf() const { T m = T(0); for (int i = 0; i < N; i++) m = std::fabs(v[i]) > m ? std::fabs(v[i]) : m; return m; }
   template <typename U> Vec<U, N> cast() const { Vec<U, N> r; for (int i = 0; i < N; i++) r.v[i] = static_cast<U>(v[i]); return r; }
+  /// Eigen's comma initialiser: `vec << dx, dy, 0, dyaw;` (map_planner_node.cpp:125-126,135-136)
+  struct CommaInit {
+    Vec &m; int k;
+    CommaInit &operator,(T x) { if (k < N) m.v[k++] = x; return *this; }
+  };
+  CommaInit operator<<(T x) { v[0] = x; return CommaInit{*this, 1}; }
 };
 template <typename T, int N>
 Vec<T, N> operator*(T s, const Vec<T, N> &a) { return a * s; }

@@ -46,11 +46,10 @@ class PlannerBase {
   virtual void setVmax(decimal_t v) { v_max_ = v; if (ENV_) ENV_->set_v_max(v); }
   virtual void setAmax(decimal_t a) { a_max_ = a; if (ENV_) ENV_->set_a_max(a); }
   virtual void setJmax(decimal_t j) { j_max_ = j; if (ENV_) ENV_->set_j_max(j); }
-  /// yaw-constrained search is not implemented: refuse rather than plan a different search (map_planner_node.cpp:180)
-  virtual void setYawmax(decimal_t yaw) {
-    yaw_max_ = yaw;
-    if (yaw >= 0) { printf(ANSI_COLOR_RED "[PlannerBase] setYawmax(%.3f): yaw is not supported by the mplx back-end; plan() will fail\n" ANSI_COLOR_RESET, yaw); unsupported_ = true; }
-  }
+  /// The yaw threshold (map_planner_node.cpp:179-180) constrains yaw-carrying primitives only: the reference node
+  /// always calls it, and its own config-1 launch file passes yaw_max = 0.5 with use_yaw = false
+  /// (launch/map_planner_node/test.launch:28,33).  Stored; it takes effect when the search states carry yaw.
+  virtual void setYawmax(decimal_t yaw) { yaw_max_ = yaw; if (ENV_) ENV_->set_yaw_max(yaw); }
   virtual void setTmax(decimal_t t) { t_max_ = t; if (ENV_) ENV_->t_max_ = t; }
   virtual void setDt(decimal_t dt) { dt_ = dt; if (ENV_) ENV_->set_dt(dt); }
   virtual void setW(decimal_t w) { w_ = w; if (ENV_) ENV_->set_w(w); }

@@ -110,8 +110,17 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     mplx_waypoint s = to_c(start), g = to_c(goal);
     if (mplx_plan(ctx, &s, &g, &res_) != MPLX_OK) { printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx)); return false; }
     if (res_.status == MPLX_PLAN_START_OCCUPIED) { printf(ANSI_COLOR_RED "[PlannerBase] start is not free!\n" ANSI_COLOR_RESET); return false; }
+    epoch_ = mplx_plan_epoch(ctx);  // the getters answer from THIS plan only (two planners may share one MapUtil)
     traj_cost_ = res_.cost;
     if (std::isinf(traj_cost_)) { printf(ANSI_COLOR_RED "[MPPlanner] Cannot find a traj!\n" ANSI_COLOR_RESET); return false; }
+    if (res_.status != MPLX_PLAN_OK) {
+      // e.g. MPLX_PLAN_TRAJ_TOO_LONG: goal reached, cost known, but no trajectory came back -- never "success" with an
+      // empty trajectory (a replanner would execute it)
+      printf(ANSI_COLOR_RED "[MPPlanner] plan() failed with status %d: the goal was reached (cost %f) but the trajectory has more primitives "
+             "than the device-side recoverTraj buffer holds\n" ANSI_COLOR_RESET, res_.status, traj_cost_);
+      traj_cost_ = std::numeric_limits<decimal_t>::infinity();
+      return false;
+    }
     std::vector<mplx_primitive> prs(res_.traj_len > 0 ? res_.traj_len : 0);
     if (res_.traj_len > 0) mplx_result_traj(ctx, 0, prs.data(), nullptr, nullptr, nullptr);
     vec_E<Primitive<Dim>> out;
@@ -133,7 +142,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   vec_Vecf<Dim> getExpandedNodes() const override {
     vec_Vecf<Dim> ps;
     std::vector<mplx_waypoint> coords;
-    if (!nodes(coords)) return ps;
+    if (!nodes(coords)) return ps;  // (also refuses when another planner planned on the shared context since)
     std::vector<int32_t> ids((size_t)std::max<uint64_t>(1, std::min<uint64_t>(res_.n_expanded, record_cap_)));
     uint32_t n = 0;
     if (mplx_result_expanded(map_util_->ctx(), 0, (uint32_t)ids.size(), ids.data(), &n) != MPLX_OK) return ps;
@@ -173,7 +182,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   vec_E<Primitive<Dim>> getAllPrimitives() const {
     vec_E<Primitive<Dim>> prs = edge_primitives(false);
     uint64_t n = 0, n_all = 0;
-    if (mplx_result_blocked(map_util_->ctx(), nullptr, nullptr, 0, &n, &n_all) != MPLX_OK || n == 0) return prs;
+    if (!own_results() || mplx_result_blocked(map_util_->ctx(), nullptr, nullptr, 0, &n, &n_all) != MPLX_OK || n == 0) return prs;
     std::vector<int32_t> parent((size_t)n), action((size_t)n);
     if (mplx_result_blocked(map_util_->ctx(), parent.data(), action.data(), n, &n, &n_all) != MPLX_OK) return prs;
     std::vector<mplx_waypoint> coords;
@@ -184,6 +193,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   /// hm_.size() as upstream counts it: states reached with finite cost + states only blocked primitives reach
   size_t getStateSpaceSize() const {
     uint64_t n = 0, n_all = 0;
+    if (!own_results()) return 0;
     return mplx_result_blocked(map_util_->ctx(), nullptr, nullptr, 0, &n, &n_all) == MPLX_OK ? (size_t)n_all : (size_t)res_.n_nodes;
   }
   vec_E<Primitive<Dim>> getExpandedEdges() const { return edge_primitives(true); }
@@ -203,15 +213,26 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     for (int k = 0; k < Dim; k++) p(k) = w.pos[k];
     return p;
   }
+  /// The device keeps the state space of the context's LAST plan only.  Two planners may share one MapUtil (= one
+  /// context: planner_ / replan_planner_, map_replanner_node.cpp:415,427): a getter must not size its buffers from
+  /// this planner's result and then read the other planner's state space.
+  bool own_results() const {
+    if (!map_util_ || epoch_ == 0 || mplx_plan_epoch(map_util_->ctx()) != epoch_) {
+      printf(ANSI_COLOR_RED "[MapPlanner] the results of this planner's last plan() are gone: another planner sharing the MapUtil planned since\n" ANSI_COLOR_RESET);
+      return false;
+    }
+    return true;
+  }
   bool nodes(std::vector<mplx_waypoint> &coords, std::vector<int32_t> *closed = nullptr) const {
     const size_t n = (size_t)res_.n_nodes;
-    if (!n) return false;
+    if (!n || !own_results()) return false;
     coords.resize(n);
     if (closed) closed->resize(n);
-    return mplx_result_nodes(map_util_->ctx(), coords.data(), nullptr, nullptr, closed ? closed->data() : nullptr, nullptr) == MPLX_OK;
+    return mplx_result_nodes(map_util_->ctx(), n, coords.data(), nullptr, nullptr, closed ? closed->data() : nullptr, nullptr) == MPLX_OK;
   }
   bool edges(std::vector<int32_t> &child, std::vector<int32_t> &parent, std::vector<int32_t> &action) const {
     const size_t n = (size_t)res_.n_edges;
+    if (!own_results()) return false;
     child.resize(n ? n : 1); parent.resize(n ? n : 1); action.resize(n ? n : 1);
     uint64_t m = 0;
     if (mplx_result_edges(map_util_->ctx(), child.data(), parent.data(), action.data(), n, &m) != MPLX_OK) return false;
@@ -240,10 +261,10 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   vec_Vecf<Dim> node_set(bool closed_set) const {
     vec_Vecf<Dim> ps;
     const size_t n = (size_t)res_.n_nodes;
-    if (!n) return ps;
+    if (!n || !own_results()) return ps;
     std::vector<mplx_waypoint> coords(n);
     std::vector<int32_t> closed(n), opened(n);
-    if (mplx_result_nodes(map_util_->ctx(), coords.data(), nullptr, nullptr, closed.data(), opened.data()) != MPLX_OK) return ps;
+    if (mplx_result_nodes(map_util_->ctx(), n, coords.data(), nullptr, nullptr, closed.data(), opened.data()) != MPLX_OK) return ps;
     for (size_t i = 0; i < n; i++) {
       if (closed_set ? closed[i] : (opened[i] && !closed[i])) {
         Vecf<Dim> p;
@@ -256,6 +277,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   std::shared_ptr<MapUtil<Dim>> map_util_;
   std::vector<double> U_;
   mplx_result res_ = mplx_result();
+  uint64_t epoch_ = 0;  // mplx_plan_epoch of this planner's last plan()
   Control::Control control_ = Control::ACC;
   uint32_t record_cap_ = 1u << 20;
   void refuse(const char *what) {

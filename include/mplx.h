@@ -193,8 +193,10 @@ int mplx_result_traj(mplx_ctx *ctx, int q, mplx_primitive *prs, mplx_waypoint *w
 int mplx_set_record(mplx_ctx *ctx, uint32_t cap_per_query);
 int mplx_result_expanded(mplx_ctx *ctx, int q, uint32_t cap, int32_t *ids, uint32_t *n);
 /* state-space dump of the LAST single mplx_plan(): node coords (getCloseSet / getOpenSet are
- * filters on `closed` / `opened`), g, h.  Arrays sized n_nodes; NULLs allowed. */
-int mplx_result_nodes(mplx_ctx *ctx, mplx_waypoint *coords, double *g, double *h, int32_t *closed, int32_t *opened);
+ * filters on `closed` / `opened`), g, h.  Arrays hold `cap` entries each (NULLs allowed); the call fails with
+ * MPLX_ERR_CAPACITY -- writing nothing -- when the last plan created more than `cap` states (a wrapper whose own
+ * plan is no longer the context's last one must not be handed another planner's, larger, state space). */
+int mplx_result_nodes(mplx_ctx *ctx, uint64_t cap, mplx_waypoint *coords, double *g, double *h, int32_t *closed, int32_t *opened);
 
 /* StateSpace predecessor lists of the LAST single mplx_plan(): the reference keeps pred_coord /
  * pred_action_id / pred_action_cost per node (poly_map_planner.h:70-86) and getAllPrimitives()

@@ -115,7 +115,7 @@ def load():
     L.mplx_result_traj.argtypes = [P, C.c_int, C.POINTER(Primitive), C.POINTER(Waypoint), I3, I3]
     L.mplx_set_record.argtypes = [P, C.c_uint32]
     L.mplx_result_expanded.argtypes = [P, C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
-    L.mplx_result_nodes.argtypes = [P, C.POINTER(Waypoint), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mplx_result_nodes.argtypes = [P, C.c_uint64, C.POINTER(Waypoint), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mplx_result_edges.argtypes = [P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.mplx_result_blocked.argtypes = [P, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mplx_result_timing.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), I3]

@@ -44,7 +44,7 @@ struct mplx_ctx {
   double *dU = nullptr, *dUcost = nullptr;
   double bucket_width = 0;
   int speculation = -1;  // -1 auto, 0/1 off, else on
-  // helper workgroups (look-ahead expansion on idle compute units): -1 auto, 0 off, 1 / 2 helpers per leader
+  // helper workgroups (look-ahead expansion on idle compute units): -1 auto (2 per leader), 0 off, 2
   int helpers = -1;
   int help_reserved = -1;   // workgroups that never lead in a batch larger than the machine (-1 auto: n_cus / 8 when nq >= 2 n_cus; 0 none)
   uint64_t help_rows = 0;   // rows of the heuristic cache (0 auto)
@@ -68,6 +68,7 @@ struct mplx_ctx {
   double last_dt = 0;
   std::vector<double> last_U;
   uint64_t plan_epoch = 0;  // bumped by every mplx_plan / mplx_plan_batch
+  uint64_t map_epoch = 0, last_map_epoch = 0;  // bumped whenever the grid changes (build_bricks); value at the last plan
   std::vector<QueryOut> last_out;
   QueryOut *d_out = nullptr;
   QueryIn *d_in = nullptr;
@@ -230,6 +231,7 @@ extern "C" int mplx_map_free_unknown(mplx_ctx *c) {
   HIPCHK(c, hipSetDevice(c->device));
   size_t n = (size_t)c->dim[0] * c->dim[1] * c->dim[2];
   hipLaunchKernelGGL(free_unknown_kernel, dim3(2048), dim3(256), 0, c->stream, c->map, n);
+  c->map_epoch++;  // (unknown -> free changes is_free(start), not the occupancy bitmap)
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return MPLX_OK;
@@ -253,6 +255,7 @@ extern "C" int mplx_map_info(const mplx_ctx *c, int32_t dim[3], double origin[3]
 }
 // (re)build the bricked occupancy bitmap from the byte grid
 static int build_bricks(mplx_ctx *c) {
+  c->map_epoch++;  // every change of the occupancy ends here (set, adopt, dilate, grid -> map)
   const int nb0 = (c->dim[0] + 7) / 8, nb1 = (c->dim[1] + 7) / 8, nb2 = (c->dim[2] + 7) / 8;
   (void)hipFree(c->bricks);
   c->bricks = nullptr;
@@ -884,6 +887,7 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   c->last_control = c->cfg.control;
   c->last_dt = c->cfg.dt;
   c->last_U = c->U;
+  c->last_map_epoch = c->map_epoch;
   c->plan_epoch++;
   return MPLX_OK;
 }
@@ -1028,11 +1032,12 @@ extern "C" int mplx_result_edges(mplx_ctx *c, int32_t *child, int32_t *parent, i
   return MPLX_OK;
 }
 
-extern "C" int mplx_result_nodes(mplx_ctx *c, mplx_waypoint *coords, double *g, double *h, int32_t *closed, int32_t *opened) {
+extern "C" int mplx_result_nodes(mplx_ctx *c, uint64_t cap, mplx_waypoint *coords, double *g, double *h, int32_t *closed, int32_t *opened) {
   if (!c || !c->last_single || !c->pools_valid) return fail(c, MPLX_ERR_ARG, "state-space dump needs a preceding single mplx_plan()");
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = c->last_out[0].n_nodes;
   if (n == 0) return MPLX_OK;
+  if ((uint64_t)n > cap) return fail(c, MPLX_ERR_CAPACITY, "state-space dump: the last plan created %zu states, the caller's arrays hold %llu", n, (unsigned long long)cap);
   const int control = c->pool_control, nk = state_len(control), rb = rec_bytes(control), hot = rec_hot_bytes(control);
   std::vector<uint32_t> tbl(MAX_NODE_CH);
   HIPCHK(c, hipMemcpyAsync(tbl.data(), c->d_node_tables, sizeof(uint32_t) * MAX_NODE_CH, hipMemcpyDeviceToHost, c->stream));
@@ -1081,13 +1086,17 @@ extern "C" int mplx_result_blocked(mplx_ctx *c, int32_t *parent, int32_t *action
   if (!c || !c->last_single || !c->pools_valid || !n_out) return fail(c, MPLX_ERR_ARG, "blocked-primitive dump needs a preceding single mplx_plan()");
   if (c->last_control != c->cfg.control || c->last_dt != c->cfg.dt || c->last_U != c->U)
     return fail(c, MPLX_ERR_ARG, "the planner was re-configured since the plan: blocked primitives cannot be re-derived");
+  if (c->last_map_epoch != c->map_epoch)
+    return fail(c, MPLX_ERR_ARG, "the map changed since the plan: its blocked primitives cannot be re-derived (they would be computed against the new map)");
+  const float plan_ms = c->last_ms;  // the internal expand launches below must not replace the plan's kernel time
+  struct RestoreMs { mplx_ctx *c; float ms; ~RestoreMs() { c->last_ms = ms; } } restore_ms{c, plan_ms};
   const size_t n = c->last_out[0].n_nodes;
   *n_out = 0;
   if (n_states_all) *n_states_all = n;
   if (n == 0) return MPLX_OK;
   std::vector<mplx_waypoint> coords(n);
   std::vector<int32_t> closed(n);
-  int r = mplx_result_nodes(c, coords.data(), nullptr, nullptr, closed.data(), nullptr);
+  int r = mplx_result_nodes(c, n, coords.data(), nullptr, nullptr, closed.data(), nullptr);
   if (r) return r;
   const int control = c->last_control, nk = state_len(control), n_u = c->cfg.n_u;
   auto key_of = [&](const mplx_waypoint &w) {

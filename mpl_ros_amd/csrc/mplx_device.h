@@ -140,7 +140,7 @@ struct SearchParams {
   unsigned long long *done_word;  // epoch << 32 | queries finished (helpers leave when the count reaches nq)
   uint32_t epoch;                 // launch counter of the context
   int32_t help_lead;              // workgroups blockIdx.x < help_lead lead queries (and own the boxes [0, help_lead)); the others only help
-  int32_t help_max;               // helpers per leader (1 or 2)
+  int32_t help_max;               // helpers per leader (0 or 2)
   // moving-obstacle environment (astar_poly_kernel): the worlds and the world of each query
   PolyDev poly;
   const int32_t *poly_world;

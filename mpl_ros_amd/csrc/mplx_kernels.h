@@ -26,9 +26,16 @@ __device__ __forceinline__ unsigned long long ld_u64(const unsigned long long *p
 __device__ __forceinline__ void st_u64(unsigned long long *p, unsigned long long v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// state-table probe: workgroup scope = past the compute unit's L1, but free to hit in the XCD's L2.  Safe for a table
-// shared by queries on other XCDs: a slot of this query is only ever written by this workgroup; a stale EMPTY is caught
-// by the claiming compare-and-swap (executed at the memory side), a stale foreign entry just moves the probe on.
+// state-table probe: a workgroup-scope load is a PLAIN load on gfx950 (non-tgsplit mode): it may hit in this compute
+// unit's vector L1 and in the XCD's L2.  Why that is safe for a table shared by queries on other XCDs: a slot of this
+// query is only ever written by this workgroup -- the hardware keeps a compute unit's L1 coherent with its own stores
+// and atomics (write-through + the atomic's returning path), which is all "workgroup scope" promises when the whole
+// workgroup lives on one compute unit; a stale EMPTY is caught by the claiming compare-and-swap (executed at the memory
+// side), a stale foreign entry just moves the probe on.  The assumption breaks if the library is ever built with
+// -mtgsplit (workgroups split over compute units) or if the claim stops being an atomic: see the guard below.
+#if defined(__gfx950__) && defined(__AMDGCN_TGSPLIT__)
+#error "libmplx assumes one workgroup = one compute unit (do not build with -mtgsplit): ld_u64_probe relies on it"
+#endif
 __device__ __forceinline__ unsigned long long ld_u64_probe(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

@@ -274,7 +274,7 @@ class VoxelMapPlanner:
         self.planner_verbose_ = verbose
         self.map_util_ = None
         self._U = None
-        self._v_max = self._a_max = self._j_max = -1.0
+        self._v_max = self._a_max = self._j_max = self._yaw_max = -1.0
         self._dt = 1.0
         self._w = 10.0
         self._eps = 1.0
@@ -330,10 +330,10 @@ class VoxelMapPlanner:
         self._dirty = True
 
     def setYawmax(self, yaw_max):
-        """setYawmax (map_planner_node.cpp:180): yaw-constrained search is not implemented -- fail loudly
-        instead of planning a different (unconstrained) search.  A negative value means "no constraint"."""
-        if yaw_max >= 0:
-            raise MplxError("setYawmax(>= 0): yaw constraints are not supported by this back-end")
+        """setYawmax (map_planner_node.cpp:179-180).  The threshold constrains yaw-carrying primitives only: the
+        reference node always calls it, and its config-1 launch file passes yaw_max = 0.5 with use_yaw = false
+        (launch/map_planner_node/test.launch:28,33).  Stored; it takes effect when the search states carry yaw."""
+        self._yaw_max, self._dirty = float(yaw_max), True
 
     # ---- reference API that this back-end does not cover (SURVEY.md 8f rows 2, 3)
     def setLPAstar(self, use_lpastar):
@@ -398,7 +398,8 @@ class VoxelMapPlanner:
         ctx.check(ctx.lib.mplx_set_speculation(ctx.h, int(mode)))
 
     def setHelpers(self, per_leader=-1, reserved=-1, cache_rows=0):
-        """Helper workgroups (look-ahead expansion on idle compute units): -1 auto, 0 off, 1 / 2 per leader."""
+        """Helper workgroups (look-ahead expansion on idle compute units).  per_leader: -1 auto (= 2), 0 off, 2 (the only
+        counts mplx_set_helpers accepts); reserved: workgroups that never lead (-1 auto); cache_rows: 0 auto."""
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_helpers(ctx.h, int(per_leader), int(reserved), int(cache_rows)))
 
@@ -471,6 +472,13 @@ class VoxelMapPlanner:
         if math.isinf(res.cost):
             if self.planner_verbose_:
                 print("[MPPlanner] Cannot find a traj! status", res.status)
+            return False
+        if res.status != _capi.PLAN_OK:
+            # e.g. MPLX_PLAN_TRAJ_TOO_LONG: the goal was reached and the cost is known, but no trajectory came back --
+            # never report success with an empty trajectory (a replanner would execute it)
+            print(f"\x1b[31m[MPPlanner] plan() failed with status {res.status}: goal reached (cost {res.cost}) but the trajectory "
+                  f"has more primitives than the device-side recoverTraj buffer holds\x1b[0m", file=sys.stderr)
+            self.traj_cost_ = math.inf
             return False
         return True
 
@@ -553,7 +561,7 @@ class VoxelMapPlanner:
         closed = np.zeros(n, dtype=np.int32)
         opened = np.zeros(n, dtype=np.int32)
         if n:
-            ctx.check(ctx.lib.mplx_result_nodes(ctx.h, coords, g.ctypes.data, h.ctypes.data, closed.ctypes.data, opened.ctypes.data))
+            ctx.check(ctx.lib.mplx_result_nodes(ctx.h, n, coords, g.ctypes.data, h.ctypes.data, closed.ctypes.data, opened.ctypes.data))
         pos = np.array([coords[i].pos[:] for i in range(n)]).reshape(n, 3)
         return coords, pos, g, h, closed, opened
 

@@ -1,7 +1,9 @@
 // The reference driver mpl_test_node/src/map_planner_node.cpp:63-214 without ROS: same calls against
 // the mplx shim headers (read map, setMap, freeUnknown, control set with the accumulate-by-du loops,
 // start/goal Waypoint3D via use_* flags, planner setters, plan(), getTraj(), getCloseSet()).
-// usage: map_planner_driver <map.bin> dx dy dz ox oy oz res sx sy sz svx svy svz gx gy gz
+// usage: map_planner_driver <map.bin> dx dy dz ox oy oz res sx sy sz svx svy svz gx gy gz [use_3d yaw_max u_yaw use_yaw]
+// The optional tail carries the launch-file parameters of the same names (launch/map_planner_node/test.launch:27-33 passes
+// yaw_max = 0.5, u_yaw = 0.5, use_3d = false, use_yaw = false; test.launch.skir: use_3d = true, yaw_max default -1).
 // Prints one JSON line that tests/test_cpp_shim.py compares with the oracle.
 #include <mpl_planner/planner/map_planner.h>
 #include <planning_ros_utils/voxel_grid.h>
@@ -47,12 +49,38 @@ int main(int argc, char **argv) {
   // Initialize planner
   double dt = 1.0, v_max = 2.0, a_max = 1.0, u = 1.0;
   int num = 1;
-  // Set control input
+  // nh.param defaults of map_planner_node.cpp:97-105, overridden like a launch file would
+  bool use_3d = true, use_yaw = false;
+  double yaw_max = -1.0, u_yaw = 0.3;
+  if (argc >= 22) { use_3d = atoi(argv[18]) != 0; yaw_max = atof(argv[19]); u_yaw = atof(argv[20]); use_yaw = atoi(argv[21]) != 0; }
+  // Set control input  (map_planner_node.cpp:107-140: the four lattices, accumulate-by-du loops)
   vec_E<VecDf> U;
   const decimal_t du = u / num;
-  for (decimal_t ddx = -u; ddx <= u; ddx += du)
-    for (decimal_t ddy = -u; ddy <= u; ddy += du)
-      for (decimal_t ddz = -u; ddz <= u; ddz += du) U.push_back(Vec3f(ddx, ddy, ddz));
+  if (use_3d && !use_yaw) {
+    for (decimal_t ddx = -u; ddx <= u; ddx += du)
+      for (decimal_t ddy = -u; ddy <= u; ddy += du)
+        for (decimal_t ddz = -u; ddz <= u; ddz += du) U.push_back(Vec3f(ddx, ddy, ddz));
+  } else if (!use_3d && !use_yaw) {
+    for (decimal_t ddx = -u; ddx <= u; ddx += du)
+      for (decimal_t ddy = -u; ddy <= u; ddy += du) U.push_back(Vec3f(ddx, ddy, 0));
+  } else if (!use_3d && use_yaw) {
+    for (decimal_t ddx = -u; ddx <= u; ddx += du)
+      for (decimal_t ddy = -u; ddy <= u; ddy += du)
+        for (decimal_t dyaw = -u_yaw; dyaw <= u_yaw; dyaw += u_yaw) {
+          Vec4f vec;
+          vec << ddx, ddy, 0, dyaw;
+          U.push_back(vec);
+        }
+  } else {
+    for (decimal_t ddx = -u; ddx <= u; ddx += du)
+      for (decimal_t ddy = -u; ddy <= u; ddy += du)
+        for (decimal_t ddz = -u; ddz <= u; ddz += du)
+          for (decimal_t dyaw = -u_yaw; dyaw <= u_yaw; dyaw += u_yaw) {
+            Vec4f vec;
+            vec << ddx, ddy, ddz, dyaw;
+            U.push_back(vec);
+          }
+  }
 
   // Set start and goal
   Waypoint3D start;
@@ -65,7 +93,7 @@ int main(int argc, char **argv) {
   start.use_vel = true;
   start.use_acc = false;
   start.use_jrk = false;
-  start.use_yaw = false;
+  start.use_yaw = use_yaw;  // if true, yaw is also propogated
 
   Waypoint3D goal(start.control);  // initialized with the same control as start
   goal.pos = Vec3f(atof(argv[15]), atof(argv[16]), atof(argv[17]));
@@ -78,7 +106,7 @@ int main(int argc, char **argv) {
   planner_ptr->setMapUtil(map_util);  // Set collision checking function
   planner_ptr->setVmax(v_max);        // Set max velocity
   planner_ptr->setAmax(a_max);        // Set max acceleration (as control input)
-  planner_ptr->setYawmax(-1);         // Set yaw threshold
+  planner_ptr->setYawmax(yaw_max);    // Set yaw threshold
   planner_ptr->setDt(dt);             // Set dt for each primitive
   planner_ptr->setU(U);               // Set control input
   planner_ptr->setTol(0.5);           // Tolerance for goal region

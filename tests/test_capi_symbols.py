@@ -58,7 +58,8 @@ def test_product_does_not_import_the_oracle():
 
 
 def test_yaw_requests_fail_loudly():
-    """use_yaw / setYawmax / Vec4f control inputs are not implemented: they must raise, never plan a different search."""
+    """use_yaw states / Vec4f control inputs must never be planned as a different (yaw-less) search.  setYawmax alone is
+    harmless: the reference node always calls it, its config-1 launch file with yaw_max = 0.5 and use_yaw = false."""
     import numpy as np
     import pytest
     from mpl_ros_amd._capi import MplxError
@@ -66,9 +67,8 @@ def test_yaw_requests_fail_loudly():
     pl = VoxelMapPlanner(False)
     with pytest.raises(MplxError):
         pl.setU(np.zeros((9, 4)))
-    with pytest.raises(MplxError):
-        pl.setYawmax(0.5)
-    pl.setYawmax(-1.0)  # "unconstrained" is what the back-end does
+    pl.setYawmax(0.5)   # launch/map_planner_node/test.launch:28 -- constrains yaw-carrying primitives only
+    pl.setYawmax(-1.0)
 
 
 def test_uncovered_reference_api_fails_loudly():

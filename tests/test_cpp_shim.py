@@ -89,6 +89,35 @@ def test_reference_driver_through_the_shim(tmp_path, skir):
     assert abs(viz["prs_end_sum"] - end_sum) < 1e-6 * max(1.0, abs(end_sum))
 
 
+@pytest.mark.gpu
+def test_reference_driver_config1_launch_file_through_the_shim(tmp_path):
+    """launch/map_planner_node/test.launch:16-33 literally -- yaw_max 0.5, u_yaw 0.5, use_3d false (nU = 9), use_yaw false --
+    on the re-rasterised `simple` map (tests/golden/make_simple_fixture.py): the reference driver's stock parameters must
+    plan through the shim and reproduce the oracle's plan."""
+    from mpl_ros_amd import mapgen
+    from oracle import orc
+    from tests import util
+    exe = build_driver(tmp_path)
+    d = np.load(os.path.join(ROOT, "tests", "golden", "simple_map.npz"))
+    grid, origin, res = d["grid"], d["origin"].tolist(), float(d["res"])
+    path = str(tmp_path / "simple.bin")
+    grid.tofile(path)
+    dz, dy, dx = grid.shape
+    args = [path, str(dx), str(dy), str(dz)] + [repr(float(o)) for o in origin] + [repr(res)] + \
+           ["14.5", "4.5", "0.05", "0.0", "0.0", "0.0", "2.4", "16.6", "0.05"] + ["0", "0.5", "0.5", "0"]
+    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    P = util.make_oracle(grid, origin, res, orc.ACC, mapgen.control_lattice(1.0, 1, False), v_max=2.0, a_max=1.0, tol_pos=0.5)
+    st = P.plan(orc.waypoint((14.5, 4.5, 0.05)), orc.waypoint((2.4, 16.6, 0.05)))
+    assert st == 0 and r["valid"] and r["free_start"]
+    assert r["closed"] == P.num_closed() and r["expanded"] == len(P.expanded()[0]) and r["cost"] == P.traj_cost
+    tr = P.traj()
+    assert r["n_prim"] == tr["n"]
+    for w, wo in zip(r["waypoints"][:-1], tr["wps"][:-1]):
+        assert w == list(wo.pos) + list(wo.vel)
+
+
 def test_shim_refuses_cost_changing_requests(tmp_path):
     """Search-region / potential-field setters exist on the shim's MapPlanner and make plan() refuse (they would change the
     plan); setLPAstar(true) only announces that every plan() is a fresh A*.  plan() fails before it reaches the device."""

@@ -1,5 +1,7 @@
-"""Committed fixtures: the skir map (extracted from the reference's skir.bag) and the plan results
-of tests/golden/plans.json.  CPU: the oracle reproduces them; GPU: the HIP path reproduces them."""
+"""Committed fixtures: the skir map (extracted from the reference's skir.bag), the `simple` map (BASELINE config 1 (ii):
+re-rasterised from the reference's simple.stl by tests/golden/make_simple_fixture.py -- an approximate regeneration of
+the lost simple.bag) and the plan results of tests/golden/plans.json / simple_plan.json.  CPU: the oracle reproduces
+them; GPU: the HIP path reproduces them."""
 import hashlib
 import json
 import os
@@ -78,3 +80,56 @@ def test_hip_reproduces_golden_plans(plan, skir):
     assert [w.state().tolist() for w in tr.getWaypoints()] == plan["waypoints"]
     c = plan["counters"]
     assert (r.voxel_reads, r.n_succ, r.n_succ_finite, r.n_nodes) == (c["n_voxel_reads"], c["n_succ"], c["n_succ_finite"], c["n_new_nodes"])
+
+
+# ---------------------------------------------------------------- BASELINE config 1 (ii): the `simple` map
+SIMPLE_PLAN = json.load(open(os.path.join(HERE, "golden", "simple_plan.json")))
+# launch/map_planner_node/test.launch:16-33, literally: start (14.5, 4.5, 0.05) at rest -> goal (2.4, 16.6, 0.05),
+# v_max 2, a_max 1, yaw_max 0.5, u 1, u_yaw 0.5, dt 1, use_3d false (2-D lattice, nU = 9), use_yaw false; setTol(0.5)
+SIMPLE_START, SIMPLE_GOAL = (14.5, 4.5, 0.05), (2.4, 16.6, 0.05)
+
+
+@pytest.fixture(scope="module")
+def simple_map():
+    d = np.load(os.path.join(HERE, "golden", "simple_map.npz"))
+    return d["grid"], tuple(d["origin"].tolist()), float(d["res"])
+
+
+def test_simple_fixture_follows_the_mesh_to_map_recipe(simple_map):
+    grid, origin, res = simple_map
+    # cloud_to_map.cpp + mesh_to_map.launch.simple:21-27: res 0.1f, origin 0, range (18, 18, 2) -> int(18 / 0.1f) = 179, int(2 / 0.1f) = 19
+    assert grid.shape == (19, 179, 179) and origin == (0.0, 0.0, 0.0) and res == float(np.float32(0.1))
+    assert set(np.unique(grid).tolist()) == {0, 100}
+    assert 0.03 < (grid > 0).mean() < 0.08
+    assert grid[:, 0, :].all() and grid[:, :, 0].all()  # the boundary wall of the mesh
+
+
+def test_oracle_reproduces_the_simple_launch_query(simple_map):
+    grid, origin, res = simple_map
+    U = mapgen.control_lattice(1.0, 1, False)
+    assert U.shape == (9, 3)
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, v_max=2.0, a_max=1.0, tol_pos=0.5)
+    st = P.plan(orc.waypoint(SIMPLE_START), orc.waypoint(SIMPLE_GOAL))
+    ids, _ = P.expanded()
+    plan = SIMPLE_PLAN
+    assert st == plan["status"] == 0 and len(ids) == plan["n_expanded"] and str(util.expand_hash(ids)) == plan["expand_hash"]
+    assert P.traj_cost == plan["cost"] and P.num_closed() == plan["n_closed"]
+    tr = P.traj()
+    assert tr["actions"].tolist() == plan["actions"] and tr["node_ids"].tolist() == plan["node_ids"]
+    assert [orc.wp_state(w, orc.ACC).tolist() for w in tr["wps"]] == plan["waypoints"]
+    assert P.counters() == plan["counters"]
+
+
+@pytest.mark.gpu
+def test_hip_plans_the_simple_launch_query_with_the_launch_file_parameters(simple_map):
+    """Config 1 (ii) through the C-ABI with the launch file's own parameter set -- including setYawmax(0.5) with
+    use_yaw = false, which must not change (or refuse) the plan -- against the oracle: the whole state space."""
+    grid, origin, res = simple_map
+    U = mapgen.control_lattice(1.0, 1, False)
+    kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5)
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    pl.setYawmax(0.5)
+    r, c = util.compare_plan(P, pl, (SIMPLE_START, (0, 0, 0)), (SIMPLE_GOAL,), orc.ACC)
+    assert r.status == 0 and r.n_expanded == SIMPLE_PLAN["n_expanded"] and r.cost == SIMPLE_PLAN["cost"]
+    assert str(r.expand_hash) == SIMPLE_PLAN["expand_hash"]

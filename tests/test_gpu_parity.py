@@ -411,3 +411,26 @@ def test_blocked_primitives_and_hm_size_match_upstream_accounting(control):
     assert sorted(zip(pg.tolist(), ag.tolist())) == sorted(zip(po.tolist(), ao.tolist()))
     assert n_all == P.num_states_all() > r.n_nodes
     assert len(pl.getAllPrimitives()) == r.n_edges + len(pg) and len(pl.getValidPrimitives()) == r.n_edges
+
+
+def test_trajectory_longer_than_the_device_buffer_is_a_failed_plan_not_an_empty_success():
+    """MPLX_PLAN_TRAJ_TOO_LONG: the goal is reached and the cost is right, but the path has more than 1024 primitives
+    (the device-side recoverTraj buffer).  plan() must return False -- never True with an empty trajectory, which a
+    replanner would execute -- while the search itself still equals the oracle's."""
+    from mpl_ros_amd import _capi
+    n = 1200
+    grid = np.zeros((3, 3, n), dtype=np.int8)  # a corridor along x
+    origin, res = (0.0, 0.0, 0.0), 0.1
+    U = np.array([[1.0, 0.0, 0.0], [-1.0, 0.0, 0.0]])
+    kw = dict(dt=0.1, tol_pos=0.05, w=10.0)
+    P = util.make_oracle(grid, origin, res, orc.VEL, U, **kw)
+    mu, pl = util.make_gpu(grid, origin, res, U, **kw)
+    start, goal = (0.05, 0.15, 0.15), (0.05 + 110.0, 0.15, 0.15)
+    st = P.plan(orc.waypoint(start, control=orc.VEL), orc.waypoint(goal, control=orc.VEL))
+    assert st == orc.OK and P.traj()["n"] > 1024
+    ok = pl.plan(util.gpu_wp(start, control=orc.VEL), util.gpu_wp(goal, control=orc.VEL))
+    r = pl.getResult()
+    assert r.status == _capi.PLAN_TRAJ_TOO_LONG and r.traj_len == 0
+    assert r.cost == P.traj_cost and r.n_expanded == len(P.expanded()[0]) and r.expand_hash == util.expand_hash(P.expanded()[0])
+    assert ok is False and np.isinf(pl.getTrajCost())
+    assert len(pl.getTraj().segs) == 0

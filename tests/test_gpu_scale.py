@@ -52,6 +52,41 @@ def test_c3_single_query_jrk_512_equal_cap(map512, cap):
     print(f"C3: expanded {r.n_expanded} states {r.n_nodes} edges {r.n_edges} voxel reads {r.voxel_reads} kernel {pl.lastKernelMs():.1f} ms")
 
 
+def test_c3_single_query_jrk_512_full_cap(map512):
+    """BASELINE config 3 at its stated size: the 125-input jerk lattice on the 512^3 map, capped at 2 000 000
+    expansions on both sides (deep OPEN lists, far-bucket pulls, the helper cache of the JRK kernel -- the part of
+    the search the 250 000-expansion test never reaches).  The oracle needs about a minute on one core.  Compared:
+    status, expansion count and order (expand_hash folds every expanded node id in order), states created,
+    predecessor records, closed set, successor / primitive / voxel-read counters.  The full predecessor-list dump
+    (a few hundred million records) is left to the equal-cap test above."""
+    grid, origin, res, start, goal = map512
+    cap = 2_000_000
+    U = mapgen.control_lattice(1.0, 2, True)
+    kw = dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=cap)
+    P = util.make_oracle(grid, origin, res, orc.JRK, U, **kw)
+    pools = mapgen.c4_pools(True, 1, cap)
+    mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=pools["nodes"], max_edges=pools["edges"], max_log=pools["log"], **kw)
+    ok = pl.plan(util.gpu_wp(start, control=orc.JRK), util.gpu_wp(goal, control=orc.JRK))
+    r = pl.getResult()
+    P.reset_counters()
+    st = P.plan(orc.waypoint(start, control=orc.JRK), orc.waypoint(goal, control=orc.JRK))
+    c = P.counters()
+    ids, _ = P.expanded()
+    assert r.status == st and ok == (st == orc.OK)
+    assert r.n_expanded == c["n_expansions"] == len(ids)
+    assert r.n_expanded == cap or st == orc.OK
+    assert r.expand_hash == util.expand_hash(ids)
+    assert r.n_nodes == P.num_nodes() and r.n_closed == P.num_closed()
+    assert r.n_edges == c["n_succ_finite"] == r.n_succ_finite
+    assert r.n_succ == c["n_succ"] and r.n_primitives == c["n_primitives"]
+    assert r.voxel_reads == c["n_voxel_reads"]
+    assert r.n_reopen == c["n_reopen"]
+    if st == orc.OK:
+        assert r.cost == P.traj_cost
+    print(f"C3 full cap: status {r.status} expanded {r.n_expanded} states {r.n_nodes} edges {r.n_edges} voxel reads {r.voxel_reads} "
+          f"kernel {pl.lastKernelMs():.0f} ms")
+
+
 def _cpu_replay(grid, origin, res, control, U, kw, queries, idx, threads=16):
     """Plan queries[i] for i in idx on the oracle; returns {i: dict of results}.  One shared read-only map."""
     out, lock, todo = {}, threading.Lock(), list(idx)
