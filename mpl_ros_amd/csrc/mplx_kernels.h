@@ -44,6 +44,13 @@ __device__ __forceinline__ void st_u32(uint32_t *p, uint32_t v) { __hip_atomic_s
 // f64 through an agent-scope (sc1, write-through / L1-bypassing) 8-byte access: data another compute unit reads or wrote
 __device__ __forceinline__ double ld_f64_agent(const double *p) { return __longlong_as_double((long long)ld_u64((const unsigned long long *)p)); }
 __device__ __forceinline__ void st_f64_agent(double *p, double v) { st_u64((unsigned long long *)p, (unsigned long long)__double_as_longlong(v)); }
+// two f64 through ONE 16-byte agent-scope (sc1, write-through) store: half the write-through transactions of two
+// st_f64_agent (an 8-byte sc1 store is counted -- and carried -- as a partial-line write of its own).  p is 16-byte aligned.
+__device__ __forceinline__ void st_f64x2_agent(double *p, double a, double b) {
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  const f64x2 v = {a, b};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ bool entry_less(double f1, double g1, uint32_t i1, double f2, double g2, uint32_t i2) {
   if (f1 != f2) return f1 < f2;
   if (g1 != g2) return g1 < g2;

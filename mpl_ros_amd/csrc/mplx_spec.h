@@ -150,9 +150,12 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
 #pragma unroll
       for (int i = 0; i < nk; i++) kk[i] = L.key[i];
       double *st = V::state(rec);
-      if constexpr (HELP) {  // helper workgroups on other compute units read the state: agent-scope (write-through) stores
+      if constexpr (HELP) {  // helper workgroups on other compute units read the state: agent-scope (write-through) stores,
+        // 16 bytes at a time (the state starts on a 64-byte boundary of the record)
+        auto sv = [&](int i) { return i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3]; };
 #pragma unroll
-        for (int i = 0; i < ns; i++) st_f64_agent(&st[i], i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3]);
+        for (int i = 0; i + 1 < ns; i += 2) st_f64x2_agent(&st[i], sv(i), sv(i + 1));
+        if constexpr (ns & 1) st_f64_agent(&st[ns - 1], sv(ns - 1));
       } else {
 #pragma unroll
         for (int i = 0; i < ns; i++) st[i] = i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3];
