@@ -324,6 +324,7 @@ static int key_equal(const int32_t *a, int na, const int32_t *b, int nb) {
 typedef struct {
   int32_t parent, action, next;
   double cost;
+  int32_t blocked, child; /* LPA*: the edge's primitive is not free in the current map (cost counts as +inf); node the entry belongs to */
 } orc_edge;
 
 typedef struct {
@@ -335,11 +336,19 @@ typedef struct {
   int32_t heap_pos;  /* -1 when not in heap */
   int32_t pred_head; /* linked list into edges in push_back (arrival) order, -1 empty */
   int32_t pred_tail;
+  double rhs;         /* LPA* one-step look-ahead value */
+  int32_t succ_built; /* LPA*: get_succ has been called for this node (its successors own pred entries for it) */
+  int32_t pad;
 } orc_node;
 
 typedef struct { /* successor emitted with +inf cost: hm_ entry + pred entry upstream, never relaxed */
   int32_t parent, action;
+  int32_t converted, pad; /* LPA*: cleared later and turned into a real pred entry */
 } orc_blocked;
+typedef struct { /* LPA* queue entry (lazy deletion) */
+  double k, kg;
+  int32_t id, pad;
+} orc_lentry;
 
 struct orc_planner {
   /* map (a7) */
@@ -369,9 +378,17 @@ struct orc_planner {
   int n_blocked, cap_blocked;
   int32_t *traj_nodes;
   int32_t *traj_actions;
+  orc_waypoint *traj_wps; /* coords of the path states at recoverTraj time (getTraj() returns the stored Trajectory) */
   int traj_len;
   double traj_cost;
   orc_counters cnt;
+  /* LPA* (mpl_oracle_lpa.inc) */
+  int use_lpa, lpa_valid;
+  orc_lentry *lq;
+  int n_lq, cap_lq;
+  int root_id, goal_id;
+  orc_waypoint lpa_goal;
+  int lpa_iterations, lpa_get_succ_calls;
 };
 
 orc_planner *orc_create(void) {
@@ -390,7 +407,9 @@ orc_planner *orc_create(void) {
 }
 static void free_search(orc_planner *p) {
   free(p->nodes); free(p->edges); free(p->table); free(p->heap); free(p->expanded);
-  free(p->traj_nodes); free(p->traj_actions); free(p->blocked);
+  free(p->traj_nodes); free(p->traj_actions); free(p->blocked); free(p->lq); free(p->traj_wps);
+  p->traj_wps = NULL;
+  p->lq = NULL; p->n_lq = p->cap_lq = 0;
   p->nodes = NULL; p->edges = NULL; p->table = NULL; p->heap = NULL; p->expanded = NULL;
   p->traj_nodes = NULL; p->traj_actions = NULL; p->blocked = NULL;
   p->n_blocked = p->cap_blocked = 0;
@@ -761,6 +780,9 @@ static int node_create(orc_planner *p, const orc_waypoint *coord, const int32_t 
   nd->opened = nd->closed = 0;
   nd->heap_pos = -1;
   nd->pred_head = nd->pred_tail = -1;
+  nd->rhs = INFINITY;
+  nd->succ_built = 0;
+  nd->pad = 0;
   if ((size_t)p->n_nodes * 2 > (size_t)p->cap_table)
     table_grow(p);
   else
@@ -777,6 +799,8 @@ static void edge_append(orc_planner *p, int child, int parent, int action, doubl
   p->edges[e].parent = parent;
   p->edges[e].action = action;
   p->edges[e].cost = cost;
+  p->edges[e].blocked = 0;
+  p->edges[e].child = child;
   p->edges[e].next = -1;
   orc_node *nd = &p->nodes[child];
   if (nd->pred_tail < 0)
@@ -858,7 +882,7 @@ static int recover_traj(orc_planner *p, int node, int start_id) {
     int min_e = -1;
     double min_rhs = INFINITY, min_g = INFINITY;
     for (int e = p->nodes[node].pred_head; e >= 0; e = p->edges[e].next) {
-      double gp = p->nodes[p->edges[e].parent].g, c = p->edges[e].cost;
+      double gp = p->nodes[p->edges[e].parent].g, c = p->edges[e].blocked ? INFINITY : p->edges[e].cost;
       if (min_rhs > gp + c) {
         min_rhs = gp + c;
         min_g = gp;
@@ -894,6 +918,9 @@ static int recover_traj(orc_planner *p, int node, int start_id) {
   p->traj_actions = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
   for (int i = 0; i <= n; i++) p->traj_nodes[i] = tn[n - i];
   for (int i = 0; i < n; i++) p->traj_actions[i] = ta[n - 1 - i];
+  free(p->traj_wps);
+  p->traj_wps = (orc_waypoint *)malloc(sizeof(orc_waypoint) * (size_t)(n + 1));
+  for (int i = 0; i <= n; i++) p->traj_wps[i] = p->nodes[p->traj_nodes[i]].coord;
   p->traj_len = n;
   free(tn); free(ta);
   return 1;
@@ -903,8 +930,11 @@ static int recover_traj(orc_planner *p, int node, int start_id) {
 /* [UNVERIFIED planner_base.h plan(): is_free(start.pos) else false; fresh StateSpace; set_goal;
  *  graph_search.h Astar(): loop order pop -> close -> get_succ -> relax -> goal test after expansion
  *  -> max_expand -> empty-queue] */
+static int lpa_plan(orc_planner *p, const orc_waypoint *start, const orc_waypoint *goal);
 int orc_plan(orc_planner *p, const orc_waypoint *start, const orc_waypoint *goal) {
+  if (p->use_lpa) return lpa_plan(p, start, goal);
   free_search(p);
+  p->lpa_valid = 0;
   p->traj_cost = INFINITY;
   if (!orc_is_free_point(p, start->pos)) return ORC_START_OCCUPIED;
   orc_set_goal(p, goal);
@@ -948,6 +978,8 @@ int orc_plan(orc_planner *p, const orc_waypoint *start, const orc_waypoint *goal
         }
         p->blocked[p->n_blocked].parent = curr;
         p->blocked[p->n_blocked].action = succ_act[s];
+        p->blocked[p->n_blocked].converted = 0;
+        p->blocked[p->n_blocked].pad = 0;
         p->n_blocked++;
         continue;
       }
@@ -996,6 +1028,8 @@ int orc_plan(orc_planner *p, const orc_waypoint *start, const orc_waypoint *goal
   p->traj_cost = p->nodes[curr].g;
   return ORC_OK;
 }
+
+#include "mpl_oracle_lpa.inc"
 
 /* ------------------------------------------------------------------ result getters */
 double orc_traj_cost(const orc_planner *p) { return p->traj_cost; }
@@ -1068,13 +1102,13 @@ int orc_traj_len(const orc_planner *p) { return p->traj_len; }
 /* primitives are rebuilt from the stored parent coord + action, like upstream forward_action */
 void orc_get_traj(const orc_planner *p, orc_primitive *prs, orc_waypoint *wps, int32_t *actions, int32_t *node_ids) {
   for (int i = 0; i < p->traj_len; i++) {
-    const orc_waypoint *from = &p->nodes[p->traj_nodes[i]].coord;
+    const orc_waypoint *from = &p->traj_wps[i];
     if (prs) orc_primitive_build(from, p->U + 3 * p->traj_actions[i], p->cfg.dt, &prs[i]);
     if (actions) actions[i] = p->traj_actions[i];
   }
   if (p->traj_len > 0 || p->traj_nodes)
     for (int i = 0; i <= p->traj_len && p->traj_nodes; i++) {
-      if (wps) wps[i] = p->nodes[p->traj_nodes[i]].coord;
+      if (wps) wps[i] = p->traj_wps[i];
       if (node_ids) node_ids[i] = p->traj_nodes[i];
     }
 }

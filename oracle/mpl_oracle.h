@@ -169,6 +169,18 @@ void orc_get_traj(const orc_planner *, orc_primitive *prs, orc_waypoint *wps /* 
 void orc_get_counters(const orc_planner *, orc_counters *);
 void orc_reset_counters(orc_planner *);
 
+/* ---- LPA* incremental replanning (mpl_oracle_lpa.inc; UNVERIFIED restatement anchored on map_replanner_node.cpp:107-255,
+ *      425-437 and poly_map_planner.h:61-93).  With orc_set_lpastar(p, 1) orc_plan() keeps and repairs its state space. ---- */
+void orc_set_lpastar(orc_planner *, int on);                /* PlannerBase::setLPAstar */
+int orc_lpa_initialized(const orc_planner *);               /* PlannerBase::initialized() */
+int orc_lpa_update_blocked(orc_planner *, int n_cells, const int32_t *cells); /* MapPlanner::updateBlockedNodes; entries changed */
+int orc_lpa_update_cleared(orc_planner *, int n_cells, const int32_t *cells); /* MapPlanner::updateClearedNodes */
+void orc_lpa_sub_state_space(orc_planner *, int time_step); /* PlannerBase::getSubStateSpace */
+int orc_lpa_iterations(const orc_planner *);                /* states popped by the last plan() */
+double orc_get_node_rhs(const orc_planner *, int id);
+int orc_get_node_opened(const orc_planner *, int id);
+int orc_get_edges_blocked(const orc_planner *, int32_t *blocked, int cap);
+
 /* ---- VoxelGrid (in-tree planning_ros_utils/src/mapping_utils/voxel_grid.cpp, restated line by line) ---- */
 typedef struct orc_grid orc_grid;
 orc_grid *orc_grid_create(const double origin[3], const double dim[3], float res);

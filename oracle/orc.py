@@ -121,6 +121,16 @@ def lib():
                                    C.POINTER(C.c_int32)]
         L.orc_get_counters.argtypes = [P, C.POINTER(Counters)]
         L.orc_reset_counters.argtypes = [P]
+        L.orc_set_lpastar.argtypes = [P, C.c_int]
+        for f in ("orc_lpa_initialized", "orc_lpa_iterations"):
+            getattr(L, f).argtypes = [P]
+        L.orc_lpa_update_blocked.argtypes = [P, C.c_int, C.c_void_p]
+        L.orc_lpa_update_cleared.argtypes = [P, C.c_int, C.c_void_p]
+        L.orc_lpa_sub_state_space.argtypes = [P, C.c_int]
+        L.orc_get_node_rhs.argtypes = [P, C.c_int]
+        L.orc_get_node_rhs.restype = C.c_double
+        L.orc_get_node_opened.argtypes = [P, C.c_int]
+        L.orc_get_edges_blocked.argtypes = [P, C.c_void_p, C.c_int]
         L.orc_primitive_build.argtypes = [C.POINTER(Waypoint), C.POINTER(C.c_double), C.c_double, C.POINTER(Primitive)]
         L.orc_primitive_evaluate.argtypes = [C.POINTER(Primitive), C.c_double, C.POINTER(Waypoint)]
         for f in ("orc_primitive_max_vel", "orc_primitive_max_acc", "orc_primitive_max_jrk"):
@@ -180,6 +190,7 @@ class Planner:
         dim = (C.c_int32 * 3)(g.shape[2], g.shape[1], g.shape[0])
         ori = (C.c_double * 3)(*[float(o) for o in origin])
         self._shape = g.shape
+        self._origin_res = (tuple(float(o) for o in origin), float(res))
         self.L.orc_set_map(self.h, g.ctypes.data, dim, ori, float(res))
 
     def set_map_shared(self, grid, origin, res):
@@ -322,6 +333,46 @@ class Planner:
             self.L.orc_get_traj(self.h, prs, wps, act, ids)
         return {"n": n, "prs": [prs[i] for i in range(n)], "wps": [wps[i] for i in range(n + 1)] if n else [],
                 "actions": np.array(act[:n], dtype=np.int32), "node_ids": np.array(ids[:n + 1] if n else [], dtype=np.int32)}
+
+    # ---- LPA* (oracle/mpl_oracle_lpa.inc)
+    def set_lpastar(self, on=True):
+        self.L.orc_set_lpastar(self.h, int(bool(on)))
+
+    def initialized(self):
+        return bool(self.L.orc_lpa_initialized(self.h))
+
+    def update_blocked(self, cells):
+        c = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 3)
+        return int(self.L.orc_lpa_update_blocked(self.h, c.shape[0], c.ctypes.data))
+
+    def update_cleared(self, cells):
+        c = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 3)
+        return int(self.L.orc_lpa_update_cleared(self.h, c.shape[0], c.ctypes.data))
+
+    def sub_state_space(self, time_step):
+        self.L.orc_lpa_sub_state_space(self.h, int(time_step))
+
+    def lpa_iterations(self):
+        return int(self.L.orc_lpa_iterations(self.h))
+
+    def node_rhs(self, i):
+        return float(self.L.orc_get_node_rhs(self.h, i))
+
+    def node_opened(self, i):
+        return bool(self.L.orc_get_node_opened(self.h, i))
+
+    def edges_blocked(self):
+        n = self.L.orc_get_edges_blocked(self.h, None, 0)
+        b = np.zeros(max(n, 1), dtype=np.int32)
+        self.L.orc_get_edges_blocked(self.h, b.ctypes.data, n)
+        return b[:n]
+
+    def set_cell(self, cells, value):
+        """Edit the map in place (the caller's shared MapUtil is mutated between plans, map_replanner_node.cpp:188,226)."""
+        g = self.get_map()
+        for x, y, z in np.asarray(cells).reshape(-1, 3):
+            g[z, y, x] = value
+        self.set_map(g, self._origin_res[0], self._origin_res[1])
 
     def counters(self):
         c = Counters()
