@@ -214,6 +214,45 @@ int mplx_result_edges(mplx_ctx *ctx, int32_t *child, int32_t *parent, int32_t *a
  * order); *n = their number (may exceed cap); *n_states_all = hm_.size() as upstream counts it. */
 int mplx_result_blocked(mplx_ctx *ctx, int32_t *parent, int32_t *action, uint64_t cap, uint64_t *n, uint64_t *n_states_all);
 
+/* ---- LPA*: incremental replanning on a state space that stays on the device between plan() calls
+ *      (PlannerBase::setLPAstar(true), map_replanner_node.cpp:425-437).  An mplx_lpa is the state space of ONE such
+ *      planner on ctx's map, with pools of its own -- an A* planner sharing the MapUtil / context (planner_ next to
+ *      replan_planner_, map_replanner_node.cpp:415,427) does not disturb it.  It plans with the set-up last given to
+ *      mplx_planner_config(ctx).  The search is Koenig & Likhachev's LPA* as upstream structures it; the un-vendored
+ *      details are restated in oracle/mpl_oracle_lpa.inc (choices L1-L6), the in-tree anchor of the repair mechanism is
+ *      PolyMapPlanner::updateNodes (poly_map_planner.h:61-93). ---- */
+typedef struct mplx_lpa mplx_lpa;
+int mplx_lpa_create(mplx_ctx *ctx, mplx_lpa **out);  /* no device work; destroy it before ctx */
+void mplx_lpa_destroy(mplx_lpa *l);
+const char *mplx_lpa_last_error(const mplx_lpa *l);
+int mplx_lpa_set_capacity(mplx_lpa *l, uint64_t nodes, uint64_t edges, uint64_t open_log); /* per state space (0 = keep); two are held */
+int mplx_lpa_set_record(mplx_lpa *l, uint32_t cap);
+/* PlannerBase::plan (map_replanner_node.cpp:141): ComputeShortestPath on the kept state space when the goal, the planner
+ * set-up and the start (= the current root) are those of the previous plan, else on a new one.  out->n_expanded = states
+ * popped by THIS call; n_nodes / n_edges = size of the whole state space. */
+int mplx_lpa_plan(mplx_lpa *l, const mplx_waypoint *start, const mplx_waypoint *goal, mplx_result *out);
+int mplx_lpa_initialized(const mplx_lpa *l);         /* PlannerBase::initialized(), map_replanner_node.cpp:195,232,244 */
+int mplx_lpa_reset(mplx_lpa *l);                     /* PlannerBase::reset() */
+/* MapPlanner::updateBlockedNodes / updateClearedNodes(const vec_Vec3i&) (map_replanner_node.cpp:196,233), to be called
+ * after the context's map was edited: every stored predecessor entry (and, for cleared, every successor that had been
+ * emitted with cost +inf) is re-evaluated against the current map -- the in-tree mechanism of poly_map_planner.h:61-93 --
+ * increaseCost / decreaseCost.  cells (n x 3 int32): the voxels the caller changed (nothing happens for an empty list).
+ * *n_changed: predecessor entries whose cost changed (the primitives upstream returns). */
+int mplx_lpa_update_blocked(mplx_lpa *l, int n_cells, const int32_t *cells, uint64_t *n_changed);
+int mplx_lpa_update_cleared(mplx_lpa *l, int n_cells, const int32_t *cells, uint64_t *n_changed);
+/* PlannerBase::getSubStateSpace(time_step) (map_replanner_node.cpp:245): re-root the state space at the time_step-th
+ * state of the last trajectory (the caller then plans from getTraj().getWaypoints()[time_step]); also compacts the pools */
+int mplx_lpa_sub_state_space(mplx_lpa *l, int32_t time_step);
+/* results: the stored trajectory of the last successful plan; the state space (rhs next to g; built = expanded at least once;
+ * blocked = the entry's primitive is not free in the current map) */
+int mplx_lpa_traj_len(const mplx_lpa *l);
+int mplx_lpa_result_traj(mplx_lpa *l, mplx_primitive *prs, mplx_waypoint *wps, int32_t *actions, int32_t *node_ids);
+int mplx_lpa_counts(const mplx_lpa *l, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *n_blocked_log);
+int mplx_lpa_result_nodes(mplx_lpa *l, uint64_t cap, mplx_waypoint *coords, double *g, double *rhs, double *h, int32_t *closed, int32_t *opened, int32_t *built);
+int mplx_lpa_result_edges(mplx_lpa *l, int32_t *child, int32_t *parent, int32_t *action, int32_t *blocked, uint64_t cap, uint64_t *n);
+int mplx_lpa_result_expanded(mplx_lpa *l, uint32_t cap, int32_t *ids, uint32_t *n);
+int mplx_lpa_last_kernel_ms(const mplx_lpa *l, float *ms);
+
 /* ---- VoxelGrid (planning_ros_utils/src/mapping_utils/voxel_grid.cpp, the mapper in front of the planner:
  *      map_replanner_node.cpp:17,181,218,329-331, cloud_to_map.cpp:11-12).  Device-resident; same
  *      semantics as the in-tree class: float resolution, truncating floatToInt (:201-203), two grids

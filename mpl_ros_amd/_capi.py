@@ -58,6 +58,9 @@ EXPORTS = [
     "mplx_grid_create", "mplx_grid_destroy", "mplx_grid_last_error", "mplx_grid_allocate", "mplx_grid_info", "mplx_grid_clear",
     "mplx_grid_add_cloud", "mplx_grid_add_cloud_inflate", "mplx_grid_decay", "mplx_grid_clear_column", "mplx_grid_fill_column",
     "mplx_grid_fill_cell", "mplx_grid_get_map", "mplx_grid_get_cloud", "mplx_grid_to_map",
+    "mplx_lpa_create", "mplx_lpa_destroy", "mplx_lpa_last_error", "mplx_lpa_set_capacity", "mplx_lpa_set_record", "mplx_lpa_plan", "mplx_lpa_initialized",
+    "mplx_lpa_reset", "mplx_lpa_update_blocked", "mplx_lpa_update_cleared", "mplx_lpa_sub_state_space", "mplx_lpa_traj_len", "mplx_lpa_result_traj",
+    "mplx_lpa_counts", "mplx_lpa_result_nodes", "mplx_lpa_result_edges", "mplx_lpa_result_expanded", "mplx_lpa_last_kernel_ms",
     "mplx_poly_create", "mplx_poly_destroy", "mplx_poly_last_error", "mplx_poly_config", "mplx_poly_begin", "mplx_poly_set_world",
     "mplx_poly_add_static", "mplx_poly_add_linear", "mplx_poly_add_nonlinear", "mplx_poly_commit", "mplx_poly_get_succ_batch", "mplx_poly_set_capacity", "mplx_poly_plan_batch", "mplx_poly_result_traj",
     "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms",
@@ -126,6 +129,27 @@ def load():
     L.mplx_kernel_name.restype = C.c_char_p
     L.mplx_plan_epoch.argtypes = [P]
     L.mplx_plan_epoch.restype = C.c_uint64
+    U64 = C.POINTER(C.c_uint64)
+    L.mplx_lpa_create.argtypes = [P, C.POINTER(P)]
+    L.mplx_lpa_destroy.argtypes = [P]
+    L.mplx_lpa_destroy.restype = None
+    L.mplx_lpa_last_error.argtypes = [P]
+    L.mplx_lpa_last_error.restype = C.c_char_p
+    L.mplx_lpa_set_capacity.argtypes = [P, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.mplx_lpa_set_record.argtypes = [P, C.c_uint32]
+    L.mplx_lpa_plan.argtypes = [P, C.POINTER(Waypoint), C.POINTER(Waypoint), C.POINTER(Result)]
+    L.mplx_lpa_initialized.argtypes = [P]
+    L.mplx_lpa_reset.argtypes = [P]
+    L.mplx_lpa_update_blocked.argtypes = [P, C.c_int, C.c_void_p, U64]
+    L.mplx_lpa_update_cleared.argtypes = [P, C.c_int, C.c_void_p, U64]
+    L.mplx_lpa_sub_state_space.argtypes = [P, C.c_int32]
+    L.mplx_lpa_traj_len.argtypes = [P]
+    L.mplx_lpa_result_traj.argtypes = [P, C.POINTER(Primitive), C.POINTER(Waypoint), I3, I3]
+    L.mplx_lpa_counts.argtypes = [P, U64, U64, U64]
+    L.mplx_lpa_result_nodes.argtypes = [P, C.c_uint64, C.POINTER(Waypoint)] + [C.c_void_p] * 6
+    L.mplx_lpa_result_edges.argtypes = [P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, U64]
+    L.mplx_lpa_result_expanded.argtypes = [P, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
+    L.mplx_lpa_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float)]
     G = C.c_void_p
     L.mplx_grid_create.argtypes = [C.c_int, D3, D3, C.c_float, C.POINTER(G)]
     L.mplx_grid_destroy.argtypes = [G]

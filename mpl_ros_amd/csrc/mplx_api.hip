@@ -1171,6 +1171,7 @@ extern "C" int mplx_last_kernel_ms(const mplx_ctx *c, float *ms) {
   *ms = c->last_ms;
   return MPLX_OK;
 }
+#include "mplx_lpa.inl"
 #include "mplx_grid.inl"
 #include "mplx_poly_search.h"
 #include "mplx_poly.inl"

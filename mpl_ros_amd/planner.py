@@ -149,6 +149,33 @@ class _Context:
             pass
 
 
+class _Lpa:
+    """The device-resident state space of one LPA* planner (mplx_lpa).  Holds its context alive: the handle must be
+    destroyed before the context."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        h = C.c_void_p()
+        code = self.lib.mplx_lpa_create(ctx.h, C.byref(h))
+        if code != _capi.OK:
+            raise MplxError(f"mplx_lpa_create failed ({code})")
+        self.h = h
+
+    def check(self, code):
+        if code != _capi.OK:
+            msg = self.lib.mplx_lpa_last_error(self.h)
+            raise MplxError(f"mplx error {code}: {msg.decode() if msg else ''}")
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.lib.mplx_lpa_destroy(self.h)
+            self.h = None
+        except Exception:
+            pass
+
+
 class VoxelMapUtil:
     """MapUtil<3>: the voxel grid lives in HBM; setMap copies it in (or adopts a device pointer)."""
 
@@ -287,6 +314,10 @@ class VoxelMapPlanner:
         self._result = None
         self._results = None
         self.traj_cost_ = math.inf
+        self._use_lpastar = False
+        self._lpa = None
+        self._cap = None
+        self._record = 0
 
     # ---- setters (PlannerBase / MapPlanner)
     def setMapUtil(self, map_util):
@@ -335,25 +366,54 @@ class VoxelMapPlanner:
         (launch/map_planner_node/test.launch:28,33).  Stored; it takes effect when the search states carry yaw."""
         self._yaw_max, self._dirty = float(yaw_max), True
 
-    # ---- reference API that this back-end does not cover (SURVEY.md 8f rows 2, 3)
+    # ---- LPA* incremental replanning (SURVEY.md 8f row 2): the state space stays on the device between plan() calls
     def setLPAstar(self, use_lpastar):
-        """setLPAstar (map_replanner_node.cpp:425,437), as include/mpl_shim's PlannerBase treats it: LPA* would reuse and
-        repair the previous state space; here every plan() is a fresh A* on the current map -- the same optimal cost, no
-        reuse -- and asking for LPA* says so on stderr."""
+        """setLPAstar (map_replanner_node.cpp:425,437): plan() repairs and re-uses the state space of the previous
+        plan (mplx_lpa_*: ComputeShortestPath of LPA* on a device-resident state space of this planner's own)."""
         self._use_lpastar = bool(use_lpastar)
-        if use_lpastar:
-            print("\x1b[31m[VoxelMapPlanner] setLPAstar(True): incremental replanning is not implemented by the mplx back-end; "
-                  "every plan() is a fresh A*\x1b[0m", file=sys.stderr)
+        if not use_lpastar:
+            self._lpa = None
 
-    def updateBlockedNodes(self, blocked_pns):   # map_replanner_node.cpp:190
-        """Map edits reach the planner through setMap / mplx_map_set_device; a fresh A* needs no list of changed cells."""
-        return False
+    def _lpa_handle(self):
+        ctx = self._ctx()
+        if self._lpa is None or self._lpa.ctx is not ctx:
+            self._lpa = _Lpa(ctx)
+            if self._cap is not None:
+                self._lpa.check(ctx.lib.mplx_lpa_set_capacity(self._lpa.h, self._cap[1], self._cap[2], self._cap[3]))
+        return self._lpa
 
-    def updateClearedNodes(self, cleared_pns):   # map_replanner_node.cpp:228
-        return False
+    def initialized(self):
+        """PlannerBase::initialized() (map_replanner_node.cpp:195,232,244): an LPA* state space exists."""
+        return bool(self._lpa is not None and self._lpa.lib.mplx_lpa_initialized(self._lpa.h))
 
-    def getSubStateSpace(self, time_step):       # map_replanner_node.cpp:246 (prunes the tree LPA* would reuse)
-        return None
+    def reset(self):
+        if self._lpa is not None:
+            self._lpa.check(self._lpa.lib.mplx_lpa_reset(self._lpa.h))
+
+    def _update_nodes(self, fn, pns):
+        if not self._use_lpastar or self._lpa is None:
+            return 0
+        self._configure(self._control)  # (another planner may have configured the shared context since)
+        c = np.ascontiguousarray(pns, dtype=np.int32).reshape(-1, 3)
+        n = C.c_uint64(0)
+        self._lpa.check(getattr(self._lpa.lib, fn)(self._lpa.h, c.shape[0], c.ctypes.data, C.byref(n)))
+        return int(n.value)
+
+    def updateBlockedNodes(self, blocked_pns):   # map_replanner_node.cpp:196
+        """After the shared MapUtil was edited: predecessor entries whose primitive is no longer free get cost inf
+        (increaseCost).  Returns the number of entries that changed (upstream returns their primitives)."""
+        return self._update_nodes("mplx_lpa_update_blocked", blocked_pns)
+
+    def updateClearedNodes(self, cleared_pns):   # map_replanner_node.cpp:233
+        return self._update_nodes("mplx_lpa_update_cleared", cleared_pns)
+
+    def getSubStateSpace(self, time_step):       # map_replanner_node.cpp:245
+        """Re-root the LPA* state space at the time_step-th state of the last trajectory; the caller then plans from
+        getTraj().getWaypoints()[time_step] (map_replanner_node.cpp:246-250)."""
+        if not self._use_lpastar or self._lpa is None:
+            return
+        self._configure(self._control)
+        self._lpa.check(self._lpa.lib.mplx_lpa_sub_state_space(self._lpa.h, int(time_step)))
 
     def _unsupported(self, what):
         raise MplxError(f"{what}: not supported by this back-end")
@@ -387,6 +447,9 @@ class VoxelMapPlanner:
     def setCapacity(self, n_slots=0, max_nodes=0, max_edges=0, max_open_log=0):
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_capacity(ctx.h, n_slots, max_nodes, max_edges, max_open_log))
+        self._cap = (n_slots, max_nodes, max_edges, max_open_log)
+        if self._lpa is not None:
+            self._lpa.check(ctx.lib.mplx_lpa_set_capacity(self._lpa.h, max_nodes, max_edges, max_open_log))
 
     def setBucketWidth(self, width):
         ctx = self._ctx()
@@ -412,6 +475,7 @@ class VoxelMapPlanner:
     def setRecord(self, cap):
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_record(ctx.h, int(cap)))
+        self._record = int(cap)
 
     def _ctx(self):
         if self.map_util_ is None:
@@ -422,6 +486,8 @@ class VoxelMapPlanner:
         """The device keeps the state space of the context's LAST plan only: refuse to answer from a plan
         another planner object made on the shared context since (instead of returning its state space)."""
         ctx = self._ctx()
+        if self._use_lpastar and self._lpa is not None and self._results is not None:
+            return ctx  # (an LPA* planner's state space is its own: nothing another planner does can replace it)
         if self._results is None or ctx.lib.mplx_plan_epoch(ctx.h) != getattr(self, "_epoch", -1):
             raise MplxError("the results of this planner's last plan() are gone: another planner sharing the MapUtil planned since")
         return ctx
@@ -460,7 +526,13 @@ class VoxelMapPlanner:
         self._configure(start.control)
         res = _capi.Result()
         s, g = start.to_c(), goal.to_c()
-        ctx.check(ctx.lib.mplx_plan(ctx.h, C.byref(s), C.byref(g), C.byref(res)))
+        if self._use_lpastar:
+            lpa = self._lpa_handle()
+            if self._record:
+                lpa.check(ctx.lib.mplx_lpa_set_record(lpa.h, self._record))
+            lpa.check(ctx.lib.mplx_lpa_plan(lpa.h, C.byref(s), C.byref(g), C.byref(res)))
+        else:
+            ctx.check(ctx.lib.mplx_plan(ctx.h, C.byref(s), C.byref(g), C.byref(res)))
         self._result = res
         self._results = [res]
         self._epoch = ctx.lib.mplx_plan_epoch(ctx.h)
@@ -499,7 +571,10 @@ class VoxelMapPlanner:
     def lastKernelMs(self):
         ctx = self._ctx()
         ms = C.c_float()
-        ctx.check(ctx.lib.mplx_last_kernel_ms(ctx.h, C.byref(ms)))
+        if self._use_lpastar and self._lpa is not None:
+            self._lpa.check(ctx.lib.mplx_lpa_last_kernel_ms(self._lpa.h, C.byref(ms)))
+        else:
+            ctx.check(ctx.lib.mplx_last_kernel_ms(ctx.h, C.byref(ms)))
         return ms.value
 
     def kernelName(self):
@@ -531,13 +606,18 @@ class VoxelMapPlanner:
         ctx = self._own_results()
         res = self._results[q]
         n = res.traj_len if res.status == _capi.PLAN_OK else 0
+        if self._use_lpastar and self._lpa is not None:
+            n = int(ctx.lib.mplx_lpa_traj_len(self._lpa.h))  # the stored Trajectory of the last SUCCESSFUL plan
         if n <= 0:
             return Trajectory3D([], [], np.zeros(0, dtype=np.int32), res.cost)
         prs = (_capi.Primitive * n)()
         wps = (_capi.Waypoint * (n + 1))()
         act = (C.c_int32 * n)()
         ids = (C.c_int32 * (n + 1))()
-        ctx.check(ctx.lib.mplx_result_traj(ctx.h, q, prs, wps, act, ids))
+        if self._use_lpastar and self._lpa is not None:
+            self._lpa.check(ctx.lib.mplx_lpa_result_traj(self._lpa.h, prs, wps, act, ids))
+        else:
+            ctx.check(ctx.lib.mplx_result_traj(ctx.h, q, prs, wps, act, ids))
         P = [Primitive3D([list(prs[i].c[k]) for k in range(3)], prs[i].t, prs[i].control) for i in range(n)]
         W = [Waypoint3D.from_c(wps[i]) for i in range(n + 1)]
         tr = Trajectory3D(P, W, np.array(act[:], dtype=np.int32), res.cost)
@@ -549,11 +629,17 @@ class VoxelMapPlanner:
         cap = int(self._results[q].n_expanded)
         ids = np.zeros(max(cap, 1), dtype=np.int32)
         n = C.c_uint32()
-        ctx.check(ctx.lib.mplx_result_expanded(ctx.h, q, cap, ids.ctypes.data, C.byref(n)))
+        if self._use_lpastar and self._lpa is not None:
+            self._lpa.check(ctx.lib.mplx_lpa_result_expanded(self._lpa.h, cap, ids.ctypes.data, C.byref(n)))
+        else:
+            ctx.check(ctx.lib.mplx_result_expanded(ctx.h, q, cap, ids.ctypes.data, C.byref(n)))
         return ids[:n.value]
 
     def _nodes(self):
         ctx = self._own_results()
+        if self._use_lpastar and self._lpa is not None:
+            st = self.lpaStateSpace()
+            return st["coords"], st["pos"], st["g"], st["h"], st["closed"], st["opened"]
         n = int(self._result.n_nodes)
         coords = (_capi.Waypoint * max(n, 1))()
         g = np.zeros(n)
@@ -564,6 +650,27 @@ class VoxelMapPlanner:
             ctx.check(ctx.lib.mplx_result_nodes(ctx.h, n, coords, g.ctypes.data, h.ctypes.data, closed.ctypes.data, opened.ctypes.data))
         pos = np.array([coords[i].pos[:] for i in range(n)]).reshape(n, 3)
         return coords, pos, g, h, closed, opened
+
+    def lpaStateSpace(self):
+        """The LPA* state space as it stands (after a plan, a map edit or a re-rooting): coords / pos / g / rhs / h /
+        closed / opened / built per state, and the predecessor entries (child, parent, action, blocked)."""
+        lpa, lib = self._lpa, self._lpa.lib
+        nn, ne, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        lpa.check(lib.mplx_lpa_counts(lpa.h, C.byref(nn), C.byref(ne), C.byref(nb)))
+        n = int(nn.value)
+        coords = (_capi.Waypoint * max(n, 1))()
+        g, rhs, h = np.zeros(n), np.zeros(n), np.zeros(n)
+        closed, opened, built = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        if n:
+            lpa.check(lib.mplx_lpa_result_nodes(lpa.h, n, coords, g.ctypes.data, rhs.ctypes.data, h.ctypes.data, closed.ctypes.data, opened.ctypes.data, built.ctypes.data))
+        m = int(ne.value)
+        child, parent, action, blocked = (np.zeros(max(m, 1), dtype=np.int32) for _ in range(4))
+        got = C.c_uint64(0)
+        lpa.check(lib.mplx_lpa_result_edges(lpa.h, child.ctypes.data, parent.ctypes.data, action.ctypes.data, blocked.ctypes.data, m, C.byref(got)))
+        m = int(got.value)
+        pos = np.array([coords[i].pos[:] for i in range(n)]).reshape(n, 3)
+        return dict(n_nodes=n, n_edges=m, n_blocked_log=int(nb.value), coords=coords, pos=pos, g=g, rhs=rhs, h=h, closed=closed, opened=opened, built=built,
+                    child=child[:m], parent=parent[:m], action=action[:m], blocked=blocked[:m])
 
     def getCloseSet(self):
         _, pos, _, _, closed, _ = self._nodes()
@@ -577,6 +684,9 @@ class VoxelMapPlanner:
         """Predecessor lists of the state space: (child, parent, action) int32 arrays, for every node in id
         order its edges in arrival order (StateSpace pred_coord / pred_action_id, poly_map_planner.h:70-86)."""
         ctx = self._own_results()
+        if self._use_lpastar and self._lpa is not None:
+            st = self.lpaStateSpace()
+            return st["child"], st["parent"], st["action"]
         n = int(self._result.n_edges)
         child = np.zeros(max(n, 1), dtype=np.int32); parent = np.zeros(max(n, 1), dtype=np.int32); action = np.zeros(max(n, 1), dtype=np.int32)
         m = C.c_uint64(0)

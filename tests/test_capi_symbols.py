@@ -72,15 +72,16 @@ def test_yaw_requests_fail_loudly():
 
 
 def test_uncovered_reference_api_fails_loudly():
-    """SURVEY.md 8(f) rows 2 and 3 are not covered.  LPA* replanning degrades to a fresh A* per plan() (same optimal cost)
-    and says so; potential-field / search-region cost would change the plan, so those setters raise."""
+    """SURVEY.md 8(f) row 3 is not covered: potential-field / search-region cost would change the plan, so those setters
+    raise.  LPA* (row 2) is covered: without a state space its update calls change nothing."""
     import pytest
     from mpl_ros_amd._capi import MplxError
     from mpl_ros_amd.planner import VoxelMapPlanner
     pl = VoxelMapPlanner(False)
     pl.setLPAstar(False)  # the default
-    pl.setLPAstar(True)   # says "every plan() is a fresh A*" on stderr, like the C++ shim; same optimal cost, no reuse
-    assert pl.updateBlockedNodes([]) is False and pl.updateClearedNodes([]) is False and pl.getSubStateSpace(1) is None
+    pl.setLPAstar(True)
+    assert not pl.initialized()
+    assert pl.updateBlockedNodes([]) == 0 and pl.updateClearedNodes([]) == 0 and pl.getSubStateSpace(1) is None
     for call in (lambda: pl.setSearchRadius([0.5, 0.5, 0.5]), lambda: pl.setSearchRegion([]),
                  lambda: pl.setPotentialRadius([1, 1, 1]), lambda: pl.setPotentialWeight(0.1), lambda: pl.setGradientWeight(0.0),
                  lambda: pl.updatePotentialMap([0, 0, 0]), lambda: pl.getPotentialCloud()):
