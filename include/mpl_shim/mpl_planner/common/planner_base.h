@@ -3,7 +3,7 @@
  *
  * MPL::PlannerBase<Dim, Coord>: what the in-tree planners derive from (poly_map_planner.h:18-93,
  * ellipsoid_planner.h) and what the nodes call: the setters, plan(start, goal),
- * getTraj / getTrajCost / getCloseSet / getOpenSet / getExpandedNodes / getAllPrimitives ..., and the protected
+ * getTraj / getTrajCost / getCloseSet / getOpenSet / getExpandedNodes / getAllPrimitives ..., setLPAstar, and the protected
  * ENV_ (std::shared_ptr<env_base<Dim>>), ss_ptr_ (std::shared_ptr<StateSpace<Dim, Coord>>), planner_verbose_.
  *
  * The search itself is the device's: MPL::MapPlanner (map_planner.h) overrides plan() with the C-ABI call.  A
@@ -37,11 +37,8 @@ class PlannerBase {
   void checkValidation() { if (ss_ptr_) ss_ptr_->checkValidation(ss_ptr_->hm_); }
   void reset() { ss_ptr_ = nullptr; traj_ = Trajectory<Dim>(); }
 
-  /// LPA* (map_replanner_node.cpp:425-437) is not implemented: asking for it is an error, not a silent A*
-  void setLPAstar(bool use_lpastar) {
-    use_lpastar_ = use_lpastar;
-    if (use_lpastar) printf(ANSI_COLOR_RED "[PlannerBase] setLPAstar(true): incremental replanning is not implemented by the mplx back-end; every plan() is a fresh A*\n" ANSI_COLOR_RESET);
-  }
+  /// LPA* (map_replanner_node.cpp:425-437): MapPlanner::plan then repairs and re-uses its device-resident state space
+  void setLPAstar(bool use_lpastar) { use_lpastar_ = use_lpastar; }
   virtual void setEpsilon(decimal_t eps) { epsilon_ = eps; }
   virtual void setVmax(decimal_t v) { v_max_ = v; if (ENV_) ENV_->set_v_max(v); }
   virtual void setAmax(decimal_t a) { a_max_ = a; if (ENV_) ENV_->set_a_max(a); }

@@ -6,8 +6,10 @@
  * (poly_map_planner.h:70-86) and calls increaseCost / decreaseCost (:91-92) and getSubStateSpace
  * (map_replanner_node.cpp:245) for LPA*-style replanning.  With this back-end the graph lives in HBM; a host
  * mirror is filled on request by MapPlanner::getStateSpace() from the device dumps (mplx_result_nodes /
- * _edges / _blocked).  Incremental replanning (increaseCost / decreaseCost / getSubStateSpace) is NOT implemented:
- * the calls exist, print an error and change nothing, so a caller cannot mistake them for working LPA*.
+ * _edges / _blocked).  Incremental replanning on the voxel / occupancy map lives on the device (MPL::MapPlanner with
+ * setLPAstar(true): mplx_lpa_*, its own state space in HBM); THIS host-side StateSpace is what planners with a host
+ * environment hold (PolyMapPlanner::updateNodes, poly_map_planner.h:61-93): its increaseCost / decreaseCost /
+ * getSubStateSpace exist, print an error and change nothing -- there is no CPU search here to repair.
  */
 #ifndef MPLX_SHIM_STATE_SPACE_H
 #define MPLX_SHIM_STATE_SPACE_H
@@ -54,7 +56,7 @@ struct StateSpace {
 
  private:
   static void unsupported(const char *what) {
-    printf(ANSI_COLOR_RED "[StateSpace] %s: incremental (LPA*) replanning is not implemented by the mplx back-end; nothing was changed\n" ANSI_COLOR_RESET, what);
+    printf(ANSI_COLOR_RED "[StateSpace] %s: this host-side state space has no search behind it (LPA* runs on the device: MPL::MapPlanner with setLPAstar(true)); nothing was changed\n" ANSI_COLOR_RESET, what);
   }
 };
 

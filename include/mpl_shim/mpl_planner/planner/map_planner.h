@@ -4,8 +4,10 @@
  * done by libmplx.so on the GPU.  Method names, argument meaning and error behaviour follow the
  * in-tree call sites: setters store parameters, plan() returns false and
  * prints a diagnostic when the start is occupied or no trajectory is found, results are returned by
- * value.  Not covered by this back-end: LPA* (setLPAstar / update*Nodes), potential fields, yaw -- each of them
- * fails loudly (planner_base.h) instead of silently planning something else.
+ * value.  setLPAstar(true): plan() repairs and re-uses a device-resident state space of this planner's own
+ * (mplx_lpa_*), updateBlockedNodes / updateClearedNodes / getSubStateSpace / initialized as map_replanner_node.cpp uses
+ * them.  Not covered by this back-end: potential fields, yaw -- each of them fails loudly instead of silently planning
+ * something else.
  */
 #ifndef MPLX_SHIM_MAP_PLANNER_H
 #define MPLX_SHIM_MAP_PLANNER_H
@@ -65,6 +67,9 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   MapPlanner(bool verbose) : Base(verbose) {
     if (planner_verbose_) printf(ANSI_COLOR_CYAN "[MapPlanner] PLANNER VERBOSE ON (mplx back-end)\n" ANSI_COLOR_RESET);
   }
+  ~MapPlanner() { if (lpa_) mplx_lpa_destroy(lpa_); }  // (before the MapUtil / context it plans on: map_util_ is a member)
+  MapPlanner(const MapPlanner &) = delete;
+  MapPlanner &operator=(const MapPlanner &) = delete;
   void setMapUtil(const std::shared_ptr<MapUtil<Dim>> &map_util) {
     map_util_ = map_util;
     this->ENV_.reset(new env_map<Dim>(map_util));
@@ -82,6 +87,21 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   /// device pools (no reference counterpart: the reference grows std containers)
   void setCapacity(int slots, uint64_t nodes, uint64_t edges, uint64_t open_log) {
     mplx_set_capacity(map_util_->ctx(), slots, nodes, edges, open_log);
+    cap_[0] = nodes; cap_[1] = edges; cap_[2] = open_log;
+    if (lpa_) mplx_lpa_set_capacity(lpa_, nodes, edges, open_log);
+  }
+  /// LPA*: a state space exists (map_replanner_node.cpp:195,232,244)
+  bool initialized() { return lpa_ && mplx_lpa_initialized(lpa_); }
+  void reset() { if (lpa_) mplx_lpa_reset(lpa_); traj_ = Trajectory<Dim>(); }
+  /// map_replanner_node.cpp:196,233 -- after the shared MapUtil was edited (setMap): predecessor entries whose primitive is
+  /// no longer free get cost inf (increaseCost) / blocked ones that are free again get their cost back (decreaseCost).
+  /// Returns the primitives of the entries that changed, like upstream (the node's commented-out publishers show them).
+  vec_E<Primitive<Dim>> updateBlockedNodes(const vec_Veci<Dim> &blocked_pns) { return update_nodes(blocked_pns, true); }
+  vec_E<Primitive<Dim>> updateClearedNodes(const vec_Veci<Dim> &cleared_pns) { return update_nodes(cleared_pns, false); }
+  /// map_replanner_node.cpp:245: re-root the LPA* state space at the time_step-th state of the last trajectory
+  void getSubStateSpace(int time_step) {
+    if (!lpa_ || !send_config(control_)) return;
+    if (mplx_lpa_sub_state_space(lpa_, time_step) != MPLX_OK) printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_lpa_last_error(lpa_));
   }
 
   /// bool PlannerBase::plan(start, goal)  (map_planner_node.cpp:187)
@@ -94,21 +114,20 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
       return false;
     }
     mplx_ctx *ctx = map_util_->ctx();
-    mplx_config cfg;
-    cfg.control = (int32_t)start.control & 15;
-    cfg.n_u = (int32_t)(U_.size() / 3);
-    cfg.U = U_.data();
-    cfg.dt = dt_; cfg.v_max = v_max_; cfg.a_max = a_max_; cfg.j_max = j_max_;
-    cfg.w = w_; cfg.eps = epsilon_;
-    cfg.tol_pos = tol_pos_; cfg.tol_vel = tol_vel_; cfg.tol_acc = tol_acc_;
-    cfg.t_max = t_max_;
-    cfg.max_expand = max_num_;
-    cfg.heur_ignore_dynamics = heur_ignore_dynamics_ ? 1 : 0;
     mplx_set_record(ctx, record_cap_);  // expansion order for getExpandedNodes()
-    control_ = (Control::Control)cfg.control;
-    if (mplx_planner_config(ctx, &cfg) != MPLX_OK) { printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx)); return false; }
+    control_ = (Control::Control)((int32_t)start.control & 15);
+    if (!send_config(control_)) return false;
     mplx_waypoint s = to_c(start), g = to_c(goal);
-    if (mplx_plan(ctx, &s, &g, &res_) != MPLX_OK) { printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx)); return false; }
+    if (this->use_lpastar_) {
+      if (!lpa_) {
+        if (mplx_lpa_create(ctx, &lpa_) != MPLX_OK) return false;
+        if (cap_[0]) mplx_lpa_set_capacity(lpa_, cap_[0], cap_[1], cap_[2]);
+      }
+      mplx_lpa_set_record(lpa_, record_cap_);
+      if (mplx_lpa_plan(lpa_, &s, &g, &res_) != MPLX_OK) { printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_lpa_last_error(lpa_)); return false; }
+    } else {
+      if (mplx_plan(ctx, &s, &g, &res_) != MPLX_OK) { printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx)); return false; }
+    }
     if (res_.status == MPLX_PLAN_START_OCCUPIED) { printf(ANSI_COLOR_RED "[PlannerBase] start is not free!\n" ANSI_COLOR_RESET); return false; }
     epoch_ = mplx_plan_epoch(ctx);  // the getters answer from THIS plan only (two planners may share one MapUtil)
     traj_cost_ = res_.cost;
@@ -122,7 +141,10 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
       return false;
     }
     std::vector<mplx_primitive> prs(res_.traj_len > 0 ? res_.traj_len : 0);
-    if (res_.traj_len > 0) mplx_result_traj(ctx, 0, prs.data(), nullptr, nullptr, nullptr);
+    if (res_.traj_len > 0) {
+      if (lpa_mode()) mplx_lpa_result_traj(lpa_, prs.data(), nullptr, nullptr, nullptr);
+      else mplx_result_traj(ctx, 0, prs.data(), nullptr, nullptr, nullptr);
+    }
     vec_E<Primitive<Dim>> out;
     for (const auto &p : prs) {
       vec_E<Vec6f> cs(Dim);
@@ -145,7 +167,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     if (!nodes(coords)) return ps;  // (also refuses when another planner planned on the shared context since)
     std::vector<int32_t> ids((size_t)std::max<uint64_t>(1, std::min<uint64_t>(res_.n_expanded, record_cap_)));
     uint32_t n = 0;
-    if (mplx_result_expanded(map_util_->ctx(), 0, (uint32_t)ids.size(), ids.data(), &n) != MPLX_OK) return ps;
+    if ((lpa_mode() ? mplx_lpa_result_expanded(lpa_, (uint32_t)ids.size(), ids.data(), &n) : mplx_result_expanded(map_util_->ctx(), 0, (uint32_t)ids.size(), ids.data(), &n)) != MPLX_OK) return ps;
     for (uint32_t i = 0; i < n; i++) ps.push_back(pos_of(coords[(size_t)ids[i]]));
     return ps;
   }
@@ -182,6 +204,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   vec_E<Primitive<Dim>> getAllPrimitives() const {
     vec_E<Primitive<Dim>> prs = edge_primitives(false);
     uint64_t n = 0, n_all = 0;
+    if (lpa_mode()) return prs;  // (the LPA* state space keeps its blocked entries as flagged predecessor entries: already in prs)
     if (!own_results() || mplx_result_blocked(map_util_->ctx(), nullptr, nullptr, 0, &n, &n_all) != MPLX_OK || n == 0) return prs;
     std::vector<int32_t> parent((size_t)n), action((size_t)n);
     if (mplx_result_blocked(map_util_->ctx(), parent.data(), action.data(), n, &n, &n_all) != MPLX_OK) return prs;
@@ -193,6 +216,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   /// hm_.size() as upstream counts it: states reached with finite cost + states only blocked primitives reach
   size_t getStateSpaceSize() const {
     uint64_t n = 0, n_all = 0;
+    if (lpa_mode()) return (size_t)res_.n_nodes;
     if (!own_results()) return 0;
     return mplx_result_blocked(map_util_->ctx(), nullptr, nullptr, 0, &n, &n_all) == MPLX_OK ? (size_t)n_all : (size_t)res_.n_nodes;
   }
@@ -216,7 +240,9 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   /// The device keeps the state space of the context's LAST plan only.  Two planners may share one MapUtil (= one
   /// context: planner_ / replan_planner_, map_replanner_node.cpp:415,427): a getter must not size its buffers from
   /// this planner's result and then read the other planner's state space.
+  bool lpa_mode() const { return this->use_lpastar_ && lpa_ != nullptr; }
   bool own_results() const {
+    if (lpa_mode()) return true;  // an LPA* planner's state space is its own
     if (!map_util_ || epoch_ == 0 || mplx_plan_epoch(map_util_->ctx()) != epoch_) {
       printf(ANSI_COLOR_RED "[MapPlanner] the results of this planner's last plan() are gone: another planner sharing the MapUtil planned since\n" ANSI_COLOR_RESET);
       return false;
@@ -228,6 +254,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     if (!n || !own_results()) return false;
     coords.resize(n);
     if (closed) closed->resize(n);
+    if (lpa_mode()) return mplx_lpa_result_nodes(lpa_, n, coords.data(), nullptr, nullptr, nullptr, closed ? closed->data() : nullptr, nullptr, nullptr) == MPLX_OK;
     return mplx_result_nodes(map_util_->ctx(), n, coords.data(), nullptr, nullptr, closed ? closed->data() : nullptr, nullptr) == MPLX_OK;
   }
   bool edges(std::vector<int32_t> &child, std::vector<int32_t> &parent, std::vector<int32_t> &action) const {
@@ -235,7 +262,8 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     if (!own_results()) return false;
     child.resize(n ? n : 1); parent.resize(n ? n : 1); action.resize(n ? n : 1);
     uint64_t m = 0;
-    if (mplx_result_edges(map_util_->ctx(), child.data(), parent.data(), action.data(), n, &m) != MPLX_OK) return false;
+    if ((lpa_mode() ? mplx_lpa_result_edges(lpa_, child.data(), parent.data(), action.data(), nullptr, n, &m)
+                    : mplx_result_edges(map_util_->ctx(), child.data(), parent.data(), action.data(), n, &m)) != MPLX_OK) return false;
     child.resize((size_t)m); parent.resize((size_t)m); action.resize((size_t)m);
     return true;
   }
@@ -264,7 +292,8 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     if (!n || !own_results()) return ps;
     std::vector<mplx_waypoint> coords(n);
     std::vector<int32_t> closed(n), opened(n);
-    if (mplx_result_nodes(map_util_->ctx(), n, coords.data(), nullptr, nullptr, closed.data(), opened.data()) != MPLX_OK) return ps;
+    if ((lpa_mode() ? mplx_lpa_result_nodes(lpa_, n, coords.data(), nullptr, nullptr, nullptr, closed.data(), opened.data(), nullptr)
+                    : mplx_result_nodes(map_util_->ctx(), n, coords.data(), nullptr, nullptr, closed.data(), opened.data())) != MPLX_OK) return ps;
     for (size_t i = 0; i < n; i++) {
       if (closed_set ? closed[i] : (opened[i] && !closed[i])) {
         Vecf<Dim> p;
@@ -274,7 +303,60 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     }
     return ps;
   }
+  /// the planner set-up onto the (possibly shared) context
+  bool send_config(Control::Control control) {
+    mplx_ctx *ctx = map_util_->ctx();
+    mplx_config cfg;
+    cfg.control = (int32_t)control & 15;
+    cfg.n_u = (int32_t)(U_.size() / 3);
+    cfg.U = U_.data();
+    cfg.dt = dt_; cfg.v_max = v_max_; cfg.a_max = a_max_; cfg.j_max = j_max_;
+    cfg.w = w_; cfg.eps = epsilon_;
+    cfg.tol_pos = tol_pos_; cfg.tol_vel = tol_vel_; cfg.tol_acc = tol_acc_;
+    cfg.t_max = t_max_;
+    cfg.max_expand = max_num_;
+    cfg.heur_ignore_dynamics = heur_ignore_dynamics_ ? 1 : 0;
+    if (mplx_planner_config(ctx, &cfg) != MPLX_OK) { printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx)); return false; }
+    return true;
+  }
+  vec_E<Primitive<Dim>> update_nodes(const vec_Veci<Dim> &pns, bool blocked) {
+    vec_E<Primitive<Dim>> changed;
+    if (!lpa_ || !mplx_lpa_initialized(lpa_) || pns.empty() || !send_config(control_)) return changed;
+    uint64_t n_nodes = 0, n_edges = 0;
+    mplx_lpa_counts(lpa_, &n_nodes, &n_edges, nullptr);
+    std::vector<int32_t> before((size_t)n_edges + 1), child((size_t)n_edges + 1);
+    uint64_t m0 = 0;
+    mplx_lpa_result_edges(lpa_, child.data(), nullptr, nullptr, before.data(), n_edges, &m0);
+    std::vector<int32_t> c(3 * pns.size(), 0);
+    for (size_t k = 0; k < pns.size(); k++)
+      for (int i = 0; i < Dim; i++) c[3 * k + i] = pns[k](i);
+    uint64_t n_changed = 0;
+    const int rc = blocked ? mplx_lpa_update_blocked(lpa_, (int)pns.size(), c.data(), &n_changed) : mplx_lpa_update_cleared(lpa_, (int)pns.size(), c.data(), &n_changed);
+    if (rc != MPLX_OK) { printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_lpa_last_error(lpa_)); return changed; }
+    if (!n_changed) return changed;
+    // the entries whose cost changed: flags that flipped, plus (cleared) the entries that did not exist before
+    mplx_lpa_counts(lpa_, &n_nodes, &n_edges, nullptr);
+    std::vector<mplx_waypoint> coords((size_t)n_nodes + 1);
+    std::vector<int32_t> ch((size_t)n_edges + 1), pa((size_t)n_edges + 1), ac((size_t)n_edges + 1), bl((size_t)n_edges + 1);
+    uint64_t m1 = 0;
+    if (mplx_lpa_result_nodes(lpa_, n_nodes, coords.data(), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr) != MPLX_OK) return changed;
+    if (mplx_lpa_result_edges(lpa_, ch.data(), pa.data(), ac.data(), bl.data(), n_edges, &m1) != MPLX_OK) return changed;
+    // (entries are listed per state in arrival order: an old entry keeps its rank inside its state's list)
+    size_t i0 = 0;
+    for (size_t e = 0; e < (size_t)m1; e++) {
+      const bool existed = i0 < (size_t)m0 && child[i0] == ch[e];
+      if (existed) {
+        if (before[i0] != bl[e]) changed.push_back(primitive_of(coords[(size_t)pa[e]], ac[e]));
+        i0++;
+      } else {
+        changed.push_back(primitive_of(coords[(size_t)pa[e]], ac[e]));
+      }
+    }
+    return changed;
+  }
   std::shared_ptr<MapUtil<Dim>> map_util_;
+  mplx_lpa *lpa_ = nullptr;
+  uint64_t cap_[3] = {0, 0, 0};
   std::vector<double> U_;
   mplx_result res_ = mplx_result();
   uint64_t epoch_ = 0;  // mplx_plan_epoch of this planner's last plan()

@@ -1,11 +1,9 @@
 // The search-region / potential-field setters of the reference's MapPlanner exist on the shim and make plan() refuse
-// (they would change the plan); setLPAstar(true) only announces the fresh-A* behaviour.  No GPU needed: plan() must
-// fail before it reaches the device.
+// (they would change the plan).  No GPU needed: plan() must fail before it reaches the device.
 #include <mpl_planner/planner/map_planner.h>
 #include <cstdio>
 int main() {
   MPL::VoxelMapPlanner planner(false);
-  planner.setLPAstar(true);
   planner.setPotentialRadius(Vec3f(1, 1, 1));
   planner.setPotentialWeight(0.1);
   planner.setGradientWeight(0.0);

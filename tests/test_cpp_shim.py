@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "mpl_ros_amd", "csrc")
 
 
-def build_driver(tmp_path):
-    exe = str(tmp_path / "map_planner_driver")
+def build_driver(tmp_path, name="map_planner_driver"):
+    exe = str(tmp_path / name)
     subprocess.check_call(["g++", "-O2", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "include", "mpl_shim"), "-o", exe,
-                           os.path.join(ROOT, "tests", "cpp", "map_planner_driver.cpp"),
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"),
                            os.path.join(LIBDIR, "libmplx.so"), "-Wl,-rpath," + LIBDIR])
     return exe
 
@@ -118,15 +118,79 @@ def test_reference_driver_config1_launch_file_through_the_shim(tmp_path):
         assert w == list(wo.pos) + list(wo.vel)
 
 
+def test_replanner_driver_compiles_and_fails_loudly_without_gpu(tmp_path):
+    import ctypes
+    from mpl_ros_amd import _capi
+    exe = build_driver(tmp_path, "map_replanner_driver")
+    h = ctypes.c_void_p()
+    if _capi.load().mplx_ctx_create(0, ctypes.byref(h)) == _capi.OK:
+        _capi.load().mplx_ctx_destroy(h)
+        pytest.skip("GPU present")
+    d = np.load(os.path.join(ROOT, "tests", "golden", "simple_map.npz"))
+    path = str(tmp_path / "simple.bin")
+    d["grid"].tofile(path)
+    dz, dy, dx = d["grid"].shape
+    out = subprocess.run([exe, path, str(dx), str(dy), str(dz)] + [repr(float(o)) for o in d["origin"]] + [repr(float(d["res"]))], capture_output=True, text=True)
+    assert out.returncode == 3 and "no HIP device" in out.stdout
+
+
+@pytest.mark.gpu
+def test_reference_replanner_through_the_shim(tmp_path):
+    """map_replanner_node.cpp's callbacks (tests/cpp/map_replanner_driver.cpp) on the `simple` map: planner_ (A*) and
+    replan_planner_ (setLPAstar(true)) share one MapUtil; add_cloud.sh / clear_cloud.sh / subtree.sh / replan.sh.  Every
+    replan line equals the oracle's A* and LPA* after the same edits."""
+    from tests import test_lpa as T
+    from oracle import orc
+    exe = build_driver(tmp_path, "map_replanner_driver")
+    sc = T.Scenario()
+    path = str(tmp_path / "simple.bin")
+    sc.grid.tofile(path)
+    dz, dy, dx = sc.grid.shape
+    out = subprocess.run([exe, path, str(dx), str(dy), str(dz)] + [repr(float(o)) for o in sc.origin] + [repr(sc.res)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [json.loads(l[l.index("{"):]) for l in out.stdout.strip().splitlines() if "{" in l]
+    replans = [l for l in lines if "lpa_cost" in l]
+    edits = [l for l in lines if "changed_primitives" in l]
+    assert len(replans) == 4 and len(edits) == 2
+    A, L = T.oracle_pair(sc)
+    start, goal = orc.waypoint(T.START, vel=T.START_V), orc.waypoint(T.GOAL)
+
+    def check(r, start):
+        sa, sl = A.plan(start, goal), L.plan(start, goal)
+        assert sa == sl == orc.OK and r["astar_valid"] and r["lpa_valid"]
+        assert r["astar_cost"] == A.traj_cost and r["lpa_cost"] == L.traj_cost == A.traj_cost
+        assert r["astar_closed"] == A.num_closed() and r["astar_expanded"] == len(A.expanded()[0])
+        assert r["lpa_expanded"] == L.lpa_iterations() and r["lpa_closed"] == L.num_closed()
+        n = L.num_nodes()
+        assert r["lpa_open"] == sum(1 for i in range(n) if L.node_opened(i) and not L.node(i)[3])
+        assert r["n_prim"] == L.traj()["n"] and r["total_time"] == float(L.traj()["n"])
+
+    check(replans[0], start)
+    new_obs = sc.add((12.55, 9.55, 0.025), (12.55, 11.05, 0.025))
+    for P in (A, L):
+        P.set_map(sc.grid, sc.origin, sc.res)
+    assert edits[0]["new_obs_cells"] == len(new_obs) and edits[0]["changed_primitives"] == L.update_blocked(new_obs) > 0
+    check(replans[1], start)
+    assert replans[1]["lpa_expanded"] < replans[1]["astar_expanded"]
+    cl = sc.clear((12.75, 9.55, 0.025), (12.65, 11.95, 0.025))
+    for P in (A, L):
+        P.set_map(sc.grid, sc.origin, sc.res)
+    assert edits[1]["cleared_cells"] == len(cl) and edits[1]["changed_primitives"] == L.update_cleared(cl)
+    check(replans[2], start)
+    w1 = L.traj()["wps"][1]
+    L.sub_state_space(1)
+    check(replans[3], orc.waypoint(tuple(w1.pos), vel=tuple(w1.vel)))
+
+
 def test_shim_refuses_cost_changing_requests(tmp_path):
     """Search-region / potential-field setters exist on the shim's MapPlanner and make plan() refuse (they would change the
-    plan); setLPAstar(true) only announces that every plan() is a fresh A*.  plan() fails before it reaches the device."""
+    plan).  plan() fails before it reaches the device."""
     exe = str(tmp_path / "shim_refusals")
     subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mpl_shim"),
                            "-o", exe, os.path.join(ROOT, "tests", "cpp", "shim_refusals.cpp"), os.path.join(LIBDIR, "libmplx.so"), "-Wl,-rpath," + LIBDIR])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "planned 0" in out.stdout
-    assert "fresh A*" in out.stdout and out.stdout.count("plan() will fail") == 4 and "plan() refused" in out.stdout
+    assert out.stdout.count("plan() will fail") == 4 and "plan() refused" in out.stdout
 
 
 REF_POLY = "/root/reference/mpl_external_planner/include"
