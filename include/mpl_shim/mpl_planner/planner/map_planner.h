@@ -6,8 +6,9 @@
  * prints a diagnostic when the start is occupied or no trajectory is found, results are returned by
  * value.  setLPAstar(true): plan() repairs and re-uses a device-resident state space of this planner's own
  * (mplx_lpa_*), updateBlockedNodes / updateClearedNodes / getSubStateSpace / initialized as map_replanner_node.cpp uses
- * them.  Not covered by this back-end: potential fields, yaw -- each of them fails loudly instead of silently planning
- * something else.
+ * them.  Search region and potential-field cost (setSearchRegion / updatePotentialMap ...) as distance_map_planner_node.cpp
+ * uses them.  Not covered by this back-end: yaw, a non-zero gradient weight -- they fail loudly instead of silently
+ * planning something else.
  */
 #ifndef MPLX_SHIM_MAP_PLANNER_H
 #define MPLX_SHIM_MAP_PLANNER_H
@@ -16,6 +17,8 @@
 #include <mpl_planner/common/planner_base.h>
 
 #include <algorithm>
+#include <array>
+#include <cstdint>
 
 namespace MPL {
 
@@ -110,10 +113,11 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     traj_ = Trajectory<Dim>();
     traj_cost_ = std::numeric_limits<decimal_t>::infinity();
     if (this->unsupported_ || start.use_yaw || goal.use_yaw || start.enable_t) {  // never a silently different search
-      printf(ANSI_COLOR_RED "[MapPlanner] plan() refused: yaw (use_yaw / setYawmax / 4-component inputs), time-keyed states, search regions and potential-field cost are not supported by the mplx back-end\n" ANSI_COLOR_RESET);
+      printf(ANSI_COLOR_RED "[MapPlanner] plan() refused: yaw (use_yaw states / 4-component inputs), time-keyed states and a non-zero gradient weight are not supported by the mplx back-end\n" ANSI_COLOR_RESET);
       return false;
     }
     mplx_ctx *ctx = map_util_->ctx();
+    if (!apply_aux()) return false;
     mplx_set_record(ctx, record_cap_);  // expansion order for getExpandedNodes()
     control_ = (Control::Control)((int32_t)start.control & 15);
     if (!send_config(control_)) return false;
@@ -172,17 +176,55 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     return ps;
   }
   void setExpandedRecord(uint32_t cap) { record_cap_ = cap; }
-  /// Search-region and potential-field cost (distance_map_planner_node.cpp:185-193,218-231) change the cost function,
-  /// i.e. the plan: not implemented by the mplx back-end, so a request makes plan() fail instead of planning without it.
-  void setSearchRadius(const Vecf<Dim> &) { refuse("setSearchRadius"); }
-  void setSearchRegion(const vec_Vecf<Dim> &, bool = false) { refuse("setSearchRegion"); }
-  void setPotentialRadius(const Vecf<Dim> &) { refuse("setPotentialRadius"); }
-  void setPotentialMapRange(const Vecf<Dim> &) { refuse("setPotentialMapRange"); }
-  void setPotentialWeight(decimal_t) { refuse("setPotentialWeight"); }
-  void setGradientWeight(decimal_t) { refuse("setGradientWeight"); }
-  void updatePotentialMap(const Vecf<Dim> &) { refuse("updatePotentialMap"); }
-  vec_Vec3f getPotentialCloud(decimal_t = 1.0) { refuse("getPotentialCloud"); return vec_Vec3f(); }
-  vec_Vecf<Dim> getSearchRegion() { refuse("getSearchRegion"); return vec_Vecf<Dim>(); }
+  /// Search-region and potential-field cost (distance_map_planner_node.cpp:185-193,199,218-224,231).  The auxiliary map
+  /// (potential 0..100 per voxel, voxels outside the search region) lives on the MapUtil's device context; plan() makes
+  /// sure the one on the context is this planner's (two planners may share a MapUtil) -- see mplx.h.  Upstream's
+  /// implementation is un-vendored: semantics P1-P3 of DESIGN.md.
+  void setSearchRadius(const Vecf<Dim> &r) { search_radius_ = v3(r); }
+  void setSearchRegion(const vec_Vecf<Dim> &path, bool dense = false) {
+    region_pts_.clear();
+    for (const auto &p : path) { const std::array<double, 3> q = v3(p); region_pts_.insert(region_pts_.end(), q.begin(), q.end()); }
+    region_dense_ = dense;
+    has_region_ = !path.empty();
+    aux_dirty_ = true;
+  }
+  void setPotentialRadius(const Vecf<Dim> &r) { pot_radius_ = v3(r); }
+  void setPotentialMapRange(const Vecf<Dim> &r) { pot_range_ = v3(r); }
+  void setPotentialWeight(decimal_t w) { pot_weight_ = w; aux_dirty_ = true; }
+  void setGradientWeight(decimal_t w) {
+    if (w != 0) refuse("setGradientWeight(!= 0)");  // only 0, the value the reference passes, is supported
+  }
+  void updatePotentialMap(const Vecf<Dim> &pos) {
+    pot_pos_ = v3(pos);
+    has_pot_ = true;
+    aux_dirty_ = true;
+    apply_aux();
+  }
+  vec_Vec3f getPotentialCloud(decimal_t h_max = 1.0) {
+    vec_Vec3f out;
+    if (!apply_aux()) return out;
+    uint64_t n = 0;
+    if (mplx_aux_cloud(map_util_->ctx(), 0, nullptr, nullptr, 0, &n) != MPLX_OK || !n) return out;
+    std::vector<double> pts(3 * (size_t)n);
+    std::vector<int8_t> vals((size_t)n);
+    if (mplx_aux_cloud(map_util_->ctx(), 0, pts.data(), vals.data(), n, &n) != MPLX_OK) return out;
+    for (uint64_t k = 0; k < n; k++) out.push_back(Vec3f(pts[3 * k], pts[3 * k + 1], Dim == 2 ? h_max * (double)vals[(size_t)k] / 100.0 : pts[3 * k + 2]));
+    return out;
+  }
+  vec_Vecf<Dim> getSearchRegion() {
+    vec_Vecf<Dim> out;
+    if (!apply_aux()) return out;
+    uint64_t n = 0;
+    if (mplx_aux_cloud(map_util_->ctx(), 1, nullptr, nullptr, 0, &n) != MPLX_OK || !n) return out;
+    std::vector<double> pts(3 * (size_t)n);
+    if (mplx_aux_cloud(map_util_->ctx(), 1, pts.data(), nullptr, n, &n) != MPLX_OK) return out;
+    for (uint64_t k = 0; k < n; k++) {
+      Vecf<Dim> p;
+      for (int i = 0; i < Dim; i++) p(i) = pts[3 * k + i];
+      out.push_back(p);
+    }
+    return out;
+  }
   /// nodes that are linked into the graph, i.e. have at least one predecessor record (map_replanner_node.cpp:94)
   /// [UNVERIFIED: the upstream body is not vendored; node-id order here, hash-map order upstream]
   vec_Vecf<Dim> getLinkedNodes() const {
@@ -354,6 +396,37 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     }
     return changed;
   }
+  static std::array<double, 3> v3(const Vecf<Dim> &v) {
+    std::array<double, 3> o = {0.0, 0.0, 0.0};
+    for (int i = 0; i < Dim; i++) o[(size_t)i] = v(i);
+    return o;
+  }
+  /// make the auxiliary map on the (possibly shared) context this planner's: region first, then the potential
+  bool apply_aux() {
+    if (!map_util_) return true;
+    mplx_ctx *ctx = map_util_->ctx();
+    uint64_t token = 0;
+    mplx_aux_token(ctx, 0, 0, &token);
+    const uint64_t me = (uint64_t)(uintptr_t)this;
+    if (!has_region_ && !has_pot_) {
+      if (token != 0 && token != me) mplx_potential_clear(ctx);  // another planner's cost terms must not leak into this plan
+      return true;
+    }
+    if (token == me && !aux_dirty_) return true;
+    if (token != me) mplx_potential_clear(ctx);
+    int rc = MPLX_OK;
+    if (has_region_) rc = mplx_search_region_set(ctx, (int)(region_pts_.size() / 3), region_pts_.data(), search_radius_.data(), region_dense_ ? 1 : 0);
+    if (rc == MPLX_OK) rc = mplx_potential_weights(ctx, pot_weight_, 0.0);
+    if (rc == MPLX_OK && has_pot_) rc = mplx_potential_update(ctx, pot_radius_.data(), pot_pos_.data(), pot_range_.data(), 1);
+    if (rc != MPLX_OK) { printf(ANSI_COLOR_RED "[MapPlanner] %s\n" ANSI_COLOR_RESET, mplx_last_error(ctx)); return false; }
+    mplx_aux_token(ctx, me, 1, nullptr);
+    aux_dirty_ = false;
+    return true;
+  }
+  std::array<double, 3> search_radius_{{0, 0, 0}}, pot_radius_{{0, 0, 0}}, pot_range_{{0, 0, 0}}, pot_pos_{{0, 0, 0}};
+  std::vector<double> region_pts_;
+  bool region_dense_ = false, has_region_ = false, has_pot_ = false, aux_dirty_ = false;
+  decimal_t pot_weight_ = 0;
   std::shared_ptr<MapUtil<Dim>> map_util_;
   mplx_lpa *lpa_ = nullptr;
   uint64_t cap_[3] = {0, 0, 0};

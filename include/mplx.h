@@ -144,6 +144,31 @@ int mplx_map_raytrace(const mplx_ctx *ctx, const double p1[3], const double p2[3
  * cap 0 to query the size); *n_out = number of voxels of the class. */
 int mplx_map_cloud(mplx_ctx *ctx, int which, double *pts, uint64_t cap, uint64_t *n_out);
 
+/* ---- potential-field cost and search region (MapPlanner::setPotentialRadius / setPotentialWeight / setGradientWeight /
+ *      setPotentialMapRange / updatePotentialMap / setSearchRadius / setSearchRegion / getPotentialCloud / getSearchRegion,
+ *      distance_map_planner_node.cpp:185-193,199,218-224,231).  One auxiliary int8 map per context next to the grid:
+ *      0..100 = potential of the voxel, < 0 = outside the search region.  While it exists, a primitive with a sample
+ *      outside the region is blocked and a free primitive costs J + w dt + potential_weight * (sum of the potential over
+ *      its collision samples); plans run on the one-node kernel.  [Upstream's implementation is un-vendored: semantics
+ *      P1-P3 of DESIGN.md, restated for the tests' CPU checker.] ---- */
+int mplx_potential_weights(mplx_ctx *ctx, double potential_weight, double gradient_weight); /* gradient_weight must be 0 */
+/* updatePotentialMap(pos, range) with setPotentialRadius(radius): every occupied voxel spreads trunc(100 (1 - d)^pow),
+ * d = sqrt(sum_i (n_i res / radius_i)^2) <= 1, to the voxels at offset n (largest value wins; occupied voxels hold
+ * 100); range (may be NULL / 0: whole map): only voxels whose centre lies within pos +- range get a value */
+int mplx_potential_update(mplx_ctx *ctx, const double radius[3], const double pos[3], const double range[3], int32_t pow_);
+/* setSearchRegion(path, dense) with setSearchRadius(radius): the voxels within +-ceil(radius_i / res) of the path's
+ * cells (a sparse path is joined up with rayTrace between consecutive points); n_pts 0 removes the region */
+int mplx_search_region_set(mplx_ctx *ctx, int n_pts, const double *pts, const double radius[3], int dense);
+int mplx_potential_clear(mplx_ctx *ctx);            /* drop the auxiliary map: plain cost, speculative kernels again */
+int mplx_aux_get(mplx_ctx *ctx, int8_t *out);       /* raw copy (all 0 when none) */
+/* Host wrappers that share one context (two planners on one MapUtil) tag the auxiliary map with an id of their own, so
+ * that a planner can tell whether the map on the context is the one it built.  do_set != 0 stores set_value; *current
+ * (may be NULL) receives the stored tag (0: nobody's; mplx_potential_clear resets it). */
+int mplx_aux_token(mplx_ctx *ctx, uint64_t set_value, int32_t do_set, uint64_t *current);
+/* getPotentialCloud (which 0: voxels with 0 < potential < 100, vals = the potential) / getSearchRegion (which 1): voxel
+ * centres, x outermost like getCloud; *n = number of voxels of the class (may exceed cap) */
+int mplx_aux_cloud(mplx_ctx *ctx, int which, double *pts, int8_t *vals, uint64_t cap, uint64_t *n);
+
 /* ---- planner configuration ---- */
 int mplx_planner_config(mplx_ctx *ctx, const mplx_config *cfg);
 /* device pools: number of queries in flight (workgroups) and the TOTAL capacities shared by all

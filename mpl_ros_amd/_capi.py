@@ -58,6 +58,7 @@ EXPORTS = [
     "mplx_grid_create", "mplx_grid_destroy", "mplx_grid_last_error", "mplx_grid_allocate", "mplx_grid_info", "mplx_grid_clear",
     "mplx_grid_add_cloud", "mplx_grid_add_cloud_inflate", "mplx_grid_decay", "mplx_grid_clear_column", "mplx_grid_fill_column",
     "mplx_grid_fill_cell", "mplx_grid_get_map", "mplx_grid_get_cloud", "mplx_grid_to_map",
+    "mplx_potential_weights", "mplx_potential_update", "mplx_search_region_set", "mplx_potential_clear", "mplx_aux_get", "mplx_aux_cloud", "mplx_aux_token",
     "mplx_lpa_create", "mplx_lpa_destroy", "mplx_lpa_last_error", "mplx_lpa_set_capacity", "mplx_lpa_set_record", "mplx_lpa_plan", "mplx_lpa_initialized",
     "mplx_lpa_reset", "mplx_lpa_update_blocked", "mplx_lpa_update_cleared", "mplx_lpa_sub_state_space", "mplx_lpa_traj_len", "mplx_lpa_result_traj",
     "mplx_lpa_counts", "mplx_lpa_result_nodes", "mplx_lpa_result_edges", "mplx_lpa_result_expanded", "mplx_lpa_last_kernel_ms",
@@ -130,6 +131,13 @@ def load():
     L.mplx_plan_epoch.argtypes = [P]
     L.mplx_plan_epoch.restype = C.c_uint64
     U64 = C.POINTER(C.c_uint64)
+    L.mplx_potential_weights.argtypes = [P, C.c_double, C.c_double]
+    L.mplx_potential_update.argtypes = [P, D3, D3, D3, C.c_int32]
+    L.mplx_search_region_set.argtypes = [P, C.c_int, C.c_void_p, D3, C.c_int]
+    L.mplx_potential_clear.argtypes = [P]
+    L.mplx_aux_get.argtypes = [P, C.c_void_p]
+    L.mplx_aux_token.argtypes = [P, C.c_uint64, C.c_int32, U64]
+    L.mplx_aux_cloud.argtypes = [P, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, U64]
     L.mplx_lpa_create.argtypes = [P, C.POINTER(P)]
     L.mplx_lpa_destroy.argtypes = [P]
     L.mplx_lpa_destroy.restype = None

@@ -34,6 +34,9 @@ struct mplx_ctx {
   int8_t *map = nullptr;
   bool own_map = false;
   uint32_t *bricks = nullptr;  // bit-packed occupancy in 8^3 bricks, rebuilt whenever the grid changes
+  int8_t *aux = nullptr;       // potential field / search region (mplx_potential_* / mplx_search_region_set); null: none
+  double pot_weight = 0.0;
+  uint64_t aux_token = 0;      // whose auxiliary map this is (host wrappers sharing the context; 0: nobody's)
   int32_t dim[3] = {0, 0, 0};
   double origin[3] = {0, 0, 0};
   double res = 0;
@@ -168,6 +171,7 @@ extern "C" void mplx_ctx_destroy(mplx_ctx *c) {
   free_batch(c);
   if (c->own_map) (void)hipFree(c->map);
   (void)hipFree(c->bricks);
+  (void)hipFree(c->aux);
   (void)hipFree(c->dU);
   (void)hipFree(c->dUcost);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -195,6 +199,10 @@ extern "C" int mplx_set_stream(mplx_ctx *c, void *s) {
 static int build_bricks(mplx_ctx *c);
 static int set_map_meta(mplx_ctx *c, const int32_t dim[3], const double origin[3], double res) {
   if (!dim || !origin || dim[0] <= 0 || dim[1] <= 0 || dim[2] <= 0 || !(res > 0)) return fail(c, MPLX_ERR_ARG, "bad map geometry");
+  if (c->aux && (dim[0] != c->dim[0] || dim[1] != c->dim[1] || dim[2] != c->dim[2])) {  // another grid: the auxiliary map goes
+    (void)hipFree(c->aux);
+    c->aux = nullptr;
+  }
   for (int i = 0; i < 3; i++) {
     c->dim[i] = dim[i];
     c->origin[i] = origin[i];
@@ -272,6 +280,7 @@ static MapDev map_dev(const mplx_ctx *c) {
   MapDev m;
   m.data = c->map;
   m.bricks = c->bricks;
+  m.aux = c->aux;
   m.nb[0] = (c->dim[0] + 7) / 8; m.nb[1] = (c->dim[1] + 7) / 8; m.nb[2] = (c->dim[2] + 7) / 8;
   for (int i = 0; i < 3; i++) {
     m.dim[i] = c->dim[i];
@@ -425,6 +434,191 @@ extern "C" int mplx_map_query(mplx_ctx *c, int n, const double *pts, int32_t *ce
   return MPLX_OK;
 }
 
+// ------------------------------------------------------------------ potential field / search region
+// MapPlanner::setPotentialRadius / setPotentialWeight / setGradientWeight / setPotentialMapRange / updatePotentialMap /
+// setSearchRadius / setSearchRegion / getPotentialCloud / getSearchRegion (distance_map_planner_node.cpp:185-193,199,
+// 218-224,231).  The implementation upstream is un-vendored; the semantics P1-P3 restated for the tests' CPU checker
+// are the ones built here.
+static int aux_ensure(mplx_ctx *c) {
+  if (c->aux) return MPLX_OK;
+  const size_t n = (size_t)c->dim[0] * c->dim[1] * c->dim[2];
+  HIPCHK(c, hipMalloc((void **)&c->aux, n));
+  HIPCHK(c, hipMemsetAsync(c->aux, 0, n, c->stream));
+  return MPLX_OK;
+}
+extern "C" int mplx_potential_weights(mplx_ctx *c, double potential_weight, double gradient_weight) {
+  if (!c) return MPLX_ERR_ARG;
+  if (gradient_weight != 0.0) return fail(c, MPLX_ERR_ARG, "setGradientWeight(%g): only 0 (the value the reference passes) is supported", gradient_weight);
+  c->pot_weight = potential_weight;
+  return MPLX_OK;
+}
+extern "C" int mplx_aux_token(mplx_ctx *c, uint64_t set_value, int32_t do_set, uint64_t *current) {
+  if (!c) return MPLX_ERR_ARG;
+  if (do_set) c->aux_token = set_value;
+  if (current) *current = c->aux_token;
+  return MPLX_OK;
+}
+extern "C" int mplx_potential_clear(mplx_ctx *c) {
+  if (!c) return MPLX_ERR_ARG;
+  c->aux_token = 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(c->aux);
+  c->aux = nullptr;
+  c->map_epoch++;
+  return MPLX_OK;
+}
+extern "C" int mplx_potential_update(mplx_ctx *c, const double radius[3], const double pos[3], const double range[3], int32_t pw) {
+  if (!c || !c->map || !radius || !pos) return fail(c, MPLX_ERR_ARG, "bad argument / no map");
+  HIPCHK(c, hipSetDevice(c->device));
+  int r = aux_ensure(c);
+  if (r) return r;
+  if (pw < 1) pw = 1;
+  // the mask H(n) = trunc(100 (1 - d)^pow), d = sqrt(sum (n_i res / radius_i)^2) <= 1
+  int rn[3];
+  for (int i = 0; i < 3; i++) rn[i] = radius[i] > 0 ? (int)ceil(radius[i] / c->res) : 0;
+  std::vector<int32_t> off;
+  std::vector<int8_t> val;
+  for (int nx = -rn[0]; nx <= rn[0]; nx++)
+    for (int ny = -rn[1]; ny <= rn[1]; ny++)
+      for (int nz = -rn[2]; nz <= rn[2]; nz++) {
+        const int nn[3] = {nx, ny, nz};
+        double s = 0.0;
+        for (int i = 0; i < 3; i++)
+          if (radius[i] > 0) {
+            const double q = (double)nn[i] * c->res / radius[i];
+            s += q * q;
+          }
+        const double d = sqrt(s);
+        if (d > 1.0) continue;
+        const double v = 1.0 - d;
+        double rr = v;
+        for (int k = 1; k < pw; k++) rr = rr * v;
+        const int h = (int)(100.0 * rr);
+        if (h <= 0) continue;
+        off.push_back(nx); off.push_back(ny); off.push_back(nz);
+        val.push_back((int8_t)(h > 100 ? 100 : h));
+      }
+  PotArgs a{};
+  for (int i = 0; i < 3; i++) { a.pos[i] = pos[i]; a.range[i] = range ? range[i] : 0.0; }
+  a.n_mask = (int32_t)val.size();
+  int32_t *doff = nullptr;
+  int8_t *dval = nullptr;
+  DevBufs bufs;
+  HIPCHK(c, bufs.alloc(&doff, sizeof(int32_t) * std::max<size_t>(off.size(), 3)));
+  HIPCHK(c, bufs.alloc(&dval, std::max<size_t>(val.size(), 1)));
+  if (!val.empty()) {
+    HIPCHK(c, hipMemcpyAsync(doff, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dval, val.data(), val.size(), hipMemcpyHostToDevice, c->stream));
+  }
+  hipLaunchKernelGGL(pot_update_kernel, dim3(4096), dim3(256), 0, c->stream, map_dev(c), c->aux, a, doff, dval);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->map_epoch++;
+  return MPLX_OK;
+}
+extern "C" int mplx_search_region_set(mplx_ctx *c, int n_pts, const double *pts, const double radius[3], int dense) {
+  if (!c || !c->map || n_pts < 0 || (n_pts > 0 && (!pts || !radius))) return fail(c, MPLX_ERR_ARG, "bad argument / no map");
+  HIPCHK(c, hipSetDevice(c->device));
+  int r = aux_ensure(c);
+  if (r) return r;
+  const size_t n = (size_t)c->dim[0] * c->dim[1] * c->dim[2];
+  c->map_epoch++;
+  if (n_pts == 0) {
+    hipLaunchKernelGGL(region_apply_kernel, dim3(4096), dim3(256), 0, c->stream, n, (const int8_t *)nullptr, c->aux);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MPLX_OK;
+  }
+  // seed cells: the path's own cells, joined up with rayTrace when the path is sparse (geometry only: host code, like mplx_map_raytrace)
+  std::vector<int32_t> seeds;
+  for (int k = 0; k < n_pts; k++) {
+    int32_t pn[3];
+    bool outside = false;
+    for (int i = 0; i < 3; i++) {
+      pn[i] = float_to_cell(pts[3 * k + i], c->origin[i], c->res);
+      if (pn[i] < 0 || pn[i] >= c->dim[i]) outside = true;
+    }
+    if (!outside) seeds.insert(seeds.end(), pn, pn + 3);
+    if (!dense && k + 1 < n_pts) {
+      int cnt = 0;
+      mplx_map_raytrace(c, pts + 3 * k, pts + 3 * (k + 1), nullptr, 0, &cnt);
+      if (cnt > 65535) cnt = 65535;
+      const size_t at = seeds.size();
+      seeds.resize(at + 3 * (size_t)cnt);
+      int got = 0;
+      if (cnt) mplx_map_raytrace(c, pts + 3 * k, pts + 3 * (k + 1), seeds.data() + at, cnt, &got);
+    }
+  }
+  int rn[3];
+  for (int i = 0; i < 3; i++) rn[i] = radius[i] > 0 ? (int)ceil(radius[i] / c->res) : 0;
+  int8_t *in = nullptr;
+  int32_t *dseeds = nullptr;
+  DevBufs bufs;
+  HIPCHK(c, bufs.alloc(&in, n));
+  HIPCHK(c, bufs.alloc(&dseeds, sizeof(int32_t) * std::max<size_t>(seeds.size(), 3)));
+  HIPCHK(c, hipMemsetAsync(in, 0, n, c->stream));
+  const int n_seeds = (int)(seeds.size() / 3);
+  if (n_seeds) {
+    HIPCHK(c, hipMemcpyAsync(dseeds, seeds.data(), sizeof(int32_t) * seeds.size(), hipMemcpyHostToDevice, c->stream));
+    const long long total = (long long)(2 * rn[0] + 1) * (2 * rn[1] + 1) * (2 * rn[2] + 1) * n_seeds;
+    hipLaunchKernelGGL(region_mark_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, c->dim[0], c->dim[1], c->dim[2], n_seeds, dseeds, rn[0], rn[1], rn[2], in);
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(region_apply_kernel, dim3(4096), dim3(256), 0, c->stream, n, (const int8_t *)in, c->aux);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+extern "C" int mplx_aux_get(mplx_ctx *c, int8_t *out) {
+  if (!c || !c->map || !out) return fail(c, MPLX_ERR_ARG, "no map");
+  const size_t n = (size_t)c->dim[0] * c->dim[1] * c->dim[2];
+  if (!c->aux) { memset(out, 0, n); return MPLX_OK; }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(out, c->aux, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MPLX_OK;
+}
+// which 0: voxels with a potential strictly between 0 and 100 (getPotentialCloud); 1: voxels of the search region
+// (getSearchRegion).  pts: voxel centres, x outermost like getCloud; vals: the potential of each (may be NULL).
+extern "C" int mplx_aux_cloud(mplx_ctx *c, int which, double *pts, int8_t *vals, uint64_t cap, uint64_t *n_out) {
+  if (!c || !c->map || which < 0 || which > 1 || !n_out || (cap > 0 && !pts)) return fail(c, MPLX_ERR_ARG, "bad argument");
+  *n_out = 0;
+  if (!c->aux) return MPLX_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  MapDev m = map_dev(c);
+  m.data = c->aux;  // the cloud kernels read `data`
+  const int w = which == 0 ? 3 : 4;
+  const int ncol = c->dim[0] * c->dim[1];
+  uint32_t *counts = nullptr;
+  unsigned long long *offs = nullptr, *dtotal = nullptr;
+  double *dpts = nullptr;
+  int8_t *dvals = nullptr;
+  DevBufs bufs;
+  HIPCHK(c, bufs.alloc(&counts, sizeof(uint32_t) * (size_t)ncol));
+  HIPCHK(c, bufs.alloc(&offs, sizeof(unsigned long long) * (size_t)ncol));
+  HIPCHK(c, bufs.alloc(&dtotal, sizeof(unsigned long long)));
+  const int grid = (ncol + 255) / 256 < 4096 ? (ncol + 255) / 256 : 4096;
+  hipLaunchKernelGGL(cloud_count_kernel, dim3(grid), dim3(256), 0, c->stream, m, w, counts);
+  hipLaunchKernelGGL(cloud_scan_kernel, dim3(1), dim3(1024), 0, c->stream, counts, offs, ncol, dtotal);
+  HIPCHK(c, hipGetLastError());
+  unsigned long long total = 0;
+  HIPCHK(c, hipMemcpyAsync(&total, dtotal, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_out = total;
+  const uint64_t nw = total < cap ? total : cap;
+  if (nw > 0) {
+    HIPCHK(c, bufs.alloc(&dpts, sizeof(double) * 3 * nw));
+    HIPCHK(c, bufs.alloc(&dvals, nw));
+    hipLaunchKernelGGL(cloud_write_kernel, dim3(grid), dim3(256), 0, c->stream, m, w, offs, (unsigned long long)nw, dpts, dvals);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(pts, dpts, sizeof(double) * 3 * nw, hipMemcpyDeviceToHost, c->stream));
+    if (vals) HIPCHK(c, hipMemcpyAsync(vals, dvals, nw, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return MPLX_OK;
+}
+
 // ------------------------------------------------------------------ configuration
 static bool control_ok(int c) { return c == CTRL_VEL || c == CTRL_ACC || c == CTRL_JRK || c == CTRL_SNP; }
 
@@ -532,6 +726,7 @@ static void fill_params(const mplx_ctx *c, SearchParams &P) {
   P.U = c->dU;
   P.ucost = c->dUcost;
   P.map = map_dev(c);
+  P.pot_weight = c->pot_weight;
   P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt * 8.0 : 1.0);
 }
 
@@ -816,7 +1011,8 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   HIPCHK(c, hipMemsetAsync(P.chunk_next, 0, 4 * sizeof(uint32_t), c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), c->stream));
-  const bool spec = c->speculation < 0 || c->speculation > 1;
+  // (the potential-field / search-region cost is read by the one-node kernels only)
+  const bool spec = (c->speculation < 0 || c->speculation > 1) && !c->aux;
   // Helper workgroups: a workgroup with no query (left) to lead expands the front of a running leader's OPEN list ahead
   // of time.  The launch holds one workgroup per compute unit at most, so all of them are resident together: for a
   // batch smaller than the machine the extra workgroups (blockIdx.x >= help_lead) help from the start; in a large
@@ -897,7 +1093,7 @@ extern "C" uint64_t mplx_plan_epoch(const mplx_ctx *c) { return c ? c->plan_epoc
 extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
   if (!c || !c->have_cfg) return "";
   const int control = c->cfg.control, n_u = c->cfg.n_u;
-  const bool spec = (c->speculation < 0 || c->speculation > 1) && (control == CTRL_ACC || control == CTRL_JRK) && n_u <= 128;
+  const bool spec = (c->speculation < 0 || c->speculation > 1) && (control == CTRL_ACC || control == CTRL_JRK) && n_u <= 128 && !c->aux;
   static thread_local char buf[64];
   const char *cn = control == CTRL_VEL ? "VEL" : control == CTRL_ACC ? "ACC" : control == CTRL_JRK ? "JRK" : "SNP";
   if (!spec) {
@@ -1023,7 +1219,7 @@ extern "C" int mplx_result_edges(mplx_ctx *c, int32_t *child, int32_t *parent, i
       if (w < cap) {
         if (child) child[w] = (int32_t)i;
         if (parent) parent[w] = (int32_t)edges[e].parent;
-        if (action) action[w] = (int32_t)edges[e].action;
+        if (action) action[w] = (int32_t)(edges[e].action & EDGE_ACTION_MASK);
       }
       w++;
     }

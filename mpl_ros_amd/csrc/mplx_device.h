@@ -25,6 +25,10 @@ constexpr uint64_t TBL_EMPTY = 0xFFFFFFFFFFFFFFFFull;
 constexpr uint32_t CLAIM_BASE = 0xFFFF0000u;  // table id field >= CLAIM_BASE: claimed in this expansion
 constexpr uint32_t FLAG_CLOSED = 1u, FLAG_OPENED = 2u;
 constexpr int MAX_TRAJ = 1024;
+// predecessor record: action field = control input (low 12 bits) | potential sum of the primitive's samples << 12
+// (bit 31 is the LPA* blocked flag): the edge cost is ucost[action] + pot_weight * sum, recomputed wherever it is needed
+constexpr uint32_t EDGE_ACTION_MASK = 0xFFFu;
+constexpr int EDGE_POT_SHIFT = 12;
 
 constexpr int NODE_CH_LOG = 15, EDGE_CH_LOG = 16, OPEN_CH_LOG = 15;
 constexpr int MAX_NODE_CH = 1024, MAX_EDGE_CH = 2048, MAX_OPEN_CH = 1024;  // per query: 33M nodes, 134M edges, 33M log
@@ -38,6 +42,8 @@ struct MapDev {
   const uint32_t *bricks;  // occupancy (value > 0) bit-packed in 8x8x8 bricks of 64 B: brick (bx,by,bz) at
                            // bx + nb0*(by + nb1*bz), bit (x&7) + 8*(y&7) + 64*(z&7); 1/8 of the bytes, and the
                            // <= 1-voxel steps of a primitive's samples mostly stay inside one 64 B line
+  const int8_t *aux;       // potential field / search region (null: none): 0..100 potential of the voxel, < 0 outside the
+                           // search region (a sample there blocks the primitive); read by the one-node kernels only
   int32_t dim[3];
   int32_t nb[3];           // bricks per axis
   double origin[3];
@@ -110,6 +116,7 @@ struct SearchParams {
   const double *U;      // n_u x 3
   const double *ucost;  // n_u: J(control) + w dt
   MapDev map;
+  double pot_weight;       // potential_weight: a free primitive costs ucost + pot_weight * (sum of the potential over its samples)
   double bucket_width;
   // shared pools
   char *node_pool, *edge_pool, *open_pool;

@@ -276,6 +276,7 @@ struct LaneSucc {
   bool valid;    // successor emitted
   bool blocked;  // is_free(pr) failed -> cost inf
   uint32_t reads;
+  uint32_t pot;  // (POT) sum of the potential over the primitive's samples
 };
 
 // One expansion unit = UL consecutive threads expanding one node (unit index ku, lane index lu inside
@@ -288,9 +289,20 @@ struct NoHook {
 // before the voxel sampling: the caller can start memory traffic that depends on the key only.
 // CACHE: units whose S.hc_row is non-zero take validity / blocked flags from the look-ahead cache entry
 // (S.hc_valid, S.hc_blocked) and skip validate_primitive and the voxel sampling altogether.
-template <int UL, int BLOCK, int CONTROL, bool CACHE = false, class SM, class Hook = NoHook>
+// POT: the auxiliary map (potential field / search region, MapDev::aux) is read next to the occupancy when it exists:
+// a sample outside the search region blocks the primitive, the potential of every sample is summed into L.pot.  Only
+// the one-unit kernels (UL == BLOCK) pass it; the speculative kernels are compiled without.
+template <int UL, int BLOCK, int CONTROL, bool CACHE = false, bool POT = false, class SM, class Hook = NoHook>
 __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int tid, bool live_unit, LaneSucc &L, Hook after_phase1 = Hook()) {
   constexpr int NQ = nq_c(CONTROL);
+  static_assert(!POT || UL == BLOCK, "the potential sum lives in the one-unit kernels' scratch");
+  const int8_t *__restrict__ aux = nullptr;
+  uint32_t *pots = nullptr;  // per-primitive potential sums: the commit's duplicate-key set is idle during the expansion
+  if constexpr (POT) {
+    aux = P.map.aux;
+    pots = (uint32_t *)S.dupset;
+    if (aux) pots[tid] = 0;
+  }
   const int ku = tid / UL, lu = tid % UL;
   const double T = P.dt;
   bool cached = false;
@@ -301,6 +313,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
   L.valid = false;
   L.blocked = false;
   L.reads = 0;
+  L.pot = 0;
   uint32_t my_cnt = 0, my_pairs = 0;
   if (live_unit && lu < P.n_u) {
     double c[3][6];
@@ -373,6 +386,13 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
       const uint32_t brick = (uint32_t)(c[0] >> 3) + (uint32_t)P.map.nb[0] * ((uint32_t)(c[1] >> 3) + (uint32_t)P.map.nb[1] * (uint32_t)(c[2] >> 3));
       const uint32_t bit = (uint32_t)(c[0] & 7) | ((uint32_t)(c[1] & 7) << 3) | ((uint32_t)(c[2] & 7) << 6);
       node_code = (P.map.bricks[brick * 16u + (bit >> 5)] >> (bit & 31u)) & 1u;
+      if constexpr (POT) {
+        if (aux && !node_code) {
+          const int av = aux[(size_t)c[0] + (size_t)P.map.dim[0] * c[1] + (size_t)P.map.dim[0] * P.map.dim[1] * c[2]];
+          if (av < 0) node_code = 1;                     // the node's own cell is outside the search region (after one read)
+          else node_code = (uint32_t)av << 8;            // its potential counts for every primitive (sample 0)
+        }
+      }
     } else {
       node_code = 2;
     }
@@ -455,6 +475,13 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
         const uint32_t brick = (uint32_t)(sx >> 3) + (uint32_t)nb0 * ((uint32_t)(sy >> 3) + (uint32_t)nb1 * (uint32_t)(sz >> 3));
         const uint32_t bit = (uint32_t)(sx & 7) | ((uint32_t)(sy & 7) << 3) | ((uint32_t)(sz & 7) << 6);
         vv[r] = (int32_t)((bricks[brick * 16u + (bit >> 5)] >> (bit & 31u)) & 1u);
+        if constexpr (POT) {
+          if (aux) {  // (clamped address; masked below when the sample is outside)
+            const int av = aux[(size_t)sx + (size_t)dx * sy + (size_t)dx * dy * sz];
+            if (av < 0) vv[r] = 1;                                  // outside the search region: blocked, like an occupied voxel
+            else if (!vv[r]) vv[r] = -av;                           // free: carry the potential (as a non-positive number)
+          }
+        }
       }
 #pragma unroll
       for (int r = 0; r < UNR; r++) {
@@ -465,6 +492,8 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
             atomicMin(&S.blk[pc], i << 1);
           else if (vv[r] > 0)
             atomicMin(&S.blk[pc], (i << 1) | 1u);
+          else if (POT && vv[r] < 0)
+            atomicAdd(&pots[pc], (uint32_t)(-vv[r]));
         }
       }
     }
@@ -491,6 +520,13 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
         atomicMin(&S.blk[pc], i << 1);
       else if (map[(size_t)cell[0] + (size_t)dx * cell[1] + (size_t)dx * dy * cell[2]] > 0)
         atomicMin(&S.blk[pc], (i << 1) | 1u);
+      else if constexpr (POT) {
+        if (aux) {
+          const int av = aux[(size_t)cell[0] + (size_t)dx * cell[1] + (size_t)dx * dy * cell[2]];
+          if (av < 0) atomicMin(&S.blk[pc], (i << 1) | 1u);
+          else if (av > 0) atomicAdd(&pots[pc], (uint32_t)av);
+        }
+      }
     }
   }
 #ifdef MPLX_FINE_TIMERS
@@ -500,10 +536,13 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
   unit_sync<UL>();
   if (L.valid && !cached) {
     uint32_t code = S.blk[tid];
-    const uint32_t nb = S.node_blk[ku];
+    const uint32_t nb = S.node_blk[ku] & 0xFFu;
     if (nb) code = nb == 2u ? 0u : 1u;  // blocked at sample 0 (outside: no voxel read)
     L.blocked = code != 0xFFFFFFFFu;
     L.reads = L.blocked ? (code >> 1) + (code & 1u) : my_cnt;
+    if constexpr (POT) {
+      if (aux && !L.blocked) L.pot = pots[tid] + (S.node_blk[ku] >> 8);
+    }
   }
 }
 
@@ -536,7 +575,7 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const Sta
     }
     __syncthreads();
     LaneSucc L;
-    expand_unit<BLOCK, BLOCK, CONTROL>(P, S, tid, true, L);
+    expand_unit<BLOCK, BLOCK, CONTROL, false, true>(P, S, tid, true, L);
     if (tid < P.n_u) {
       SuccOut &o = out[(size_t)k * P.n_u + tid];
       for (int ax = 0; ax < 3; ax++) {
@@ -549,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const Sta
       o.t = S.cur[0][12] + P.dt;
       o.control = P.control;
       o.enable_t = 0;
-      o.cost = L.valid ? (L.blocked ? INFINITY : P.ucost[tid]) : 0.0;
+      o.cost = L.valid ? (L.blocked ? INFINITY : (P.map.aux ? P.ucost[tid] + P.pot_weight * (double)L.pot : P.ucost[tid])) : 0.0;
       o.action = tid;
       o.valid = L.valid ? 1 : 0;
 #pragma unroll
@@ -926,7 +965,8 @@ __device__ __forceinline__ void open_push(const QView<BLOCK, CONTROL, SM> &Q, ui
 // NK: key ints (key_len_c(CONTROL), + 1 when the state's time is part of the key); lane_cost: cost of this lane's
 // primitive (the voxel environment's cost depends on the control input only: P.ucost[tid]).
 template <int BLOCK, int CONTROL, class SM, int NK = key_len_c(CONTROL)>
-__device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64, double lane_cost) {
+__device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64, double lane_cost,
+                                                uint32_t action_tag) {
   using V = QView<BLOCK, CONTROL, SM>;
   const SearchParams &P = Q.P;
   SM &S = Q.S;
@@ -1013,7 +1053,7 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
     EdgeRec *e = Q.edge(base_edges + (sc >> 12));
     e->parent = S.cur_id;
     e->next = old_pred;
-    e->action = (uint32_t)tid;
+    e->action = action_tag;  // control input | potential sum << EDGE_POT_SHIFT
     V::pred(rec) = base_edges + (sc >> 12);
     tg = S.cur_g + lane_cost;
     improved = tg < old_g;
@@ -1231,7 +1271,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         }
         LaneSucc L;
         MPLX_TIC(tx);
-        expand_unit<BLOCK, BLOCK, CONTROL>(P, S, tid, true, L);
+        expand_unit<BLOCK, BLOCK, CONTROL, false, true>(P, S, tid, true, L);
         MPLX_TOC(S, 1, tx);
         MPLX_TIC(tc);
         const bool act = L.valid && !L.blocked;
@@ -1264,11 +1304,14 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
           }
         }
         __syncthreads();
+        // edge cost: J + w dt of the control input, plus the potential term when a potential map exists
+        const double lane_cost = act ? (P.map.aux ? P.ucost[tid] + P.pot_weight * (double)L.pot : P.ucost[tid]) : 0.0;
+        const uint32_t action_tag = (uint32_t)tid | (L.pot << EDGE_POT_SHIFT);
         if (!S.flag) {
-          commit_parallel(Q, tid, q, act, L, h64, act ? P.ucost[tid] : 0.0);
+          commit_parallel(Q, tid, q, act, L, h64, lane_cost, action_tag);
         } else {
           // rare: two control inputs reach the same key -> commit one successor at a time, in order
-          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel(Q, tid, q, act && tid == i, L, h64, act ? P.ucost[tid] : 0.0);
+          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel(Q, tid, q, act && tid == i, L, h64, lane_cost, action_tag);
         }
         __syncthreads();
         MPLX_TOC(S, 2, tc);
@@ -1312,12 +1355,13 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
           for (uint32_t e = V::pred(Q.node(node)); e != NIL; e = Q.edge(e)->next) {
             const EdgeRec er = *Q.edge(e);
             double gp = V::g(Q.node(er.parent));
-            double rhs = gp + P.ucost[er.action];
+            const double ec = P.map.aux ? P.ucost[er.action & EDGE_ACTION_MASK] + P.pot_weight * (double)(er.action >> EDGE_POT_SHIFT) : P.ucost[er.action & EDGE_ACTION_MASK];
+            double rhs = gp + ec;
             if (rhs < min_rhs || (rhs == min_rhs && gp >= min_g)) { min_rhs = rhs; min_g = gp; best = e; }
           }
           if (best == NIL) { ok = false; break; }
           if (len >= MAX_TRAJ) { too_long = true; break; }
-          ta[len] = (int32_t)Q.edge(best)->action;
+          ta[len] = (int32_t)(Q.edge(best)->action & EDGE_ACTION_MASK);
           node = Q.edge(best)->parent;
           len++;
           tn[len] = (int32_t)node;
@@ -1425,7 +1469,8 @@ __global__ void map_cells_kernel(MapDev m, int n, const int32_t *cells, int8_t *
 // MapUtil::getCloud / getFreeCloud / getUnknownCloud: voxel centres (n + 0.5) res + origin of the
 // voxels of one class, in the order of the reference's loops (x outermost, z innermost).
 // which: 0 occupied (> 0), 1 free (== 0), 2 unknown (< 0).  Pass 1 counts per (x, y) column.
-__device__ __forceinline__ bool cloud_match(int8_t v, int which) { return which == 0 ? v > 0 : which == 1 ? v == 0 : v < 0; }
+// (which 3 / 4 are asked of the auxiliary map: voxels with a potential strictly between 0 and 100; voxels of the search region)
+__device__ __forceinline__ bool cloud_match(int8_t v, int which) { return which == 0 ? v > 0 : which == 1 ? v == 0 : which == 2 ? v < 0 : which == 3 ? (v > 0 && v < 100) : v >= 0; }
 __global__ void cloud_count_kernel(MapDev m, int which, uint32_t *counts) {
   const int ncol = m.dim[0] * m.dim[1];
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncol; c += gridDim.x * blockDim.x) {
@@ -1462,7 +1507,7 @@ __global__ __launch_bounds__(1024) void cloud_scan_kernel(const uint32_t *counts
   }
   if (tid == 0) *total = carry;
 }
-__global__ void cloud_write_kernel(MapDev m, int which, const unsigned long long *offs, unsigned long long cap, double *pts) {
+__global__ void cloud_write_kernel(MapDev m, int which, const unsigned long long *offs, unsigned long long cap, double *pts, int8_t *vals = nullptr) {
   const int ncol = m.dim[0] * m.dim[1];
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncol; c += gridDim.x * blockDim.x) {
     const int x = c % m.dim[0], y = c / m.dim[0];
@@ -1473,9 +1518,63 @@ __global__ void cloud_write_kernel(MapDev m, int which, const unsigned long long
         pts[3 * o] = ((double)x + 0.5) * m.res + m.origin[0];
         pts[3 * o + 1] = ((double)y + 0.5) * m.res + m.origin[1];
         pts[3 * o + 2] = ((double)z + 0.5) * m.res + m.origin[2];
+        if (vals) vals[o] = m.data[(size_t)x + (size_t)m.dim[0] * y + (size_t)m.dim[0] * m.dim[1] * z];
       }
       o++;
     }
+  }
+}
+
+// ---- potential field / search region (MapDev::aux): 0..100 potential, < 0 outside the search region
+struct PotArgs {
+  double pos[3], range[3];
+  int32_t n_mask;
+};
+// updatePotentialMap: gather form of "every occupied voxel spreads mask value H(n) to voxel + n, a voxel keeps the
+// largest value"; occupied voxels hold 100; with a range only voxels whose centre lies within pos +- range get a value
+__global__ void pot_update_kernel(MapDev m, int8_t *aux, PotArgs a, const int32_t *__restrict__ off, const int8_t *__restrict__ val) {
+  const size_t n = (size_t)m.dim[0] * m.dim[1] * m.dim[2];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c[3] = {(int)(i % m.dim[0]), (int)((i / m.dim[0]) % m.dim[1]), (int)(i / ((size_t)m.dim[0] * m.dim[1]))};
+    const bool outside_region = aux[i] < 0;
+    bool in_range = true;
+    for (int k = 0; k < 3; k++)
+      if (a.range[k] > 0 && fabs(((double)c[k] + 0.5) * m.res + m.origin[k] - a.pos[k]) > a.range[k]) in_range = false;
+    int best = 0;
+    if (in_range) {
+      if (m.data[i] > 0) {
+        best = 100;
+      } else {
+        for (int k = 0; k < a.n_mask; k++) {
+          const int sx = c[0] - off[3 * k], sy = c[1] - off[3 * k + 1], sz = c[2] - off[3 * k + 2];
+          if (sx < 0 || sx >= m.dim[0] || sy < 0 || sy >= m.dim[1] || sz < 0 || sz >= m.dim[2]) continue;
+          if (val[k] > best && m.data[(size_t)sx + (size_t)m.dim[0] * sy + (size_t)m.dim[0] * m.dim[1] * sz] > 0) best = val[k];
+        }
+      }
+    }
+    aux[i] = outside_region ? (int8_t)-1 : (int8_t)best;
+  }
+}
+// setSearchRegion: one thread per (seed cell, offset inside +-rn): mark the voxel
+__global__ void region_mark_kernel(int dx, int dy, int dz, int n_seeds, const int32_t *seeds, int rn0, int rn1, int rn2, int8_t *in) {
+  const long long per = (long long)(2 * rn0 + 1) * (2 * rn1 + 1) * (2 * rn2 + 1);
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= per * n_seeds) return;
+  const int s = (int)(t / per);
+  long long r = t % per;
+  const int ax = (int)(r % (2 * rn0 + 1)) - rn0;
+  r /= (2 * rn0 + 1);
+  const int ay = (int)(r % (2 * rn1 + 1)) - rn1, az = (int)(r / (2 * rn1 + 1)) - rn2;
+  const int x = seeds[3 * s] + ax, y = seeds[3 * s + 1] + ay, z = seeds[3 * s + 2] + az;
+  if (x < 0 || x >= dx || y < 0 || y >= dy || z < 0 || z >= dz) return;
+  in[(size_t)x + (size_t)dx * y + (size_t)dx * dy * z] = 1;
+}
+// in == null: remove the region (hidden voxels become potential 0)
+__global__ void region_apply_kernel(size_t n, const int8_t *in, int8_t *aux) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int8_t v = aux[i];
+    if (!in || in[i]) { if (v < 0) aux[i] = 0; }
+    else aux[i] = -1;
   }
 }
 

@@ -187,9 +187,9 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
         }
         __syncthreads();
         if (!S.flag) {
-          commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid, q, act, L, h64, lane_cost);
+          commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid, q, act, L, h64, lane_cost, (uint32_t)tid);
         } else {
-          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid, q, act && tid == i, L, h64, lane_cost);
+          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid, q, act && tid == i, L, h64, lane_cost, (uint32_t)tid);
         }
         __syncthreads();
         if (S.status >= 0) break;

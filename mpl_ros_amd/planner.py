@@ -415,30 +415,101 @@ class VoxelMapPlanner:
         self._configure(self._control)
         self._lpa.check(self._lpa.lib.mplx_lpa_sub_state_space(self._lpa.h, int(time_step)))
 
-    def _unsupported(self, what):
-        raise MplxError(f"{what}: not supported by this back-end")
+    # ---- potential-field cost and search region (distance_map_planner_node.cpp:185-193,199,218-224,231)
+    # The auxiliary map lives on the MapUtil's device context; a planner re-sends its own when another planner sharing
+    # the MapUtil has replaced (or removed) it since.
+    @staticmethod
+    def _v3(v):
+        v = [float(x) for x in v]
+        return v + [0.0] * (3 - len(v))
 
-    # (these change the cost function, i.e. the plan: refused, never ignored)
     def setSearchRadius(self, radius):           # distance_map_planner_node.cpp:185
-        self._unsupported("setSearchRadius (search region)")
+        self._search_radius = self._v3(radius)
 
-    def setSearchRegion(self, path, dense=False):
-        self._unsupported("setSearchRegion (search region)")
+    def setSearchRegion(self, path, dense=False):  # distance_map_planner_node.cpp:186
+        """The voxels within the search radius of `path` (waypoint positions; joined up with rayTrace unless dense):
+        primitives that leave the region are blocked."""
+        pts = np.array([self._v3(p) for p in path], dtype=np.float64).reshape(-1, 3)
+        self._region = (pts, bool(dense))
+        self._aux_dirty = True
 
-    def setPotentialRadius(self, radius):        # distance_map_planner_node.cpp:186
-        self._unsupported("setPotentialRadius (potential-field cost)")
+    def setPotentialRadius(self, radius):        # distance_map_planner_node.cpp:187
+        self._pot_radius = self._v3(radius)
 
-    def setPotentialWeight(self, w):             # distance_map_planner_node.cpp:187
-        self._unsupported("setPotentialWeight (potential-field cost)")
+    def setPotentialMapRange(self, range_):      # (commented out at distance_map_planner_node.cpp:190,221)
+        self._pot_range = self._v3(range_)
 
-    def setGradientWeight(self, w):              # distance_map_planner_node.cpp:188
-        self._unsupported("setGradientWeight (potential-field cost)")
+    def setPotentialWeight(self, w):             # distance_map_planner_node.cpp:188
+        self._pot_weight = float(w)
+        self._aux_dirty = True
 
-    def updatePotentialMap(self, pos, range_=None):
-        self._unsupported("updatePotentialMap (potential-field cost)")
+    def setGradientWeight(self, w):              # distance_map_planner_node.cpp:189
+        if float(w) != 0.0:
+            raise MplxError("setGradientWeight: only 0 (the value the reference passes) is supported by this back-end")
+        self._grad_weight = 0.0
+
+    def updatePotentialMap(self, pos, range_=None):  # distance_map_planner_node.cpp:191
+        """Build the potential map around the obstacles of the CURRENT map (setPotentialRadius first)."""
+        if getattr(self, "_pot_radius", None) is None:
+            raise MplxError("setPotentialRadius first")
+        self._pot_call = (self._v3(pos), self._v3(range_) if range_ is not None else getattr(self, "_pot_range", [0.0, 0.0, 0.0]))
+        self._aux_dirty = True
+        self._apply_aux()
+
+    def _has_aux(self):
+        return getattr(self, "_region", None) is not None or getattr(self, "_pot_call", None) is not None
+
+    def _apply_aux(self):
+        """Make the context's auxiliary map this planner's: region first, then the potential (which keeps the region)."""
+        ctx = self._ctx()
+        owner = getattr(ctx, "aux_owner", None)
+        mine = owner is not None and owner() is self
+        if not self._has_aux():
+            if owner is not None and not mine:
+                ctx.check(ctx.lib.mplx_potential_clear(ctx.h))  # another planner's cost terms must not leak into this plan
+                ctx.aux_owner = None
+            return
+        if mine and not getattr(self, "_aux_dirty", True):
+            return
+        d3 = lambda v: (C.c_double * 3)(*v)
+        if not mine:
+            ctx.check(ctx.lib.mplx_potential_clear(ctx.h))
+        region = getattr(self, "_region", None)
+        if region is not None:
+            pts, dense = region
+            if getattr(self, "_search_radius", None) is None:
+                raise MplxError("setSearchRadius first")
+            ctx.check(ctx.lib.mplx_search_region_set(ctx.h, pts.shape[0], pts.ctypes.data, d3(self._search_radius), int(dense)))
+        ctx.check(ctx.lib.mplx_potential_weights(ctx.h, getattr(self, "_pot_weight", 0.0), 0.0))
+        call = getattr(self, "_pot_call", None)
+        if call is not None:
+            pos, rng = call
+            ctx.check(ctx.lib.mplx_potential_update(ctx.h, d3(self._pot_radius), d3(pos), d3(rng), 1))
+        ctx.aux_owner = weakref.ref(self)
+        self._aux_dirty = False
+
+    def _aux_cloud(self, which):
+        ctx = self._ctx()
+        n = C.c_uint64(0)
+        ctx.check(ctx.lib.mplx_aux_cloud(ctx.h, which, None, None, 0, C.byref(n)))
+        pts = np.empty((max(n.value, 1), 3), dtype=np.float64)
+        vals = np.empty(max(n.value, 1), dtype=np.int8)
+        ctx.check(ctx.lib.mplx_aux_cloud(ctx.h, which, pts.ctypes.data, vals.ctypes.data, n.value, C.byref(n)))
+        return pts[:n.value], vals[:n.value]
 
     def getPotentialCloud(self, h_max=1.0):      # distance_map_planner_node.cpp:231
-        self._unsupported("getPotentialCloud (potential-field cost)")
+        """Voxels with a potential strictly between 0 and 100 as (x, y, z) points; the 2-D planner lifts them to
+        z = h_max * potential / 100 (a height field for display)."""
+        self._apply_aux()
+        pts, vals = self._aux_cloud(0)
+        if isinstance(self, OccMapPlanner):
+            pts = pts.copy()
+            pts[:, 2] = float(h_max) * vals.astype(np.float64) / 100.0
+        return pts
+
+    def getSearchRegion(self):                   # distance_map_planner_node.cpp:199
+        self._apply_aux()
+        return self._aux_cloud(1)[0]
 
     def setTol(self, tol_pos, tol_vel=-1.0, tol_acc=-1.0):
         self._tol, self._dirty = (float(tol_pos), float(tol_vel), float(tol_acc)), True
@@ -524,6 +595,7 @@ class VoxelMapPlanner:
         if getattr(start, "use_yaw", False) or getattr(goal, "use_yaw", False):
             raise MplxError("use_yaw waypoints are not supported by this back-end (yaw would be ignored)")
         self._configure(start.control)
+        self._apply_aux()
         res = _capi.Result()
         s, g = start.to_c(), goal.to_c()
         if self._use_lpastar:
@@ -558,6 +630,7 @@ class VoxelMapPlanner:
         """Independent queries on the shared map in one launch; returns the list of results."""
         ctx = self._ctx()
         self._configure(starts[0].control)
+        self._apply_aux()
         n = len(starts)
         S = (_capi.Waypoint * n)(*[s.to_c() for s in starts])
         G = (_capi.Waypoint * n)(*[g.to_c() for g in goals])
@@ -744,6 +817,7 @@ class VoxelMapPlanner:
     def getSuccBatch(self, nodes):
         ctx = self._ctx()
         self._configure(nodes[0].control)
+        self._apply_aux()
         K = len(nodes)
         N = (_capi.Waypoint * K)(*[n.to_c() for n in nodes])
         out = (_capi.Succ * (K * self._U.shape[0]))()

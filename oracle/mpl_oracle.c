@@ -382,6 +382,10 @@ struct orc_planner {
   int traj_len;
   double traj_cost;
   orc_counters cnt;
+  /* potential field / search region (mpl_oracle_pot.inc): 0..100 potential, -1 outside the search region */
+  int8_t *aux;
+  int has_pot, has_region;
+  double pot_weight, grad_weight;
   /* LPA* (mpl_oracle_lpa.inc) */
   int use_lpa, lpa_valid;
   orc_lentry *lq;
@@ -417,6 +421,8 @@ static void free_search(orc_planner *p) {
   p->n_heap = p->cap_heap = p->n_expanded = p->cap_expanded = p->n_closed = p->traj_len = 0;
 }
 void orc_destroy(orc_planner *p) {
+  free(p->aux);
+  p->aux = NULL;
   if (!p) return;
   free_search(p);
   if (p->map_owned) free(p->map);
@@ -425,7 +431,9 @@ void orc_destroy(orc_planner *p) {
 }
 
 /* ------------------------------------------------------------------ MapUtil (a7) */
+void orc_potential_clear(orc_planner *p);
 void orc_set_map(orc_planner *p, const int8_t *data, const int32_t dim[3], const double origin[3], double res) {
+  if (p->aux && (dim[0] != p->dim[0] || dim[1] != p->dim[1] || dim[2] != p->dim[2])) orc_potential_clear(p);
   if (p->map_owned) free(p->map);
   size_t n = (size_t)dim[0] * dim[1] * dim[2];
   p->map = (int8_t *)malloc(n);
@@ -703,6 +711,8 @@ double orc_heuristic(const orc_planner *p, const orc_waypoint *s) {
   return cal_heur(p, s, &p->goal);
 }
 
+#include "mpl_oracle_pot.inc"
+
 /* ------------------------------------------------------------------ env_map::get_succ (a8) */
 /* [IN-TREE env_poly_map.h:45-69, env_cloud.h:50-70 for the control flow;
  *  UNVERIFIED env_map.h for `tn == curr` + validate + is_free(pr) ? J + w dt : inf] */
@@ -721,7 +731,10 @@ int orc_get_succ(orc_planner *p, const orc_waypoint *curr, orc_waypoint *succ, d
     int nkt = orc_waypoint_key(&tn, kt);
     if (key_equal(kt, nkt, kc, nkc) || !orc_validate_primitive(&pr, p->cfg.v_max, p->cfg.a_max, p->cfg.j_max)) continue;
     tn.t = curr->t + p->cfg.dt; /* [IN-TREE env_cloud.h:65] */
-    double cost = orc_is_free_primitive(p, &pr) ? orc_primitive_J(&pr, pr.control) + p->cfg.w * p->cfg.dt : INFINITY;
+    long potsum = 0;
+    const int free_ = p->aux ? prim_traverse(p, &pr, &potsum) : orc_is_free_primitive(p, &pr);
+    double cost = free_ ? orc_primitive_J(&pr, pr.control) + p->cfg.w * p->cfg.dt : INFINITY;
+    if (free_ && p->aux) cost = cost + p->pot_weight * (double)potsum; /* [P3 of mpl_oracle_pot.inc] */
     succ[n] = tn;
     succ_cost[n] = cost;
     action_idx[n] = i;

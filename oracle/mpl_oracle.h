@@ -169,6 +169,14 @@ void orc_get_traj(const orc_planner *, orc_primitive *prs, orc_waypoint *wps /* 
 void orc_get_counters(const orc_planner *, orc_counters *);
 void orc_reset_counters(orc_planner *);
 
+/* ---- potential-field cost and search region of the map planner (mpl_oracle_pot.inc; UNVERIFIED restatement anchored on
+ *      distance_map_planner_node.cpp:185-193,218-224,231) ---- */
+void orc_set_potential_weights(orc_planner *, double potential_weight, double gradient_weight);
+void orc_potential_update(orc_planner *, const double radius[3], const double pos[3], const double range[3], int pow_);
+void orc_search_region_set(orc_planner *, int n_pts, const double *pts, const double radius[3], int dense);
+void orc_potential_clear(orc_planner *);
+void orc_aux_get(const orc_planner *, int8_t *out); /* 0..100 potential, -1 outside the search region */
+
 /* ---- LPA* incremental replanning (mpl_oracle_lpa.inc; UNVERIFIED restatement anchored on map_replanner_node.cpp:107-255,
  *      425-437 and poly_map_planner.h:61-93).  With orc_set_lpastar(p, 1) orc_plan() keeps and repairs its state space. ---- */
 void orc_set_lpastar(orc_planner *, int on);                /* PlannerBase::setLPAstar */

@@ -121,6 +121,12 @@ def lib():
                                    C.POINTER(C.c_int32)]
         L.orc_get_counters.argtypes = [P, C.POINTER(Counters)]
         L.orc_reset_counters.argtypes = [P]
+        D3 = C.POINTER(C.c_double)
+        L.orc_set_potential_weights.argtypes = [P, C.c_double, C.c_double]
+        L.orc_potential_update.argtypes = [P, D3, D3, D3, C.c_int]
+        L.orc_search_region_set.argtypes = [P, C.c_int, C.c_void_p, D3, C.c_int]
+        L.orc_potential_clear.argtypes = [P]
+        L.orc_aux_get.argtypes = [P, C.c_void_p]
         L.orc_set_lpastar.argtypes = [P, C.c_int]
         for f in ("orc_lpa_initialized", "orc_lpa_iterations"):
             getattr(L, f).argtypes = [P]
@@ -333,6 +339,26 @@ class Planner:
             self.L.orc_get_traj(self.h, prs, wps, act, ids)
         return {"n": n, "prs": [prs[i] for i in range(n)], "wps": [wps[i] for i in range(n + 1)] if n else [],
                 "actions": np.array(act[:n], dtype=np.int32), "node_ids": np.array(ids[:n + 1] if n else [], dtype=np.int32)}
+
+    # ---- potential field / search region (oracle/mpl_oracle_pot.inc)
+    def set_potential_weights(self, potential_weight, gradient_weight=0.0):
+        self.L.orc_set_potential_weights(self.h, float(potential_weight), float(gradient_weight))
+
+    def update_potential_map(self, radius, pos, range_=(0, 0, 0), pow_=1):
+        d3 = lambda v: (C.c_double * 3)(*[float(x) for x in v])
+        self.L.orc_potential_update(self.h, d3(radius), d3(pos), d3(range_), int(pow_))
+
+    def set_search_region(self, path, radius, dense=False):
+        pts = np.ascontiguousarray(path, dtype=np.float64).reshape(-1, 3)
+        self.L.orc_search_region_set(self.h, pts.shape[0], pts.ctypes.data, (C.c_double * 3)(*[float(x) for x in radius]), int(bool(dense)))
+
+    def clear_potential(self):
+        self.L.orc_potential_clear(self.h)
+
+    def aux_map(self):
+        a = np.empty(self._shape, dtype=np.int8)
+        self.L.orc_aux_get(self.h, a.ctypes.data)
+        return a
 
     # ---- LPA* (oracle/mpl_oracle_lpa.inc)
     def set_lpastar(self, on=True):

@@ -71,9 +71,9 @@ def test_yaw_requests_fail_loudly():
     pl.setYawmax(-1.0)
 
 
-def test_uncovered_reference_api_fails_loudly():
-    """SURVEY.md 8(f) row 3 is not covered: potential-field / search-region cost would change the plan, so those setters
-    raise.  LPA* (row 2) is covered: without a state space its update calls change nothing."""
+def test_reference_api_that_needs_no_device_behaves():
+    """Without a state space the LPA* update calls change nothing; the potential-field setters only store (the device is
+    touched by updatePotentialMap / plan); a gradient weight other than the reference's 0 is refused, never ignored."""
     import pytest
     from mpl_ros_amd._capi import MplxError
     from mpl_ros_amd.planner import VoxelMapPlanner
@@ -82,8 +82,8 @@ def test_uncovered_reference_api_fails_loudly():
     pl.setLPAstar(True)
     assert not pl.initialized()
     assert pl.updateBlockedNodes([]) == 0 and pl.updateClearedNodes([]) == 0 and pl.getSubStateSpace(1) is None
-    for call in (lambda: pl.setSearchRadius([0.5, 0.5, 0.5]), lambda: pl.setSearchRegion([]),
-                 lambda: pl.setPotentialRadius([1, 1, 1]), lambda: pl.setPotentialWeight(0.1), lambda: pl.setGradientWeight(0.0),
-                 lambda: pl.updatePotentialMap([0, 0, 0]), lambda: pl.getPotentialCloud()):
-        with pytest.raises(MplxError):
-            call()
+    pl.setSearchRadius([0.5, 0.5]); pl.setPotentialRadius([1.5, 1.5]); pl.setPotentialWeight(10); pl.setGradientWeight(0)
+    with pytest.raises(MplxError):
+        pl.setGradientWeight(0.5)
+    with pytest.raises(MplxError):
+        pl.updatePotentialMap([0, 0])  # no MapUtil yet

@@ -182,15 +182,46 @@ def test_reference_replanner_through_the_shim(tmp_path):
     check(replans[3], orc.waypoint(tuple(w1.pos), vel=tuple(w1.vel)))
 
 
+@pytest.mark.gpu
+def test_reference_distance_map_planner_through_the_shim(tmp_path):
+    """distance_map_planner_node.cpp:103-231 (tests/cpp/distance_map_planner_driver.cpp): plain plan, plan inside the search
+    region with the potential field, plan with the potential on the whole map -- costs and closed sets equal the oracle's."""
+    from tests import test_potential as T
+    from oracle import orc
+    exe = build_driver(tmp_path, "distance_map_planner_driver")
+    grid, origin, res = T.slice_map()
+    path = str(tmp_path / "occ.bin")
+    grid.tofile(path)
+    out = subprocess.run([exe, path, str(grid.shape[2]), str(grid.shape[1]), repr(origin[0]), repr(origin[1]), repr(res)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    last = out.stdout.strip().splitlines()[-1]
+    r = json.loads(last[last.index("{"):])
+    P, wps = T.first_path()
+    assert r["cost0"] == P.traj_cost and r["closed0"] == P.num_closed()
+    Q = T.oracle(0.5)
+    Q.set_search_region(wps, (0.5, 0.5, 0))
+    Q.set_potential_weights(10, 0)
+    Q.update_potential_map((1.5, 1.5, 0), T.START)
+    assert Q.plan(orc.waypoint(T.START), orc.waypoint(T.GOAL)) == orc.OK
+    assert r["cost1"] == Q.traj_cost and r["closed1"] == Q.num_closed() and r["region"] == int((Q.aux_map() >= 0).sum())
+    R = T.oracle(0.5)
+    R.set_potential_weights(10, 0)
+    R.update_potential_map((1.5, 1.5, 0), T.START)
+    assert R.plan(orc.waypoint(T.START), orc.waypoint(T.GOAL)) == orc.OK
+    a = R.aux_map()
+    assert r["cost2"] == R.traj_cost and r["closed2"] == R.num_closed()
+    assert r["potential_cloud"] == int(((a > 0) & (a < 100)).sum()) and r["zmax"] == a[(a > 0) & (a < 100)].max() / 100.0
+
+
 def test_shim_refuses_cost_changing_requests(tmp_path):
-    """Search-region / potential-field setters exist on the shim's MapPlanner and make plan() refuse (they would change the
-    plan).  plan() fails before it reaches the device."""
+    """A non-zero gradient weight (never passed by the reference) makes plan() refuse; the other potential-field /
+    search-region setters only store.  plan() fails before it reaches the device."""
     exe = str(tmp_path / "shim_refusals")
     subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mpl_shim"),
                            "-o", exe, os.path.join(ROOT, "tests", "cpp", "shim_refusals.cpp"), os.path.join(LIBDIR, "libmplx.so"), "-Wl,-rpath," + LIBDIR])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "planned 0" in out.stdout
-    assert out.stdout.count("plan() will fail") == 4 and "plan() refused" in out.stdout
+    assert out.stdout.count("plan() will fail") == 1 and "plan() refused" in out.stdout
 
 
 REF_POLY = "/root/reference/mpl_external_planner/include"
