@@ -402,6 +402,9 @@ def bench_c5(args):
     obs_bytes = sum(104 + 32 * len(o.poly) + 104 * len(o.segs) for o in worlds[0].nonlinear) + 104 + 32 * 4
     alg = n_exp * (48 + 16) + n_prims * obs_bytes + nsf * ((48 + 16) + (2 * 7 * 4 + 8))
     k_ms = kernel_ms / args.steps
+    longest = int(np.argmax([r.n_expanded for r in R]))
+    cyc = team.cycles(longest)
+    per_exp = {k: v / max(R[longest].n_expanded, 1) for k, v in cyc.items()}
     out = {"metric": "node_expansions_per_s", "value": n_exp * args.steps / elapsed, "unit": "expansions/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
@@ -411,6 +414,7 @@ def bench_c5(args):
                       "robots": 16, "n_primitives": 9},
            "expansions_per_step": n_exp, "plan_status_counts": {str(k): int(v) for k, v in enumerate(np.bincount([r.status for r in R], minlength=7))},
            "tick_ms": 1e3 * elapsed / args.steps,
+           "cycles_per_expansion_longest_robot": per_exp,
            "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "traffic": None, "kernel": "astar_poly_kernel<256>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
                         "note": "16 workgroups (one per robot): the obstacle data stays in L2 and the expansion is f64 root solving; latency bound"}}

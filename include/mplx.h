@@ -345,6 +345,8 @@ int mplx_poly_result_traj(mplx_poly *p, int32_t q, int32_t *actions, int32_t *no
 int mplx_poly_set_record(mplx_poly *p, uint32_t cap_per_query);
 int mplx_poly_result_expanded(mplx_poly *p, int32_t q, uint32_t cap, int32_t *ids, uint32_t *n);
 int mplx_poly_last_kernel_ms(const mplx_poly *p, float *ms);
+/* shader-clock cycles query q of the last batch spent in [0] pop, [1] get_succ (primitives + collide), [2] look-up + commit */
+int mplx_poly_result_cycles(mplx_poly *p, int32_t q, uint64_t cyc[10]);
 
 /* ---- measurement ---- */
 /* device-clock begin / end (seconds since the first query of the batch started) and workgroup of query q */

@@ -965,8 +965,9 @@ __device__ __forceinline__ void open_push(const QView<BLOCK, CONTROL, SM> &Q, ui
 // NK: key ints (key_len_c(CONTROL), + 1 when the state's time is part of the key); lane_cost: cost of this lane's
 // primitive (the voxel environment's cost depends on the control input only: P.ucost[tid]).
 template <int BLOCK, int CONTROL, class SM, int NK = key_len_c(CONTROL)>
+// have_v0: the caller has already loaded the first table slot of the lane's key (v0_in), e.g. while other work was in flight
 __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64, double lane_cost,
-                                                uint32_t action_tag) {
+                                                uint32_t action_tag, bool have_v0 = false, unsigned long long v0_in = 0) {
   using V = QView<BLOCK, CONTROL, SM>;
   const SearchParams &P = Q.P;
   SM &S = Q.S;
@@ -983,7 +984,7 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
   const size_t mask = (size_t)P.table_mask;
   size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & mask;
   unsigned long long v0 = TBL_EMPTY;
-  if (act) v0 = ld_u64(&P.table[pos]);
+  if (act) v0 = have_v0 ? v0_in : ld_u64(&P.table[pos]);
   double hspec = 0.0;
 #ifndef MPLX_NO_HSPEC
   if (act && P.eps != 0.0) hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);

@@ -11,13 +11,16 @@ struct PolySuccOut {
 };
 
 // env_poly_map::get_succ for K nodes: one workgroup per node.  Lane i < n_u builds primitive i (end state, bounding
-// box, validate_primitive, intrinsic cost); then the (primitive, obstacle) pairs are spread over the lanes -- every
-// pair is one collide() -- and the start-point test isFree(start.pos, t) over the obstacles; results are OR-ed in LDS.
+// box, validate_primitive, intrinsic cost); then isFree(pr, t) of all of them against all obstacles spread over the lanes
+// below the pair level (poly_collide_all, mplx_poly_dev.h) and the start-point test isFree(start.pos, t) over the
+// obstacles; results are OR-ed in LDS.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void poly_get_succ_kernel(PolyDev D, int K, const int32_t *world_of, const double *states, PolySuccOut *out, int32_t *flags) {
   __shared__ double cs[POLY_MAX_U][2][6];
   __shared__ int32_t valid[POLY_MAX_U], hit[POLY_MAX_U];
-  __shared__ int32_t start_hit, unsupported;
+  __shared__ int32_t start_hit, unsupported, hp_max;
+  __shared__ PolyPrep prep[POLY_MAX_OBS];
+  __shared__ uint32_t hit_idx[POLY_MAX_U * POLY_MAX_OBS], uns_idx[POLY_MAX_U * POLY_MAX_OBS];
   const int tid = threadIdx.x;
   for (int k = blockIdx.x; k < K; k += gridDim.x) {
     const double *st = states + 9 * (size_t)k;
@@ -30,35 +33,22 @@ __global__ __launch_bounds__(BLOCK) void poly_get_succ_kernel(PolyDev D, int K, 
       poly_prim_build(D.control, pos, vel, u, c);
       for (int i = 0; i < 2; i++)
         for (int j = 0; j < 6; j++) cs[tid][i][j] = c[i][j];
-      const double ex = pp_p(c[0], T), ey = pp_p(c[1], T);
+      const double ex = pp_p_auto(c[0], T), ey = pp_p_auto(c[1], T);
       valid[tid] = (poly_inside(W.bbox, 4, ex, ey) && poly_validate(D.control, c, T, D.v_max)) ? 1 : 0;
       hit[tid] = 0;
     }
     __syncthreads();
-    // isFree(start.pos, t): start = pr.evaluate(0) = the node position for every primitive
-    for (int j = tid; j < W.n_obs; j += BLOCK)
-      if (obs_point_hits(D, D.obs[W.obs_off + j], pp_p(cs[0][0], 0.0), pp_p(cs[0][1], 0.0), t_rel)) start_hit = 1;
-    const int pairs = D.n_u * W.n_obs;
-    for (int e = tid; e < pairs; e += BLOCK) {
-      const int i = e / W.n_obs, j = e % W.n_obs;
-      if (!valid[i]) continue;
-      double c[2][6];
-      for (int a = 0; a < 2; a++)
-        for (int b = 0; b < 6; b++) c[a][b] = cs[i][a][b];
-      const int r = obs_prim_hits(D, c, T, D.obs[W.obs_off + j], t_rel);
-      if (r < 0) unsupported = 1;
-      if (r > 0) hit[i] = 1;
-    }
-    __syncthreads();
+    // isFree(start.pos, t) (start = pr.evaluate(0) = the node position for every primitive) and isFree(pr, t)
+    poly_collide_all<BLOCK>(D, W, cs, valid, D.n_u, T, t_rel, prep, hit_idx, uns_idx, &hp_max, hit, &unsupported, &start_hit, tid, 0, PolyNoHook());
     if (tid < D.n_u) {
       PolySuccOut &o = out[(size_t)k * D.n_u + tid];
       double c[2][6];
       for (int a = 0; a < 2; a++)
         for (int b = 0; b < 6; b++) c[a][b] = cs[tid][a][b];
-      o.state[0] = pp_p(c[0], T); o.state[1] = pp_p(c[1], T);
-      o.state[2] = pp_v(c[0], T); o.state[3] = pp_v(c[1], T);
-      o.state[4] = pp_a(c[0], T); o.state[5] = pp_a(c[1], T);
-      o.state[6] = pp_j(c[0], T); o.state[7] = pp_j(c[1], T);
+      o.state[0] = pp_p_auto(c[0], T); o.state[1] = pp_p_auto(c[1], T);
+      o.state[2] = pp_v_auto(c[0], T); o.state[3] = pp_v_auto(c[1], T);
+      o.state[4] = pp_a_auto(c[0], T); o.state[5] = pp_a_auto(c[1], T);
+      o.state[6] = pp_j_auto(c[0], T); o.state[7] = pp_j_auto(c[1], T);
       o.state[8] = st[8] + D.dt;
       o.action = tid;
       o.valid = valid[tid];
@@ -97,6 +87,8 @@ struct mplx_poly {
   mplx_ctx *ctx = nullptr;
   int32_t *d_world_of = nullptr;
   int world_cap = 0;
+  mplx::PolyPrep *d_prep_cache = nullptr;  // per workgroup x time level x obstacle (mplx_poly_dev.h)
+  int prep_cache_slots = 0;
 };
 
 static int pfail(mplx_poly *p, int code, const char *fmt, ...) {
@@ -143,6 +135,7 @@ extern "C" void mplx_poly_destroy(mplx_poly *p) {
   poly_free_dev(p);
   (void)hipFree(p->d_U);
   (void)hipFree(p->d_world_of);
+  (void)hipFree(p->d_prep_cache);
   mplx_ctx_destroy(p->ctx);
   (void)hipStreamDestroy(p->stream);
   delete p;
@@ -184,8 +177,33 @@ extern "C" int mplx_poly_set_world(mplx_poly *p, int32_t world, const double ori
   W.bbox[3] = mplx::PolyHP{(ori[0] + dim[0]) - dim[0] / 2, (ori[1] + dim[1]) - 0.0, 0.0, 1.0};
   return MPLX_OK;
 }
+// bounding radius of the polyhedron {x : n_i . (x - p_i) <= 0} around the origin of its own frame (pruning only):
+// largest norm of a vertex; +inf when the normals do not positively span the plane (unbounded) or no vertex is found
+static double poly_radius(int n_hp, const double *hp) {
+  std::vector<double> ang;
+  for (int i = 0; i < n_hp; i++) ang.push_back(atan2(hp[4 * i + 3], hp[4 * i + 2]));
+  std::sort(ang.begin(), ang.end());
+  double gap = n_hp ? ang.front() + 2 * M_PI - ang.back() : 2 * M_PI;
+  for (size_t i = 1; i < ang.size(); i++) gap = std::max(gap, ang[i] - ang[i - 1]);
+  if (n_hp < 3 || gap >= M_PI - 1e-9) return INFINITY;
+  double r = -1.0, scale = 1.0;
+  for (int i = 0; i < n_hp; i++) scale = std::max(scale, std::max(fabs(hp[4 * i]), fabs(hp[4 * i + 1])));
+  for (int i = 0; i < n_hp; i++)
+    for (int k = i + 1; k < n_hp; k++) {
+      const double a1 = hp[4 * i + 2], b1 = hp[4 * i + 3], c1 = a1 * hp[4 * i] + b1 * hp[4 * i + 1];
+      const double a2 = hp[4 * k + 2], b2 = hp[4 * k + 3], c2 = a2 * hp[4 * k] + b2 * hp[4 * k + 1];
+      const double det = a1 * b2 - a2 * b1;
+      if (fabs(det) < 1e-12) continue;
+      const double x = (c1 * b2 - c2 * b1) / det, y = (a1 * c2 - a2 * c1) / det;
+      bool in = true;
+      for (int m = 0; m < n_hp && in; m++) in = hp[4 * m + 2] * (x - hp[4 * m]) + hp[4 * m + 3] * (y - hp[4 * m + 1]) <= 1e-9 * scale;
+      if (in) r = std::max(r, sqrt(x * x + y * y));
+    }
+  return r < 0 ? INFINITY : r;
+}
 static int poly_add(mplx_poly *p, int32_t world, int kind, int n_hp, const double *hp, mplx::PolyObs &o) {
   if (!p || world < 0 || world >= (int)p->worlds.size() || n_hp <= 0 || !hp) return pfail(p, MPLX_ERR_ARG, "bad argument");
+  o.radius = poly_radius(n_hp, hp);
   o.kind = kind;
   o.hp_off = (int32_t)p->hps.size();
   o.n_hp = n_hp;
@@ -223,6 +241,11 @@ extern "C" int mplx_poly_add_nonlinear(mplx_poly *p, int32_t world, int32_t n_hp
   }
   o.total_t = total;
   o.start_t = start_t;
+  o.fast = n_seg > 0 ? 1 : 0;  // VEL / ACC segments (checked above: +0.0 leading coefficients) with positive durations
+  for (int i = 0; i < n_seg; i++) {
+    const mplx::PolySeg &sg = p->segs[(size_t)o.seg_off + (size_t)i];
+    if (!(sg.T > 0) || !mplx::lead_pzero(sg.c[0]) || !mplx::lead_pzero(sg.c[1])) o.fast = 0;
+  }
   o.dis_front = dis_front ? 1 : 0;
   o.dis_back = dis_back ? 1 : 0;
   // representative point p_ = traj.evaluate(start_t).pos (simple_obstacle.h:126); not used by the collision tests
@@ -256,7 +279,9 @@ extern "C" int mplx_poly_commit(mplx_poly *p) {
   return MPLX_OK;
 }
 static mplx::PolyDev poly_dev(const mplx_poly *p) {
-  mplx::PolyDev D;
+  mplx::PolyDev D{};
+  D.cum = nullptr;
+  D.prep_cache = nullptr;
   D.hps = p->d_hps; D.segs = p->d_segs; D.obs = p->d_obs; D.worlds = p->d_worlds;
   D.control = p->control; D.n_u = p->n_u; D.U = p->d_U;
   D.dt = p->dt; D.v_max = p->v_max; D.a_max = p->a_max; D.j_max = p->j_max; D.w = p->w;
@@ -364,6 +389,17 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   P.next_query = c->d_next;
   P.poly = poly_dev(p);
   P.poly_world = p->d_world_of;
+  {
+    const size_t per = (size_t)mplx::POLY_CACHE_LEVELS * mplx::POLY_MAX_OBS;
+    if (p->prep_cache_slots < slots) {
+      (void)hipFree(p->d_prep_cache);
+      p->d_prep_cache = nullptr;
+      PCHK(p, hipMalloc((void **)&p->d_prep_cache, sizeof(mplx::PolyPrep) * per * (size_t)slots));
+      p->prep_cache_slots = slots;
+    }
+    PCHK(p, hipMemsetAsync(p->d_prep_cache, 0, sizeof(mplx::PolyPrep) * per * (size_t)slots, c->stream));  // tag_q 0: empty
+    P.poly.prep_cache = p->d_prep_cache;
+  }
   hipStream_t st = c->stream;
   PCHK(p, hipMemcpyAsync(p->d_world_of, world_of, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
   PCHK(p, hipMemcpyAsync(c->d_order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
@@ -409,6 +445,8 @@ extern "C" int mplx_poly_result_traj(mplx_poly *p, int32_t q, int32_t *actions, 
     }
   return MPLX_OK;
 }
+// shader-clock cycles query q of the last batch spent in [0] pop, [1] get_succ (primitives + collide), [2] look-up + commit
+extern "C" int mplx_poly_result_cycles(mplx_poly *p, int32_t q, uint64_t cyc[10]) { return p ? mplx_result_cycles(p->ctx, q, cyc) : MPLX_ERR_ARG; }
 extern "C" int mplx_poly_last_kernel_ms(const mplx_poly *p, float *ms) { return p ? mplx_last_kernel_ms(p->ctx, ms) : MPLX_ERR_ARG; }
 extern "C" int mplx_poly_result_expanded(mplx_poly *p, int32_t q, uint32_t cap, int32_t *ids, uint32_t *n) {
   if (!p) return MPLX_ERR_ARG;

@@ -25,7 +25,10 @@ struct PolyHP { double px, py, nx, ny; };            // Hyperplane2D: point p_, 
 struct PolySeg { double c[2][6]; double T; };        // Primitive2D of an obstacle trajectory
 struct PolyObs {
   int32_t kind;                                      // 0 static, 1 linear, 2 nonlinear
-  int32_t hp_off, n_hp, seg_off, n_seg, dis_front, dis_back, pad;
+  int32_t hp_off, n_hp, seg_off, n_seg, dis_front, dis_back;
+  int32_t cum_off;                                   // (device staging) offset of this trajectory's segment start times in PolyDev::cum
+  double radius;                                     // bounding radius of the polyhedron around its reference point (+inf: unknown / unbounded): pruning only
+  int32_t fast, pad2;                                // trajectory of VEL / ACC segments with positive durations (set at commit): shortcuts that need it
   double p[2], v[2], cov_v, start_t, total_t;        // representative point, velocity (linear), trajectory start / length
 };
 struct PolyWorld {                                   // what one planner sees: bounding box + obstacle set + start time
@@ -41,6 +44,9 @@ struct PolyDev {
   int32_t control, n_u;
   const double *U;                                   // n_u x 2
   double dt, v_max, a_max, j_max, w;
+  const double *cum;                                 // null, or per trajectory n_seg + 1 segment start times (cum[0] = 0, cum[k + 1] = segs[k].T + cum[k]:
+                                                     // the very sums the loops below accumulate), staged with the world in LDS
+  struct PolyPrep *prep_cache;                       // null, or per workgroup POLY_CACHE_LEVELS x POLY_MAX_OBS prepared obstacles (below)
 };
 
 // ---- Primitive1D as include/mpl_shim/mpl_basis/primitive.h writes it (left-to-right products)
@@ -50,6 +56,30 @@ MPLX_HD double pp_p(const double *c, double t) {
 MPLX_HD double pp_v(const double *c, double t) { return c[0] / 24 * t * t * t * t + c[1] / 6 * t * t * t + c[2] / 2 * t * t + c[3] * t + c[4]; }
 MPLX_HD double pp_a(const double *c, double t) { return c[0] / 6 * t * t * t + c[1] / 2 * t * t + c[2] * t + c[3]; }
 MPLX_HD double pp_j(const double *c, double t) { return c[0] / 2 * t * t + c[1] * t + c[2]; }
+// +0.0 exactly (a -0.0 coefficient would make the dropped terms -0.0, and a sum of those is not absorbed the same way)
+MPLX_HD bool is_pzero(double x) { return x == 0.0 && !__builtin_signbit(x); }
+MPLX_HD bool lead_pzero(const double *c) { return is_pzero(c[0]) && is_pzero(c[1]) && is_pzero(c[2]); }
+// short evaluation of a polynomial whose three leading coefficients are zero (VEL / ACC primitives and trajectories):
+// with t >= 0 the dropped terms are +0.0, so (x + 0.0) reproduces the full expression bit for bit (as pos_at_c in mplx_math.h)
+MPLX_HD double pp_p_auto(const double *c, double t) {
+  if (lead_pzero(c) && t >= 0.0) return ((c[3] / 2 * t * t + 0.0) + c[4] * t) + c[5];
+  return pp_p(c, t);
+}
+// the same for the derivatives: with c0 = c1 = c2 = 0 and t >= 0 every dropped term is +0.0
+MPLX_HD double pp_v_auto(const double *c, double t) {
+  if (lead_pzero(c) && t >= 0.0) return (c[3] * t + 0.0) + c[4];
+  return pp_v(c, t);
+}
+MPLX_HD double pp_a_auto(const double *c, double t) {
+  if (lead_pzero(c) && t >= 0.0) return c[3] + 0.0;
+  return pp_a(c, t);
+}
+MPLX_HD double pp_j_auto(const double *c, double t) {
+  if (lead_pzero(c) && t >= 0.0) return 0.0;
+  return pp_j(c, t);
+}
+// x / k for a divisor k > 0: a zero numerator keeps its sign, so the division is only executed for x != 0
+MPLX_HD double div_nz(double x, double k) { return x == 0.0 ? x : x / k; }
 // Primitive1D::J(t, control): double sum over the derivative's monomial coefficients, ascending (i, j)
 MPLX_HD double pp_J(const double *c, double t, int control) {
   const int k = (control & 15) == CTRL_VEL ? 1 : (control & 15) == CTRL_ACC ? 2 : (control & 15) == CTRL_JRK ? 3 : 4;
@@ -79,20 +109,20 @@ MPLX_HD bool poly_inside(const PolyHP *hp, int n_hp, double x, double y) {
 }
 // Trajectory::evaluate(time) of an obstacle trajectory (include/mpl_shim/mpl_basis/trajectory.h): clamp to
 // [0, total], find the segment by the cumulative times, evaluate at the local time
-MPLX_HD void traj_eval(const PolySeg *segs, int n_seg, double total_t, double time, double pos[2], double vel[2], double acc[2], double jrk[2]) {
+MPLX_HD void traj_eval(const PolySeg *segs, int n_seg, double total_t, double time, double pos[2], double vel[2], double acc[2], double jrk[2], const double *cum = nullptr) {
   pos[0] = pos[1] = vel[0] = vel[1] = acc[0] = acc[1] = jrk[0] = jrk[1] = 0.0;
   if (n_seg <= 0) return;
   const double tau = time < 0 ? 0 : (time > total_t ? total_t : time);
   double t0 = 0.0;
   for (int id = 0; id < n_seg; id++) {
-    const double t1 = segs[id].T + t0;
+    const double t1 = cum ? cum[id + 1] : segs[id].T + t0;
     if ((tau >= t0 && tau < t1) || id + 1 == n_seg) {
       const double lt = tau - t0;
-      for (int k = 0; k < 2; k++) {
-        pos[k] = pp_p(segs[id].c[k], lt);
-        vel[k] = pp_v(segs[id].c[k], lt);
-        acc[k] = pp_a(segs[id].c[k], lt);
-        jrk[k] = pp_j(segs[id].c[k], lt);
+      for (int k = 0; k < 2; k++) {  // (lt >= 0: the short forms apply to VEL / ACC segments)
+        pos[k] = pp_p_auto(segs[id].c[k], lt);
+        vel[k] = pp_v_auto(segs[id].c[k], lt);
+        acc[k] = pp_a_auto(segs[id].c[k], lt);
+        jrk[k] = pp_j_auto(segs[id].c[k], lt);
       }
       return;
     }
@@ -140,9 +170,10 @@ MPLX_HD bool obs_inside_nonlinear(const PolyDev &D, const PolyObs &o, double x, 
   if (t > o.total_t && !o.dis_back) return poly_inside(D.hps + o.hp_off, o.n_hp, x - wp[0], y - wp[1]);
   return false;
 }
+MPLX_HD bool obs_inside_nonlinear_pos(const PolyDev &D, const PolyObs &o, double x, double y, double t, int id0 = 0);  // (below: position only)
 // PolyMapUtil::isFree(pt, t) restricted to one obstacle (poly_map_util.h:75-88)
 MPLX_HD bool obs_point_hits(const PolyDev &D, const PolyObs &o, double x, double y, double t_rel) {
-  return o.kind == 0 ? obs_inside_static(D, o, x, y) : o.kind == 1 ? obs_inside_linear(D, o, x, y, t_rel) : obs_inside_nonlinear(D, o, x, y, t_rel);
+  return o.kind == 0 ? obs_inside_static(D, o, x, y) : o.kind == 1 ? obs_inside_linear(D, o, x, y, t_rel) : obs_inside_nonlinear_pos(D, o, x, y, t_rel);
 }
 
 // collide(pr, PolyhedronObstacle) with the obstacle's representative point (px, py) (primitive_geometry_utils.h:5-44)
@@ -280,6 +311,441 @@ MPLX_HD int obs_prim_hits(const PolyDev &D, const double cs[2][6], double T, con
   return o.kind == 0 ? collide_static_at(D, cs, T, o, o.p[0], o.p[1]) : o.kind == 1 ? collide_linear(D, cs, T, o, t_rel) : collide_nonlinear(D, cs, T, o, t_rel);
 }
 
+
+// ------------------------------------------------------------------ get_succ spread over a workgroup
+// isFree(pr, t) of all primitives of one node against all obstacles, decomposed below the (primitive, obstacle) pair:
+// the reference's collide() loops -- obstacle-trajectory segment x hyperplane x root -- run one (segment, hyperplane)
+// per lane, and what only depends on the obstacle and the node's time (which segments the primitive's time span
+// overlaps, the obstacle's state at their start) is prepared once per obstacle instead of once per pair.  Every
+// arithmetic expression and every sum order is the one of the functions above (the boolean results are OR-ed, which
+// has no order); an "unsupported degree" only counts when the reference's loop would have reached it before a hit.
+// [one lane per pair, all loops serial, took 50 k cycles per expansion: 78 % of a search]
+constexpr int POLY_SLOTS = 3;     // trajectory segments one primitive may overlap here (more: that pair runs the serial collide())
+constexpr int POLY_MAX_OBS = 64;  // obstacles prepared per node (a world with more runs the serial collide() per pair)
+struct PolySlot {
+  double T, t_residual, start_t, seg_T;  // segment start time, max(T - traj_t, 0), evaluation time, segment duration
+  double wp[2], wv[2], wa[2], wj[2];     // obstacle state at start_t
+};
+struct PolyPrep {
+  int32_t mode;     // 0 cannot collide, 1 static polyhedron at (px, py), 2 linear, 3 trajectory slots, 4 serial collide()
+  int32_t n_slots;
+  double px, py;
+  // pruning (conservative, never changes a result): during the primitive's time span every point of the obstacle stays
+  // within `reach` (per axis) of (cx, cy); +inf: no bound known
+  double cx, cy, reach;
+  int32_t id0;       // first segment the span overlaps (mode 3)
+  int32_t start_hit; // isFree(start.pos, t) fails against this obstacle (the node position is the same for every primitive)
+  unsigned long long tag_t;  // (cache) bits of the time the entry was prepared for
+  long long tag_q;           // (cache) query + 1 of the launch (0: empty; the host clears the cache per launch)
+  PolySlot slot[POLY_SLOTS];
+};
+constexpr double POLY_PRUNE_EPS = 1e-6;
+// What poly_prepare computes depends on the obstacle and on the node's TIME only, and a search visits few distinct times
+// (start + k dt): the prepared obstacles are kept per time level in HBM (per workgroup) and re-used by every later
+// expansion at that level.  An entry is valid for (query, exact time bits); anything else recomputes and overwrites.
+constexpr int POLY_CACHE_LEVELS = 64;
+// position part of traj_eval (same segment selection)
+// id0: a segment known to start at or before `time` (0 when nothing is known).  With strictly increasing segment start
+// times the scan from id0 finds the segment the scan from 0 finds; callers pass id0 > 0 only for such trajectories
+// (PolyObs::fast) and only together with cum.
+MPLX_HD void traj_pos(const PolySeg *segs, int n_seg, double total_t, double time, double pos[2], const double *cum = nullptr, int id0 = 0) {
+  pos[0] = pos[1] = 0.0;
+  if (n_seg <= 0) return;
+  const double tau = time < 0 ? 0 : (time > total_t ? total_t : time);
+  double t0 = (cum && id0 > 0) ? cum[id0] : 0.0;
+  for (int id = (cum && id0 > 0) ? id0 : 0; id < n_seg; id++) {
+    const double t1 = cum ? cum[id + 1] : segs[id].T + t0;
+    if ((tau >= t0 && tau < t1) || id + 1 == n_seg) {
+      const double lt = tau - t0;
+      pos[0] = pp_p_auto(segs[id].c[0], lt);
+      pos[1] = pp_p_auto(segs[id].c[1], lt);
+      return;
+    }
+    t0 = t1;
+  }
+}
+MPLX_HD bool obs_inside_nonlinear_pos(const PolyDev &D, const PolyObs &o, double x, double y, double t, int id0) {
+  t += o.start_t;
+  double wp[2];
+  traj_pos(D.segs + o.seg_off, o.n_seg, o.total_t, t, wp, D.cum ? D.cum + o.cum_off : nullptr, o.fast ? id0 : 0);
+  if (t <= o.total_t && t >= 0) return poly_inside(D.hps + o.hp_off, o.n_hp, x - wp[0], y - wp[1]);
+  if (t < 0 && !o.dis_front) return poly_inside(D.hps + o.hp_off, o.n_hp, x - wp[0], y - wp[1]);
+  if (t > o.total_t && !o.dis_back) return poly_inside(D.hps + o.hp_off, o.n_hp, x - wp[0], y - wp[1]);
+  return false;
+}
+// state of a trajectory at `time`, the segment known (fast trajectories: start times strictly increase, so segment id
+// with cum[id] <= time < cum[id + 1] is the one traj_eval's scan finds)
+MPLX_HD void seg_eval(const PolySeg &sg, double lt, double pos[2], double vel[2], double acc[2], double jrk[2]) {
+  for (int k = 0; k < 2; k++) {
+    pos[k] = pp_p_auto(sg.c[k], lt);
+    vel[k] = pp_v_auto(sg.c[k], lt);
+    acc[k] = pp_a_auto(sg.c[k], lt);
+    jrk[k] = pp_j_auto(sg.c[k], lt);
+  }
+}
+// per obstacle: the head of collide() for a primitive of duration prT starting at t (relative to the world's start),
+// the start-point test isFree((x0, y0), t) and the pruning bound
+MPLX_HD void poly_prepare_time(const PolyDev &D, const PolyObs &o, double prT, double t, PolyPrep &R) {
+  R.n_slots = 0;
+  R.id0 = 0;
+  R.px = o.p[0];
+  R.py = o.p[1];
+  R.cx = o.p[0];
+  R.cy = o.p[1];
+  R.reach = INFINITY;
+  R.start_hit = 0;
+  if (o.kind == 0) {
+    R.mode = 1;
+    R.reach = o.radius + POLY_PRUNE_EPS;
+    return;
+  }
+  if (o.kind == 1) {
+    R.mode = 2;
+    return;
+  }
+  const PolySeg *segs = D.segs + o.seg_off;
+  const double *cum = D.cum ? D.cum + o.cum_off : nullptr;
+  const bool fast = o.fast && cum;
+  const double traj_t = t + o.start_t;
+  int start_id = -1;
+  double T = 0.0;
+  for (int i = 0; i < o.n_seg; i++) {
+    const double T1 = cum ? cum[i + 1] : T + segs[i].T;
+    if (traj_t >= T && traj_t < T1) {
+      start_id = i;
+      break;
+    }
+    T = T1;  // (T += segs[i].T: the same sum)
+  }
+  if (start_id < 0) {
+    double wp[2], wv[2], wa[2], wj[2];
+    traj_eval(segs, o.n_seg, o.total_t, traj_t, wp, wv, wa, wj, cum);
+    const bool there = (traj_t <= o.total_t && traj_t >= 0) || (traj_t < 0 && !o.dis_front) || (traj_t > o.total_t && !o.dis_back);
+    R.mode = there ? 1 : 0;
+    R.px = wp[0];
+    R.py = wp[1];
+    R.cx = wp[0];
+    R.cy = wp[1];
+    R.reach = o.radius + POLY_PRUNE_EPS;
+    return;
+  }
+  R.mode = 3;
+  R.id0 = start_id;
+  double disp[2] = {0.0, 0.0};
+  for (int id = start_id; id < o.n_seg; id++) {
+    const double t_residual = T - traj_t < 0 ? 0 : T - traj_t;
+    const double start_t = t_residual <= 0 ? traj_t : T;
+    if (t_residual > prT) break;
+    if (R.n_slots == POLY_SLOTS) { R.mode = 4; break; }
+    PolySlot &S = R.slot[R.n_slots++];
+    S.T = T; S.t_residual = t_residual; S.start_t = start_t; S.seg_T = segs[id].T;
+    if (fast) {  // (start_t lies inside segment id: what traj_eval's scan finds; VEL / ACC segment, lt >= 0: the short forms)
+      const double lt = start_t - T;
+      for (int k = 0; k < 2; k++) {
+        const double c3 = segs[id].c[k][3], c4 = segs[id].c[k][4], c5 = segs[id].c[k][5];
+        S.wp[k] = ((c3 / 2 * lt * lt + 0.0) + c4 * lt) + c5;
+        S.wv[k] = (c3 * lt + 0.0) + c4;
+        S.wa[k] = c3 + 0.0;
+        S.wj[k] = 0.0;
+      }
+    }
+    else traj_eval(segs, o.n_seg, o.total_t, start_t, S.wp, S.wv, S.wa, S.wj, cum);
+    for (int k = 0; k < 2; k++) disp[k] += fabs(S.wv[k]) * prT + 0.5 * fabs(S.wa[k]) * prT * prT;
+    T = cum ? cum[id + 1] : T + segs[id].T;
+  }
+  if (R.mode == 3 && fast) {  // VEL / ACC segments: |c(t) - c(traj_t)| <= sum over the slots of |v| prT + |a| prT^2 / 2
+    R.cx = R.slot[0].wp[0];
+    R.cy = R.slot[0].wp[1];
+    R.reach = (disp[0] > disp[1] ? disp[0] : disp[1]) + o.radius + POLY_PRUNE_EPS;
+  }
+}
+// isFree((x0, y0), t) against one obstacle, from its prepared state: PolyMapUtil::isFree(pt, t) (poly_map_util.h:75-88)
+//   static: inside(p_);  trajectory outside its time span: inside(clamped end) unless it has disappeared (mode 0);
+//   inside its span: the obstacle at traj_t = slot 0's evaluation point (the first slot starts at traj_t)
+MPLX_HD bool poly_start_test(const PolyDev &D, const PolyObs &o, const PolyPrep &R, double x0, double y0, double t) {
+  if (R.mode == 0) return false;
+  if (R.mode == 1) return poly_inside(D.hps + o.hp_off, o.n_hp, x0 - R.px, y0 - R.py);
+  if (R.mode == 2) return obs_inside_linear(D, o, x0, y0, t);
+  if (R.mode == 3) return poly_inside(D.hps + o.hp_off, o.n_hp, x0 - R.slot[0].wp[0], y0 - R.slot[0].wp[1]);
+  return obs_inside_nonlinear_pos(D, o, x0, y0, t, 0);
+}
+// one (slot, hyperplane) of collide(): 1 hit, 0 free, -1 unsupported degree
+MPLX_HD int poly_item(const PolyDev &D, const double (*cs)[6], double prT, const PolyObs &o, const PolyPrep &R, int s, int h, double t) {
+  const PolyHP *hp = D.hps + o.hp_off;
+  const double n[2] = {hp[h].nx, hp[h].ny};
+  double a = 0, b = 0, c = 0, d = 0, e = 0, f = 0;
+  if (R.mode == 1) {  // collide_static_at(..., R.px, R.py), hyperplane h
+    for (int i = 0; i < 2; i++) {
+      a += n[i] * cs[i][0];
+      b += n[i] * cs[i][1];
+      c += n[i] * cs[i][2];
+      d += n[i] * cs[i][3];
+      e += n[i] * cs[i][4];
+      f += n[i] * cs[i][5];
+    }
+    a = div_nz(a, 120.0); b = div_nz(b, 24.0); c = div_nz(c, 6.0); d *= 0.5;  // (x / 2 == x * 0.5 exactly; e /= 1.0 is the identity)
+    {
+      double sm = 0.0;
+      sm += n[0] * (hp[h].px + R.px);
+      sm += n[1] * (hp[h].py + R.py);
+      f -= sm;
+    }
+    double ts[2];
+    const int nr = solve_le2(a, b, c, d, e, f, ts);
+    if (nr < 0) return -1;
+    for (int r = 0; r < nr; r++) {
+      const double it = ts[r];
+      if (it >= 0 && it <= prT) {
+        const double wx = pp_p_auto(cs[0], it), wy = pp_p_auto(cs[1], it);
+        if (poly_inside(hp, o.n_hp, wx - R.px, wy - R.py)) return 1;
+      }
+    }
+    return 0;
+  }
+  if (R.mode == 2) {  // collide_linear, hyperplane h
+    const double cov_v[2] = {o.v[0] + n[0] * o.cov_v, o.v[1] + n[1] * o.cov_v};
+    for (int i = 0; i < 2; i++) {
+      a += n[i] * cs[i][0];
+      b += n[i] * cs[i][1];
+      c += n[i] * cs[i][2];
+      d += n[i] * cs[i][3];
+      e += n[i] * cs[i][4];
+      f += n[i] * cs[i][5];
+    }
+    a = div_nz(a, 120.0); b = div_nz(b, 24.0); c = div_nz(c, 6.0); d *= 0.5;
+    {
+      double sm = 0.0;
+      sm += n[0] * cov_v[0];
+      sm += n[1] * cov_v[1];
+      e -= sm;
+      double s2 = 0.0;
+      s2 += n[0] * ((hp[h].px + o.p[0]) + cov_v[0] * t);
+      s2 += n[1] * ((hp[h].py + o.p[1]) + cov_v[1] * t);
+      f -= s2;
+    }
+    double ts[2];
+    const int nr = solve_le2(a, b, c, d, e, f, ts);
+    if (nr < 0) return -1;
+    for (int r = 0; r < nr; r++) {
+      const double it = ts[r];
+      if (it >= 0 && it <= prT) {
+        const double wx = pp_p_auto(cs[0], it), wy = pp_p_auto(cs[1], it);
+        if (obs_inside_linear(D, o, wx, wy, it + t)) return 1;
+      }
+    }
+    return 0;
+  }
+  // collide_nonlinear: segment slot s, hyperplane h
+  const PolySlot &S = R.slot[s];
+  const double hpp[2] = {hp[h].px, hp[h].py};
+  for (int i = 0; i < 2; i++) {
+    a += n[i] * cs[i][0];
+    b += n[i] * cs[i][1];
+    c += n[i] * cs[i][2] - n[i] * S.wj[i];
+    d += n[i] * cs[i][3] - n[i] * S.wa[i];
+    e += n[i] * cs[i][4] - n[i] * S.wv[i];
+    f += n[i] * cs[i][5] - n[i] * (hpp[i] + S.wp[i]);
+  }
+  a = div_nz(a, 120.0); b = div_nz(b, 24.0); c = div_nz(c, 6.0); d *= 0.5;
+  double ts[2];
+  const int nr = solve_le2(a, b, c, d, e, f, ts);
+  if (nr < 0) return -1;
+  for (int r = 0; r < nr; r++) {
+    const double it = ts[r];
+    if (it >= S.t_residual && it <= prT && S.T + S.seg_T >= it + S.start_t && S.T <= it + S.start_t) {
+      const double cx = pp_p_auto(cs[0], it), cy = pp_p_auto(cs[1], it);
+      if (obs_inside_nonlinear_pos(D, o, cx, cy, it + t, R.id0)) return 1;
+    }
+  }
+  return 0;
+}
+
+#ifdef __HIPCC__
+// isFree(pr, t_rel) of every valid primitive (cs[i], i < n_u) against every obstacle of world W, the workgroup's lanes
+// spread over (primitive, obstacle, segment slot, hyperplane); ORs into hit[i], sets *unsupported.  LDS scratch:
+// prep[POLY_MAX_OBS], hit_idx / uns_idx[POLY_MAX_U * POLY_MAX_OBS], hp_max.  Every thread of the workgroup must call.
+// cache_q: query + 1 (tags the per-level cache entries); mid_hook(): called by every thread once the obstacles are
+// prepared, before the (long) item loop -- the caller can put memory traffic of its own in flight there
+struct PolyNoHook { __device__ __forceinline__ void operator()() const {} };
+template <int BLOCK, class Hook = PolyNoHook>
+__device__ __forceinline__ void poly_collide_all(const PolyDev &D, const PolyWorld &W, const double (*cs)[2][6], const int32_t *valid, int n_u, double T, double t_rel,
+                                                 PolyPrep *prep, uint32_t *hit_idx, uint32_t *uns_idx, int32_t *hp_max, int32_t *hit, int32_t *unsupported, int32_t *start_hit,
+                                                 int tid, long long cache_q, Hook mid_hook, unsigned long long *cyc = nullptr) {
+  const int n_obs = W.n_obs;
+  unsigned long long tc0 = __builtin_readcyclecounter();
+  const double x0 = pp_p_auto(cs[0][0], 0.0), y0 = pp_p_auto(cs[0][1], 0.0);  // pr.evaluate(0): the node position, whatever the primitive
+  if (n_obs > POLY_MAX_OBS) {  // (uniform) a crowded world: one lane per pair, the reference's loops as they are
+    for (int j = tid; j < n_obs; j += BLOCK)
+      if (obs_point_hits(D, D.obs[W.obs_off + j], x0, y0, t_rel)) *start_hit = 1;
+    const int pairs = n_u * n_obs;
+    for (int e = tid; e < pairs; e += BLOCK) {
+      const int i = e / n_obs, j = e % n_obs;
+      if (!valid[i]) continue;
+      double c[2][6];
+      for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 6; b++) c[a][b] = cs[i][a][b];
+      const int r = obs_prim_hits(D, c, T, D.obs[W.obs_off + j], t_rel);
+      if (r < 0) *unsupported = 1;
+      if (r > 0) hit[i] = 1;
+    }
+    __syncthreads();
+    mid_hook();
+    return;
+  }
+  // hit_idx[n_pairs .. ] doubles as the list of pairs that survive the pruning (u32 each), uns_idx[n_pairs] as its length
+  const int n_pairs = n_u * n_obs;
+  if (tid == 0) { *hp_max = 1; uns_idx[POLY_MAX_U * POLY_MAX_OBS - 1] = 0u; }
+  for (int e = tid; e < n_pairs; e += BLOCK) { hit_idx[e] = 0xFFFFFFFFu; uns_idx[e] = 0xFFFFFFFFu; }
+  if (tid < n_obs) {
+    const PolyObs &o = D.obs[W.obs_off + tid];
+    PolyPrep &R = prep[tid];
+    // the time-dependent part comes from the per-level cache when this (query, time) has been prepared before
+    PolyPrep *ce = nullptr;
+    if (D.prep_cache && T > 0) {
+      const double lv = t_rel / T;
+      const int k = lv >= 0 && lv < (double)POLY_CACHE_LEVELS ? (int)(lv + 0.5) : -1;
+      if (k >= 0 && k < POLY_CACHE_LEVELS) ce = D.prep_cache + ((size_t)blockIdx.x * POLY_CACHE_LEVELS + (size_t)k) * POLY_MAX_OBS + tid;
+    }
+    const unsigned long long tbits = (unsigned long long)__double_as_longlong(t_rel);
+    if (ce && ce->tag_q == cache_q && ce->tag_t == tbits) {
+      R = *ce;
+    } else {
+      poly_prepare_time(D, o, T, t_rel, R);
+      R.tag_t = tbits;
+      R.tag_q = cache_q;
+      if (ce) *ce = R;
+    }
+    if (poly_start_test(D, o, R, x0, y0, t_rel)) *start_hit = 1;
+    atomicMax(hp_max, o.n_hp);
+  }
+  __syncthreads();
+  mid_hook();
+  if (cyc && tid == 0) { const unsigned long long now = __builtin_readcyclecounter(); cyc[5] += now - tc0; tc0 = now; }
+  // pruning: a primitive stays within |v| T + |u| T^2 / 2 (per axis) of the node, an obstacle within its reach of
+  // (cx, cy); further apart than the two together (plus a margin far above rounding) they cannot meet.  Conservative:
+  // a pruned pair is one whose collide() returns false.  [16 robots in a 10 m arena: most pairs]
+  uint32_t *plist = hit_idx + POLY_MAX_U * POLY_MAX_OBS / 2, *plen = &uns_idx[POLY_MAX_U * POLY_MAX_OBS - 1];
+  const bool can_list = n_pairs <= POLY_MAX_U * POLY_MAX_OBS / 2 - 1;
+  for (int pair = tid; pair < n_pairs; pair += BLOCK) {
+    const int i = pair / n_obs, j = pair - i * n_obs;
+    if (!valid[i] || prep[j].mode == 0) continue;
+    bool keep = true;
+    const PolyPrep &R = prep[j];
+    if (R.reach < INFINITY && lead_pzero(cs[i][0]) && lead_pzero(cs[i][1])) {
+      const double rx = fabs(cs[i][0][4]) * T + 0.5 * fabs(cs[i][0][3]) * T * T + R.reach + POLY_PRUNE_EPS;
+      const double ry = fabs(cs[i][1][4]) * T + 0.5 * fabs(cs[i][1][3]) * T * T + R.reach + POLY_PRUNE_EPS;
+      keep = !(fabs(x0 - R.cx) > rx || fabs(y0 - R.cy) > ry);
+    }
+    if (keep && can_list) plist[atomicAdd(plen, 1u)] = (uint32_t)pair;
+  }
+  __syncthreads();
+  // items: (surviving pair, sub) with sub = slot * HP + hyperplane padded to a power of two, so that the decode is shifts
+  const int HP = *hp_max;
+  int sub_log = 0;
+  while ((1 << sub_log) < POLY_SLOTS * HP) sub_log++;
+  const int n_list = can_list ? (int)*plen : n_pairs, total = n_list << sub_log;
+  for (int e = tid; e < total; e += BLOCK) {
+    const int li = e >> sub_log, sub = e & ((1 << sub_log) - 1);
+    const int pair = can_list ? (int)plist[li] : li;
+    const int i = pair / n_obs, j = pair - i * n_obs;
+    if (!valid[i] || sub >= POLY_SLOTS * HP) continue;
+    const int s = sub / HP, h = sub - s * HP;
+    const PolyPrep &R = prep[j];
+    const PolyObs &o = D.obs[W.obs_off + j];
+    const int mode = R.mode;
+    if (mode == 0) continue;
+    if (mode == 4) { if (sub != 0) continue; }
+    else if (h >= o.n_hp || (mode == 3 ? s >= R.n_slots : s != 0)) continue;
+    const uint32_t idx = (uint32_t)(s * HP + h);
+    if (hit_idx[pair] < idx) continue;  // the reference's loop has already returned (a benign race: only saves work)
+    int r;
+    if (mode == 4) {
+      double c[2][6];
+      for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 6; b++) c[a][b] = cs[i][a][b];
+      r = obs_prim_hits(D, c, T, o, t_rel);
+    } else {
+      r = poly_item(D, cs[i], T, o, R, s, h, t_rel);
+    }
+    if (r > 0) atomicMin(&hit_idx[pair], idx);
+    if (r < 0) atomicMin(&uns_idx[pair], idx);
+  }
+  if (cyc && tid == 0) { const unsigned long long now = __builtin_readcyclecounter(); cyc[6] += now - tc0; tc0 = now; }
+  __syncthreads();
+  if (cyc && tid == 0) { const unsigned long long now = __builtin_readcyclecounter(); cyc[7] += now - tc0; tc0 = now; }
+  for (int e = tid; e < n_pairs; e += BLOCK) {
+    const uint32_t hi = hit_idx[e], ui = uns_idx[e];
+    if (hi != 0xFFFFFFFFu && hi < ui) hit[e / n_obs] = 1;   // collide() returned true before meeting an unsupported degree
+    else if (ui != 0xFFFFFFFFu) *unsupported = 1;
+  }
+  __syncthreads();
+}
+#endif
+
+#ifdef __HIPCC__
+// The obstacle set of one world staged in LDS for the duration of a search (every traj_eval / collide() walks the
+// trajectory's segments: from global memory that is a chain of dependent L2 round trips per call -- 7-10 k cycles per
+// expansion before staging).  Worlds that do not fit keep reading global memory.
+constexpr int POLY_LDS_HPS = 256, POLY_LDS_SEGS = 256;
+struct PolyWorldLds {
+  PolyObs obs[POLY_MAX_OBS];
+  PolyHP hps[POLY_LDS_HPS];
+  PolySeg segs[POLY_LDS_SEGS];
+  double cum[POLY_LDS_SEGS + POLY_MAX_OBS];
+  int32_t ok, n_hps, n_segs, pad;
+};
+// every thread of the workgroup calls; returns the PolyDev / PolyWorld to use (LDS-backed when the world fits)
+template <int BLOCK>
+__device__ __forceinline__ void poly_stage_world(const PolyDev &D, const PolyWorld &W, PolyWorldLds &L, int tid, PolyDev &DL, PolyWorld &WL) {
+  DL = D;
+  WL = W;
+  if (tid == 0) {
+    int nh = 0, ns = 0;
+    bool fits = W.n_obs <= POLY_MAX_OBS;
+    for (int j = 0; j < W.n_obs && fits; j++) {
+      const PolyObs &o = D.obs[W.obs_off + j];
+      nh += o.n_hp;
+      ns += o.n_seg;
+      fits = nh <= POLY_LDS_HPS && ns <= POLY_LDS_SEGS;
+    }
+    L.ok = fits ? 1 : 0;
+    if (fits) {  // per obstacle: its offsets inside the LDS arrays, its segment start times
+      int hoff = 0, soff = 0, coff = 0;
+      for (int j = 0; j < W.n_obs; j++) {
+        PolyObs o = D.obs[W.obs_off + j];
+        const int gs = o.seg_off;
+        o.hp_off = hoff; o.seg_off = soff; o.cum_off = coff;
+        double t0 = 0.0;
+        L.cum[coff] = 0.0;
+        for (int k = 0; k < o.n_seg; k++) {
+          t0 = D.segs[gs + k].T + t0;
+          L.cum[coff + k + 1] = t0;
+        }
+        L.obs[j] = o;
+        hoff += o.n_hp; soff += o.n_seg; coff += o.n_seg + 1;
+      }
+      L.n_hps = hoff;
+      L.n_segs = soff;
+    }
+  }
+  __syncthreads();
+  if (!L.ok) return;
+  // copy hyperplanes and segments (global offsets re-read from the global records: obstacle j's range)
+  for (int j = 0; j < W.n_obs; j++) {
+    const PolyObs &g = D.obs[W.obs_off + j];
+    const PolyObs &l = L.obs[j];
+    for (int k = tid; k < g.n_hp; k += BLOCK) L.hps[l.hp_off + k] = D.hps[g.hp_off + k];
+    for (int k = tid; k < g.n_seg; k += BLOCK) L.segs[l.seg_off + k] = D.segs[g.seg_off + k];
+  }
+  __syncthreads();
+  DL.obs = L.obs;
+  DL.hps = L.hps;
+  DL.segs = L.segs;
+  DL.cum = L.cum;
+  WL.obs_off = 0;
+}
+#endif
+
 // Primitive<2>(curr, u, dt) coefficients (mpl_shim primitive.h) for VEL / ACC
 MPLX_HD void poly_prim_build(int control, const double pos[2], const double vel[2], const double u[2], double cs[2][6]) {
   for (int i = 0; i < 2; i++) {
@@ -293,13 +759,36 @@ MPLX_HD void poly_prim_build(int control, const double pos[2], const double vel[
 MPLX_HD bool poly_validate(int control, const double cs[2][6], double T, double v_max) {
   if ((control & 15) != CTRL_ACC) return true;
   for (int i = 0; i < 2; i++) {
-    const double m = fmax(fabs(pp_v(cs[i], 0.0)), fabs(pp_v(cs[i], T)));
+    const double m = fmax(fabs(pp_v_auto(cs[i], 0.0)), fabs(pp_v_auto(cs[i], T)));
     if (v_max > 0 && m > v_max) return false;
   }
   return true;
 }
 // env_poly_map::calculate_intrinsic_cost: pr.J(pr.control()) + 0.001 * pr.J(Control::VEL) + w dt (env_poly_map.h:71-73)
 MPLX_HD double poly_intrinsic_cost(int control, const double cs[2][6], double T, double w, double dt) {
+  if ((control & 15) == CTRL_ACC && lead_pzero(cs[0]) && lead_pzero(cs[1])) {
+    // Primitive1D::J's double sum with the structurally zero coefficients of an ACC primitive taken out: the dropped
+    // terms are +-0.0 added to a non-negative running sum, i.e. no-ops.  J(ACC): q = {c3, 0, 0, 0}: the (0, 0) term;
+    // J(VEL): q = {c4, c3, 0, 0, 0}: terms (0,0), (0,1), (1,0), (1,1) in that order.
+    double jc = 0, jv = 0;
+    for (int k = 0; k < 2; k++) {
+      const double q0 = cs[k][3] / 1.0;
+      double s = 0.0;
+      s += q0 * q0 * T / 1.0;
+      jc += s;
+    }
+    for (int k = 0; k < 2; k++) {
+      const double q0 = cs[k][4] / 1.0, q1 = cs[k][3] / 1.0;
+      const double t2 = T * T, t3 = t2 * T;
+      double s = 0.0;
+      s += q0 * q0 * T / 1.0;
+      s += q0 * q1 * t2 / 2.0;
+      s += q1 * q0 * t2 / 2.0;
+      s += q1 * q1 * t3 / 3.0;
+      jv += s;
+    }
+    return jc + 0.001 * jv + w * dt;
+  }
   double jc = 0;
   for (int k = 0; k < 2; k++) jc += pp_J(cs[k], T, control);
   double jv = 0;

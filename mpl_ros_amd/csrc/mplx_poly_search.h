@@ -21,11 +21,14 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
   __shared__ Smem<BLOCK> S;
   __shared__ double pcs[POLY_MAX_U][2][6];
   __shared__ int32_t pvalid[POLY_MAX_U], phit[POLY_MAX_U];
-  __shared__ int32_t pstart_hit, punsupported;
+  __shared__ int32_t pstart_hit, punsupported, php_max;
+  __shared__ PolyPrep pprep[POLY_MAX_OBS];
+  __shared__ uint32_t phit_idx[POLY_MAX_U * POLY_MAX_OBS], puns_idx[POLY_MAX_U * POLY_MAX_OBS];
+  __shared__ PolyWorldLds wlds;
   using V = QView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
-  const PolyDev &D = P.poly;
+  const PolyDev &DG = P.poly;
   for (;;) {
     if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
     __syncthreads();
@@ -33,8 +36,12 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
     if (qi >= P.nq) break;
     const int q = P.order[qi];
     const QueryIn &in = P.queries[q];
-    const PolyWorld W = D.worlds[P.poly_world[q]];
+    const PolyWorld WG = DG.worlds[P.poly_world[q]];
     const unsigned long long t_begin = wall_clock64();
+    // the world's obstacles into LDS for the whole search (every collide() walks their trajectories)
+    PolyDev D;
+    PolyWorld W;
+    poly_stage_world<BLOCK>(DG, WG, wlds, tid, D, W);
     for (int i = tid; i < 2 * NB; i += BLOCK) S.cnt[0][i] = 0;
     if (tid == 0) {
       S.n_near = 0; S.n_nodes = 0; S.n_edges = 0; S.n_log = 0;
@@ -104,7 +111,9 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
           evict_half(Q, tid);
           __syncthreads();
         }
+        MPLX_TIC(tp);
         const bool popped = pop_min<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid);
+        MPLX_TOC(S, 0, tp);
         if (!popped) {
           if (tid == 0) S.status = 1;
           __syncthreads();
@@ -120,6 +129,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
           pstart_hit = 0;
         }
         // ---- env_poly_map::get_succ(curr): S.cur[0] = pos3 vel3 ... , S.cur[0][12] = curr.t
+        MPLX_TIC(tx);
         const double T = P.dt, cur_t = S.cur[0][12], t_rel = cur_t - W.start_t;
         LaneSucc L;
         L.valid = false; L.blocked = false; L.reads = 0;
@@ -130,8 +140,8 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
           poly_prim_build(CONTROL, pos, vel, u, c);
           for (int i = 0; i < 2; i++)
             for (int j = 0; j < 6; j++) pcs[tid][i][j] = c[i][j];
-          L.tn.p[0] = pp_p(c[0], T); L.tn.p[1] = pp_p(c[1], T); L.tn.p[2] = 0.0;
-          L.tn.v[0] = pp_v(c[0], T); L.tn.v[1] = pp_v(c[1], T); L.tn.v[2] = 0.0;
+          L.tn.p[0] = pp_p_auto(c[0], T); L.tn.p[1] = pp_p_auto(c[1], T); L.tn.p[2] = 0.0;
+          L.tn.v[0] = pp_v_auto(c[0], T); L.tn.v[1] = pp_v_auto(c[1], T); L.tn.v[2] = 0.0;
           for (int k = 0; k < 3; k++) { L.tn.a[k] = 0.0; L.tn.j[k] = 0.0; }
           pvalid[tid] = (poly_inside(W.bbox, 4, L.tn.p[0], L.tn.p[1]) && poly_validate(CONTROL, c, T, P.v_max)) ? 1 : 0;
           phit[tid] = 0;
@@ -139,21 +149,21 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
           state_key_c<CONTROL>(L.tn, L.key);
           L.key[ns] = (int32_t)round((cur_t + P.dt) / 0.1);
         }
-        __syncthreads();
-        for (int j = tid; j < W.n_obs; j += BLOCK)
-          if (obs_point_hits(D, D.obs[W.obs_off + j], pp_p(pcs[0][0], 0.0), pp_p(pcs[0][1], 0.0), t_rel)) pstart_hit = 1;
-        const int pairs = P.n_u * W.n_obs;
-        for (int e = tid; e < pairs; e += BLOCK) {
-          const int i = e / W.n_obs, j = e % W.n_obs;
-          if (!pvalid[i]) continue;
-          double c[2][6];
-          for (int a = 0; a < 2; a++)
-            for (int b = 0; b < 6; b++) c[a][b] = pcs[i][a][b];
-          const int r = obs_prim_hits(D, c, T, D.obs[W.obs_off + j], t_rel);
-          if (r < 0) punsupported = 1;
-          if (r > 0) phit[i] = 1;
+        // first probe of the state table for every valid successor, issued now: its round trip overlaps the collision tests
+        unsigned long long h64 = 0, v0 = TBL_EMPTY;
+        if (tid < P.n_u && pvalid[tid]) {
+          h64 = key_hash64(L.key, NK);
+          v0 = ld_u64(&P.table[(size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask]);
         }
         __syncthreads();
+        MPLX_TOC(S, 3, tx);
+        // isFree(start.pos, t) and isFree(pr, t) of all primitives against all obstacles
+        poly_collide_all<BLOCK>(D, W, pcs, pvalid, P.n_u, T, t_rel, pprep, phit_idx, puns_idx, &php_max, phit, &punsupported, &pstart_hit, tid, (long long)q + 1,
+                                [&]() {  // the table slot has arrived: start fetching the record it names (the commit reads it)
+                                  const uint32_t vid = (uint32_t)v0;
+                                  if (v0 != TBL_EMPTY && vid < CLAIM_BASE && (v0 >> 32) == ((h64 >> 48) << 16 | (unsigned long long)(uint32_t)q))
+                                    __builtin_prefetch(Q.node(vid), 0, 3);
+                                }, S.cyc);
         if (tid < P.n_u) {
           L.valid = pvalid[tid] != 0;
           L.blocked = L.valid && (pstart_hit || phit[tid]);
@@ -169,13 +179,13 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
             if (punsupported) S.status = 5;
           }
         }
-        unsigned long long h64 = 0;
         S.dupset[tid] = 0;
         S.dupset[tid + BLOCK] = 0;
         __syncthreads();
+        MPLX_TOC(S, 1, tx);
+        MPLX_TIC(tc);
         if (S.status >= 0) break;
         if (act) {
-          h64 = key_hash64(L.key, NK);
           const unsigned long long hv = h64 | 1ull;
           uint32_t sl = (uint32_t)(h64 >> 7) & (2 * BLOCK - 1);
           for (;;) {
@@ -187,11 +197,12 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
         }
         __syncthreads();
         if (!S.flag) {
-          commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid, q, act, L, h64, lane_cost, (uint32_t)tid);
+          commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid, q, act, L, h64, lane_cost, (uint32_t)tid, true, v0);
         } else {
           for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid, q, act && tid == i, L, h64, lane_cost, (uint32_t)tid);
         }
         __syncthreads();
+        MPLX_TOC(S, 2, tc);
         if (S.status >= 0) break;
         if (tid == 0) {
           State s;

@@ -180,6 +180,12 @@ class PolyTeam:
         self.check(self.lib.mplx_poly_result_expanded(self.h, q, cap, ids.ctypes.data, C.byref(n)))
         return ids[:n.value]
 
+    def cycles(self, q):
+        """shader-clock cycles query q spent in pop / get_succ / look-up + commit"""
+        cyc = (C.c_uint64 * 10)()
+        self.check(self.lib.mplx_poly_result_cycles(self.h, int(q), cyc))
+        return dict(pop=int(cyc[0]), get_succ=int(cyc[1]), commit=int(cyc[2]), primitives=int(cyc[3]), start_test=int(cyc[4]), prepare=int(cyc[5]), items_lane0=int(cyc[6]), items_wait=int(cyc[7]))
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self.check(self.lib.mplx_poly_last_kernel_ms(self.h, C.byref(ms)))
