@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the query-sharded multi-process path (map broadcast, static round-robin
+"""CPU, world sizes 2 / 4 / 8, gloo: the query-sharded multi-process path (map broadcast, static round-robin
 shard, no collective on the search path, gather at the end).  The per-rank search is done by the CPU
 oracle here; on GPUs bench.py runs the same plumbing with backend "nccl" (= RCCL) and the HIP planner."""
 import os
@@ -69,12 +69,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_query_sharding_matches_single_process():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_query_sharding_matches_single_process(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     lpt, rr, ref, _ = q.get(timeout=240)
