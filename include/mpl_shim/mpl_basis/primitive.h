@@ -71,15 +71,23 @@ class Primitive {
     if (cs.size() > (size_t)Dim) pr_yaw_ = Primitive1D(cs.back());  // 4th entry of the message form = yaw
   }
   /// from a state and a control input (test_primitive_collide.cpp:15, obstacle_config.hpp:24)
+  /// a use_yaw state adds the yaw channel yaw(t) = yaw0 + u(Dim) t (Vec4f inputs, map_planner_node.cpp:125-126)
   Primitive(const Waypoint<Dim> &p, const VecDf &u, decimal_t t) : t_(t), control_(p.control) {
+    const int kind = (int)p.control & 15;
     for (int i = 0; i < Dim; i++) {
       Vec6f c;
-      if (p.control == Control::VEL) { c(4) = u(i); c(5) = p.pos(i); }
-      else if (p.control == Control::ACC) { c(3) = u(i); c(4) = p.vel(i); c(5) = p.pos(i); }
-      else if (p.control == Control::JRK) { c(2) = u(i); c(3) = p.acc(i); c(4) = p.vel(i); c(5) = p.pos(i); }
-      else if (p.control == Control::SNP) { c(1) = u(i); c(2) = p.jrk(i); c(3) = p.acc(i); c(4) = p.vel(i); c(5) = p.pos(i); }
+      if (kind == Control::VEL) { c(4) = u(i); c(5) = p.pos(i); }
+      else if (kind == Control::ACC) { c(3) = u(i); c(4) = p.vel(i); c(5) = p.pos(i); }
+      else if (kind == Control::JRK) { c(2) = u(i); c(3) = p.acc(i); c(4) = p.vel(i); c(5) = p.pos(i); }
+      else if (kind == Control::SNP) { c(1) = u(i); c(2) = p.jrk(i); c(3) = p.acc(i); c(4) = p.vel(i); c(5) = p.pos(i); }
       else printf("Null Primitive, check the control set-up of the Waypoint!\n");
       prs_[i] = Primitive1D(c);
+    }
+    if (p.use_yaw) {
+      Vec6f c;
+      c(4) = (int)u.size() > Dim ? u(Dim) : 0.0;
+      c(5) = p.yaw;
+      pr_yaw_ = Primitive1D(c);
     }
   }
   Primitive1D pr(int k) const { return prs_[k]; }
@@ -93,6 +101,13 @@ class Primitive {
       p.vel(k) = prs_[k].v(t);
       p.acc(k) = prs_[k].a(t);
       p.jrk(k) = prs_[k].j(t);
+    }
+    if (p.use_yaw) {  // [UNVERIFIED upstream: the yaw of a state is kept in [-pi, pi]]
+      const decimal_t pi = 3.141592653589793;
+      decimal_t q = pr_yaw_.p(t);
+      while (q > pi) q -= 2 * pi;
+      while (q < -pi) q += 2 * pi;
+      p.yaw = q;
     }
     return p;
   }
@@ -125,7 +140,8 @@ typedef Primitive<3> Primitive3D;
 
 /// validate_primitive(pr, v_max, a_max, j_max[, yaw_max]) (env_poly_map.h:58, env_cloud.h:62): a control kind checks the
 /// derivatives below its own order (ACC: vel; JRK: vel, acc; SNP: vel, acc, jrk); a limit <= 0 is not checked
-/// [UNVERIFIED rule, same as the oracle's and the device's].  yaw_max >= 0 is refused: yaw is not implemented.
+/// [UNVERIFIED rule, same as the device's].  The yaw threshold is applied by the device search (validate_yaw of
+/// mplx_math.h); this host-side helper checks the derivative limits only.
 template <int Dim>
 bool validate_primitive(const Primitive<Dim> &pr, decimal_t mv = 0, decimal_t ma = 0, decimal_t mj = 0, decimal_t myaw = 0) {
   const int c = pr.control() & 15;

@@ -45,16 +45,14 @@ class PlannerBase {
   virtual void setJmax(decimal_t j) { j_max_ = j; if (ENV_) ENV_->set_j_max(j); }
   /// The yaw threshold (map_planner_node.cpp:179-180) constrains yaw-carrying primitives only: the reference node
   /// always calls it, and its own config-1 launch file passes yaw_max = 0.5 with use_yaw = false
-  /// (launch/map_planner_node/test.launch:28,33).  Stored; it takes effect when the search states carry yaw.
+  /// (launch/map_planner_node/test.launch:28,33).  It takes effect when the search states carry yaw (use_yaw).
   virtual void setYawmax(decimal_t yaw) { yaw_max_ = yaw; if (ENV_) ENV_->set_yaw_max(yaw); }
   virtual void setTmax(decimal_t t) { t_max_ = t; if (ENV_) ENV_->t_max_ = t; }
   virtual void setDt(decimal_t dt) { dt_ = dt; if (ENV_) ENV_->set_dt(dt); }
   virtual void setW(decimal_t w) { w_ = w; if (ENV_) ENV_->set_w(w); }
   virtual void setMaxNum(int num) { max_num_ = num; }
   virtual void setU(const vec_E<VecDf> &U) {
-    U_vec_ = U;
-    for (const auto &u : U)
-      if (u.size() > Dim) { printf(ANSI_COLOR_RED "[PlannerBase] setU: control inputs with a yaw component are not supported by the mplx back-end; plan() will fail\n" ANSI_COLOR_RESET); unsupported_ = true; break; }
+    U_vec_ = U;  // (Dim + 1 components: the last one is the yaw rate of the use_yaw lattices, map_planner_node.cpp:119-139)
     if (ENV_) ENV_->set_u(U);
   }
   virtual void setTol(decimal_t tol_pos, decimal_t tol_vel = -1, decimal_t tol_acc = -1) {
@@ -113,7 +111,7 @@ class PlannerBase {
   int max_num_ = -1;
   bool planner_verbose_ = false;
   bool use_lpastar_ = false;
-  bool unsupported_ = false;  // a yaw request was made: plan() must fail
+  bool unsupported_ = false;  // a request this back-end does not cover was made: plan() must fail
   // the set-up as the setters received it (re-applied when an environment is created later)
   decimal_t v_max_ = -1, a_max_ = -1, j_max_ = -1, yaw_max_ = -1, dt_ = 1.0, w_ = 10;
   decimal_t tol_pos_ = 0.5, tol_vel_ = -1, tol_acc_ = -1, t_max_ = std::numeric_limits<decimal_t>::infinity();

@@ -7,7 +7,7 @@
  * value.  setLPAstar(true): plan() repairs and re-uses a device-resident state space of this planner's own
  * (mplx_lpa_*), updateBlockedNodes / updateClearedNodes / getSubStateSpace / initialized as map_replanner_node.cpp uses
  * them.  Search region and potential-field cost (setSearchRegion / updatePotentialMap ...) as distance_map_planner_node.cpp
- * uses them.  Not covered by this back-end: yaw, a non-zero gradient weight -- they fail loudly instead of silently
+ * uses them.  Not covered by this back-end: a non-zero gradient weight, time-keyed states -- they fail loudly instead of silently
  * planning something else.
  */
 #ifndef MPLX_SHIM_MAP_PLANNER_H
@@ -81,11 +81,14 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   void setU(const vec_E<VecDf> &U) override {
     Base::setU(U);
     U_.clear();
+    U_yaw_.clear();
     for (const auto &u : U) {
       U_.push_back(u(0));
       U_.push_back(u(1));
       U_.push_back(Dim == 3 ? u(2) : 0.0);
+      if ((int)u.size() > Dim) U_yaw_.push_back(u(Dim));  // yaw rate (Vec4f inputs, map_planner_node.cpp:125-126,135-136)
     }
+    if (U_yaw_.size() != U.size()) U_yaw_.clear();
   }
   /// device pools (no reference counterpart: the reference grows std containers)
   void setCapacity(int slots, uint64_t nodes, uint64_t edges, uint64_t open_log) {
@@ -112,14 +115,14 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     if (planner_verbose_) { start.print("Start:"); goal.print("Goal:"); }
     traj_ = Trajectory<Dim>();
     traj_cost_ = std::numeric_limits<decimal_t>::infinity();
-    if (this->unsupported_ || start.use_yaw || goal.use_yaw || start.enable_t) {  // never a silently different search
-      printf(ANSI_COLOR_RED "[MapPlanner] plan() refused: yaw (use_yaw states / 4-component inputs), time-keyed states and a non-zero gradient weight are not supported by the mplx back-end\n" ANSI_COLOR_RESET);
+    if (this->unsupported_ || start.enable_t || (!U_yaw_.empty() && !start.use_yaw)) {  // never a silently different search
+      printf(ANSI_COLOR_RED "[MapPlanner] plan() refused: time-keyed states, a non-zero gradient weight and a yaw-rate lattice over yaw-less states are not supported by the mplx back-end\n" ANSI_COLOR_RESET);
       return false;
     }
     mplx_ctx *ctx = map_util_->ctx();
     if (!apply_aux()) return false;
     mplx_set_record(ctx, record_cap_);  // expansion order for getExpandedNodes()
-    control_ = (Control::Control)((int32_t)start.control & 15);
+    control_ = (Control::Control)((int32_t)start.control & 31);  // (bit 16 = use_yaw = MPLX_YAW)
     if (!send_config(control_)) return false;
     mplx_waypoint s = to_c(start), g = to_c(goal);
     if (this->use_lpastar_) {
@@ -151,9 +154,11 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     }
     vec_E<Primitive<Dim>> out;
     for (const auto &p : prs) {
-      vec_E<Vec6f> cs(Dim);
+      vec_E<Vec6f> cs(Dim + ((p.control & MPLX_YAW) ? 1 : 0));
       for (int ax = 0; ax < Dim; ax++)
         for (int k = 0; k < 6; k++) cs[ax](k) = p.c[ax][k];
+      if (p.control & MPLX_YAW)
+        for (int k = 0; k < 6; k++) cs[Dim](k) = p.cyaw[k];
       out.push_back(Primitive<Dim>(cs, p.t, (Control::Control)p.control));
     }
     traj_ = Trajectory<Dim>(out);
@@ -270,7 +275,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     mplx_waypoint c = mplx_waypoint();
     for (int i = 0; i < Dim; i++) { c.pos[i] = w.pos(i); c.vel[i] = w.vel(i); c.acc[i] = w.acc(i); c.jrk[i] = w.jrk(i); }
     c.yaw = w.yaw; c.t = w.t;
-    c.control = (int32_t)w.control & 15;
+    c.control = (int32_t)w.control & 31;
     c.enable_t = w.enable_t ? 1 : 0;
     return c;
   }
@@ -324,8 +329,11 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     Waypoint<Dim> w(control_);
     for (int k = 0; k < Dim; k++) { w.pos(k) = c.pos[k]; w.vel(k) = c.vel[k]; w.acc(k) = c.acc[k]; w.jrk(k) = c.jrk[k]; }
     w.t = c.t;
-    VecDf u(Dim);
+    w.yaw = c.yaw;
+    const bool yaw_in = w.use_yaw && !U_yaw_.empty();
+    VecDf u(Dim + (yaw_in ? 1 : 0));
     for (int k = 0; k < Dim; k++) u(k) = U_[3 * (size_t)action + k];
+    if (yaw_in) u(Dim) = U_yaw_[(size_t)action];
     return Primitive<Dim>(w, u, dt_);
   }
   vec_Vecf<Dim> node_set(bool closed_set) const {
@@ -349,7 +357,10 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   bool send_config(Control::Control control) {
     mplx_ctx *ctx = map_util_->ctx();
     mplx_config cfg;
-    cfg.control = (int32_t)control & 15;
+    cfg.control = (int32_t)control & 31;
+    cfg.U_yaw = U_yaw_.empty() ? nullptr : U_yaw_.data();
+    cfg.yaw_max = this->yaw_max_;
+    cfg.tol_yaw = -1;
     cfg.n_u = (int32_t)(U_.size() / 3);
     cfg.U = U_.data();
     cfg.dt = dt_; cfg.v_max = v_max_; cfg.a_max = a_max_; cfg.j_max = j_max_;
@@ -430,7 +441,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   std::shared_ptr<MapUtil<Dim>> map_util_;
   mplx_lpa *lpa_ = nullptr;
   uint64_t cap_[3] = {0, 0, 0};
-  std::vector<double> U_;
+  std::vector<double> U_, U_yaw_;
   mplx_result res_ = mplx_result();
   uint64_t epoch_ = 0;  // mplx_plan_epoch of this planner's last plan()
   Control::Control control_ = Control::ACC;

@@ -42,9 +42,12 @@ extern "C" {
 #define MPLX_ACC 3
 #define MPLX_JRK 7
 #define MPLX_SNP 15
+/* use_yaw bit of Waypoint::control (map_planner_node.cpp:165 start.use_yaw): OR it into mplx_config.control to search
+ * over yaw-carrying states (mplx_waypoint.yaw of start / goal is then read, mplx_config.U_yaw / yaw_max / tol_yaw apply) */
+#define MPLX_YAW 16
 
 /* Waypoint<3>: search-state record (fields used in-tree: map_planner_node.cpp:155-171,
- * env_poly_map.h:63-64).  yaw is carried but not propagated by this back-end. */
+ * env_poly_map.h:63-64).  yaw is read and propagated by searches configured with MPLX_YAW only. */
 typedef struct {
   double pos[3], vel[3], acc[3], jrk[3];
   double yaw, t;
@@ -59,6 +62,7 @@ typedef struct {
   double t;
   int32_t control;
   int32_t pad;
+  double cyaw[6]; /* yaw channel (MPLX_YAW searches): yaw(t) = cyaw[4] t + cyaw[5]; zeros otherwise */
 } mplx_primitive;
 
 /* Planner set-up = the setter calls of PlannerBase / MapPlanner
@@ -75,6 +79,11 @@ typedef struct {
   double t_max;     /* +inf unless set */
   int32_t max_expand; /* setMaxNum; <= 0 unlimited */
   int32_t heur_ignore_dynamics;
+  /* yaw-carrying searches (control | MPLX_YAW): the 4th column of the Vec4f lattice (map_planner_node.cpp:119-139),
+   * setYawmax (map_planner_node.cpp:182; <= 0: no validate_yaw) and setTol's yaw tolerance (< 0: disabled) */
+  const double *U_yaw; /* n_u, host pointer, copied; NULL: no yaw input (the yaw stays) */
+  double yaw_max;
+  double tol_yaw;
 } mplx_config;
 
 /* One successor of env_map::get_succ (vec_E<Waypoint>& succ, succ_cost, action_idx:

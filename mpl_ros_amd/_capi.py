@@ -21,7 +21,8 @@ class Waypoint(C.Structure):
 
 
 class Primitive(C.Structure):
-    _fields_ = [("c", (C.c_double * 6) * 3), ("t", C.c_double), ("control", C.c_int32), ("pad", C.c_int32)]
+    _fields_ = [("c", (C.c_double * 6) * 3), ("t", C.c_double), ("control", C.c_int32), ("pad", C.c_int32),
+                ("cyaw", C.c_double * 6)]
 
 
 class Config(C.Structure):
@@ -29,7 +30,8 @@ class Config(C.Structure):
                 ("dt", C.c_double), ("v_max", C.c_double), ("a_max", C.c_double), ("j_max", C.c_double),
                 ("w", C.c_double), ("eps", C.c_double),
                 ("tol_pos", C.c_double), ("tol_vel", C.c_double), ("tol_acc", C.c_double),
-                ("t_max", C.c_double), ("max_expand", C.c_int32), ("heur_ignore_dynamics", C.c_int32)]
+                ("t_max", C.c_double), ("max_expand", C.c_int32), ("heur_ignore_dynamics", C.c_int32),
+                ("U_yaw", C.POINTER(C.c_double)), ("yaw_max", C.c_double), ("tol_yaw", C.c_double)]
 
 
 class Succ(C.Structure):

@@ -45,6 +45,12 @@ struct mplx_ctx {
   mplx_config cfg{};
   std::vector<double> U;
   double *dU = nullptr, *dUcost = nullptr;
+  // yaw-carrying states (cfg.control had MPLX_YAW; cfg.control itself keeps the four derivative bits only)
+  bool yaw = false;
+  std::vector<double> Uyaw;  // per control input, zeros when the lattice has no yaw column
+  double *dUyaw = nullptr, *d_traj_yaw = nullptr;
+  bool last_yaw = false;
+  std::vector<double> last_Uyaw;
   double bucket_width = 0;
   int speculation = -1;  // -1 auto, 0/1 off, else on
   // helper workgroups (look-ahead expansion on idle compute units): -1 auto (2 per leader), 0 off, 2
@@ -155,11 +161,11 @@ static void free_pools(mplx_ctx *c) {
 }
 static void free_batch(mplx_ctx *c) {
   (void)hipFree(c->d_out); (void)hipFree(c->d_in); (void)hipFree(c->d_traj_nodes); (void)hipFree(c->d_traj_actions);
-  (void)hipFree(c->d_traj_states); (void)hipFree(c->d_rec); (void)hipFree(c->d_next); (void)hipFree(c->d_order);
+  (void)hipFree(c->d_traj_states); (void)hipFree(c->d_traj_yaw); (void)hipFree(c->d_rec); (void)hipFree(c->d_next); (void)hipFree(c->d_order);
   (void)hipFree(c->d_node_tables); (void)hipFree(c->d_edge_tables);
   c->d_out = nullptr; c->d_in = nullptr; c->d_traj_nodes = c->d_traj_actions = c->d_rec = c->d_next = c->d_order = nullptr;
   c->d_node_tables = nullptr; c->d_edge_tables = nullptr;
-  c->d_traj_states = nullptr;
+  c->d_traj_states = c->d_traj_yaw = nullptr;
   c->batch_cap = 0;
 }
 
@@ -174,6 +180,7 @@ extern "C" void mplx_ctx_destroy(mplx_ctx *c) {
   (void)hipFree(c->aux);
   (void)hipFree(c->dU);
   (void)hipFree(c->dUcost);
+  (void)hipFree(c->dUyaw);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -624,13 +631,19 @@ static bool control_ok(int c) { return c == CTRL_VEL || c == CTRL_ACC || c == CT
 
 extern "C" int mplx_planner_config(mplx_ctx *c, const mplx_config *cfg) {
   if (!c || !cfg || !cfg->U) return fail(c, MPLX_ERR_ARG, "null argument");
-  if (!control_ok(cfg->control)) return fail(c, MPLX_ERR_ARG, "unsupported control %d", cfg->control);
+  if (!control_ok(cfg->control & ~MPLX_YAW)) return fail(c, MPLX_ERR_ARG, "unsupported control %d", cfg->control);
   if (cfg->n_u <= 0 || cfg->n_u > 256) return fail(c, MPLX_ERR_ARG, "n_u must be in [1,256], got %d", cfg->n_u);
   if (!(cfg->dt > 0)) return fail(c, MPLX_ERR_ARG, "dt must be > 0");
   HIPCHK(c, hipSetDevice(c->device));
   c->cfg = *cfg;
+  c->yaw = (cfg->control & MPLX_YAW) != 0;
+  c->cfg.control = cfg->control & ~MPLX_YAW;
+  cfg = &c->cfg;
   c->U.assign(cfg->U, cfg->U + 3 * (size_t)cfg->n_u);
   c->cfg.U = c->U.data();
+  c->Uyaw.assign((size_t)cfg->n_u, 0.0);
+  if (c->yaw && cfg->U_yaw) c->Uyaw.assign(cfg->U_yaw, cfg->U_yaw + cfg->n_u);
+  c->cfg.U_yaw = c->Uyaw.data();
   // per-control edge cost J(control) + w dt: depends on the control input only
   std::vector<double> ucost(cfg->n_u);
   for (int i = 0; i < cfg->n_u; i++) {
@@ -640,7 +653,12 @@ extern "C" int mplx_planner_config(mplx_ctx *c, const mplx_config *cfg) {
   }
   (void)hipFree(c->dU);
   (void)hipFree(c->dUcost);
-  c->dU = c->dUcost = nullptr;
+  (void)hipFree(c->dUyaw);
+  c->dU = c->dUcost = c->dUyaw = nullptr;
+  if (c->yaw) {
+    HIPCHK(c, hipMalloc((void **)&c->dUyaw, sizeof(double) * cfg->n_u));
+    HIPCHK(c, hipMemcpyAsync(c->dUyaw, c->Uyaw.data(), sizeof(double) * cfg->n_u, hipMemcpyHostToDevice, c->stream));
+  }
   HIPCHK(c, hipMalloc((void **)&c->dU, sizeof(double) * 3 * cfg->n_u));
   HIPCHK(c, hipMalloc((void **)&c->dUcost, sizeof(double) * cfg->n_u));
   HIPCHK(c, hipMemcpyAsync(c->dU, c->U.data(), sizeof(double) * 3 * cfg->n_u, hipMemcpyHostToDevice, c->stream));
@@ -727,6 +745,14 @@ static void fill_params(const mplx_ctx *c, SearchParams &P) {
   P.ucost = c->dUcost;
   P.map = map_dev(c);
   P.pot_weight = c->pot_weight;
+  P.U_yaw = c->yaw ? c->dUyaw : nullptr;
+  P.yaw_max = c->yaw ? g.yaw_max : 0.0;
+  P.tol_yaw = c->yaw ? g.tol_yaw : -1.0;
+  P.yaw_cos = 1.0;
+  if (P.yaw_max > 0) {  // cos(yaw_max) by the same deterministic sequence the kernels evaluate the yaw direction with
+    double sn;
+    det_sincos(P.yaw_max, &sn, &P.yaw_cos);
+  }
   P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt * 8.0 : 1.0);
 }
 
@@ -818,6 +844,7 @@ static int ensure_batch(mplx_ctx *c, int nq) {
   HIPCHK(c, hipMalloc((void **)&c->d_traj_nodes, sizeof(int32_t) * (size_t)nq * (MAX_TRAJ + 1)));
   HIPCHK(c, hipMalloc((void **)&c->d_traj_actions, sizeof(int32_t) * (size_t)nq * MAX_TRAJ));
   HIPCHK(c, hipMalloc((void **)&c->d_traj_states, sizeof(double) * (size_t)nq * (MAX_TRAJ + 1) * 13));
+  HIPCHK(c, hipMalloc((void **)&c->d_traj_yaw, sizeof(double) * (size_t)nq * (MAX_TRAJ + 1)));
   HIPCHK(c, hipMalloc((void **)&c->d_next, sizeof(int32_t)));
   HIPCHK(c, hipMalloc((void **)&c->d_order, sizeof(int32_t) * nq));
   HIPCHK(c, hipMalloc((void **)&c->d_node_tables, sizeof(uint32_t) * (size_t)nq * MAX_NODE_CH));
@@ -840,7 +867,16 @@ static void wp_to_state(const mplx_waypoint &w, State &s) {
 static int pick_block(int n_u) { return n_u <= 64 ? 64 : (n_u <= 128 ? 128 : 256); }
 
 template <int BLOCK>
-static void launch_astar(int control, int grid, hipStream_t s, const SearchParams &P) {
+static void launch_astar(int control, bool yaw, int grid, hipStream_t s, const SearchParams &P) {
+  if (yaw) {
+    switch (control) {
+      case CTRL_VEL: hipLaunchKernelGGL((astar_kernel<BLOCK, CTRL_VEL, true>), dim3(grid), dim3(BLOCK), 0, s, P); break;
+      case CTRL_ACC: hipLaunchKernelGGL((astar_kernel<BLOCK, CTRL_ACC, true>), dim3(grid), dim3(BLOCK), 0, s, P); break;
+      case CTRL_JRK: hipLaunchKernelGGL((astar_kernel<BLOCK, CTRL_JRK, true>), dim3(grid), dim3(BLOCK), 0, s, P); break;
+      default: hipLaunchKernelGGL((astar_kernel<BLOCK, CTRL_SNP, true>), dim3(grid), dim3(BLOCK), 0, s, P); break;
+    }
+    return;
+  }
   switch (control) {
     case CTRL_VEL: hipLaunchKernelGGL((astar_kernel<BLOCK, CTRL_VEL>), dim3(grid), dim3(BLOCK), 0, s, P); break;
     case CTRL_ACC: hipLaunchKernelGGL((astar_kernel<BLOCK, CTRL_ACC>), dim3(grid), dim3(BLOCK), 0, s, P); break;
@@ -849,12 +885,21 @@ static void launch_astar(int control, int grid, hipStream_t s, const SearchParam
   }
 }
 template <int BLOCK>
-static void launch_expand(int control, int grid, hipStream_t s, const SearchParams &P, const State *n, const double *t, int K, SuccOut *o) {
+static void launch_expand(int control, int grid, hipStream_t s, const SearchParams &P, const State *n, const double *t, int K, SuccOut *o, const double *yaw) {
+  if (yaw) {
+    switch (control) {
+      case CTRL_VEL: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_VEL, true>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o, yaw); break;
+      case CTRL_ACC: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_ACC, true>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o, yaw); break;
+      case CTRL_JRK: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_JRK, true>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o, yaw); break;
+      default: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_SNP, true>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o, yaw); break;
+    }
+    return;
+  }
   switch (control) {
-    case CTRL_VEL: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_VEL>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o); break;
-    case CTRL_ACC: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_ACC>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o); break;
-    case CTRL_JRK: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_JRK>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o); break;
-    default: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_SNP>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o); break;
+    case CTRL_VEL: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_VEL>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o, nullptr); break;
+    case CTRL_ACC: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_ACC>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o, nullptr); break;
+    case CTRL_JRK: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_JRK>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o, nullptr); break;
+    default: hipLaunchKernelGGL((expand_kernel<BLOCK, CTRL_SNP>), dim3(grid), dim3(BLOCK), 0, s, P, n, t, K, o, nullptr); break;
   }
 }
 
@@ -880,15 +925,16 @@ extern "C" int mplx_expand_batch(mplx_ctx *c, int K, const mplx_waypoint *nodes,
   SearchParams P{};
   fill_params(c, P);
   std::vector<State> hs(K);
-  std::vector<double> ht(K);
+  std::vector<double> ht(K), hy(K);
   for (int i = 0; i < K; i++) {
     mplx_waypoint w = nodes[i];
     w.control = c->cfg.control;
     wp_to_state(w, hs[i]);
     ht[i] = nodes[i].t;
+    hy[i] = nodes[i].yaw;
   }
   State *dn = nullptr;
-  double *dt = nullptr;
+  double *dt = nullptr, *dyaw = nullptr;
   SuccOut *dout = nullptr;
   const size_t no = (size_t)K * P.n_u;
   DevBufs bufs;
@@ -897,12 +943,16 @@ extern "C" int mplx_expand_batch(mplx_ctx *c, int K, const mplx_waypoint *nodes,
   HIPCHK(c, bufs.alloc(&dout, sizeof(SuccOut) * no));
   HIPCHK(c, hipMemcpyAsync(dn, hs.data(), sizeof(State) * K, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(dt, ht.data(), sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
+  if (c->yaw) {
+    HIPCHK(c, bufs.alloc(&dyaw, sizeof(double) * K));
+    HIPCHK(c, hipMemcpyAsync(dyaw, hy.data(), sizeof(double) * K, hipMemcpyHostToDevice, c->stream));
+  }
   const int grid = K < 4096 ? K : 4096;
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   switch (pick_block(P.n_u)) {
-    case 64: launch_expand<64>(P.control, grid, c->stream, P, dn, dt, K, dout); break;
-    case 128: launch_expand<128>(P.control, grid, c->stream, P, dn, dt, K, dout); break;
-    default: launch_expand<256>(P.control, grid, c->stream, P, dn, dt, K, dout); break;
+    case 64: launch_expand<64>(P.control, grid, c->stream, P, dn, dt, K, dout, dyaw); break;
+    case 128: launch_expand<128>(P.control, grid, c->stream, P, dn, dt, K, dout, dyaw); break;
+    default: launch_expand<256>(P.control, grid, c->stream, P, dn, dt, K, dout, dyaw); break;
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
@@ -971,14 +1021,16 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   std::vector<QueryIn> in(nq);
   for (int i = 0; i < nq; i++) {
     if (starts[i].enable_t) return fail(c, MPLX_ERR_ARG, "enable_t is not supported by the voxel-map environment");
-    if (!control_ok(goals[i].control)) return fail(c, MPLX_ERR_ARG, "bad goal control");
+    if (!control_ok(goals[i].control & ~MPLX_YAW)) return fail(c, MPLX_ERR_ARG, "bad goal control");
     mplx_waypoint s = starts[i];
     s.control = c->cfg.control;
     wp_to_state(s, in[i].start);
     wp_to_state(goals[i], in[i].goal);
     in[i].start_t = starts[i].t;
-    in[i].goal_control = goals[i].control;
+    in[i].goal_control = goals[i].control & ~MPLX_YAW;
     in[i].pad = 0;
+    in[i].start_yaw = c->yaw ? starts[i].yaw : 0.0;
+    in[i].goal_yaw = c->yaw ? goals[i].yaw : 0.0;
   }
   if (nq >= 0xFFFF) return fail(c, MPLX_ERR_ARG, "at most 65534 queries per batch");
   // launch order: longest expected search first (straight-line distance), so the tail of the batch
@@ -1002,6 +1054,7 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   P.order = c->d_order;
   P.out = c->d_out;
   P.traj_nodes = c->d_traj_nodes; P.traj_actions = c->d_traj_actions; P.traj_states = c->d_traj_states;
+  P.traj_yaw = c->d_traj_yaw;
   P.rec_ids = c->cap_rec ? c->d_rec : nullptr;
   P.node_tables = c->d_node_tables;
   P.edge_tables = c->d_edge_tables;
@@ -1012,7 +1065,8 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   HIPCHK(c, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), c->stream));
   // (the potential-field / search-region cost is read by the one-node kernels only)
-  const bool spec = (c->speculation < 0 || c->speculation > 1) && !c->aux;
+  // ... and so are yaw-carrying states
+  const bool spec = (c->speculation < 0 || c->speculation > 1) && !c->aux && !c->yaw;
   // Helper workgroups: a workgroup with no query (left) to lead expands the front of a running leader's OPEN list ahead
   // of time.  The launch holds one workgroup per compute unit at most, so all of them are resident together: for a
   // batch smaller than the machine the extra workgroups (blockIdx.x >= help_lead) help from the start; in a large
@@ -1059,9 +1113,9 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   }
   if (!launched && !(spec && mplx_launch_spec(c->speculation, grid, c->stream, P))) {
     switch (pick_block(P.n_u)) {
-      case 64: launch_astar<64>(P.control, slots, c->stream, P); break;
-      case 128: launch_astar<128>(P.control, slots, c->stream, P); break;
-      default: launch_astar<256>(P.control, slots, c->stream, P); break;
+      case 64: launch_astar<64>(P.control, c->yaw, slots, c->stream, P); break;
+      case 128: launch_astar<128>(P.control, c->yaw, slots, c->stream, P); break;
+      default: launch_astar<256>(P.control, c->yaw, slots, c->stream, P); break;
     }
   }
   HIPCHK(c, hipGetLastError());
@@ -1083,6 +1137,8 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   c->last_control = c->cfg.control;
   c->last_dt = c->cfg.dt;
   c->last_U = c->U;
+  c->last_yaw = c->yaw;
+  c->last_Uyaw = c->Uyaw;
   c->last_map_epoch = c->map_epoch;
   c->plan_epoch++;
   return MPLX_OK;
@@ -1093,11 +1149,11 @@ extern "C" uint64_t mplx_plan_epoch(const mplx_ctx *c) { return c ? c->plan_epoc
 extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
   if (!c || !c->have_cfg) return "";
   const int control = c->cfg.control, n_u = c->cfg.n_u;
-  const bool spec = (c->speculation < 0 || c->speculation > 1) && (control == CTRL_ACC || control == CTRL_JRK) && n_u <= 128 && !c->aux;
+  const bool spec = (c->speculation < 0 || c->speculation > 1) && (control == CTRL_ACC || control == CTRL_JRK) && n_u <= 128 && !c->aux && !c->yaw;
   static thread_local char buf[64];
   const char *cn = control == CTRL_VEL ? "VEL" : control == CTRL_ACC ? "ACC" : control == CTRL_JRK ? "JRK" : "SNP";
   if (!spec) {
-    snprintf(buf, sizeof(buf), "astar_kernel<%d,%s>", pick_block(n_u), cn);
+    snprintf(buf, sizeof(buf), c->yaw ? "astar_kernel<%d,%s,yaw>" : "astar_kernel<%d,%s>", pick_block(n_u), cn);
   } else {
     int ul, k;
     if (n_u <= 32 && c->speculation == 8) { ul = 64; k = 8; }
@@ -1122,13 +1178,14 @@ extern "C" int mplx_result_traj(mplx_ctx *c, int q, mplx_primitive *prs, mplx_wa
   const int len = c->last_out[q].traj_len;
   if (c->last_out[q].status != MPLX_PLAN_OK || len <= 0) return MPLX_OK;  // (MPLX_PLAN_TRAJ_TOO_LONG: cost only)
   std::vector<int32_t> tn(len + 1), ta(len);
-  std::vector<double> ts((size_t)(len + 1) * 13);
+  std::vector<double> ts((size_t)(len + 1) * 13), ty((size_t)len + 1, 0.0);
+  if (c->last_yaw) HIPCHK(c, hipMemcpyAsync(ty.data(), c->d_traj_yaw + (size_t)q * (MAX_TRAJ + 1), sizeof(double) * (len + 1), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(tn.data(), c->d_traj_nodes + (size_t)q * (MAX_TRAJ + 1), sizeof(int32_t) * (len + 1), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(ta.data(), c->d_traj_actions + (size_t)q * MAX_TRAJ, sizeof(int32_t) * len, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(ts.data(), c->d_traj_states + (size_t)q * (MAX_TRAJ + 1) * 13, sizeof(double) * (len + 1) * 13, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   // device order is goal -> start; emit start -> goal.  Control kind, dt and U are the ones the plan ran with.
-  const int control = c->last_control;
+  const int control = c->last_control, out_control = control | (c->last_yaw ? MPLX_YAW : 0);
   for (int i = 0; i <= len; i++) {
     const double *s = &ts[(size_t)(len - i) * 13];
     if (wps) {
@@ -1138,7 +1195,8 @@ extern "C" int mplx_result_traj(mplx_ctx *c, int q, mplx_primitive *prs, mplx_wa
         w.pos[k] = s[k]; w.vel[k] = s[3 + k]; w.acc[k] = s[6 + k]; w.jrk[k] = s[9 + k];
       }
       w.t = s[12];
-      w.control = control;
+      w.yaw = ty[len - i];
+      w.control = out_control;
     }
     if (node_ids) node_ids[i] = tn[len - i];
   }
@@ -1151,7 +1209,11 @@ extern "C" int mplx_result_traj(mplx_ctx *c, int q, mplx_primitive *prs, mplx_wa
       memset(&p, 0, sizeof(p));
       for (int ax = 0; ax < 3; ax++) prim_build_axis(control, s[ax], s[3 + ax], s[6 + ax], s[9 + ax], c->last_U[3 * a + ax], p.c[ax]);
       p.t = c->last_dt;
-      p.control = control;
+      p.control = out_control;
+      if (c->last_yaw) {  // the VEL-type yaw channel from the parent's yaw
+        p.cyaw[4] = c->last_Uyaw[a];
+        p.cyaw[5] = ty[len - i];
+      }
     }
   }
   return MPLX_OK;
@@ -1263,8 +1325,9 @@ extern "C" int mplx_result_nodes(mplx_ctx *c, uint64_t cap, mplx_waypoint *coord
           double *dst = d < 3 ? w.pos : d < 6 ? w.vel : d < 9 ? w.acc : w.jrk;
           dst[d % 3] = st[d];
         }
-        w.t = st[nk];
-        w.control = control;
+        w.t = st[nk + (c->last_yaw ? 1 : 0)];
+        if (c->last_yaw) w.yaw = st[nk];
+        w.control = control | (c->last_yaw ? MPLX_YAW : 0);
       }
     }
   }
@@ -1280,7 +1343,7 @@ extern "C" int mplx_result_nodes(mplx_ctx *c, uint64_t cap, mplx_waypoint *coord
 // blocked primitives reach).  Needs the map and the planner set-up of that plan to be still in place.
 extern "C" int mplx_result_blocked(mplx_ctx *c, int32_t *parent, int32_t *action, uint64_t cap, uint64_t *n_out, uint64_t *n_states_all) {
   if (!c || !c->last_single || !c->pools_valid || !n_out) return fail(c, MPLX_ERR_ARG, "blocked-primitive dump needs a preceding single mplx_plan()");
-  if (c->last_control != c->cfg.control || c->last_dt != c->cfg.dt || c->last_U != c->U)
+  if (c->last_control != c->cfg.control || c->last_dt != c->cfg.dt || c->last_U != c->U || c->last_yaw != c->yaw || c->last_Uyaw != c->Uyaw)
     return fail(c, MPLX_ERR_ARG, "the planner was re-configured since the plan: blocked primitives cannot be re-derived");
   if (c->last_map_epoch != c->map_epoch)
     return fail(c, MPLX_ERR_ARG, "the map changed since the plan: its blocked primitives cannot be re-derived (they would be computed against the new map)");
@@ -1303,6 +1366,10 @@ extern "C" int mplx_result_blocked(mplx_ctx *c, int32_t *parent, int32_t *action
     int32_t k[MAX_KEY];
     state_key(control, st, k);
     std::string s((const char *)k, sizeof(int32_t) * (size_t)nk);
+    if (c->last_yaw) {
+      const int32_t yk = (int32_t)round(w.yaw / KEY_RES_YAW);
+      s.append((const char *)&yk, sizeof(yk));
+    }
     return s;
   };
   std::vector<std::string> keys(n);
@@ -1333,7 +1400,7 @@ extern "C" int mplx_result_blocked(mplx_ctx *c, int32_t *parent, int32_t *action
           if (action) action[w] = a;
         }
         w++;
-        std::string ks((const char *)sc.key, sizeof(int32_t) * (size_t)nk);
+        std::string ks = c->last_yaw ? key_of(sc.wp) : std::string((const char *)sc.key, sizeof(int32_t) * (size_t)nk);
         if (!std::binary_search(sorted_keys.begin(), sorted_keys.end(), ks)) only_blocked.push_back(ks);
       }
   }

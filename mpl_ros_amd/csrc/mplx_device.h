@@ -55,6 +55,7 @@ struct QueryIn {
   double start_t;
   int32_t goal_control;
   int32_t pad;
+  double start_yaw, goal_yaw;  // (yaw-carrying states only)
 };
 
 // device copy of mplx_result + diagnostics (host reads it back)
@@ -114,6 +115,8 @@ struct SearchParams {
   double dt, v_max, a_max, j_max, w, eps, tol_pos, tol_vel, tol_acc, t_max;
   int32_t max_expand, heur_ignore_dynamics;
   const double *U;      // n_u x 3
+  const double *U_yaw;  // n_u yaw rates (the 4th component of Vec4f control inputs), or null
+  double yaw_max, yaw_cos, tol_yaw;  // setYawmax (<= 0: no validate_yaw), cos(yaw_max) by det_sincos, yaw tolerance of is_goal (< 0: none)
   const double *ucost;  // n_u: J(control) + w dt
   MapDev map;
   double pot_weight;       // potential_weight: a free primitive costs ucost + pot_weight * (sum of the potential over its samples)
@@ -134,6 +137,7 @@ struct SearchParams {
   int32_t *traj_nodes;            // nq x (MAX_TRAJ+1)
   int32_t *traj_actions;          // nq x MAX_TRAJ
   double *traj_states;            // nq x (MAX_TRAJ+1) x 13
+  double *traj_yaw;               // nq x (MAX_TRAJ+1): yaw of the path states (yaw-carrying searches), or null
   int32_t *rec_ids;               // nq x cap_rec (optional)
   uint32_t *node_tables;          // nq x MAX_NODE_CH: chunk table of each query (state-space dump)
   uint32_t *edge_tables;          // nq x MAX_EDGE_CH: chunk table of the predecessor records
@@ -160,7 +164,7 @@ struct SuccOut {
   int32_t control, enable_t;
   double cost;
   int32_t action, valid;
-  int32_t key[12];
+  int32_t key[12];  // (a yaw-carrying state's yaw key follows the nkey - 1 others)
   int32_t nkey, voxel_reads;
 };
 

@@ -168,6 +168,7 @@ struct Smem {
   double tmp_d0;
   unsigned long long c_expanded, c_closed, c_prims, c_succ, c_succ_finite, c_reads, c_push, c_reopen, c_refill, c_evict, c_hash;
   unsigned long long cyc[10];
+  double cur_yaw[KUNITS];  // yaw of the node(s) being expanded (yaw-carrying searches)
 };
 
 #define MPLX_TIC(var) const unsigned long long var = __builtin_readcyclecounter()
@@ -277,6 +278,8 @@ struct LaneSucc {
   bool blocked;  // is_free(pr) failed -> cost inf
   uint32_t reads;
   uint32_t pot;  // (POT) sum of the potential over the primitive's samples
+  double yaw;    // (YAW) successor yaw, normalised, and its key integer round(yaw / 0.1)
+  int32_t yaw_key;
 };
 
 // One expansion unit = UL consecutive threads expanding one node (unit index ku, lane index lu inside
@@ -292,7 +295,9 @@ struct NoHook {
 // POT: the auxiliary map (potential field / search region, MapDev::aux) is read next to the occupancy when it exists:
 // a sample outside the search region blocks the primitive, the potential of every sample is summed into L.pot.  Only
 // the one-unit kernels (UL == BLOCK) pass it; the speculative kernels are compiled without.
-template <int UL, int BLOCK, int CONTROL, bool CACHE = false, bool POT = false, class SM, class Hook = NoHook>
+// YAW: the states carry yaw (use_yaw lattices): successor yaw = normalise(yaw + u_yaw dt), its key integer takes part in
+// "tn == curr", and validate_yaw joins validate_primitive (mplx_math.h).  One-unit kernels only.
+template <int UL, int BLOCK, int CONTROL, bool CACHE = false, bool POT = false, bool YAW = false, class SM, class Hook = NoHook>
 __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int tid, bool live_unit, LaneSucc &L, Hook after_phase1 = Hook()) {
   constexpr int NQ = nq_c(CONTROL);
   static_assert(!POT || UL == BLOCK, "the potential sum lives in the one-unit kernels' scratch");
@@ -331,6 +336,16 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
     bool same = true;
 #pragma unroll
     for (int i = 0; i < key_len_c(CONTROL); i++) same = same && (L.key[i] == S.cur_key[ku][i]);
+    bool yaw_ok = true;
+    if constexpr (YAW) {
+      static_assert(UL == BLOCK, "yaw-carrying states are expanded by the one-unit kernels");
+      const double yaw0 = S.cur_yaw[ku], uy = P.U_yaw ? P.U_yaw[lu] : 0.0;
+      L.yaw = normalize_yaw((uy * T + 0.0) + yaw0);  // the VEL-type yaw channel evaluated at T, normalised like evaluate()
+      L.yaw_key = (int32_t)round(L.yaw / KEY_RES_YAW);
+      same = same && L.yaw_key == (int32_t)round(yaw0 / KEY_RES_YAW);
+      if (P.yaw_max > 0)  // validate_yaw: both ends, planar velocity against the yaw direction
+        yaw_ok = yaw_end_ok(vel_at_c<CONTROL>(c[0], 0.0), vel_at_c<CONTROL>(c[1], 0.0), normalize_yaw(yaw0 + 0.0), P.yaw_cos) && yaw_end_ok(L.tn.v[0], L.tn.v[1], L.yaw, P.yaw_cos);
+    }
     double max_v = 0.0;
     bool ok;
     if (cached) {  // decided ahead of time by a helper workgroup: nothing left to sample
@@ -349,6 +364,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
 #else
       ok = !same && validate_and_maxv_c<CONTROL>(c, T, P.v_max, P.a_max, P.j_max, &max_v);
 #endif
+      ok = ok && yaw_ok;
     }
     if (ok) {
       int n = (int)ceil(max_v * T / P.map.res);
@@ -559,14 +575,16 @@ __device__ __forceinline__ void fill_uq(const SearchParams &P, SM &S, int tid) {
 }
 
 // ------------------------------------------------------------------ expand_kernel (unit-test entry)
-template <int BLOCK, int CONTROL>
-__global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const State *nodes, const double *node_t, int K, SuccOut *out) {
+// node_yaw (YAW): yaw of each node
+template <int BLOCK, int CONTROL, bool YAW = false>
+__global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const State *nodes, const double *node_t, int K, SuccOut *out, const double *node_yaw = nullptr) {
   __shared__ Smem<BLOCK> S;
   const int tid = threadIdx.x;
   fill_uq<BLOCK, CONTROL>(P, S, tid);
   for (int k = blockIdx.x; k < K; k += gridDim.x) {
     if (tid < 12) S.cur[0][tid] = ((const double *)&nodes[k])[tid];
     if (tid == 12) S.cur[0][12] = node_t[k];
+    if (YAW && tid == 13) S.cur_yaw[0] = node_yaw[k];
     __syncthreads();
     if (tid == 0) {
       State s;
@@ -575,7 +593,7 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const Sta
     }
     __syncthreads();
     LaneSucc L;
-    expand_unit<BLOCK, BLOCK, CONTROL, false, true>(P, S, tid, true, L);
+    expand_unit<BLOCK, BLOCK, CONTROL, false, true, YAW>(P, S, tid, true, L);
     if (tid < P.n_u) {
       SuccOut &o = out[(size_t)k * P.n_u + tid];
       for (int ax = 0; ax < 3; ax++) {
@@ -584,9 +602,9 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const Sta
         o.acc[ax] = L.tn.a[ax];
         o.jrk[ax] = L.tn.j[ax];
       }
-      o.yaw = 0;
+      o.yaw = YAW ? L.yaw : 0.0;
       o.t = S.cur[0][12] + P.dt;
-      o.control = P.control;
+      o.control = YAW ? (P.control | CTRL_YAW_BIT) : P.control;
       o.enable_t = 0;
       o.cost = L.valid ? (L.blocked ? INFINITY : (P.map.aux ? P.ucost[tid] + P.pot_weight * (double)L.pot : P.ucost[tid])) : 0.0;
       o.action = tid;
@@ -594,6 +612,10 @@ __global__ __launch_bounds__(BLOCK) void expand_kernel(SearchParams P, const Sta
 #pragma unroll
       for (int i = 0; i < 12; i++) o.key[i] = i < key_len_c(CONTROL) ? L.key[i] : 0;
       o.nkey = P.nk;
+      if constexpr (YAW) {
+        if (key_len_c(CONTROL) < 12) o.key[key_len_c(CONTROL)] = L.yaw_key;  // (SNP + yaw: 13 integers, the yaw key is not reported here)
+        o.nkey = P.nk + 1;
+      }
       o.voxel_reads = (int32_t)L.reads;
     }
     __syncthreads();
@@ -964,7 +986,8 @@ __device__ __forceinline__ void open_push(const QView<BLOCK, CONTROL, SM> &Q, ui
 // sequential loop over the control inputs would assign.
 // NK: key ints (key_len_c(CONTROL), + 1 when the state's time is part of the key); lane_cost: cost of this lane's
 // primitive (the voxel environment's cost depends on the control input only: P.ucost[tid]).
-template <int BLOCK, int CONTROL, class SM, int NK = key_len_c(CONTROL)>
+// YAW: the state's yaw key is the (NK + 1)-th key integer, its yaw the state double before t
+template <int BLOCK, int CONTROL, class SM, int NK = key_len_c(CONTROL), bool YAW = false>
 // have_v0: the caller has already loaded the first table slot of the lane's key (v0_in), e.g. while other work was in flight
 __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64, double lane_cost,
                                                 uint32_t action_tag, bool have_v0 = false, unsigned long long v0_in = 0) {
@@ -987,7 +1010,11 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
   if (act) v0 = have_v0 ? v0_in : ld_u64(&P.table[pos]);
   double hspec = 0.0;
 #ifndef MPLX_NO_HSPEC
-  if (act && P.eps != 0.0) hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
+  if (act && P.eps != 0.0) {
+    // get_heur is 0 when the state's key equals the goal's: with yaw the yaw key is part of that comparison
+    if (YAW && L.yaw_key != S.hp.goal_yaw_key) hspec = cal_heur(S.hp, CONTROL, L.tn);
+    else hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
+  }
 #endif
   if (act) {
     const unsigned long long claim = tagq | (unsigned long long)(CLAIM_BASE + (uint32_t)tid);
@@ -1010,6 +1037,7 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
         bool eq = true;
 #pragma unroll
         for (int i = 0; i < nk; i++) eq = eq && (kk[i] == L.key[i]);
+        if constexpr (YAW) eq = eq && kk[nk] == L.yaw_key;
         if (eq) {
           role = 1; id = vid; rec = r;
           old_g = rg; hval = rh; fl = rfl; old_pred = rpred;
@@ -1040,7 +1068,13 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
     double *st = V::state(rec);
 #pragma unroll
     for (int i = 0; i < ns; i++) st[i] = i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3];
-    st[ns] = S.cur[0][12] + P.dt;
+    if constexpr (YAW) {
+      kk[nk] = L.yaw_key;
+      st[ns] = L.yaw;
+      st[ns + 1] = S.cur[0][12] + P.dt;
+    } else {
+      st[ns] = S.cur[0][12] + P.dt;
+    }
 #ifdef MPLX_NO_HSPEC
     hspec = P.eps == 0.0 ? 0.0 : get_heur(S.hp, CONTROL, L.tn, L.key, nk);
 #endif
@@ -1086,7 +1120,8 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
 
 // ------------------------------------------------------------------ pop the minimum valid OPEN entry
 // On success S.cur_id / S.cur_g / S.cur / S.cur_key describe the node to expand and it is closed.
-template <int BLOCK, int CONTROL, class SM, int NK = key_len_c(CONTROL)>
+// EXTRA: state doubles between the control-kind's own and t (1 for yaw-carrying states: the yaw, delivered in S.cur_yaw)
+template <int BLOCK, int CONTROL, class SM, int NK = key_len_c(CONTROL), int EXTRA = 0>
 __device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL, SM> &Q, int tid) {
   using V = QView<BLOCK, CONTROL, SM>;
   SM &S = Q.S;
@@ -1132,7 +1167,7 @@ __device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL, SM> &Q, int 
     const uint32_t fl = V::flags(rec);
     double sval = 0.0;
     int32_t kval = 0;
-    if (tid <= ns) sval = V::state(rec)[tid];
+    if (tid <= ns + EXTRA) sval = V::state(rec)[tid];
     if (tid < nk) kval = V::key(rec)[tid];
     if (tid == 0) {  // remove from the near set
       const uint32_t last = n - 1;
@@ -1143,9 +1178,11 @@ __device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL, SM> &Q, int 
     // stale?  (node improved since this entry was pushed, or already closed)
     const bool ok = __double_as_longlong(rg) == __double_as_longlong(bg) && !(fl & FLAG_CLOSED);
     if (ok) {
-      if (tid <= ns) S.cur[0][tid < ns ? tid : 12] = sval;
+      if (tid < ns) S.cur[0][tid] = sval;
+      if (EXTRA && tid == ns) S.cur_yaw[0] = sval;
+      if (tid == ns + EXTRA) S.cur[0][12] = sval;
       if (tid >= ns && tid < 12) S.cur[0][tid] = 0.0;
-      if (tid < nk) S.cur_key[0][tid] = kval;
+      if (tid < nk && tid < MAX_KEY) S.cur_key[0][tid] = kval;
       if (tid == 0) {
         S.cur_id = bi;
         S.cur_g = bg;
@@ -1158,13 +1195,22 @@ __device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL, SM> &Q, int 
 }
 
 // ------------------------------------------------------------------ astar_kernel
-template <int BLOCK, int CONTROL>
+// YAW: yaw-carrying states (use_yaw lattices, map_planner_node.cpp:119-139,165): one more key integer, one more state
+// double, validate_yaw; edge costs and the heuristic are those of the yaw-less search [UNVERIFIED upstream: Jyaw is a
+// trajectory metric (map_planner_node.cpp:214), not part of calculate_intrinsic_cost]
+template <int BLOCK, int CONTROL, bool YAW = false>
 __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
   __shared__ Smem<BLOCK> S;
   using V = QView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
-  constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
+  constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL), NKY = nk + (YAW ? 1 : 0), EX = YAW ? 1 : 0;
+  // is_goal with the yaw tolerance of a yaw-carrying search
+  auto goal_reached = [&](const State &s, double yaw, const QueryIn &in) {
+    bool g = is_goal_state(s, in.goal, in.goal_control & 15, P.tol_pos, P.tol_vel, P.tol_acc);
+    if (YAW && g && P.tol_yaw >= 0) g = fabs(yaw - in.goal_yaw) <= P.tol_yaw;
+    return g;
+  };
   fill_uq<BLOCK, CONTROL>(P, S, tid);
   for (;;) {
     if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
@@ -1190,6 +1236,8 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
       S.hp.goal_control = in.goal_control;
       S.hp.goal = in.goal;
       S.hp.goal_nkey = state_key(in.goal_control, in.goal, S.hp.goal_key);
+      S.hp.goal_yaw = in.goal_yaw;
+      S.hp.goal_yaw_key = (int32_t)round(in.goal_yaw / KEY_RES_YAW);
       // PlannerBase::plan: start must be free; Astar: already at goal -> cost 0
       int32_t c[3];
       bool free_ = true;
@@ -1201,7 +1249,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
       double cost0 = INFINITY;
       if (!free_)
         S.status = 2;
-      else if (in.start_t >= P.t_max || is_goal_state(in.start, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) {
+      else if (in.start_t >= P.t_max || goal_reached(in.start, in.start_yaw, in)) {
         S.status = 0;
         cost0 = 0.0;
       }
@@ -1217,19 +1265,23 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
     if (S.status < 0) {
       // ---- start node (id 0)
       if (tid == 0) {
-        int32_t key[MAX_KEY];
+        int32_t key[MAX_KEY + 1];
         state_key_c<CONTROL>(in.start, key);
+        const int32_t ykey = (int32_t)round(in.start_yaw / KEY_RES_YAW);
+        if (YAW) key[nk] = ykey;
         char *rec = Q.node(0);
-        for (int i = 0; i < nk; i++) V::key(rec)[i] = key[i];
+        for (int i = 0; i < NKY; i++) V::key(rec)[i] = key[i];
         const double *src = (const double *)&in.start;
         for (int i = 0; i < ns; i++) V::state(rec)[i] = src[i];
-        V::state(rec)[ns] = in.start_t;
-        double h = P.eps == 0.0 ? 0.0 : get_heur(S.hp, CONTROL, in.start, key, nk);
+        if (YAW) V::state(rec)[ns] = in.start_yaw;
+        V::state(rec)[ns + EX] = in.start_t;
+        double h = 0.0;
+        if (P.eps != 0.0) h = (YAW && ykey != S.hp.goal_yaw_key) ? cal_heur(S.hp, CONTROL, in.start) : get_heur(S.hp, CONTROL, in.start, key, nk);
         V::h(rec) = h;
         V::g(rec) = 0.0;
         V::flags(rec) = FLAG_OPENED;
         V::pred(rec) = NIL;
-        const unsigned long long h64 = key_hash64(key, nk);
+        const unsigned long long h64 = key_hash64(key, NKY);
         const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
         size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
         for (;;) {  // shared table: the home slot may belong to another query
@@ -1255,7 +1307,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
           MPLX_TOC(S, 3, te);
         }
         MPLX_TIC(tp);
-        const bool popped = pop_min(Q, tid);
+        const bool popped = pop_min<BLOCK, CONTROL, Smem<BLOCK>, NKY, EX>(Q, tid);
         MPLX_TOC(S, 0, tp);
         if (!popped) {
           if (tid == 0) S.status = 1;  // OPEN empty
@@ -1272,7 +1324,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         }
         LaneSucc L;
         MPLX_TIC(tx);
-        expand_unit<BLOCK, BLOCK, CONTROL, false, true>(P, S, tid, true, L);
+        expand_unit<BLOCK, BLOCK, CONTROL, false, true, YAW>(P, S, tid, true, L);
         MPLX_TOC(S, 1, tx);
         MPLX_TIC(tc);
         const bool act = L.valid && !L.blocked;
@@ -1294,7 +1346,15 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         S.dupset[tid + BLOCK] = 0;
         __syncthreads();
         if (act) {
-          h64 = key_hash64(L.key, nk);
+          if constexpr (YAW) {
+            int32_t kk[MAX_KEY + 1];
+#pragma unroll
+            for (int i = 0; i < nk; i++) kk[i] = L.key[i];
+            kk[nk] = L.yaw_key;
+            h64 = key_hash64(kk, NKY);
+          } else {
+            h64 = key_hash64(L.key, nk);
+          }
           const unsigned long long hv = h64 | 1ull;
           uint32_t sl = (uint32_t)(h64 >> 7) & (2 * BLOCK - 1);
           for (;;) {
@@ -1309,10 +1369,10 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         const double lane_cost = act ? (P.map.aux ? P.ucost[tid] + P.pot_weight * (double)L.pot : P.ucost[tid]) : 0.0;
         const uint32_t action_tag = (uint32_t)tid | (L.pot << EDGE_POT_SHIFT);
         if (!S.flag) {
-          commit_parallel(Q, tid, q, act, L, h64, lane_cost, action_tag);
+          commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, nk, YAW>(Q, tid, q, act, L, h64, lane_cost, action_tag);
         } else {
           // rare: two control inputs reach the same key -> commit one successor at a time, in order
-          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel(Q, tid, q, act && tid == i, L, h64, lane_cost, action_tag);
+          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, nk, YAW>(Q, tid, q, act && tid == i, L, h64, lane_cost, action_tag);
         }
         __syncthreads();
         MPLX_TOC(S, 2, tc);
@@ -1321,7 +1381,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         if (tid == 0) {
           State s;
           for (int i = 0; i < 12; i++) ((double *)&s)[i] = S.cur[0][i];
-          if (S.cur[0][12] >= P.t_max || is_goal_state(s, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc))
+          if (S.cur[0][12] >= P.t_max || goal_reached(s, S.cur_yaw[0], in))
             S.status = 0;
           else if (P.max_expand > 0 && S.c_expanded >= (unsigned long long)P.max_expand)
             S.status = 3;
@@ -1377,7 +1437,8 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
           for (int i = 0; i <= len; i++) {
             const double *st = V::state(Q.node((uint32_t)tn[i]));
             for (int k = 0; k < 12; k++) ts[i * 13 + k] = k < ns ? st[k] : 0.0;
-            ts[i * 13 + 12] = st[ns];
+            ts[i * 13 + 12] = st[ns + EX];
+            if (YAW && P.traj_yaw) P.traj_yaw[(size_t)q * (MAX_TRAJ + 1) + i] = st[ns];
           }
         } else {
           status = 1;

@@ -201,6 +201,7 @@ extern "C" int mplx_lpa_plan(mplx_lpa *l, const mplx_waypoint *start, const mplx
   if (r) return lfail(l, r, "%s", c->err.c_str());
   if (start->enable_t) return lfail(l, MPLX_ERR_ARG, "enable_t is not supported by the voxel-map environment");
   if (!control_ok(goal->control)) return lfail(l, MPLX_ERR_ARG, "bad goal control");
+  if (c->yaw) return lfail(l, MPLX_ERR_ARG, "LPA* over yaw-carrying states is not supported (no caller in the reference: map_replanner_node.cpp plans without yaw)");
   if (c->aux) return lfail(l, MPLX_ERR_ARG, "LPA* with a potential field / search region on the context is not supported (the edge cost would not be a function of the control input)");
   LCHK(l, hipSetDevice(c->device));
   if ((r = lpa_ensure(l)) != MPLX_OK) return r;

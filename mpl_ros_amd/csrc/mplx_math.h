@@ -353,6 +353,60 @@ MPLX_HD int32_t float_to_cell_inv(double p, double origin, double res, double in
   return (int32_t)round(div_by_inv(p - origin, res, inv_res) - 0.5);
 }
 
+// ------------------------------------------------------------------ yaw (Waypoint::yaw, use_yaw lattices: map_planner_node.cpp:119-139,165,179)
+// A yaw-carrying primitive adds a VEL-type channel yaw(t) = yaw0 + u_yaw t (Primitive::pr_yaw); evaluate() normalises the
+// angle, the Waypoint key gains round(yaw / 0.1), validate_primitive gains validate_yaw [UNVERIFIED upstream, restated
+// in the tests' CPU checker]: at t = 0 and t = T, when the planar velocity is not zero, its direction must lie within
+// yaw_max of the yaw direction: v_hat . (cos yaw, sin yaw) >= cos(yaw_max).
+// sin / cos are evaluated by ONE fixed sequence of + - * (Cody-Waite reduction to [-pi/4, pi/4], Taylor polynomials in
+// Horner form) on host and device alike, so that the comparison above falls the same way on both (libm and the
+// device math library may differ in the last bit).  |error| < 2e-16 for |x| <= 8.
+constexpr double KEY_RES_YAW = 0.1;
+constexpr int CTRL_YAW_BIT = 16;  // Control::*xYAW = base | 0b10000
+MPLX_HD void det_sincos(double x, double *sn, double *cs) {
+  const double two_over_pi = 0.63661977236758138, pio2_hi = 1.5707963267948966, pio2_lo = 6.123233995736766e-17;
+  const double kf = round(x * two_over_pi);
+  const double r = (x - kf * pio2_hi) - kf * pio2_lo;
+  const double r2 = r * r;
+  // sin r = r (1 - r2/6 (1 - r2/20 (1 - r2/42 (1 - r2/72 (1 - r2/110 (1 - r2/156 (1 - r2/210)))))))
+  double ps = 1.0 - r2 / 210.0;
+  ps = 1.0 - r2 / 156.0 * ps;
+  ps = 1.0 - r2 / 110.0 * ps;
+  ps = 1.0 - r2 / 72.0 * ps;
+  ps = 1.0 - r2 / 42.0 * ps;
+  ps = 1.0 - r2 / 20.0 * ps;
+  ps = 1.0 - r2 / 6.0 * ps;
+  const double s = r * ps;
+  // cos r = 1 - r2/2 (1 - r2/12 (1 - r2/30 (1 - r2/56 (1 - r2/90 (1 - r2/132 (1 - r2/182 (1 - r2/240)))))))
+  double pc = 1.0 - r2 / 240.0;
+  pc = 1.0 - r2 / 182.0 * pc;
+  pc = 1.0 - r2 / 132.0 * pc;
+  pc = 1.0 - r2 / 90.0 * pc;
+  pc = 1.0 - r2 / 56.0 * pc;
+  pc = 1.0 - r2 / 30.0 * pc;
+  pc = 1.0 - r2 / 12.0 * pc;
+  const double c = 1.0 - r2 / 2.0 * pc;
+  const int k = (int)kf & 3;
+  *sn = k == 0 ? s : k == 1 ? c : k == 2 ? -s : -c;
+  *cs = k == 0 ? c : k == 1 ? -s : k == 2 ? -c : s;
+}
+// normalize_angle [UNVERIFIED upstream]: into [-pi, pi] by steps of 2 pi
+MPLX_HD double normalize_yaw(double q) {
+  const double pi = 3.141592653589793;
+  while (q > pi) q -= 2.0 * pi;
+  while (q < -pi) q += 2.0 * pi;
+  return q;
+}
+// one end of validate_yaw: planar velocity (vx, vy) against the yaw direction
+MPLX_HD bool yaw_end_ok(double vx, double vy, double yaw, double cos_max) {
+  if (vx == 0.0 && vy == 0.0) return true;
+  const double n = sqrt(vx * vx + vy * vy);
+  double sn, cs;
+  det_sincos(yaw, &sn, &cs);
+  const double d = vx / n * cs + vy / n * sn;
+  return !(d < cos_max);
+}
+
 // ------------------------------------------------------------------ polynomial real roots
 // Derivative-chain isolation + safeguarded Newton/bisection, basic arithmetic only (deterministic
 // on host and device).  Coefficients ascending: a[0] + a[1] x + ... + a[N] x^N.
@@ -534,6 +588,8 @@ struct HeurParams {
   State goal;
   int32_t goal_key[MAX_KEY];
   int goal_nkey;
+  int goal_yaw_key;  // (yaw-carrying searches) round(goal.yaw / 0.1) and the goal's yaw
+  double goal_yaw;
 };
 
 // min over T >= |dp|_inf / v_max of (optimal-control effort to reach the goal in T) + w T
@@ -547,7 +603,8 @@ MPLX_HD double cal_heur(const HeurParams &hp, int control, const State &s) {
   if (hp.heur_ignore_dynamics) return v_max > 0 ? w * linf3(s.p, goal.p) / v_max : w * linf3(s.p, goal.p);
   const double *v0 = s.v, *v1 = goal.v, *a0 = s.a, *a1 = goal.a;
   double t_bar = v_max > 0 ? linf3(s.p, goal.p) / v_max : 0.0;
-  int gc = hp.goal_control;
+  const int gc = hp.goal_control & 15;  // (the yaw bit does not select another cost-to-go)
+  control &= 15;
   if (control == CTRL_JRK && gc == CTRL_JRK) {
     double a0ma1[3] = {a0[0] - a1[0], a0[1] - a1[1], a0[2] - a1[2]};
     double v0pv1[3] = {v0[0] + v1[0], v0[1] + v1[1], v0[2] + v1[2]};
@@ -591,7 +648,7 @@ MPLX_HD double cal_heur(const HeurParams &hp, int control, const State &s) {
 
 // get_heur: 0 when the state's key equals the goal's key
 MPLX_HD double get_heur(const HeurParams &hp, int control, const State &s, const int32_t *key, int nkey) {
-  if (control == hp.goal_control && nkey == hp.goal_nkey) {
+  if ((control & 15) == (hp.goal_control & 15) && nkey == hp.goal_nkey) {
     bool eq = true;
     for (int i = 0; i < nkey; i++) eq = eq && (key[i] == hp.goal_key[i]);
     if (eq) return 0.0;

@@ -64,10 +64,21 @@ def carve_bubble(grid, pt, origin, res, radius=5):
     grid[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]] = VAL_FREE
 
 
-def control_lattice(u=1.0, num=1, use_3d=True):
-    """U as an (nU, 3) float64 array; loops accumulate `dx += du` like the reference driver."""
+def control_lattice(u=1.0, num=1, use_3d=True, u_yaw=None):
+    """U as an (nU, 3) float64 array; loops accumulate `dx += du` like the reference driver.
+    u_yaw: the use_yaw lattices (map_planner_node.cpp:119-139): (nU, 4), yaw rates -u_yaw, 0, u_yaw innermost."""
     du = u / num
     out = []
+
+    def emit(x, y, z):
+        if u_yaw is None:
+            out.append((x, y, z))
+            return
+        q = -u_yaw
+        while q <= u_yaw:
+            out.append((x, y, z, q))
+            q += u_yaw
+
     x = -u
     while x <= u:
         y = -u
@@ -75,10 +86,10 @@ def control_lattice(u=1.0, num=1, use_3d=True):
             if use_3d:
                 z = -u
                 while z <= u:
-                    out.append((x, y, z))
+                    emit(x, y, z)
                     z += du
             else:
-                out.append((x, y, 0.0))
+                emit(x, y, 0.0)
             y += du
         x += du
     return np.array(out, dtype=np.float64)

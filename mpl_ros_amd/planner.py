@@ -36,7 +36,6 @@ class Waypoint3D:
         self.yaw = 0.0
         self.t = 0.0
         self.enable_t = False
-        self.use_yaw = False  # carried, never propagated: plan() refuses use_yaw states (no silent loss)
         self.control = control
 
     # use_pos .. use_jrk view the control bits, like the union in the reference's Waypoint
@@ -50,6 +49,7 @@ class Waypoint3D:
     use_vel = property(lambda s: s._bit(2), lambda s, v: s._set(2, v))
     use_acc = property(lambda s: s._bit(4), lambda s, v: s._set(4, v))
     use_jrk = property(lambda s: s._bit(8), lambda s, v: s._set(8, v))
+    use_yaw = property(lambda s: s._bit(16), lambda s, v: s._set(16, v))  # (map_planner_node.cpp:165)
 
     def to_c(self):
         w = _capi.Waypoint()
@@ -78,16 +78,23 @@ class Waypoint3D:
             parts.append(self.acc)
         if self.control & 8:
             parts.append(self.jrk)
+        if self.control & 16:
+            parts.append(np.array([self.yaw]))
         return np.concatenate(parts)
 
 
 class Primitive3D:
     """Primitive<3> as its coefficient table (pr(i).coeff(), t(), control())."""
 
-    def __init__(self, coeffs, t, control):
+    def __init__(self, coeffs, t, control, yaw_coeff=None):
         self._c = np.array(coeffs, dtype=np.float64).reshape(3, 6)
         self._t = float(t)
         self._control = control
+        self._cyaw = np.zeros(6) if yaw_coeff is None else np.array(yaw_coeff, dtype=np.float64)
+
+    def pr_yaw(self):
+        """Coefficients of the yaw channel (use_yaw primitives): yaw(t) = c[4] t + c[5]."""
+        return self._cyaw
 
     def coeff(self, i):
         return self._c[i]
@@ -301,6 +308,7 @@ class VoxelMapPlanner:
         self.planner_verbose_ = verbose
         self.map_util_ = None
         self._U = None
+        self._U_yaw = None
         self._v_max = self._a_max = self._j_max = self._yaw_max = -1.0
         self._dt = 1.0
         self._w = 10.0
@@ -353,17 +361,18 @@ class VoxelMapPlanner:
 
     def setU(self, U):
         U = np.asarray(U, dtype=np.float64)
+        self._U_yaw = None
         if U.ndim == 2 and U.shape[1] == 4:
             # Vec4f control inputs (x, y, z, yaw rate) of the use_yaw lattices, map_planner_node.cpp:119-139
-            raise MplxError("4-component control inputs (use_yaw) are not supported by this back-end: the yaw "
-                            "component would be dropped silently")
+            self._U_yaw = np.ascontiguousarray(U[:, 3], dtype=np.float64)
+            U = U[:, :3]
         self._U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, 3)
         self._dirty = True
 
     def setYawmax(self, yaw_max):
         """setYawmax (map_planner_node.cpp:179-180).  The threshold constrains yaw-carrying primitives only: the
         reference node always calls it, and its config-1 launch file passes yaw_max = 0.5 with use_yaw = false
-        (launch/map_planner_node/test.launch:28,33).  Stored; it takes effect when the search states carry yaw."""
+        (launch/map_planner_node/test.launch:28,33).  It takes effect when the search states carry yaw (use_yaw)."""
         self._yaw_max, self._dirty = float(yaw_max), True
 
     # ---- LPA* incremental replanning (SURVEY.md 8f row 2): the state space stays on the device between plan() calls
@@ -583,6 +592,9 @@ class VoxelMapPlanner:
         cfg.t_max = self._t_max
         cfg.max_expand = self._max_num
         cfg.heur_ignore_dynamics = int(self._heur_ignore_dynamics)
+        if self._U_yaw is not None:
+            cfg.U_yaw = self._U_yaw.ctypes.data_as(C.POINTER(C.c_double))
+        cfg.yaw_max, cfg.tol_yaw = self._yaw_max, -1.0
         ctx.check(ctx.lib.mplx_planner_config(ctx.h, C.byref(cfg)))
         ctx.cfg_owner = weakref.ref(self)
         self._control = control
@@ -591,9 +603,11 @@ class VoxelMapPlanner:
     # ---- planning
     def plan(self, start, goal):
         """bool PlannerBase::plan(start, goal)."""
+        if self._U_yaw is not None and not start.use_yaw:
+            # (upstream would build yaw-less primitives from the first three components; nothing in the reference does
+            # this, and dropping the column silently would plan something else than what was asked for)
+            raise MplxError("a 4-component lattice (setU with a yaw column) needs use_yaw start states")
         ctx = self._ctx()
-        if getattr(start, "use_yaw", False) or getattr(goal, "use_yaw", False):
-            raise MplxError("use_yaw waypoints are not supported by this back-end (yaw would be ignored)")
         self._configure(start.control)
         self._apply_aux()
         res = _capi.Result()
@@ -691,7 +705,7 @@ class VoxelMapPlanner:
             self._lpa.check(ctx.lib.mplx_lpa_result_traj(self._lpa.h, prs, wps, act, ids))
         else:
             ctx.check(ctx.lib.mplx_result_traj(ctx.h, q, prs, wps, act, ids))
-        P = [Primitive3D([list(prs[i].c[k]) for k in range(3)], prs[i].t, prs[i].control) for i in range(n)]
+        P = [Primitive3D([list(prs[i].c[k]) for k in range(3)], prs[i].t, prs[i].control, list(prs[i].cyaw)) for i in range(n)]
         W = [Waypoint3D.from_c(wps[i]) for i in range(n + 1)]
         tr = Trajectory3D(P, W, np.array(act[:], dtype=np.int32), res.cost)
         tr.node_ids = np.array(ids[:], dtype=np.int32)

@@ -22,6 +22,7 @@
 #define ORC_HASH_RES_ACC 0.1
 #define ORC_HASH_RES_JRK 0.1
 #define ORC_HASH_RES_T 0.1
+#define ORC_HASH_RES_YAW 0.1
 
 /* ------------------------------------------------------------------ small helpers */
 static double pw(double t, int n) { /* t^n by repeated multiplication, left to right */
@@ -186,9 +187,10 @@ void orc_primitive_build(const orc_waypoint *p, const double *u, double dt, orc_
   memset(out, 0, sizeof(*out));
   out->t = dt;
   out->control = p->control;
+  out->cyaw[5] = p->yaw; /* (no yaw input: the yaw stays) */
   for (int i = 0; i < 3; i++) {
     double *c = out->c[i];
-    switch (p->control) {
+    switch (p->control & 15) {
       case ORC_VEL: c[4] = u[i]; c[5] = p->pos[i]; break;
       case ORC_ACC: c[3] = u[i]; c[4] = p->vel[i]; c[5] = p->pos[i]; break;
       case ORC_JRK: c[2] = u[i]; c[3] = p->acc[i]; c[4] = p->vel[i]; c[5] = p->pos[i]; break;
@@ -196,6 +198,45 @@ void orc_primitive_build(const orc_waypoint *p, const double *u, double dt, orc_
       default: break;
     }
   }
+}
+/* [UNVERIFIED primitive.h ctor with a Vec4f input] the yaw channel is a VEL-type Primitive1D: yaw(t) = yaw0 + u_yaw t */
+void orc_primitive_build_yaw(const orc_waypoint *p, const double *u, double u_yaw, double dt, orc_primitive *out) {
+  orc_primitive_build(p, u, dt, out);
+  out->cyaw[4] = u_yaw;
+}
+/* deterministic sin / cos and angle normalisation: the same sequences of + - * as mplx_math.h (the decision of
+ * validate_yaw must fall the same way on host and device; libm and the device library may differ in the last bit) */
+static void det_sincos(double x, double *sn, double *cs) {
+  const double two_over_pi = 0.63661977236758138, pio2_hi = 1.5707963267948966, pio2_lo = 6.123233995736766e-17;
+  const double kf = round(x * two_over_pi);
+  const double r = (x - kf * pio2_hi) - kf * pio2_lo;
+  const double r2 = r * r;
+  double ps = 1.0 - r2 / 210.0;
+  ps = 1.0 - r2 / 156.0 * ps;
+  ps = 1.0 - r2 / 110.0 * ps;
+  ps = 1.0 - r2 / 72.0 * ps;
+  ps = 1.0 - r2 / 42.0 * ps;
+  ps = 1.0 - r2 / 20.0 * ps;
+  ps = 1.0 - r2 / 6.0 * ps;
+  const double s = r * ps;
+  double pc = 1.0 - r2 / 240.0;
+  pc = 1.0 - r2 / 182.0 * pc;
+  pc = 1.0 - r2 / 132.0 * pc;
+  pc = 1.0 - r2 / 90.0 * pc;
+  pc = 1.0 - r2 / 56.0 * pc;
+  pc = 1.0 - r2 / 30.0 * pc;
+  pc = 1.0 - r2 / 12.0 * pc;
+  const double c = 1.0 - r2 / 2.0 * pc;
+  const int k = (int)kf & 3;
+  *sn = k == 0 ? s : k == 1 ? c : k == 2 ? -s : -c;
+  *cs = k == 0 ? c : k == 1 ? -s : k == 2 ? -c : s;
+}
+/* [UNVERIFIED angle normalisation of Primitive::evaluate] into [-pi, pi] by steps of 2 pi */
+static double normalize_yaw(double q) {
+  const double pi = 3.141592653589793;
+  while (q > pi) q -= 2.0 * pi;
+  while (q < -pi) q += 2.0 * pi;
+  return q;
 }
 void orc_primitive_evaluate(const orc_primitive *pr, double t, orc_waypoint *out) {
   memset(out, 0, sizeof(*out));
@@ -206,6 +247,27 @@ void orc_primitive_evaluate(const orc_primitive *pr, double t, orc_waypoint *out
     out->acc[k] = p1_a(pr->c[k], t);
     out->jrk[k] = p1_j(pr->c[k], t);
   }
+  if (pr->control & ORC_YAW) out->yaw = normalize_yaw(p1_p(pr->cyaw, t));
+}
+/* [UNVERIFIED primitive.h validate_yaw(pr, my)] at both ends of the primitive, when the planar velocity is not zero,
+ * its direction must lie within my of the yaw direction: v_hat . (cos yaw, sin yaw) >= cos(my).  my <= 0: no check. */
+int orc_validate_yaw(const orc_primitive *pr, double my) {
+  if (my <= 0) return 1;
+  double sm, cmax;
+  det_sincos(my, &sm, &cmax);
+  const double ts[2] = {0.0, pr->t};
+  for (int e = 0; e < 2; e++) {
+    orc_waypoint w;
+    orc_primitive_evaluate(pr, ts[e], &w);
+    const double vx = w.vel[0], vy = w.vel[1];
+    if (vx == 0.0 && vy == 0.0) continue;
+    const double n = sqrt(vx * vx + vy * vy);
+    double sn, cs;
+    det_sincos(w.yaw, &sn, &cs);
+    const double d = vx / n * cs + vy / n * sn;
+    if (d < cmax) return 0;
+  }
+  return 1;
 }
 
 /* [UNVERIFIED primitive.h extrema_* / max_*]  extrema of v on (0,t) = roots of a(t); the loop
@@ -260,9 +322,10 @@ double orc_primitive_max_jrk(const orc_primitive *pr, int k) {
 /* [UNVERIFIED primitive.h validate_primitive / validate_xxx]  ACC checks vel; JRK checks vel,acc;
  * SNP checks vel,acc,jrk; VEL checks nothing.  A limit <= 0 disables its check. */
 int orc_validate_primitive(const orc_primitive *pr, double mv, double ma, double mj) {
-  int chk_v = pr->control == ORC_ACC || pr->control == ORC_JRK || pr->control == ORC_SNP;
-  int chk_a = pr->control == ORC_JRK || pr->control == ORC_SNP;
-  int chk_j = pr->control == ORC_SNP;
+  const int ctl = pr->control & 15;
+  int chk_v = ctl == ORC_ACC || ctl == ORC_JRK || ctl == ORC_SNP;
+  int chk_a = ctl == ORC_JRK || ctl == ORC_SNP;
+  int chk_j = ctl == ORC_SNP;
   if (chk_v)
     for (int i = 0; i < 3; i++)
       if (mv > 0 && orc_primitive_max_vel(pr, i) > mv) return 0;
@@ -280,6 +343,7 @@ int orc_validate_primitive(const orc_primitive *pr, double mv, double ma, double
  * sum_i sum_j q_i q_j t^(i+j+1)/(i+j+1) over the monomial coefficients q of the derivative, in
  * ascending (i,j) order.  Same value analytically (ACC control: u^2 t). */
 double orc_primitive_J(const orc_primitive *pr, int control) {
+  control &= 15; /* (Primitive::J(control) sums the position channels; the yaw effort is Jyaw, not part of the edge cost) */
   int k = control == ORC_VEL ? 1 : control == ORC_ACC ? 2 : control == ORC_JRK ? 3 : 4;
   static const double fact[6] = {1, 1, 2, 6, 24, 120};
   double total = 0.0;
@@ -310,6 +374,7 @@ int orc_waypoint_key(const orc_waypoint *w, int32_t *key) {
     if (w->control & 4) key[n++] = (int32_t)round(w->acc[i] / ORC_HASH_RES_ACC);
     if (w->control & 8) key[n++] = (int32_t)round(w->jrk[i] / ORC_HASH_RES_JRK);
   }
+  if (w->control & ORC_YAW) key[n++] = (int32_t)round(w->yaw / ORC_HASH_RES_YAW); /* [UNVERIFIED] use_yaw: yaw / 0.1 */
   if (w->enable_t) key[n++] = (int32_t)round(w->t / ORC_HASH_RES_T);
   return n;
 }
@@ -329,7 +394,7 @@ typedef struct {
 
 typedef struct {
   orc_waypoint coord;
-  int32_t key[13];
+  int32_t key[16];
   int32_t nkey;
   double g, h;
   int32_t opened, closed;
@@ -358,7 +423,7 @@ struct orc_planner {
   double origin[3], res;
   /* config */
   orc_config cfg;
-  double *U;
+  double *U, *U_yaw;
   orc_waypoint goal;
   int has_goal;
   /* state space */
@@ -403,7 +468,8 @@ orc_planner *orc_create(void) {
   p->cfg.w = 10.0;
   p->cfg.eps = 1.0;
   p->cfg.tol_pos = 0.5;
-  p->cfg.tol_vel = p->cfg.tol_acc = -1.0;
+  p->cfg.tol_vel = p->cfg.tol_acc = p->cfg.tol_yaw = -1.0;
+  p->cfg.yaw_max = -1.0;
   p->cfg.t_max = INFINITY;
   p->cfg.max_expand = -1;
   p->traj_cost = INFINITY;
@@ -423,6 +489,7 @@ static void free_search(orc_planner *p) {
 void orc_destroy(orc_planner *p) {
   free(p->aux);
   p->aux = NULL;
+  free(p->U_yaw);
   if (!p) return;
   free_search(p);
   if (p->map_owned) free(p->map);
@@ -597,6 +664,13 @@ void orc_set_config(orc_planner *p, const orc_config *cfg) {
   p->U = (double *)malloc(sizeof(double) * 3 * (size_t)cfg->n_u);
   memcpy(p->U, cfg->U, sizeof(double) * 3 * (size_t)cfg->n_u);
   p->cfg.U = p->U;
+  free(p->U_yaw);
+  p->U_yaw = NULL;
+  if (cfg->U_yaw) {
+    p->U_yaw = (double *)malloc(sizeof(double) * (size_t)cfg->n_u);
+    memcpy(p->U_yaw, cfg->U_yaw, sizeof(double) * (size_t)cfg->n_u);
+  }
+  p->cfg.U_yaw = p->U_yaw;
 }
 void orc_set_goal(orc_planner *p, const orc_waypoint *goal) {
   p->goal = *goal;
@@ -619,6 +693,7 @@ int orc_is_goal(const orc_planner *p, const orc_waypoint *s) {
   int goaled = linf3(s->pos, p->goal.pos) <= p->cfg.tol_pos;
   if (goaled && (p->goal.control & 2) && p->cfg.tol_vel >= 0) goaled = linf3(s->vel, p->goal.vel) <= p->cfg.tol_vel;
   if (goaled && (p->goal.control & 4) && p->cfg.tol_acc >= 0) goaled = linf3(s->acc, p->goal.acc) <= p->cfg.tol_acc;
+  if (goaled && (s->control & ORC_YAW) && p->cfg.tol_yaw >= 0) goaled = fabs(s->yaw - p->goal.yaw) <= p->cfg.tol_yaw; /* [UNVERIFIED] */
   return goaled;
 }
 /* min over candidate times t >= t_bar of  a t - c/t - d/2/t^2 - e/3/t^3 - f/4/t^4 - g/5/t^5,
@@ -663,7 +738,8 @@ static double cal_heur(const orc_planner *p, const orc_waypoint *s, const orc_wa
   if (p->cfg.heur_ignore_dynamics) return v_max > 0 ? w * linf3(s->pos, goal->pos) / v_max : w * linf3(s->pos, goal->pos);
   const double *v0 = s->vel, *v1 = goal->vel, *a0 = s->acc, *a1 = goal->acc;
   double t_bar = v_max > 0 ? linf3(s->pos, goal->pos) / v_max : 0.0;
-  if (s->control == ORC_JRK && goal->control == ORC_JRK) {
+  const int sc = s->control & 15, gc = goal->control & 15; /* [UNVERIFIED] the yaw bit does not select another cost-to-go */
+  if (sc == ORC_JRK && gc == ORC_JRK) {
     double a0ma1[3] = {a0[0] - a1[0], a0[1] - a1[1], a0[2] - a1[2]};
     double v0pv1[3] = {v0[0] + v1[0], v0[1] + v1[1], v0[2] + v1[2]};
     double c = -9 * dot3(a0, a0) + 6 * dot3(a0, a1) - 9 * dot3(a1, a1);
@@ -672,7 +748,7 @@ static double cal_heur(const orc_planner *p, const orc_waypoint *s, const orc_wa
     double f = 2880 * dot3(dp, v0pv1);
     double g = -3600 * dot3(dp, dp);
     return heur_min6(w, c, d, e, f, g, t_bar);
-  } else if (s->control == ORC_JRK && goal->control == ORC_ACC) {
+  } else if (sc == ORC_JRK && gc == ORC_ACC) {
     double c = -8 * dot3(a0, a0);
     double d = -112 * dot3(a0, v0) - 48 * dot3(a0, v1);
     double e = 240 * dot3(a0, dp) - 384 * dot3(v0, v0) - 432 * dot3(v0, v1) - 144 * dot3(v1, v1);
@@ -680,32 +756,32 @@ static double cal_heur(const orc_planner *p, const orc_waypoint *s, const orc_wa
     double f = dot3(dp, q);
     double g = -1600 * dot3(dp, dp);
     return heur_min6(w, c, d, e, f, g, t_bar);
-  } else if (s->control == ORC_JRK && goal->control == ORC_VEL) {
+  } else if (sc == ORC_JRK && gc == ORC_VEL) {
     double c = -5 * dot3(a0, a0);
     double d = -40 * dot3(a0, v0);
     double e = 60 * dot3(a0, dp) - 60 * dot3(v0, v0);
     double f = 160 * dot3(dp, v0);
     double g = -100 * dot3(dp, dp);
     return heur_min6(w, c, d, e, f, g, t_bar);
-  } else if (s->control == ORC_ACC && goal->control == ORC_ACC) {
+  } else if (sc == ORC_ACC && gc == ORC_ACC) {
     double v0pv1[3] = {v0[0] + v1[0], v0[1] + v1[1], v0[2] + v1[2]};
     double c1 = -36 * dot3(dp, dp);
     double c2 = 24 * dot3(v0pv1, dp);
     double c3 = -4 * (dot3(v0, v0) + dot3(v0, v1) + dot3(v1, v1));
     return heur_min4(w, c3, c2, c1, w, t_bar);
-  } else if (s->control == ORC_ACC && goal->control == ORC_VEL) {
+  } else if (sc == ORC_ACC && gc == ORC_VEL) {
     double c1 = -9 * dot3(dp, dp);
     double c2 = 12 * dot3(v0, dp);
     double c3 = -3 * dot3(v0, v0);
     return heur_min4(w, c3, c2, c1, w, t_bar);
-  } else if (s->control == ORC_VEL && goal->control == ORC_VEL) {
+  } else if (sc == ORC_VEL && gc == ORC_VEL) {
     return (w + 1) * sqrt(dot3(dp, dp));
   }
   return v_max > 0 ? w * sqrt(dot3(dp, dp)) / v_max : w * sqrt(dot3(dp, dp));
 }
 /* [UNVERIFIED env_base::get_heur] 0 when the state hashes equal to the goal */
 double orc_heuristic(const orc_planner *p, const orc_waypoint *s) {
-  int32_t ka[13], kb[13];
+  int32_t ka[16], kb[16];
   int na = orc_waypoint_key(s, ka), nb = orc_waypoint_key(&p->goal, kb);
   if (s->control == p->goal.control && key_equal(ka, na, kb, nb)) return 0;
   return cal_heur(p, s, &p->goal);
@@ -718,18 +794,20 @@ double orc_heuristic(const orc_planner *p, const orc_waypoint *s) {
  *  UNVERIFIED env_map.h for `tn == curr` + validate + is_free(pr) ? J + w dt : inf] */
 int orc_get_succ(orc_planner *p, const orc_waypoint *curr, orc_waypoint *succ, double *succ_cost, int32_t *action_idx) {
   int n = 0;
-  int32_t kc[13], kt[13];
+  int32_t kc[16], kt[16];
   int nkc = orc_waypoint_key(curr, kc);
   p->cnt.n_expansions++;
   for (int i = 0; i < p->cfg.n_u; i++) {
     orc_primitive pr;
     orc_waypoint tn;
-    orc_primitive_build(curr, p->U + 3 * i, p->cfg.dt, &pr);
+    if ((curr->control & ORC_YAW) && p->U_yaw) orc_primitive_build_yaw(curr, p->U + 3 * i, p->U_yaw[i], p->cfg.dt, &pr);
+    else orc_primitive_build(curr, p->U + 3 * i, p->cfg.dt, &pr);
     p->cnt.n_primitives++;
     orc_primitive_evaluate(&pr, p->cfg.dt, &tn);
     tn.enable_t = 0; /* compared before tn.t is assigned; env_map never sets enable_t */
     int nkt = orc_waypoint_key(&tn, kt);
     if (key_equal(kt, nkt, kc, nkc) || !orc_validate_primitive(&pr, p->cfg.v_max, p->cfg.a_max, p->cfg.j_max)) continue;
+    if ((pr.control & ORC_YAW) && !orc_validate_yaw(&pr, p->cfg.yaw_max)) continue; /* validate_primitive(pr, mv, ma, mj, myaw) */
     tn.t = curr->t + p->cfg.dt; /* [IN-TREE env_cloud.h:65] */
     long potsum = 0;
     const int free_ = p->aux ? prim_traverse(p, &pr, &potsum) : orc_is_free_primitive(p, &pr);
@@ -958,7 +1036,7 @@ int orc_plan(orc_planner *p, const orc_waypoint *start, const orc_waypoint *goal
   orc_waypoint *succ = (orc_waypoint *)malloc(sizeof(orc_waypoint) * (size_t)p->cfg.n_u);
   double *succ_cost = (double *)malloc(sizeof(double) * (size_t)p->cfg.n_u);
   int32_t *succ_act = (int32_t *)malloc(sizeof(int32_t) * (size_t)p->cfg.n_u);
-  int32_t key[13];
+  int32_t key[16];
   int nkey = orc_waypoint_key(start, key);
   int start_id = node_create(p, start, key, nkey);
   p->nodes[start_id].g = 0;
@@ -1116,7 +1194,10 @@ int orc_traj_len(const orc_planner *p) { return p->traj_len; }
 void orc_get_traj(const orc_planner *p, orc_primitive *prs, orc_waypoint *wps, int32_t *actions, int32_t *node_ids) {
   for (int i = 0; i < p->traj_len; i++) {
     const orc_waypoint *from = &p->traj_wps[i];
-    if (prs) orc_primitive_build(from, p->U + 3 * p->traj_actions[i], p->cfg.dt, &prs[i]);
+    if (prs) {
+      if ((from->control & ORC_YAW) && p->U_yaw) orc_primitive_build_yaw(from, p->U + 3 * p->traj_actions[i], p->U_yaw[p->traj_actions[i]], p->cfg.dt, &prs[i]);
+      else orc_primitive_build(from, p->U + 3 * p->traj_actions[i], p->cfg.dt, &prs[i]);
+    }
     if (actions) actions[i] = p->traj_actions[i];
   }
   if (p->traj_len > 0 || p->traj_nodes)

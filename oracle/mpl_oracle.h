@@ -68,17 +68,18 @@ extern "C" {
 
 /* Control bit flags (UNVERIFIED recollection of mpl_basis/control.h): a Waypoint's control is the
  * union of its use_pos/use_vel/use_acc/use_jrk/use_yaw bits. */
-enum { ORC_VEL = 1, ORC_ACC = 3, ORC_JRK = 7, ORC_SNP = 15 };
+enum { ORC_VEL = 1, ORC_ACC = 3, ORC_JRK = 7, ORC_SNP = 15, ORC_YAW = 16 /* use_yaw bit: Control::*xYAW = base | 16 */ };
 
 typedef struct {
   double pos[3], vel[3], acc[3], jrk[3];
   double yaw, t;
-  int32_t control;  /* ORC_VEL / ORC_ACC / ORC_JRK / ORC_SNP */
+  int32_t control;  /* ORC_VEL / ORC_ACC / ORC_JRK / ORC_SNP, | ORC_YAW when the state carries yaw (use_yaw) */
   int32_t enable_t; /* time is part of the key (false for env_map) */
 } orc_waypoint;
 
 typedef struct {
   double c[3][6]; /* per-axis coefficients, convention above */
+  double cyaw[6]; /* yaw channel (Primitive::pr_yaw): a VEL-type primitive, yaw(t) = cyaw[4] t + cyaw[5] */
   double t;
   int32_t control;
   int32_t pad;
@@ -95,6 +96,9 @@ typedef struct {
   double t_max;      /* +inf unless set */
   int32_t max_expand; /* <=0: unlimited */
   int32_t heur_ignore_dynamics;
+  const double *U_yaw; /* n_u yaw rates: the 4th component of the Vec4f control inputs (map_planner_node.cpp:119-139); NULL: none */
+  double yaw_max;      /* setYawmax; <= 0 disables validate_yaw */
+  double tol_yaw;      /* < 0 disables the yaw term of is_goal */
 } orc_config;
 
 typedef struct {
@@ -111,6 +115,9 @@ typedef struct orc_planner orc_planner;
 
 /* ---- basis (a3,a4,a5,a6,a9 of SURVEY 8a) ---- */
 void orc_primitive_build(const orc_waypoint *p, const double *u, double dt, orc_primitive *out);
+/* with the yaw rate of a Vec4f control input (the state carries yaw: control & ORC_YAW) */
+void orc_primitive_build_yaw(const orc_waypoint *p, const double *u, double u_yaw, double dt, orc_primitive *out);
+int orc_validate_yaw(const orc_primitive *pr, double yaw_max);
 void orc_primitive_evaluate(const orc_primitive *pr, double t, orc_waypoint *out);
 double orc_primitive_max_vel(const orc_primitive *pr, int k);
 double orc_primitive_max_acc(const orc_primitive *pr, int k);

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liborc.so")
 
 VEL, ACC, JRK, SNP = 1, 3, 7, 15
+YAW = 16  # use_yaw bit of a control kind (Control::*xYAW)
 OK, NO_PATH, START_OCCUPIED, MAX_EXPAND = 0, 1, 2, 3
 
 
@@ -23,7 +24,7 @@ class Waypoint(C.Structure):
 
 
 class Primitive(C.Structure):
-    _fields_ = [("c", (C.c_double * 6) * 3), ("t", C.c_double), ("control", C.c_int32), ("pad", C.c_int32)]
+    _fields_ = [("c", (C.c_double * 6) * 3), ("cyaw", C.c_double * 6), ("t", C.c_double), ("control", C.c_int32), ("pad", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -31,7 +32,8 @@ class Config(C.Structure):
                 ("dt", C.c_double), ("v_max", C.c_double), ("a_max", C.c_double), ("j_max", C.c_double),
                 ("w", C.c_double), ("eps", C.c_double),
                 ("tol_pos", C.c_double), ("tol_vel", C.c_double), ("tol_acc", C.c_double),
-                ("t_max", C.c_double), ("max_expand", C.c_int32), ("heur_ignore_dynamics", C.c_int32)]
+                ("t_max", C.c_double), ("max_expand", C.c_int32), ("heur_ignore_dynamics", C.c_int32),
+                ("U_yaw", C.POINTER(C.c_double)), ("yaw_max", C.c_double), ("tol_yaw", C.c_double)]
 
 
 class Counters(C.Structure):
@@ -145,14 +147,20 @@ def lib():
         L.orc_primitive_J.argtypes = [C.POINTER(Primitive), C.c_int]
         L.orc_primitive_J.restype = C.c_double
         L.orc_validate_primitive.argtypes = [C.POINTER(Primitive), C.c_double, C.c_double, C.c_double]
+        L.orc_primitive_build_yaw.argtypes = [C.POINTER(Waypoint), C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(Primitive)]
+        L.orc_validate_yaw.argtypes = [C.POINTER(Primitive), C.c_double]
         L.orc_waypoint_key.argtypes = [C.POINTER(Waypoint), C.POINTER(C.c_int32)]
         L.orc_poly_roots_above.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
 
-def waypoint(pos, vel=(0, 0, 0), acc=(0, 0, 0), jrk=(0, 0, 0), control=ACC, t=0.0):
+def waypoint(pos, vel=(0, 0, 0), acc=(0, 0, 0), jrk=(0, 0, 0), control=ACC, t=0.0, yaw=None):
+    """yaw: not None makes it a yaw-carrying state (use_yaw: control | YAW)"""
     w = Waypoint()
+    if yaw is not None:
+        w.yaw = float(yaw)
+        control |= YAW
     w.pos[:] = [float(x) for x in pos]
     w.vel[:] = [float(x) for x in vel]
     w.acc[:] = [float(x) for x in acc]
@@ -172,6 +180,8 @@ def wp_state(w, control=None):
         out += list(w.acc)
     if control & 8:
         out += list(w.jrk)
+    if control & YAW:
+        out.append(w.yaw)
     return np.array(out, dtype=np.float64)
 
 
@@ -240,8 +250,12 @@ class Planner:
 
     def set_config(self, control, U, dt=1.0, v_max=-1.0, a_max=-1.0, j_max=-1.0, w=10.0, eps=1.0,
                    tol_pos=0.5, tol_vel=-1.0, tol_acc=-1.0, t_max=float("inf"), max_expand=-1,
-                   heur_ignore_dynamics=False):
-        self._U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, 3)
+                   heur_ignore_dynamics=False, yaw_max=-1.0, tol_yaw=-1.0):
+        """U: (n, 3), or (n, 4) with the yaw rate as 4th component (the Vec4f inputs of map_planner_node.cpp:119-139)"""
+        U = np.asarray(U, dtype=np.float64)
+        U = U.reshape(-1, U.shape[-1])
+        self._U_yaw = np.ascontiguousarray(U[:, 3]) if U.shape[1] == 4 else None
+        self._U = np.ascontiguousarray(U[:, :3], dtype=np.float64).reshape(-1, 3)
         cfg = Config()
         cfg.control = control
         cfg.n_u = self._U.shape[0]
@@ -252,6 +266,8 @@ class Planner:
         cfg.t_max = t_max
         cfg.max_expand = max_expand
         cfg.heur_ignore_dynamics = int(heur_ignore_dynamics)
+        cfg.U_yaw = self._U_yaw.ctypes.data_as(C.POINTER(C.c_double)) if self._U_yaw is not None else None
+        cfg.yaw_max, cfg.tol_yaw = float(yaw_max), float(tol_yaw)
         self.cfg = cfg
         self.L.orc_set_config(self.h, C.byref(cfg))
 

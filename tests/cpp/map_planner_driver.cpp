@@ -133,6 +133,8 @@ int main(int argc, char **argv) {
   auto ws = traj.getWaypoints();
   for (size_t i = 0; i < ws.size(); i++)
     printf("%s[%.17g, %.17g, %.17g, %.17g, %.17g, %.17g]", i ? ", " : "", ws[i].pos(0), ws[i].pos(1), ws[i].pos(2), ws[i].vel(0), ws[i].vel(1), ws[i].vel(2));
+  printf("], \"jyaw\": %.17g, \"yaws\": [", traj.Jyaw());
+  for (size_t i = 0; i < ws.size(); i++) printf("%s%.17g", i ? ", " : "", ws[i].yaw);
   // the replanner's obstacle probe (map_replanner_node.cpp:177-184): cells of the start-goal ray that are occupied
   vec_Vec3i pns = map_util->rayTrace(start.pos, goal.pos);
   size_t ray_occ = 0;

@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_the_header():
     assert C.sizeof(_capi.Waypoint) == 14 * 8 + 8
-    assert C.sizeof(_capi.Primitive) == 18 * 8 + 8 + 8
+    assert C.sizeof(_capi.Primitive) == 18 * 8 + 8 + 8 + 6 * 8  # c[3][6], t, control + pad, cyaw[6]
+    assert C.sizeof(_capi.Config) == 8 + 8 + 10 * 8 + 8 + 8 + 2 * 8  # control n_u | U | 10 doubles | 2 ints | U_yaw | yaw_max tol_yaw
     assert C.sizeof(_capi.Succ) == C.sizeof(_capi.Waypoint) + 8 + 8 + 48 + 8
     assert C.sizeof(_capi.Result) == 16 + 13 * 8
 
@@ -55,20 +56,6 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".inl")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no CPU fallback", ""), f
-
-
-def test_yaw_requests_fail_loudly():
-    """use_yaw states / Vec4f control inputs must never be planned as a different (yaw-less) search.  setYawmax alone is
-    harmless: the reference node always calls it, its config-1 launch file with yaw_max = 0.5 and use_yaw = false."""
-    import numpy as np
-    import pytest
-    from mpl_ros_amd._capi import MplxError
-    from mpl_ros_amd.planner import VoxelMapPlanner
-    pl = VoxelMapPlanner(False)
-    with pytest.raises(MplxError):
-        pl.setU(np.zeros((9, 4)))
-    pl.setYawmax(0.5)   # launch/map_planner_node/test.launch:28 -- constrains yaw-carrying primitives only
-    pl.setYawmax(-1.0)
 
 
 def test_reference_api_that_needs_no_device_behaves():

@@ -118,6 +118,37 @@ def test_reference_driver_config1_launch_file_through_the_shim(tmp_path):
         assert w == list(wo.pos) + list(wo.vel)
 
 
+@pytest.mark.gpu
+def test_reference_driver_with_use_yaw_through_the_shim(tmp_path):
+    """The reference driver's `use_yaw = true` branch (map_planner_node.cpp:119-127,165): Vec4f lattice (27 inputs),
+    start.use_yaw, goal(start.control), setYawmax(0.5) -- through the shim, against the oracle's yaw-carrying search."""
+    from mpl_ros_amd import mapgen
+    from oracle import orc
+    from tests import util
+    exe = build_driver(tmp_path)
+    d = np.load(os.path.join(ROOT, "tests", "golden", "simple_map.npz"))
+    grid, origin, res = d["grid"], d["origin"].tolist(), float(d["res"])
+    path = str(tmp_path / "simple.bin")
+    grid.tofile(path)
+    dz, dy, dx = grid.shape
+    args = [path, str(dx), str(dy), str(dz)] + [repr(float(o)) for o in origin] + [repr(res)] + \
+           ["14.5", "4.5", "0.05", "0.0", "0.0", "0.0", "2.4", "16.6", "0.05"] + ["0", "0.5", "0.5", "1"]
+    out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    U = mapgen.control_lattice(1.0, 1, False, u_yaw=0.5)
+    P = util.make_oracle(grid, origin, res, orc.ACC | orc.YAW, U, v_max=2.0, a_max=1.0, tol_pos=0.5, yaw_max=0.5)
+    st = P.plan(orc.waypoint((14.5, 4.5, 0.05), yaw=0.0), orc.waypoint((2.4, 16.6, 0.05), yaw=0.0))
+    assert st == 0 and r["valid"]
+    assert r["closed"] == P.num_closed() and r["expanded"] == len(P.expanded()[0]) and r["cost"] == P.traj_cost
+    tr = P.traj()
+    assert r["n_prim"] == tr["n"]
+    for w, y, wo in zip(r["waypoints"][:-1], r["yaws"][:-1], tr["wps"][:-1]):
+        assert w == list(wo.pos) + list(wo.vel) and y == wo.yaw
+    assert r["yaws"][-1] == tr["wps"][-1].yaw
+    assert r["jyaw"] == sum(U[a][3] ** 2 * 1.0 for a in tr["actions"])  # map_planner_node.cpp:214
+
+
 def test_replanner_driver_compiles_and_fails_loudly_without_gpu(tmp_path):
     import ctypes
     from mpl_ros_amd import _capi

@@ -20,7 +20,7 @@ def make_oracle(grid, origin, res, control, U, **kw):
 
 def make_gpu(grid, origin, res, U, v_max=-1.0, a_max=-1.0, j_max=-1.0, dt=1.0, w=10.0, eps=1.0, tol_pos=0.5,
              tol_vel=-1.0, tol_acc=-1.0, max_expand=-1, heur_ignore_dynamics=False, t_max=float("inf"),
-             n_slots=1, max_nodes=1 << 20, max_edges=1 << 22, max_log=1 << 21, record=0, spec=-1):
+             n_slots=1, max_nodes=1 << 20, max_edges=1 << 22, max_log=1 << 21, record=0, spec=-1, yaw_max=-1.0):
     from mpl_ros_amd.planner import VoxelMapPlanner, VoxelMapUtil
     mu = VoxelMapUtil()
     dz, dy, dx = grid.shape
@@ -31,6 +31,7 @@ def make_gpu(grid, origin, res, U, v_max=-1.0, a_max=-1.0, j_max=-1.0, dt=1.0, w
     pl.setVmax(v_max); pl.setAmax(a_max); pl.setJmax(j_max); pl.setDt(dt); pl.setW(w); pl.setEpsilon(eps)
     pl.setTol(tol_pos, tol_vel, tol_acc); pl.setMaxNum(max_expand); pl.setHeurIgnoreDynamics(heur_ignore_dynamics)
     pl.setTmax(t_max)
+    pl.setYawmax(yaw_max)
     pl.setU(U)
     pl.setCapacity(n_slots, max_nodes, max_edges, max_log)
     pl.setSpeculation(spec)
@@ -39,9 +40,11 @@ def make_gpu(grid, origin, res, U, v_max=-1.0, a_max=-1.0, j_max=-1.0, dt=1.0, w
     return mu, pl
 
 
-def gpu_wp(pos, vel=(0, 0, 0), acc=(0, 0, 0), jrk=(0, 0, 0), control=orc.ACC, t=0.0):
+def gpu_wp(pos, vel=(0, 0, 0), acc=(0, 0, 0), jrk=(0, 0, 0), control=orc.ACC, t=0.0, yaw=None):
     from mpl_ros_amd.planner import Waypoint3D
     w = Waypoint3D(control)
+    if yaw is not None:
+        w.use_yaw, w.yaw = True, float(yaw)
     w.pos, w.vel, w.acc, w.jrk = np.array(pos, float), np.array(vel, float), np.array(acc, float), np.array(jrk, float)
     w.t = t
     return w
@@ -66,14 +69,16 @@ def random_states(rng, n, control, lo, hi, v_max=2.0, a_max=1.0):
     return out
 
 
-def compare_plan(P, pl, start, goal, control, check_traj=True):
-    """Run the same query on the oracle (P) and on the HIP planner (pl); assert bit-exact agreement."""
-    so = orc.waypoint(start[0], vel=start[1], acc=start[2] if len(start) > 2 else (0, 0, 0), control=control)
-    go = orc.waypoint(goal[0], vel=goal[1] if len(goal) > 1 else (0, 0, 0), control=control)
+def compare_plan(P, pl, start, goal, control, check_traj=True, yaw=None):
+    """Run the same query on the oracle (P) and on the HIP planner (pl); assert bit-exact agreement.
+    yaw: (start yaw, goal yaw) makes the states yaw-carrying (use_yaw)."""
+    ys, yg = yaw if yaw is not None else (None, None)
+    so = orc.waypoint(start[0], vel=start[1], acc=start[2] if len(start) > 2 else (0, 0, 0), control=control, yaw=ys)
+    go = orc.waypoint(goal[0], vel=goal[1] if len(goal) > 1 else (0, 0, 0), control=control, yaw=yg)
     P.reset_counters()
     st_o = P.plan(so, go)
-    sg = gpu_wp(start[0], vel=start[1], acc=start[2] if len(start) > 2 else (0, 0, 0), control=control)
-    gg = gpu_wp(goal[0], vel=goal[1] if len(goal) > 1 else (0, 0, 0), control=control)
+    sg = gpu_wp(start[0], vel=start[1], acc=start[2] if len(start) > 2 else (0, 0, 0), control=control, yaw=ys)
+    gg = gpu_wp(goal[0], vel=goal[1] if len(goal) > 1 else (0, 0, 0), control=control, yaw=yg)
     ok = pl.plan(sg, gg)
     r = pl.getResult()
     assert r.status == st_o, (r.status, st_o)
@@ -110,8 +115,10 @@ def compare_plan(P, pl, start, goal, control, check_traj=True):
         assert np.array_equal(tg.actions, to["actions"])
         assert np.array_equal(tg.node_ids, to["node_ids"])
         for wg, wo in zip(tg.getWaypoints(), to["wps"]):
-            assert np.array_equal(wg.state(), orc.wp_state(wo, control))  # bit-exact (<= 1e-6 required)
+            assert wg.control == wo.control
+            assert np.array_equal(wg.state(), orc.wp_state(wo, wo.control))  # bit-exact (<= 1e-6 required); yaw included when carried
         for pg, po in zip(tg.segs, to["prs"]):
             for k in range(3):
                 assert np.array_equal(pg.coeff(k), np.array(po.c[k][:]))
+            assert np.array_equal(pg.pr_yaw(), np.array(po.cyaw[:]))
     return r, c
