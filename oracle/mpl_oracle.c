@@ -1175,7 +1175,9 @@ int orc_num_states_all(const orc_planner *p) {
   for (int i = 0; i < p->n_blocked; i++) {
     orc_primitive pr;
     orc_waypoint tn;
-    orc_primitive_build(&p->nodes[p->blocked[i].parent].coord, p->U + 3 * p->blocked[i].action, p->cfg.dt, &pr);
+    const orc_waypoint *from = &p->nodes[p->blocked[i].parent].coord;
+    if ((from->control & ORC_YAW) && p->U_yaw) orc_primitive_build_yaw(from, p->U + 3 * p->blocked[i].action, p->U_yaw[p->blocked[i].action], p->cfg.dt, &pr);
+    else orc_primitive_build(from, p->U + 3 * p->blocked[i].action, p->cfg.dt, &pr);
     orc_primitive_evaluate(&pr, p->cfg.dt, &tn);
     tn.enable_t = 0;
     int32_t *k = keys + 14 * (size_t)m;
