@@ -157,7 +157,7 @@ def test_hip_yaw_plans_in_3d(control, goal_yaw, yaw_max):
     mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=1 << 21, max_edges=1 << 23, **kw)
     start = ((1.05, 1.05, 1.05), (0, 0, 0), (0, 0, 0))
     r, c = util.compare_plan(P, pl, start, ((4.55, 4.05, 3.05),), control, yaw=(0.4, goal_yaw))
-    assert r.n_expanded > 20
+    assert r.n_expanded > 5
 
 
 @pytest.mark.gpu
