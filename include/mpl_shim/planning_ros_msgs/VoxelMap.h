@@ -5,15 +5,14 @@
  */
 #ifndef MPLX_SHIM_VOXELMAP_MSG_H
 #define MPLX_SHIM_VOXELMAP_MSG_H
+#include <planning_ros_msgs/Header.h>
+
 #include <string>
 #include <vector>
 
 namespace planning_ros_msgs {
 struct Point3 {
   double x = 0, y = 0, z = 0;
-};
-struct HeaderLite {
-  std::string frame_id;
 };
 struct VoxelMap {
   HeaderLite header;

@@ -375,6 +375,19 @@ const char *mplx_kernel_name(const mplx_ctx *ctx);
 uint64_t mplx_plan_epoch(const mplx_ctx *ctx);
 const char *mplx_version(void);
 
+/* ---- after the search: refinement and sampling (host arithmetic, no context, no device) ----
+ * TrajSolver3D(control).setWaypoints(wps).setDts(dts).solve(), map_planner_node.cpp:217-227: minimum-derivative
+ * piecewise polynomial through n_wp waypoints (control kind VEL / ACC / JRK: minimum velocity / acceleration / jerk);
+ * the control bits of every waypoint say which of its derivatives are fixed (the node sets the intermediate ones to
+ * VEL = position only).  prs: n_wp - 1 primitives out.  MPLX_ERR_ARG: fewer than 2 waypoints, a time <= 0, a singular
+ * system, or MPLX_SNP (septic segments do not fit a Primitive: traj_solver_node.cpp:67 "does not work"). */
+int mplx_traj_solve(int32_t control, int32_t n_wp, const mplx_waypoint *wps, const double *dts, mplx_primitive *prs);
+/* Trajectory::sample(N), trajectory_extractor.hpp:9-30: N + 1 equally spaced states of the piecewise trajectory
+ * (pos / vel / acc / jrk / yaw / t filled), yaw_dot (N + 1, may be NULL) */
+int mplx_traj_sample(int32_t n_prs, const mplx_primitive *prs, int32_t N, mplx_waypoint *out, double *yaw_dot);
+/* Trajectory::J(control) summed over the primitives (map_planner_node.cpp:210-214); control MPLX_YAW: Jyaw */
+double mplx_traj_J(int32_t n_prs, const mplx_primitive *prs, int32_t control);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,18 +105,61 @@ class Primitive3D:
     def control(self):
         return self._control
 
+    def to_c(self):
+        p = _capi.Primitive()
+        for k in range(3):
+            p.c[k][:] = [float(x) for x in self._c[k]]
+        p.cyaw[:] = [float(x) for x in self._cyaw]
+        p.t, p.control = self._t, int(self._control)
+        return p
+
+    @staticmethod
+    def from_c(p):
+        return Primitive3D([list(p.c[k]) for k in range(3)], p.t, p.control, list(p.cyaw))
+
 
 class Trajectory3D:
-    def __init__(self, prs, wps, actions, cost):
+    def __init__(self, prs, wps=None, actions=None, cost=math.nan):
         self.segs = prs
         self._wps = wps
         self.actions = actions
         self.cost = cost
 
+    def _c_prs(self):
+        return (_capi.Primitive * max(len(self.segs), 1))(*[p.to_c() for p in self.segs])
+
+    def sample(self, N):
+        """Trajectory::sample(N) (trajectory_extractor.hpp:9-10): N + 1 equally spaced states; each carries .yaw_dot."""
+        if not self.segs or N <= 0:
+            return []
+        out = (_capi.Waypoint * (N + 1))()
+        yd = np.zeros(N + 1)
+        _check(None, _capi.load().mplx_traj_sample(len(self.segs), self._c_prs(), int(N), out, yd.ctypes.data), _capi.load())
+        ws = [Waypoint3D.from_c(out[i]) for i in range(N + 1)]
+        for w, y in zip(ws, yd):
+            w.yaw_dot = float(y)
+        return ws
+
+    def J(self, control):
+        """Trajectory::J(control): total effort of the derivative `control` selects (map_planner_node.cpp:210-214)."""
+        return float(_capi.load().mplx_traj_J(len(self.segs), self._c_prs(), int(control) & 15))
+
+    def Jyaw(self):
+        return float(_capi.load().mplx_traj_J(len(self.segs), self._c_prs(), 16))
+
     def getPrimitives(self):
         return self.segs
 
     def getWaypoints(self):
+        """States at the segment joints (map_planner_node.cpp:217); a search result carries the search's own states."""
+        if self._wps is None:
+            ts = np.concatenate([[0.0], np.cumsum([p.t() for p in self.segs])])
+            ws = []
+            for i, p in enumerate(self.segs + self.segs[-1:]):
+                one = Trajectory3D([p]).sample(1)[0 if i < len(self.segs) else 1]
+                one.t = float(ts[i])
+                ws.append(one)
+            self._wps = ws
         return self._wps
 
     def getSegmentTimes(self):
