@@ -386,7 +386,7 @@ int mplx_traj_solve(int32_t control, int32_t n_wp, const mplx_waypoint *wps, con
  * (pos / vel / acc / jrk / yaw / t filled), yaw_dot (N + 1, may be NULL) */
 int mplx_traj_sample(int32_t n_prs, const mplx_primitive *prs, int32_t N, mplx_waypoint *out, double *yaw_dot);
 /* Trajectory::J(control) summed over the primitives (map_planner_node.cpp:210-214); control MPLX_YAW: Jyaw */
-double mplx_traj_J(int32_t n_prs, const mplx_primitive *prs, int32_t control);
+double mplx_traj_effort(int32_t n_prs, const mplx_primitive *prs, int32_t control);
 
 #ifdef __cplusplus
 }

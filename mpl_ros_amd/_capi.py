@@ -67,7 +67,7 @@ EXPORTS = [
     "mplx_poly_create", "mplx_poly_destroy", "mplx_poly_last_error", "mplx_poly_config", "mplx_poly_begin", "mplx_poly_set_world",
     "mplx_poly_add_static", "mplx_poly_add_linear", "mplx_poly_add_nonlinear", "mplx_poly_commit", "mplx_poly_get_succ_batch", "mplx_poly_set_capacity", "mplx_poly_plan_batch", "mplx_poly_result_traj",
     "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms", "mplx_poly_result_cycles",
-    "mplx_traj_solve", "mplx_traj_sample", "mplx_traj_J",
+    "mplx_traj_solve", "mplx_traj_sample", "mplx_traj_effort",
 ]
 
 
@@ -135,8 +135,8 @@ def load():
     L.mplx_plan_epoch.restype = C.c_uint64
     L.mplx_traj_solve.argtypes = [C.c_int32, C.c_int32, C.POINTER(Waypoint), D3, C.POINTER(Primitive)]
     L.mplx_traj_sample.argtypes = [C.c_int32, C.POINTER(Primitive), C.c_int32, C.POINTER(Waypoint), C.c_void_p]
-    L.mplx_traj_J.argtypes = [C.c_int32, C.POINTER(Primitive), C.c_int32]
-    L.mplx_traj_J.restype = C.c_double
+    L.mplx_traj_effort.argtypes = [C.c_int32, C.POINTER(Primitive), C.c_int32]
+    L.mplx_traj_effort.restype = C.c_double
     U64 = C.POINTER(C.c_uint64)
     L.mplx_potential_weights.argtypes = [P, C.c_double, C.c_double]
     L.mplx_potential_update.argtypes = [P, D3, D3, D3, C.c_int32]

@@ -55,7 +55,7 @@ extern "C" int mplx_traj_sample(int32_t n_prs, const mplx_primitive *prs, int32_
   return MPLX_OK;
 }
 
-extern "C" double mplx_traj_J(int32_t n_prs, const mplx_primitive *prs, int32_t control) {
+extern "C" double mplx_traj_effort(int32_t n_prs, const mplx_primitive *prs, int32_t control) {
   double j = 0;
   for (int i = 0; i < n_prs; i++) {
     const Primitive3D p = to_primitive(prs[i]);

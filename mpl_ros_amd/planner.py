@@ -142,10 +142,10 @@ class Trajectory3D:
 
     def J(self, control):
         """Trajectory::J(control): total effort of the derivative `control` selects (map_planner_node.cpp:210-214)."""
-        return float(_capi.load().mplx_traj_J(len(self.segs), self._c_prs(), int(control) & 15))
+        return float(_capi.load().mplx_traj_effort(len(self.segs), self._c_prs(), int(control) & 15))
 
     def Jyaw(self):
-        return float(_capi.load().mplx_traj_J(len(self.segs), self._c_prs(), 16))
+        return float(_capi.load().mplx_traj_effort(len(self.segs), self._c_prs(), 16))
 
     def getPrimitives(self):
         return self.segs
