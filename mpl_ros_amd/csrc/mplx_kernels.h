@@ -97,6 +97,59 @@ __device__ __forceinline__ int row_incl_min(int x, int identity) {  // rows of 1
   y = (int)dpp_u32<0x118, 0xf>((uint32_t)identity, (uint32_t)x); x = y < x ? y : x;
   return x;
 }
+// minimum of x over the 64 lanes of the wave, in every lane (x >= 0 or +inf; every lane active): a DPP inclusive
+// minimum scan (lanes without a source see +inf) and a read of lane 63
+__device__ __forceinline__ double wave_min_f64(double x) {
+  constexpr unsigned long long INF = 0x7FF0000000000000ull;
+#define MPLX_MIN_STEP(CTRL, MASK)                                                                                        \
+  {                                                                                                                      \
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);                                            \
+    const uint32_t lo = dpp_u32<CTRL, MASK>((uint32_t)INF, (uint32_t)b), hi = dpp_u32<CTRL, MASK>((uint32_t)(INF >> 32), (uint32_t)(b >> 32)); \
+    const double y = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));                              \
+    x = y < x ? y : x;                                                                                                   \
+  }
+  MPLX_MIN_STEP(0x111, 0xf) MPLX_MIN_STEP(0x112, 0xf) MPLX_MIN_STEP(0x114, 0xf) MPLX_MIN_STEP(0x118, 0xf) MPLX_MIN_STEP(0x142, 0xa) MPLX_MIN_STEP(0x143, 0xc)
+#undef MPLX_MIN_STEP
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)__double_as_longlong(x), 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)__double_as_longlong(x) >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+#define MPLX_MIN_STEP(CTRL, MASK) { const uint32_t y = dpp_u32<CTRL, MASK>(0xFFFFFFFFu, x); x = y < x ? y : x; }
+  MPLX_MIN_STEP(0x111, 0xf) MPLX_MIN_STEP(0x112, 0xf) MPLX_MIN_STEP(0x114, 0xf) MPLX_MIN_STEP(0x118, 0xf) MPLX_MIN_STEP(0x142, 0xa) MPLX_MIN_STEP(0x143, 0xc)
+#undef MPLX_MIN_STEP
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+// The wave's smallest OPEN entry under entry_less -- (f, g, id) in lexicographic order; `have` false: the lane holds
+// none -- delivered to every lane; false when no lane holds one.  One DPP minimum per level, further levels only among
+// the lanes that tie (instead of six butterfly steps of ds_bpermute on all four fields).
+__device__ __forceinline__ bool wave_min_entry(bool have, double &f, double &g, uint32_t &id, uint32_t &pos) {
+  unsigned long long m = __ballot(have);
+  if (!m) return false;
+  if (m & (m - 1ull)) {
+    const double fm = wave_min_f64(have ? f : INFINITY);
+    m = __ballot(have && f == fm);
+    if (m & (m - 1ull)) {
+      const bool tie = have && f == fm;
+      const double gm = wave_min_f64(tie ? g : INFINITY);
+      m = __ballot(tie && g == gm);
+      if (m & (m - 1ull)) {
+        const bool tie2 = tie && g == gm;
+        const uint32_t im = wave_min_u32(tie2 ? id : 0xFFFFFFFFu);
+        m = __ballot(tie2 && id == im);
+      }
+    }
+  }
+  const int w = __ffsll((long long)m) - 1;
+  const unsigned long long fb = (unsigned long long)__double_as_longlong(f), gb = (unsigned long long)__double_as_longlong(g);
+  const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fb, w), f1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fb >> 32), w);
+  const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gb, w), g1 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gb >> 32), w);
+  f = __longlong_as_double((long long)(((unsigned long long)f1 << 32) | f0));
+  g = __longlong_as_double((long long)(((unsigned long long)g1 << 32) | g0));
+  id = (uint32_t)__builtin_amdgcn_readlane((int)id, w);
+  pos = (uint32_t)__builtin_amdgcn_readlane((int)pos, w);
+  return true;
+}
 // value held by the last lane of my segment (uniform per segment)
 template <int WIDTH>
 __device__ __forceinline__ uint32_t segment_last(uint32_t x, int lane) {
@@ -1140,12 +1193,7 @@ __device__ __forceinline__ bool pop_min(const QView<BLOCK, CONTROL, SM> &Q, int 
       uint32_t id = S.near_id[i];
       if (bp == NIL || entry_less(f, g, id, bf, bg, bi)) { bf = f; bg = g; bi = id; bp = i; }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      double of = __shfl_xor(bf, d, 64), og = __shfl_xor(bg, d, 64);
-      uint32_t oi = __shfl_xor(bi, d, 64), op = __shfl_xor(bp, d, 64);
-      if (op != NIL && (bp == NIL || entry_less(of, og, oi, bf, bg, bi))) { bf = of; bg = og; bi = oi; bp = op; }
-    }
+    if (!wave_min_entry(bp != NIL, bf, bg, bi, bp)) bp = NIL;
     if constexpr (BLOCK > 64) {
       if ((tid & 63) == 0) {
         S.red_f[tid >> 6] = bf; S.red_g[tid >> 6] = bg; S.red_id[tid >> 6] = bi; S.red_pos[tid >> 6] = bp;

@@ -180,12 +180,7 @@ __device__ __forceinline__ bool lpa_pop(const QView<BLOCK, CONTROL> &Q, int tid,
       uint32_t id = S.near_id[i];
       if (bp == NIL || entry_less(f, g, id, bf, bg, bi)) { bf = f; bg = g; bi = id; bp = i; }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      double of = __shfl_xor(bf, d, 64), og = __shfl_xor(bg, d, 64);
-      uint32_t oi = __shfl_xor(bi, d, 64), op = __shfl_xor(bp, d, 64);
-      if (op != NIL && (bp == NIL || entry_less(of, og, oi, bf, bg, bi))) { bf = of; bg = og; bi = oi; bp = op; }
-    }
+    if (!wave_min_entry(bp != NIL, bf, bg, bi, bp)) bp = NIL;
     if constexpr (BLOCK > 64) {
       if ((tid & 63) == 0) {
         S.red_f[tid >> 6] = bf; S.red_g[tid >> 6] = bg; S.red_id[tid >> 6] = bi; S.red_pos[tid >> 6] = bp;
