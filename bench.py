@@ -497,10 +497,11 @@ def bench_c5(args):
     print(json.dumps(out), flush=True)
 
 
-def _cpu_run(cfg, queries, order, budget_s, procs):
+def _cpu_run(cfg, queries, order, budget_s, procs, caps=None):
     """`procs` worker PROCESSES (oracle/cpu_worker.py), one query at a time each, all mapping ONE read-only copy
     of the voxel map.  A dispatcher thread per worker hands out the next query of `order` until the budget is
-    spent; queries still running then are given a grace period and dropped afterwards."""
+    spent; queries still running then are given a grace period and dropped afterwards.  caps: per-query expansion
+    cap (query index -> cap) for the queries that are timed over a prefix of their search only."""
     import subprocess
     import threading
     workers = []
@@ -530,7 +531,8 @@ def _cpu_run(cfg, queries, order, budget_s, procs):
             i = order[k]
             s, g = queries[i]
             try:
-                w.stdin.write(f"{i} {s[0]!r} {s[1]!r} {s[2]!r} {g[0]!r} {g[1]!r} {g[2]!r}\n")
+                cap = f" {caps[i]}" if caps and i in caps else ""
+                w.stdin.write(f"{i} {s[0]!r} {s[1]!r} {s[2]!r} {g[0]!r} {g[1]!r} {g[2]!r}{cap}\n")
                 w.stdin.flush()
                 line = w.stdout.readline()
             except (BrokenPipeError, ValueError):
@@ -566,7 +568,13 @@ def cpu_baseline(grid, origin, res, control, U, max_expand, queries, gpu_expansi
     -march=native on this host when gcc is present.  Two legs, steady clock around plan() only:
       N processes (one query at a time each; independent queries are the only parallelism the reference offers),
       1 process   (the reference planner's actual mode).
-    value = expansions of the completed N-process sample / its wall time."""
+    value = expansions of the N-process sample / its wall time.
+
+    The sample is chosen BEFORE the CPU runs, from the expansion counts the GPU reported, so that it has the batch's own
+    mix and not "whatever finished in time": the queries sorted by expansion count, every k-th one taken (k sized to the
+    budget at an assumed 2.5e4 expansions/s per core); a sampled query longer than one core can finish within the budget
+    is timed over its first L expansions only (the cap is passed to the worker; such a query counts L expansions and is
+    left out of the parity check).  Dispatch is longest first."""
     import tempfile
     from oracle import orc
     native = orc.use_native()
@@ -581,12 +589,25 @@ def cpu_baseline(grid, origin, res, control, U, max_expand, queries, gpu_expansi
     try:
         procs = max(1, min(procs, len(queries)))
         order = list(range(len(queries)))
-        multi = _cpu_run(cfg, queries, order, budget_s, procs)
-        per_query = dict(multi["per_query"])
+        caps = {}
+        if procs > 1:
+            rate = 2.5e4
+            L = int(rate * budget_s * 0.7)
+            by_size = sorted(order, key=lambda i: (gpu_expansions[i], i))
+            work = [min(gpu_expansions[i], L) for i in by_size]
+            target = rate * budget_s * procs * 0.6
+            stride = max(1, int(np.ceil(sum(work) / max(target, 1.0))))
+            sample = by_size[stride // 2::stride]
+            caps = {i: L for i in sample if gpu_expansions[i] > L and (max_expand <= 0 or L < max_expand)}
+            order = sorted(sample, key=lambda i: -min(gpu_expansions[i], L))
+        multi = _cpu_run(cfg, queries, order, budget_s * (1.0 if not caps else 4.0), procs, caps)
+        per_query = {k: v for k, v in multi["per_query"].items() if k not in caps}
         out = {"value": multi["n_exp"] / multi["wall"], "unit": "expansions/s", "cores": procs, "kind": "port",
                "build": "gcc -O3 -march=native -ffp-contract=off" if native else "gcc -O3 -ffp-contract=off (portable)",
                "value_per_core": multi["n_exp"] / max(multi["busy"], 1e-9),
-               "sample": f"{multi['nq']} of the first {multi['next']} of the {len(queries)} queries of rank 0 completed within the budget "
+               "sample": (f"{multi['nq']} of the first {multi['next']} of the {len(queries)} queries of rank 0 completed within the budget " if procs == 1 else
+                          f"every {stride}-th of the {len(queries)} queries of rank 0 in order of their expansion count (chosen before the CPU ran: the batch's own mix), "
+                          f"{multi['nq']} of {len(order)} completed; the {len(caps)} sampled queries above {L} expansions timed over their first {L} only; ") +
                          f"({multi['n_exp']} expansions, {multi['wall']:.1f} s wall, {multi['busy']:.1f} core-s of plan()); {procs} worker "
                          f"processes, one read-only map shared through /dev/shm",
                "plan_latency_ms": {"p50": 1e3 * float(np.percentile(multi["lat"], 50)) if multi["lat"] else None,
@@ -594,7 +615,8 @@ def cpu_baseline(grid, origin, res, control, U, max_expand, queries, gpu_expansi
                                    "mean": 1e3 * multi["busy"] / max(multi["nq"], 1)}}
         if procs > 1:
             # 1-process leg on queries the N-process leg did not reach, skipping the heavy tail so the leg stays bounded
-            rest = [i for i in order[multi["next"]:] if gpu_expansions[i] <= 600_000]
+            done = set(multi["per_query"])
+            rest = [i for i in range(len(queries)) if i not in done and gpu_expansions[i] <= 600_000]
             single = _cpu_run(cfg, queries, rest, max(4.0, budget_s * 0.6), 1)
             per_query.update(single["per_query"])
             out["single_thread"] = {"value": single["n_exp"] / max(single["busy"], 1e-9), "cores": 1,

@@ -5,7 +5,8 @@ allocator locks the way N threads of one process do; the voxel map is ONE read-o
 all of them (orc_set_map_shared).
 
     python oracle/cpu_worker.py '<json config>'      config: map (npy path), origin, res, control, U, kw, native
-    stdin : "<index> sx sy sz gx gy gz\\n" ...        stdout: {"i":..,"status":..,"n_expanded":..,...}\\n
+    stdin : "<index> sx sy sz gx gy gz [cap]\\n" ...  stdout: {"i":..,"status":..,"n_expanded":..,...}\\n
+    cap (optional): expansion cap of THIS query (a long query of the sample is timed over its first `cap` expansions)
 """
 import json
 import os
@@ -33,12 +34,17 @@ def main():
     control = cfg["control"]
     P.set_config(control, np.array(cfg["U"], dtype=np.float64), **cfg["kw"])
     print(json.dumps({"ready": True}), flush=True)
+    capped = False
     for line in sys.stdin:
         f = line.split()
         if not f:
             break
         i = int(f[0])
         s, g = [float(x) for x in f[1:4]], [float(x) for x in f[4:7]]
+        cap = int(f[7]) if len(f) > 7 else None
+        if cap is not None or capped:
+            P.set_config(control, np.array(cfg["U"], dtype=np.float64), **(dict(cfg["kw"], max_expand=cap) if cap is not None else cfg["kw"]))
+            capped = cap is not None
         P.reset_counters()
         t0 = time.perf_counter()
         st = P.plan(orc.waypoint(s, control=control), orc.waypoint(g, control=control))
