@@ -317,7 +317,9 @@ int mplx_grid_to_map(mplx_grid *g, int inflated, mplx_ctx *ctx);
  *      mpl_external_planner/include/mpl_external_planner/poly_map_planner/ (env_poly_map.h:45-73, poly_map_util.h:72-109,
  *      primitive_geometry_utils.h:5-173, simple_obstacle.h), 2-D like the multi-robot node.  One object holds several
  *      WORLDS -- what one robot's planner sees: bounding box, start time, static / linear / nonlinear obstacles -- so
- *      that the 16 planners of a decentralised tick (robot_team.hpp:33-66) run in one launch.  VEL / ACC control. ---- */
+ *      that the 16 planners of a decentralised tick (robot_team.hpp:33-66) run in one launch.  get_succ: any control kind
+ *      (poly_map_planner_node.cpp:73-85 exposes use_acc / use_jrk) and obstacle trajectories of any degree <= 5, through the
+ *      general solve(a, b, c, d, e, f) of primitive_geometry_utils.h:28,71,148; the search: ACC or JRK states. ---- */
 typedef struct mplx_poly mplx_poly;
 typedef struct {
   double state[9];     /* tn: pos2 vel2 acc2 jrk2, t = curr.t + dt (enable_t, env_poly_map.h:63-64) */
@@ -328,7 +330,7 @@ typedef struct {
 int mplx_poly_create(int device, mplx_poly **out);
 void mplx_poly_destroy(mplx_poly *p);
 const char *mplx_poly_last_error(const mplx_poly *p);
-/* planner set-up: control kind (MPLX_VEL / MPLX_ACC), control inputs U (n_u x 2), dt, limits, time weight w */
+/* planner set-up: control kind (MPLX_VEL / ACC / JRK / SNP), control inputs U (n_u x 2), dt, limits, time weight w */
 int mplx_poly_config(mplx_poly *p, int32_t control, int32_t n_u, const double *U, double dt, double v_max, double a_max, double j_max, double w);
 /* (re)build the worlds: begin(n), set_world + add_* per world, commit() uploads them */
 int mplx_poly_begin(mplx_poly *p, int32_t n_worlds);
@@ -345,7 +347,8 @@ int mplx_poly_get_succ_batch(mplx_poly *p, int32_t K, const int32_t *world_of, c
 /* PlannerBase::plan through env_poly_map for n queries in ONE launch, one workgroup per query (the planners of a
  * decentralised tick, robot.hpp:92-133): query k plans in world world_of[k] from starts[k] (pos2 vel2 acc2 jrk2 t) to
  * goals[k] (pos2 vel2 ...).  States are keyed with their time (enable_t, env_poly_map.h:63-64).  setEpsilon / setTol /
- * setMaxNum / setHeurIgnoreDynamics are the eps / tol_* / max_expand / heur_ignore_dynamics arguments.  ACC control. */
+ * setMaxNum / setHeurIgnoreDynamics are the eps / tol_* / max_expand / heur_ignore_dynamics arguments.  ACC or JRK control
+ * (an SNP state keyed with its time would need 13 key integers; refused). */
 int mplx_poly_set_capacity(mplx_poly *p, int32_t n_slots, uint64_t total_nodes, uint64_t total_edges, uint64_t total_open_log);
 int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *world_of, const double *starts, const double *goals, double eps, double tol_pos,
                          double tol_vel, int32_t max_expand, int32_t heur_ignore_dynamics, mplx_result *out);

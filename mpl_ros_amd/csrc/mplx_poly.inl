@@ -14,7 +14,7 @@ struct PolySuccOut {
 // box, validate_primitive, intrinsic cost); then isFree(pr, t) of all of them against all obstacles spread over the lanes
 // below the pair level (poly_collide_all, mplx_poly_dev.h) and the start-point test isFree(start.pos, t) over the
 // obstacles; results are OR-ed in LDS.
-template <int BLOCK>
+template <int BLOCK, bool GEN = false>
 __global__ __launch_bounds__(BLOCK) void poly_get_succ_kernel(PolyDev D, int K, const int32_t *world_of, const double *states, PolySuccOut *out, int32_t *flags) {
   __shared__ double cs[POLY_MAX_U][2][6];
   __shared__ int32_t valid[POLY_MAX_U], hit[POLY_MAX_U];
@@ -28,18 +28,18 @@ __global__ __launch_bounds__(BLOCK) void poly_get_succ_kernel(PolyDev D, int K, 
     const double T = D.dt, t_rel = st[8] - W.start_t;
     if (tid == 0) { start_hit = 0; unsupported = 0; }
     if (tid < D.n_u) {
-      const double pos[2] = {st[0], st[1]}, vel[2] = {st[2], st[3]}, u[2] = {D.U[2 * tid], D.U[2 * tid + 1]};
+      const double pos[2] = {st[0], st[1]}, vel[2] = {st[2], st[3]}, acc[2] = {st[4], st[5]}, jrk[2] = {st[6], st[7]}, u[2] = {D.U[2 * tid], D.U[2 * tid + 1]};
       double c[2][6];
-      poly_prim_build(D.control, pos, vel, u, c);
+      poly_prim_build(D.control, pos, vel, u, c, acc, jrk);
       for (int i = 0; i < 2; i++)
         for (int j = 0; j < 6; j++) cs[tid][i][j] = c[i][j];
       const double ex = pp_p_auto(c[0], T), ey = pp_p_auto(c[1], T);
-      valid[tid] = (poly_inside(W.bbox, 4, ex, ey) && poly_validate(D.control, c, T, D.v_max)) ? 1 : 0;
+      valid[tid] = (poly_inside(W.bbox, 4, ex, ey) && poly_validate(D.control, c, T, D.v_max, D.a_max, D.j_max)) ? 1 : 0;
       hit[tid] = 0;
     }
     __syncthreads();
     // isFree(start.pos, t) (start = pr.evaluate(0) = the node position for every primitive) and isFree(pr, t)
-    poly_collide_all<BLOCK>(D, W, cs, valid, D.n_u, T, t_rel, prep, hit_idx, uns_idx, &hp_max, hit, &unsupported, &start_hit, tid, 0, PolyNoHook());
+    poly_collide_all<BLOCK, PolyNoHook, GEN>(D, W, cs, valid, D.n_u, T, t_rel, prep, hit_idx, uns_idx, &hp_max, hit, &unsupported, &start_hit, tid, 0, PolyNoHook());
     if (tid < D.n_u) {
       PolySuccOut &o = out[(size_t)k * D.n_u + tid];
       double c[2][6];
@@ -68,6 +68,7 @@ struct mplx_poly {
   // configuration
   bool have_cfg = false;
   int control = 0, n_u = 0;
+  bool any_high_degree = false;  // an obstacle trajectory has a segment above degree two (set by mplx_poly_add_nonlinear, cleared by mplx_poly_begin)
   double dt = 1, v_max = -1, a_max = -1, j_max = -1, w = 10;
   std::vector<double> U;
   // worlds being assembled on the host
@@ -144,7 +145,7 @@ extern "C" const char *mplx_poly_last_error(const mplx_poly *p) { return p ? p->
 
 extern "C" int mplx_poly_config(mplx_poly *p, int32_t control, int32_t n_u, const double *U, double dt, double v_max, double a_max, double j_max, double w) {
   if (!p || !U) return pfail(p, MPLX_ERR_ARG, "null argument");
-  if (!(control == CTRL_VEL || control == CTRL_ACC)) return pfail(p, MPLX_ERR_ARG, "the moving-obstacle environment supports VEL / ACC control (hyperplane equations up to degree 2), got %d", control);
+  if (!control_ok(control)) return pfail(p, MPLX_ERR_ARG, "control kind %d is not one of VEL / ACC / JRK / SNP", control);
   if (n_u <= 0 || n_u > POLY_MAX_U) return pfail(p, MPLX_ERR_ARG, "n_u must be in [1,%d]", POLY_MAX_U);
   if (!(dt > 0)) return pfail(p, MPLX_ERR_ARG, "dt must be > 0");
   PCHK(p, hipSetDevice(p->device));
@@ -164,6 +165,7 @@ extern "C" int mplx_poly_begin(mplx_poly *p, int32_t n_worlds) {
   p->hps.clear(); p->segs.clear(); p->obs.clear(); p->obs_world.clear();
   p->worlds.assign((size_t)n_worlds, mplx::PolyWorld());
   p->committed = false;
+  p->any_high_degree = false;
   return MPLX_OK;
 }
 // PolyMapUtil::setBoundingBox (poly_map_util.h:40-50) + setStartTime (:19)
@@ -234,7 +236,7 @@ extern "C" int mplx_poly_add_nonlinear(mplx_poly *p, int32_t world, int32_t n_hp
     mplx::PolySeg s;
     for (int k = 0; k < 6; k++) { s.c[0][k] = segs[13 * i + k]; s.c[1][k] = segs[13 * i + 6 + k]; }
     for (int ax = 0; ax < 2; ax++)
-      if (s.c[ax][0] != 0 || s.c[ax][1] != 0 || s.c[ax][2] != 0) return pfail(p, MPLX_ERR_ARG, "obstacle trajectories must be VEL / ACC primitives (c0 = c1 = c2 = 0)");
+      if (s.c[ax][0] != 0 || s.c[ax][1] != 0 || s.c[ax][2] != 0) p->any_high_degree = true;  // (JRK / SNP robots: the general solve())
     s.T = segs[13 * i + 12];
     total = s.T + total;  // Trajectory: taus.push_back(pr.t() + taus.back())
     p->segs.push_back(s);
@@ -278,6 +280,8 @@ extern "C" int mplx_poly_commit(mplx_poly *p) {
   p->committed = true;
   return MPLX_OK;
 }
+// hyperplane equations above degree two can occur: JRK / SNP primitives, or an obstacle trajectory with such segments
+static bool poly_general(const mplx_poly *p) { return p->control == CTRL_JRK || p->control == CTRL_SNP || p->any_high_degree; }
 static mplx::PolyDev poly_dev(const mplx_poly *p) {
   mplx::PolyDev D{};
   D.cum = nullptr;
@@ -308,13 +312,16 @@ extern "C" int mplx_poly_get_succ_batch(mplx_poly *p, int32_t K, const int32_t *
   PCHK(p, hipMemcpyAsync(dw, world_of, sizeof(int32_t) * K, hipMemcpyHostToDevice, p->stream));
   PCHK(p, hipMemcpyAsync(ds, states, sizeof(double) * 9 * K, hipMemcpyHostToDevice, p->stream));
   PCHK(p, hipMemsetAsync(dflags, 0, sizeof(int32_t), p->stream));
-  hipLaunchKernelGGL((mplx::poly_get_succ_kernel<256>), dim3(K < 4096 ? K : 4096), dim3(256), 0, p->stream, poly_dev(p), K, dw, ds, dout, dflags);
+  if (poly_general(p))
+    hipLaunchKernelGGL((mplx::poly_get_succ_kernel<256, true>), dim3(K < 4096 ? K : 4096), dim3(256), 0, p->stream, poly_dev(p), K, dw, ds, dout, dflags);
+  else
+    hipLaunchKernelGGL((mplx::poly_get_succ_kernel<256, false>), dim3(K < 4096 ? K : 4096), dim3(256), 0, p->stream, poly_dev(p), K, dw, ds, dout, dflags);
   PCHK(p, hipGetLastError());
   int32_t flags = 0;
   PCHK(p, hipMemcpyAsync(out, dout, sizeof(mplx::PolySuccOut) * no, hipMemcpyDeviceToHost, p->stream));
   PCHK(p, hipMemcpyAsync(&flags, dflags, sizeof(int32_t), hipMemcpyDeviceToHost, p->stream));
   PCHK(p, hipStreamSynchronize(p->stream));
-  if (flags & 1) return pfail(p, MPLX_ERR_ARG, "a hyperplane equation of degree > 2 was met (JRK / SNP trajectories are not supported by the moving-obstacle environment)");
+  if (flags & 1) return pfail(p, MPLX_ERR_ARG, "internal: a hyperplane equation of degree > 2 was met by the quadratic-only kernel");
   return MPLX_OK;
 }
 
@@ -330,14 +337,16 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   if (!p || n <= 0 || !world_of || !starts || !goals || !out) return pfail(p, MPLX_ERR_ARG, "bad argument");
   if (!p->have_cfg) return pfail(p, MPLX_ERR_ARG, "mplx_poly_config first");
   if (!p->committed) return pfail(p, MPLX_ERR_ARG, "mplx_poly_commit first");
-  if (p->control != CTRL_ACC) return pfail(p, MPLX_ERR_ARG, "the moving-obstacle search is built for ACC control (the multi-robot configuration)");
+  if (p->control != CTRL_ACC && p->control != CTRL_JRK)
+    return pfail(p, MPLX_ERR_ARG, "the moving-obstacle search runs ACC or JRK states (time-keyed: an SNP state's key would need 13 integers; VEL states have no caller)");
   for (int k = 0; k < n; k++)
     if (world_of[k] < 0 || world_of[k] >= (int)p->worlds.size()) return pfail(p, MPLX_ERR_ARG, "world index out of range");
   mplx_ctx *c = p->ctx;
   PCHK(p, hipSetDevice(p->device));
-  // the internal context carries the record layout (ACC) and the pools; its own voxel set-up stays unused
+  // the internal context carries the record layout and the pools; its own voxel set-up stays unused
   c->cfg = mplx_config();
-  c->cfg.control = CTRL_ACC;
+  c->yaw = false;
+  c->cfg.control = p->control;
   c->cfg.n_u = p->n_u;
   c->cfg.dt = p->dt; c->cfg.v_max = p->v_max; c->cfg.a_max = p->a_max; c->cfg.j_max = p->j_max;
   c->cfg.w = p->w; c->cfg.eps = eps;
@@ -370,8 +379,9 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
     memset(&q, 0, sizeof(q));
     q.start.p[0] = s[0]; q.start.p[1] = s[1]; q.start.v[0] = s[2]; q.start.v[1] = s[3];
     q.goal.p[0] = g[0]; q.goal.p[1] = g[1]; q.goal.v[0] = g[2]; q.goal.v[1] = g[3];
+    if (p->control == CTRL_JRK) { q.start.a[0] = s[4]; q.start.a[1] = s[5]; q.goal.a[0] = g[4]; q.goal.a[1] = g[5]; }
     q.start_t = s[8];
-    q.goal_control = CTRL_ACC;
+    q.goal_control = p->control;
     order[(size_t)k] = k;
   }
   SearchParams P = c->pools;
@@ -408,7 +418,12 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   PCHK(p, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * (size_t)n, hipMemcpyHostToDevice, st));
   PCHK(p, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), st));
   PCHK(p, hipEventRecord(c->ev0, st));
-  hipLaunchKernelGGL((mplx::astar_poly_kernel<256>), dim3(slots), dim3(256), 0, st, P);
+  if (p->control == CTRL_JRK)
+    hipLaunchKernelGGL((mplx::astar_poly_kernel<256, CTRL_JRK, true>), dim3(slots), dim3(256), 0, st, P);
+  else if (poly_general(p))
+    hipLaunchKernelGGL((mplx::astar_poly_kernel<256, CTRL_ACC, true>), dim3(slots), dim3(256), 0, st, P);
+  else
+    hipLaunchKernelGGL((mplx::astar_poly_kernel<256, CTRL_ACC, false>), dim3(slots), dim3(256), 0, st, P);
   PCHK(p, hipGetLastError());
   PCHK(p, hipEventRecord(c->ev1, st));
   c->last_out.resize((size_t)n);
@@ -418,12 +433,13 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   for (int k = 0; k < n; k++) fill_result(c->last_out[(size_t)k], out[k]);
   c->last_nq = n;
   c->last_single = (n == 1);
-  c->last_control = CTRL_ACC;
+  c->last_control = p->control;
+  c->last_yaw = false;
   c->last_dt = p->dt;
   c->last_U = c->U;
   c->plan_epoch++;
   for (int k = 0; k < n; k++)
-    if (out[k].status == MPLX_PLAN_INTERNAL) return pfail(p, MPLX_ERR_ARG, "a hyperplane equation of degree > 2 was met (JRK / SNP trajectories are not supported)");
+    if (out[k].status == MPLX_PLAN_INTERNAL) return pfail(p, MPLX_ERR_ARG, "internal: a hyperplane equation of degree > 2 was met by the quadratic-only kernel");
   return MPLX_OK;
 }
 // trajectory of query q of the last mplx_poly_plan_batch: actions[traj_len], node_ids[traj_len + 1], states (traj_len + 1) x 9
@@ -440,7 +456,8 @@ extern "C" int mplx_poly_result_traj(mplx_poly *p, int32_t q, int32_t *actions, 
     for (int i = 0; i <= len; i++) {
       double *s = states + 9 * (size_t)i;
       s[0] = wps[(size_t)i].pos[0]; s[1] = wps[(size_t)i].pos[1]; s[2] = wps[(size_t)i].vel[0]; s[3] = wps[(size_t)i].vel[1];
-      s[4] = s[5] = s[6] = s[7] = 0.0;
+      s[4] = wps[(size_t)i].acc[0]; s[5] = wps[(size_t)i].acc[1];
+      s[6] = s[7] = 0.0;
       s[8] = wps[(size_t)i].t;
     }
   return MPLX_OK;

@@ -11,8 +11,11 @@
 // Every sum keeps the reference's order (e.g. `a += n(i) * cs[i](0)` over i, then `a /= 120`), so results are
 // bit-identical to the host evaluation; compiled -ffp-contract=off like the rest.
 //
-// Restricted to VEL / ACC primitives and obstacle trajectories (what the multi-robot node uses): the hyperplane
-// equation is then at most quadratic in t.  A higher degree is reported (POLY_UNSUPPORTED), never approximated.
+// Two builds of every routine (template flag GEN).  GEN = false: VEL / ACC primitives and obstacle trajectories (what
+// the multi-robot node uses) -- the hyperplane equation is then at most quadratic in t, and a higher degree is reported
+// (never approximated).  GEN = true: any degree up to five through solve_any6, the statement-for-statement restatement of
+// include/mpl_shim/mpl_basis/math.h's solve() (poly_map_planner_node.cpp:73-85 exposes use_acc / use_jrk; obstacle
+// trajectories of JRK robots are cubic).  The host launches GEN = true only when a degree above two can occur.
 #pragma once
 #include "mplx_math.h"
 
@@ -146,6 +149,120 @@ MPLX_HD int solve_le2(double a, double b, double c, double d, double e, double f
   return 0;
 }
 
+// ---- solve(a, b, c, d, e, f) for any degree (include/mpl_shim/mpl_basis/math.h, statement for statement: the
+// compiled-reference checker of the tests links that very header).  Degree <= 2: the formulas of solve_le2.  Degree 3..5:
+// real_roots() -- the roots of the derivative (recursively) and the Cauchy bound split the axis into monotone pieces,
+// every sign change is bisected (200 steps at most, until hi - lo <= 4e-16 |hi + lo|), roots ascending.
+MPLX_HD double poly_eval_n(const double *a, int n, double x) {
+  double r = a[n];
+  for (int i = n - 1; i >= 0; i--) r = r * x + a[i];
+  return r;
+}
+// roots of sum a[i] x^i (a[n] != 0, 2 <= n <= 5) given the roots of its derivative (crit, ascending)
+MPLX_HD int poly_roots_level(const double *a, int n, const double *crit, int n_crit, double *out) {
+  double m = 0;
+  for (int i = 0; i < n; i++) m = fabs(a[i] / a[n]) > m ? fabs(a[i] / a[n]) : m;
+  const double bound = 1.0 + m;  // Cauchy
+  double xs[7];
+  int nx = 0;
+  xs[nx++] = -bound;
+  for (int k = 0; k < n_crit; k++)
+    if (crit[k] > -bound && crit[k] < bound) xs[nx++] = crit[k];
+  xs[nx++] = bound;
+  int no = 0;
+  for (int k = 0; k + 1 < nx; k++) {
+    double lo = xs[k], hi = xs[k + 1], flo = poly_eval_n(a, n, lo);
+    const double fhi = poly_eval_n(a, n, hi);
+    if (flo == 0.0) {
+      if (no == 0 || out[no - 1] != lo) out[no++] = lo;
+      continue;
+    }
+    if (fhi == 0.0 || (flo < 0) == (fhi < 0)) {
+      if (fhi == 0.0 && k + 2 == nx) out[no++] = hi;
+      continue;
+    }
+    for (int it = 0; it < 200 && hi - lo > 4e-16 * fabs(hi + lo); it++) {
+      const double mid = 0.5 * (lo + hi), fm = poly_eval_n(a, n, mid);
+      if (fm == 0.0) { lo = hi = mid; break; }
+      if ((fm < 0) == (flo < 0)) { lo = mid; flo = fm; } else hi = mid;
+    }
+    out[no++] = 0.5 * (lo + hi);
+  }
+  return no;
+}
+// real_roots(a, n), 1 <= n <= 5, a[n] != 0: the recursion unrolled -- the chain of derivatives downwards, the roots upwards
+MPLX_HD int poly_real_roots(const double *a, int n, double *out) {
+  double P[5][6];
+  int deg[5], L = 0;
+  for (int i = 0; i <= n; i++) P[0][i] = a[i];
+  deg[0] = n;
+  bool no_crit = false;  // the deepest level's derivative is a constant: no critical points
+  while (deg[L] >= 2) {
+    const int nn = deg[L];
+    for (int i = 1; i <= nn; i++) P[L + 1][i - 1] = P[L][i] * i;
+    int nd = nn - 1;
+    while (nd > 0 && P[L + 1][nd] == 0.0) nd--;
+    if (nd < 1) { no_crit = true; break; }
+    deg[L + 1] = nd;
+    L++;
+  }
+  double ra[5], rb[5];
+  double *cur = ra, *nxt = rb;
+  int nc = 0;
+  if (deg[L] == 1) {
+    cur[0] = -P[L][0] / P[L][1];
+    nc = 1;
+  } else {  // (no_crit) a level of degree >= 2 whose derivative has no root
+    nc = poly_roots_level(P[L], deg[L], cur, 0, nxt);
+    double *t = cur; cur = nxt; nxt = t;
+  }
+  (void)no_crit;
+  for (int k = L - 1; k >= 0; k--) {
+    nc = poly_roots_level(P[k], deg[k], cur, nc, nxt);
+    double *t = cur; cur = nxt; nxt = t;
+  }
+  for (int i = 0; i < nc; i++) out[i] = cur[i];
+  return nc;
+}
+#ifdef __HIPCC__
+#define MPLX_NOINLINE __noinline__
+#else
+#define MPLX_NOINLINE
+#endif
+// solve(a, b, c, d, e, f): a t^5 + b t^4 + c t^3 + d t^2 + e t + f = 0; ts has room for 5
+MPLX_HD MPLX_NOINLINE int solve_any6(double a, double b, double c, double d, double e, double f, double *ts) {
+  const double co[6] = {f, e, d, c, b, a};
+  if (a != 0) return poly_real_roots(co, 5, ts);
+  if (b != 0) return poly_real_roots(co, 4, ts);
+  if (c != 0) return poly_real_roots(co, 3, ts);
+  return solve_le2(0, 0, 0, d, e, f, ts);
+}
+template <bool GEN>
+MPLX_HD int solve_poly(double a, double b, double c, double d, double e, double f, double *ts) {
+  if constexpr (GEN) {
+    if (a != 0 || b != 0 || c != 0) return solve_any6(a, b, c, d, e, f, ts);
+  }
+  return solve_le2(a, b, c, d, e, f, ts);
+}
+constexpr int POLY_MAX_ROOTS = 5;
+// Primitive1D::max_abs(k, t): max over [0, t] of |d^k p| (k = 1 vel, 2 acc, 3 jrk): the end points and the interior
+// stationary points, which are the roots `solve` returns for the next derivative (mpl_shim primitive.h extrema())
+MPLX_HD double poly_max_abs(const double *c, int k, double t) {
+  const double f0 = k == 1 ? pp_v(c, 0.0) : k == 2 ? pp_a(c, 0.0) : pp_j(c, 0.0);
+  const double f1 = k == 1 ? pp_v(c, t) : k == 2 ? pp_a(c, t) : pp_j(c, t);
+  double m = fabs(f0) < fabs(f1) ? fabs(f1) : fabs(f0);  // std::max(|f(0)|, |f(t)|)
+  double ts[POLY_MAX_ROOTS];
+  const int nr = k == 1 ? solve_any6(0, 0, c[0] / 6, c[1] / 2, c[2], c[3], ts) : k == 2 ? solve_any6(0, 0, 0, c[0] / 2, c[1], c[2], ts) : solve_any6(0, 0, 0, 0, c[0], c[1], ts);
+  for (int r = 0; r < nr; r++) {
+    const double x = ts[r];
+    if (x > 0 && x < t) {
+      const double fx = fabs(k == 1 ? pp_v(c, x) : k == 2 ? pp_a(c, x) : pp_j(c, x));
+      m = m < fx ? fx : m;
+    }
+  }
+  return m;
+}
+
 // obstacle.inside(pt[, t]) of the three classes (simple_obstacle.h:29, :87-90, :131-142)
 MPLX_HD bool obs_inside_static(const PolyDev &D, const PolyObs &o, double x, double y) { return poly_inside(D.hps + o.hp_off, o.n_hp, x - o.p[0], y - o.p[1]); }
 MPLX_HD bool obs_inside_linear(const PolyDev &D, const PolyObs &o, double x, double y, double t) {
@@ -178,6 +295,7 @@ MPLX_HD bool obs_point_hits(const PolyDev &D, const PolyObs &o, double x, double
 
 // collide(pr, PolyhedronObstacle) with the obstacle's representative point (px, py) (primitive_geometry_utils.h:5-44)
 // returns 1 hit, 0 free, -1 unsupported degree
+template <bool GEN = false>
 MPLX_HD int collide_static_at(const PolyDev &D, const double cs[2][6], double T, const PolyObs &o, double px, double py) {
   const PolyHP *hp = D.hps + o.hp_off;
   for (int h = 0; h < o.n_hp; h++) {
@@ -198,8 +316,8 @@ MPLX_HD int collide_static_at(const PolyDev &D, const double cs[2][6], double T,
       s += n[1] * (hp[h].py + py);
       f -= s;
     }
-    double ts[2];
-    const int nr = solve_le2(a, b, c, d, e, f, ts);
+    double ts[GEN ? POLY_MAX_ROOTS : 2];
+    const int nr = solve_poly<GEN>(a, b, c, d, e, f, ts);
     if (nr < 0) return -1;
     for (int r = 0; r < nr; r++) {
       const double it = ts[r];
@@ -212,6 +330,7 @@ MPLX_HD int collide_static_at(const PolyDev &D, const double cs[2][6], double T,
   return 0;
 }
 // collide(pr, PolyhedronLinearObstacle, t) (primitive_geometry_utils.h:46-94)
+template <bool GEN = false>
 MPLX_HD int collide_linear(const PolyDev &D, const double cs[2][6], double T, const PolyObs &o, double t) {
   const PolyHP *hp = D.hps + o.hp_off;
   for (int h = 0; h < o.n_hp; h++) {
@@ -237,8 +356,8 @@ MPLX_HD int collide_linear(const PolyDev &D, const double cs[2][6], double T, co
       s2 += n[1] * ((hp[h].py + o.p[1]) + cov_v[1] * t);
       f -= s2;
     }
-    double ts[2];
-    const int nr = solve_le2(a, b, c, d, e, f, ts);
+    double ts[GEN ? POLY_MAX_ROOTS : 2];
+    const int nr = solve_poly<GEN>(a, b, c, d, e, f, ts);
     if (nr < 0) return -1;
     for (int r = 0; r < nr; r++) {
       const double it = ts[r];
@@ -251,6 +370,7 @@ MPLX_HD int collide_linear(const PolyDev &D, const double cs[2][6], double T, co
   return 0;
 }
 // collide(pr, PolyhedronNonlinearObstacle, t) (primitive_geometry_utils.h:96-173)
+template <bool GEN = false>
 MPLX_HD int collide_nonlinear(const PolyDev &D, const double cs[2][6], double prT, const PolyObs &o, double t) {
   const PolySeg *segs = D.segs + o.seg_off;
   const double traj_t = t + o.start_t;
@@ -266,9 +386,9 @@ MPLX_HD int collide_nonlinear(const PolyDev &D, const double cs[2][6], double pr
   if (start_id < 0) {  // outside the trajectory's time span: its clamped end state as a static obstacle, or nothing
     double wp[2], wv[2], wa[2], wj[2];
     traj_eval(segs, o.n_seg, o.total_t, traj_t, wp, wv, wa, wj);
-    if (traj_t <= o.total_t && traj_t >= 0) return collide_static_at(D, cs, prT, o, wp[0], wp[1]);
-    if (traj_t < 0 && !o.dis_front) return collide_static_at(D, cs, prT, o, wp[0], wp[1]);
-    if (traj_t > o.total_t && !o.dis_back) return collide_static_at(D, cs, prT, o, wp[0], wp[1]);
+    if (traj_t <= o.total_t && traj_t >= 0) return collide_static_at<GEN>(D, cs, prT, o, wp[0], wp[1]);
+    if (traj_t < 0 && !o.dis_front) return collide_static_at<GEN>(D, cs, prT, o, wp[0], wp[1]);
+    if (traj_t > o.total_t && !o.dis_back) return collide_static_at<GEN>(D, cs, prT, o, wp[0], wp[1]);
     return 0;
   }
   const PolyHP *hp = D.hps + o.hp_off;
@@ -291,8 +411,8 @@ MPLX_HD int collide_nonlinear(const PolyDev &D, const double cs[2][6], double pr
         f += n[i] * cs[i][5] - n[i] * (hpp[i] + wp[i]);
       }
       a /= 120; b /= 24; c /= 6; d /= 2;
-      double ts[2];
-      const int nr = solve_le2(a, b, c, d, e, f, ts);
+      double ts[GEN ? POLY_MAX_ROOTS : 2];
+      const int nr = solve_poly<GEN>(a, b, c, d, e, f, ts);
       if (nr < 0) return -1;
       for (int r = 0; r < nr; r++) {
         const double it = ts[r];
@@ -307,8 +427,9 @@ MPLX_HD int collide_nonlinear(const PolyDev &D, const double cs[2][6], double pr
   return 0;
 }
 // PolyMapUtil::isFree(pr, t) restricted to one obstacle (poly_map_util.h:92-109; the start-point test is separate)
+template <bool GEN = false>
 MPLX_HD int obs_prim_hits(const PolyDev &D, const double cs[2][6], double T, const PolyObs &o, double t_rel) {
-  return o.kind == 0 ? collide_static_at(D, cs, T, o, o.p[0], o.p[1]) : o.kind == 1 ? collide_linear(D, cs, T, o, t_rel) : collide_nonlinear(D, cs, T, o, t_rel);
+  return o.kind == 0 ? collide_static_at<GEN>(D, cs, T, o, o.p[0], o.p[1]) : o.kind == 1 ? collide_linear<GEN>(D, cs, T, o, t_rel) : collide_nonlinear<GEN>(D, cs, T, o, t_rel);
 }
 
 
@@ -470,6 +591,7 @@ MPLX_HD bool poly_start_test(const PolyDev &D, const PolyObs &o, const PolyPrep 
   return obs_inside_nonlinear_pos(D, o, x0, y0, t, 0);
 }
 // one (slot, hyperplane) of collide(): 1 hit, 0 free, -1 unsupported degree
+template <bool GEN = false>
 MPLX_HD int poly_item(const PolyDev &D, const double (*cs)[6], double prT, const PolyObs &o, const PolyPrep &R, int s, int h, double t) {
   const PolyHP *hp = D.hps + o.hp_off;
   const double n[2] = {hp[h].nx, hp[h].ny};
@@ -490,8 +612,8 @@ MPLX_HD int poly_item(const PolyDev &D, const double (*cs)[6], double prT, const
       sm += n[1] * (hp[h].py + R.py);
       f -= sm;
     }
-    double ts[2];
-    const int nr = solve_le2(a, b, c, d, e, f, ts);
+    double ts[GEN ? POLY_MAX_ROOTS : 2];
+    const int nr = solve_poly<GEN>(a, b, c, d, e, f, ts);
     if (nr < 0) return -1;
     for (int r = 0; r < nr; r++) {
       const double it = ts[r];
@@ -523,8 +645,8 @@ MPLX_HD int poly_item(const PolyDev &D, const double (*cs)[6], double prT, const
       s2 += n[1] * ((hp[h].py + o.p[1]) + cov_v[1] * t);
       f -= s2;
     }
-    double ts[2];
-    const int nr = solve_le2(a, b, c, d, e, f, ts);
+    double ts[GEN ? POLY_MAX_ROOTS : 2];
+    const int nr = solve_poly<GEN>(a, b, c, d, e, f, ts);
     if (nr < 0) return -1;
     for (int r = 0; r < nr; r++) {
       const double it = ts[r];
@@ -547,8 +669,8 @@ MPLX_HD int poly_item(const PolyDev &D, const double (*cs)[6], double prT, const
     f += n[i] * cs[i][5] - n[i] * (hpp[i] + S.wp[i]);
   }
   a = div_nz(a, 120.0); b = div_nz(b, 24.0); c = div_nz(c, 6.0); d *= 0.5;
-  double ts[2];
-  const int nr = solve_le2(a, b, c, d, e, f, ts);
+  double ts[GEN ? POLY_MAX_ROOTS : 2];
+  const int nr = solve_poly<GEN>(a, b, c, d, e, f, ts);
   if (nr < 0) return -1;
   for (int r = 0; r < nr; r++) {
     const double it = ts[r];
@@ -567,7 +689,7 @@ MPLX_HD int poly_item(const PolyDev &D, const double (*cs)[6], double prT, const
 // cache_q: query + 1 (tags the per-level cache entries); mid_hook(): called by every thread once the obstacles are
 // prepared, before the (long) item loop -- the caller can put memory traffic of its own in flight there
 struct PolyNoHook { __device__ __forceinline__ void operator()() const {} };
-template <int BLOCK, class Hook = PolyNoHook>
+template <int BLOCK, class Hook = PolyNoHook, bool GEN = false>
 __device__ __forceinline__ void poly_collide_all(const PolyDev &D, const PolyWorld &W, const double (*cs)[2][6], const int32_t *valid, int n_u, double T, double t_rel,
                                                  PolyPrep *prep, uint32_t *hit_idx, uint32_t *uns_idx, int32_t *hp_max, int32_t *hit, int32_t *unsupported, int32_t *start_hit,
                                                  int tid, long long cache_q, Hook mid_hook, unsigned long long *cyc = nullptr) {
@@ -584,7 +706,7 @@ __device__ __forceinline__ void poly_collide_all(const PolyDev &D, const PolyWor
       double c[2][6];
       for (int a = 0; a < 2; a++)
         for (int b = 0; b < 6; b++) c[a][b] = cs[i][a][b];
-      const int r = obs_prim_hits(D, c, T, D.obs[W.obs_off + j], t_rel);
+      const int r = obs_prim_hits<GEN>(D, c, T, D.obs[W.obs_off + j], t_rel);
       if (r < 0) *unsupported = 1;
       if (r > 0) hit[i] = 1;
     }
@@ -663,9 +785,9 @@ __device__ __forceinline__ void poly_collide_all(const PolyDev &D, const PolyWor
       double c[2][6];
       for (int a = 0; a < 2; a++)
         for (int b = 0; b < 6; b++) c[a][b] = cs[i][a][b];
-      r = obs_prim_hits(D, c, T, o, t_rel);
+      r = obs_prim_hits<GEN>(D, c, T, o, t_rel);
     } else {
-      r = poly_item(D, cs[i], T, o, R, s, h, t_rel);
+      r = poly_item<GEN>(D, cs[i], T, o, R, s, h, t_rel);
     }
     if (r > 0) atomicMin(&hit_idx[pair], idx);
     if (r < 0) atomicMin(&uns_idx[pair], idx);
@@ -746,22 +868,37 @@ __device__ __forceinline__ void poly_stage_world(const PolyDev &D, const PolyWor
 }
 #endif
 
-// Primitive<2>(curr, u, dt) coefficients (mpl_shim primitive.h) for VEL / ACC
-MPLX_HD void poly_prim_build(int control, const double pos[2], const double vel[2], const double u[2], double cs[2][6]) {
+// Primitive<2>(curr, u, dt) coefficients (mpl_shim primitive.h)
+MPLX_HD void poly_prim_build(int control, const double pos[2], const double vel[2], const double u[2], double cs[2][6], const double *acc = nullptr, const double *jrk = nullptr) {
   for (int i = 0; i < 2; i++) {
     for (int k = 0; k < 6; k++) cs[i][k] = 0.0;
-    if ((control & 15) == CTRL_VEL) { cs[i][4] = u[i]; cs[i][5] = pos[i]; }
-    else { cs[i][3] = u[i]; cs[i][4] = vel[i]; cs[i][5] = pos[i]; }
+    const int kind = control & 15;
+    if (kind == CTRL_VEL) { cs[i][4] = u[i]; cs[i][5] = pos[i]; }
+    else if (kind == CTRL_ACC) { cs[i][3] = u[i]; cs[i][4] = vel[i]; cs[i][5] = pos[i]; }
+    else if (kind == CTRL_JRK) { cs[i][2] = u[i]; cs[i][3] = acc ? acc[i] : 0.0; cs[i][4] = vel[i]; cs[i][5] = pos[i]; }
+    else { cs[i][1] = u[i]; cs[i][2] = jrk ? jrk[i] : 0.0; cs[i][3] = acc ? acc[i] : 0.0; cs[i][4] = vel[i]; cs[i][5] = pos[i]; }
   }
 }
 // validate_primitive for VEL / ACC (mpl_shim primitive.h): ACC checks max |vel| per axis against v_max > 0; the
 // velocity of such a primitive is monotone, so its extrema are the end points
-MPLX_HD bool poly_validate(int control, const double cs[2][6], double T, double v_max) {
-  if ((control & 15) != CTRL_ACC) return true;
-  for (int i = 0; i < 2; i++) {
-    const double m = fmax(fabs(pp_v_auto(cs[i], 0.0)), fabs(pp_v_auto(cs[i], T)));
-    if (v_max > 0 && m > v_max) return false;
+// JRK / SNP: the general statement (max_vel / max_acc / max_jrk with their interior extrema)
+MPLX_HD bool poly_validate(int control, const double cs[2][6], double T, double v_max, double a_max = -1.0, double j_max = -1.0) {
+  const int kind = control & 15;
+  if (kind == CTRL_VEL) return true;
+  if (kind == CTRL_ACC) {
+    for (int i = 0; i < 2; i++) {
+      const double m = fmax(fabs(pp_v_auto(cs[i], 0.0)), fabs(pp_v_auto(cs[i], T)));
+      if (v_max > 0 && m > v_max) return false;
+    }
+    return true;
   }
+  for (int i = 0; i < 2; i++)
+    if (v_max > 0 && poly_max_abs(cs[i], 1, T) > v_max) return false;
+  for (int i = 0; i < 2; i++)
+    if (a_max > 0 && poly_max_abs(cs[i], 2, T) > a_max) return false;
+  if (kind == CTRL_SNP)
+    for (int i = 0; i < 2; i++)
+      if (j_max > 0 && poly_max_abs(cs[i], 3, T) > j_max) return false;
   return true;
 }
 // env_poly_map::calculate_intrinsic_cost: pr.J(pr.control()) + 0.001 * pr.J(Control::VEL) + w dt (env_poly_map.h:71-73)

@@ -14,9 +14,11 @@
 
 namespace mplx {
 
-template <int BLOCK>
+// CONTROL: ACC (the multi-robot node) or JRK (poly_map_planner_node.cpp:73-85, use_acc); GEN: hyperplane equations above
+// degree two can occur (JRK primitives, obstacle trajectories with cubic or higher segments): solve_any6
+template <int BLOCK, int CONTROL = CTRL_ACC, bool GEN = false>
 __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
-  constexpr int CONTROL = CTRL_ACC;
+  static_assert(CONTROL == CTRL_ACC || CONTROL == CTRL_JRK, "time-keyed states: the key of an SNP state would need 13 integers");
   constexpr int ns = key_len_c(CONTROL), NK = ns + 1;
   __shared__ Smem<BLOCK> S;
   __shared__ double pcs[POLY_MAX_U][2][6];
@@ -135,15 +137,16 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
         L.valid = false; L.blocked = false; L.reads = 0;
         double lane_cost = 0.0;
         if (tid < P.n_u) {
-          const double pos[2] = {S.cur[0][0], S.cur[0][1]}, vel[2] = {S.cur[0][3], S.cur[0][4]}, u[2] = {D.U[2 * tid], D.U[2 * tid + 1]};
+          const double pos[2] = {S.cur[0][0], S.cur[0][1]}, vel[2] = {S.cur[0][3], S.cur[0][4]}, acc[2] = {S.cur[0][6], S.cur[0][7]}, u[2] = {D.U[2 * tid], D.U[2 * tid + 1]};
           double c[2][6];
-          poly_prim_build(CONTROL, pos, vel, u, c);
+          poly_prim_build(CONTROL, pos, vel, u, c, acc);
           for (int i = 0; i < 2; i++)
             for (int j = 0; j < 6; j++) pcs[tid][i][j] = c[i][j];
           L.tn.p[0] = pp_p_auto(c[0], T); L.tn.p[1] = pp_p_auto(c[1], T); L.tn.p[2] = 0.0;
           L.tn.v[0] = pp_v_auto(c[0], T); L.tn.v[1] = pp_v_auto(c[1], T); L.tn.v[2] = 0.0;
           for (int k = 0; k < 3; k++) { L.tn.a[k] = 0.0; L.tn.j[k] = 0.0; }
-          pvalid[tid] = (poly_inside(W.bbox, 4, L.tn.p[0], L.tn.p[1]) && poly_validate(CONTROL, c, T, P.v_max)) ? 1 : 0;
+          if constexpr (CONTROL == CTRL_JRK) { L.tn.a[0] = pp_a_auto(c[0], T); L.tn.a[1] = pp_a_auto(c[1], T); }
+          pvalid[tid] = (poly_inside(W.bbox, 4, L.tn.p[0], L.tn.p[1]) && poly_validate(CONTROL, c, T, P.v_max, P.a_max, P.j_max)) ? 1 : 0;
           phit[tid] = 0;
           lane_cost = poly_intrinsic_cost(CONTROL, c, T, P.w, P.dt);
           state_key_c<CONTROL>(L.tn, L.key);
@@ -158,12 +161,13 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
         __syncthreads();
         MPLX_TOC(S, 3, tx);
         // isFree(start.pos, t) and isFree(pr, t) of all primitives against all obstacles
-        poly_collide_all<BLOCK>(D, W, pcs, pvalid, P.n_u, T, t_rel, pprep, phit_idx, puns_idx, &php_max, phit, &punsupported, &pstart_hit, tid, (long long)q + 1,
-                                [&]() {  // the table slot has arrived: start fetching the record it names (the commit reads it)
+        auto hook = [&]() {  // the table slot has arrived: start fetching the record it names (the commit reads it)
                                   const uint32_t vid = (uint32_t)v0;
                                   if (v0 != TBL_EMPTY && vid < CLAIM_BASE && (v0 >> 32) == ((h64 >> 48) << 16 | (unsigned long long)(uint32_t)q))
                                     __builtin_prefetch(Q.node(vid), 0, 3);
-                                }, S.cyc);
+                                };
+        poly_collide_all<BLOCK, decltype(hook), GEN>(D, W, pcs, pvalid, P.n_u, T, t_rel, pprep, phit_idx, puns_idx, &php_max, phit, &punsupported, &pstart_hit, tid, (long long)q + 1,
+                                hook, S.cyc);
         if (tid < P.n_u) {
           L.valid = pvalid[tid] != 0;
           L.blocked = L.valid && (pstart_hit || phit[tid]);
@@ -229,9 +233,9 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
       int len = 0;
       auto edge_cost = [&](uint32_t parent, uint32_t action) {  // calculate_intrinsic_cost of Primitive(parent, U[action], dt)
         const double *st = V::state(Q.node(parent));
-        const double pos[2] = {st[0], st[1]}, vel[2] = {st[3], st[4]}, u[2] = {D.U[2 * action], D.U[2 * action + 1]};
+        const double pos[2] = {st[0], st[1]}, vel[2] = {st[3], st[4]}, acc[2] = {CONTROL == CTRL_JRK ? st[6] : 0.0, CONTROL == CTRL_JRK ? st[7] : 0.0}, u[2] = {D.U[2 * action], D.U[2 * action + 1]};
         double c[2][6];
-        poly_prim_build(CONTROL, pos, vel, u, c);
+        poly_prim_build(CONTROL, pos, vel, u, c, acc);
         return poly_intrinsic_cost(CONTROL, c, P.dt, P.w, P.dt);
       };
       if (status == 0 && goal_id == NIL) {

@@ -12,7 +12,7 @@ import numpy as np
 from . import _capi
 from ._capi import MplxError
 
-VEL, ACC = _capi.VEL, _capi.ACC
+VEL, ACC, JRK, SNP = _capi.VEL, _capi.ACC, _capi.JRK, _capi.SNP
 
 
 def rectangle(hx, hy=None):
@@ -63,6 +63,20 @@ def acc_segs(p0, v0, us, dt):
         rows.append([0, 0, 0, u[0], v[0], p[0], 0, 0, 0, u[1], v[1], p[1], dt])
         p = u / 2 * dt * dt + v * dt + p
         v = u * dt + v
+    return np.array(rows)
+
+
+def jrk_segs(p0, v0, a0, us, dt):
+    """Trajectory of JRK primitives from (p0, v0, a0) under the jerk inputs `us` (what a JRK robot's plan looks like to
+    the others: cubic segments, poly_map_planner_node.cpp:73-85 use_acc): rows {cx[6], cy[6], T}."""
+    p, v, a = np.array(p0, float), np.array(v0, float), np.array(a0, float)
+    rows = []
+    for u in us:
+        u = np.array(u, float)
+        rows.append([0, 0, u[0], a[0], v[0], p[0], 0, 0, u[1], a[1], v[1], p[1], dt])
+        p = u / 6 * dt ** 3 + a / 2 * dt * dt + v * dt + p
+        v = u / 2 * dt * dt + a * dt + v
+        a = u * dt + a
     return np.array(rows)
 
 

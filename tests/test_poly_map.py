@@ -116,7 +116,8 @@ def test_team2_tick_get_succ_matches_the_compiled_reference():
     assert n_fin > 1000 and n_inf > 100
 
 
-def _compare_plans(team, refs, world_of, starts, goals, **kw):
+def _compare_plans(team, refs, world_of, starts, goals, compare_acc=False, **kw):
+    cols = [0, 1, 2, 3, 4, 5, 8] if compare_acc else [0, 1, 2, 3, 8]  # (JRK states carry their acceleration)
     team.set_record(1 << 16)
     R = team.plan_batch(world_of, starts, goals, **kw)
     n_ok = 0
@@ -133,7 +134,7 @@ def _compare_plans(team, refs, world_of, starts, goals, **kw):
             assert np.array_equal(act, ref["actions"]) and np.array_equal(ids, ref["node_ids"]), k
             for i, nid in enumerate(ids):  # waypoint states: position, velocity and time of every node of the path
                 s, _, _ = refs[w].node(int(nid))
-                assert np.array_equal(st[i][[0, 1, 2, 3, 8]], s[[0, 1, 2, 3, 8]]), (k, i)
+                assert np.array_equal(st[i][cols], s[cols]), (k, i)
         else:
             assert np.isinf(r.cost)
     return R, n_ok
@@ -180,3 +181,82 @@ def test_team2_tick_plans_match():
     R, n_ok = _compare_plans(team, refs, np.arange(16), starts, goals, max_expand=20000)
     print("Team2 tick:", [(r.status, int(r.n_expanded)) for r in R], "kernel ms", team.last_kernel_ms())
     assert n_ok >= 12
+
+
+# ---------------------------------------------------------------- beyond VEL / ACC (round 3): the general solve()
+# poly_map_planner_node.cpp:73-85 exposes use_acc / use_jrk (JRK / SNP robots); collide() then meets hyperplane equations
+# of degree 3..5 and calls the general solve(a, b, c, d, e, f) (primitive_geometry_utils.h:28,71,148).  The device's
+# statement of it is checked bit for bit on the host (tests/test_math_host.py); here the whole environment.
+def random_world_general(rng, dt=0.5):
+    """random_world plus obstacles that follow JRK trajectories (cubic segments: what a JRK robot's plan looks like)"""
+    W = random_world(rng, dt=dt)
+    for _ in range(3):
+        n = int(rng.integers(1, 6))
+        us = U9[rng.integers(0, 9, n)]
+        segs = pm.jrk_segs(rng.uniform((1, -4), (9, 4)), np.round(rng.uniform(-1, 1, 2), 1), np.round(rng.uniform(-0.5, 0.5, 2), 1), us, dt)
+        W.nonlinear.append(pm.NonlinearObstacle(pm.rectangle(0.5), segs, start_t=float(rng.choice([0.0, 0.3, -0.5, 2.0])),
+                                                disappear_front=bool(rng.integers(0, 2)), disappear_back=bool(rng.integers(0, 2))))
+    return W
+
+
+def random_states_general(rng, n, control, dt=0.5):
+    s = random_states(rng, n, dt)
+    if control & 4:
+        s[:, 4:6] = np.round(rng.uniform(-1, 1, (n, 2)), 1)
+    if control & 8:
+        s[:, 6:8] = np.round(rng.uniform(-1, 1, (n, 2)), 1)
+    return s
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("control", [pm.JRK, pm.SNP, pm.ACC, pm.VEL])
+def test_get_succ_of_any_control_kind_matches_the_compiled_reference(control):
+    rng = np.random.default_rng(500 + control)
+    dt = 0.5
+    worlds = [random_world_general(rng, dt=dt) for _ in range(6)]
+    team = pm.PolyTeam()
+    kw = dict(dt=dt, v_max=2.0, a_max=1.0, j_max=1.5, w=10.0)
+    team.configure(control, U9, **kw)
+    team.set_worlds(worlds)
+    refs = [refpoly.RefWorld(W, control, U9, **kw) for W in worlds]
+    K = 500
+    world_of = rng.integers(0, len(worlds), K)
+    states = random_states_general(rng, K, control, dt)
+    n_fin, n_inf = _compare_get_succ(team, worlds, refs, world_of, states, 9)
+    assert n_fin > 200 and n_inf > 100  # both outcomes are exercised
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("control,general_obstacles", [(pm.JRK, True), (pm.JRK, False), (pm.ACC, True)])
+def test_plans_beyond_acc_match_a_search_over_the_compiled_reference_environment(control, general_obstacles):
+    """JRK states (keyed with position, velocity, acceleration and time) and / or obstacles on cubic trajectories: whole
+    plans against the best-first search over the reference's env_poly_map::get_succ, bit-exact like the ACC case."""
+    rng = np.random.default_rng(700 + control + int(general_obstacles))
+    dt = 0.5
+    worlds = [(random_world_general if general_obstacles else random_world)(rng, dt=dt) for _ in range(6)]
+    team = pm.PolyTeam()
+    kw = dict(dt=dt, v_max=2.0, a_max=1.0, w=10.0)
+    team.configure(control, U9, **kw)
+    team.set_worlds(worlds)
+    team.set_capacity(16, 1 << 20, 1 << 22, 1 << 21)
+    refs = [refpoly.RefWorld(W, control, U9, **kw) for W in worlds]
+    n = 10
+    world_of = rng.integers(0, len(worlds), n)
+    starts, goals = np.zeros((n, 9)), np.zeros((n, 9))
+    starts[:, 0:2] = np.round(rng.uniform((0.5, -4.5), (3.0, 4.5), (n, 2)), 1)
+    starts[:, 8] = rng.integers(0, 3, n) * dt
+    goals[:, 0:2] = np.round(rng.uniform((7.0, -4.5), (9.5, 4.5), (n, 2)), 1)
+    R, n_ok = _compare_plans(team, refs, world_of, starts, goals, compare_acc=control == pm.JRK, max_expand=3000)
+    assert n_ok >= 3
+
+
+@pytest.mark.gpu
+def test_snp_search_is_refused_loudly():
+    team = pm.PolyTeam()
+    team.configure(pm.SNP, U9, dt=0.5, v_max=2.0, a_max=1.0, j_max=1.0)
+    W = pm.PolyWorld((0.0, -5.0), (10.0, 10.0))
+    team.set_worlds([W])
+    with pytest.raises(pm.MplxError):
+        team.plan_batch([0], np.zeros((1, 9)), np.zeros((1, 9)))
