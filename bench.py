@@ -327,7 +327,7 @@ def main():
             # longest query does (device clock, last step, max over the ranks) -- the floor of the strong-scaling line
             "tail_bound": {"longest_query_ms": longest_ms, "note": "strong scaling of ONE 1024-query stream is bounded below by the longest query alone; "
                                                                       "query throughput over N GPUs is in `throughput` (N > 1)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "limiter": "latency (serial pop -> look-up -> commit chain of the longest query; see roofline.valu)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": pl.kernelName(), "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
                          "bytes_per_expansion": alg / max(n_exp, 1), "launch": "rank 0's share of the stream"},
