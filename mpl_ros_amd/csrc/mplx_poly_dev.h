@@ -447,7 +447,7 @@ struct PolySlot {
   double T, t_residual, start_t, seg_T;  // segment start time, max(T - traj_t, 0), evaluation time, segment duration
   double wp[2], wv[2], wa[2], wj[2];     // obstacle state at start_t
 };
-struct PolyPrep {
+struct alignas(16) PolyPrep {  // (a multiple of 16 bytes: a time level of the cache is copied to LDS in 16-byte words)
   int32_t mode;     // 0 cannot collide, 1 static polyhedron at (px, py), 2 linear, 3 trajectory slots, 4 serial collide()
   int32_t n_slots;
   double px, py;
@@ -692,7 +692,9 @@ struct PolyNoHook { __device__ __forceinline__ void operator()() const {} };
 template <int BLOCK, class Hook = PolyNoHook, bool GEN = false>
 __device__ __forceinline__ void poly_collide_all(const PolyDev &D, const PolyWorld &W, const double (*cs)[2][6], const int32_t *valid, int n_u, double T, double t_rel,
                                                  PolyPrep *prep, uint32_t *hit_idx, uint32_t *uns_idx, int32_t *hp_max, int32_t *hit, int32_t *unsupported, int32_t *start_hit,
-                                                 int tid, long long cache_q, Hook mid_hook, unsigned long long *cyc = nullptr) {
+                                                 int tid, long long cache_q, Hook mid_hook, unsigned long long *cyc = nullptr, unsigned long long *lds_level = nullptr) {
+  // lds_level (LDS, 2 words, or null): the (query, time) the entries of prep[] were prepared for by an earlier call of
+  // this workgroup -- an expansion at the same time level re-uses them where they lie
   const int n_obs = W.n_obs;
   unsigned long long tc0 = __builtin_readcyclecounter();
   const double x0 = pp_p_auto(cs[0][0], 0.0), y0 = pp_p_auto(cs[0][1], 0.0);  // pr.evaluate(0): the node position, whatever the primitive
@@ -718,29 +720,39 @@ __device__ __forceinline__ void poly_collide_all(const PolyDev &D, const PolyWor
   const int n_pairs = n_u * n_obs;
   if (tid == 0) { *hp_max = 1; uns_idx[POLY_MAX_U * POLY_MAX_OBS - 1] = 0u; }
   for (int e = tid; e < n_pairs; e += BLOCK) { hit_idx[e] = 0xFFFFFFFFu; uns_idx[e] = 0xFFFFFFFFu; }
+  // the time-dependent part comes from the per-level cache when this (query, time) has been prepared before: the level's
+  // entries lie contiguously in HBM / L2 and are copied by the whole workgroup in 16-byte words (one lane copying its own
+  // 368-byte entry word by word cost most of this phase); a level that is already in LDS is not copied at all
+  const unsigned long long tbits = (unsigned long long)__double_as_longlong(t_rel);
+  PolyPrep *level = nullptr;
+  if (D.prep_cache && T > 0 && cache_q != 0) {  // (uniform)
+    const double lv = t_rel / T;
+    const int k = lv >= 0 && lv < (double)POLY_CACHE_LEVELS ? (int)(lv + 0.5) : -1;
+    if (k >= 0 && k < POLY_CACHE_LEVELS) level = D.prep_cache + ((size_t)blockIdx.x * POLY_CACHE_LEVELS + (size_t)k) * POLY_MAX_OBS;
+  }
+  const bool in_lds = lds_level && cache_q != 0 && lds_level[0] == (unsigned long long)cache_q && lds_level[1] == tbits;  // (uniform: written behind a barrier)
+  if (level && !in_lds) {
+    static_assert(sizeof(PolyPrep) % 16 == 0, "16-byte words");
+    const uint4 *src = (const uint4 *)level;
+    uint4 *dst = (uint4 *)prep;
+    const int nw = n_obs * (int)(sizeof(PolyPrep) / 16);
+    for (int i = tid; i < nw; i += BLOCK) dst[i] = src[i];
+    __syncthreads();
+  }
   if (tid < n_obs) {
     const PolyObs &o = D.obs[W.obs_off + tid];
     PolyPrep &R = prep[tid];
-    // the time-dependent part comes from the per-level cache when this (query, time) has been prepared before
-    PolyPrep *ce = nullptr;
-    if (D.prep_cache && T > 0) {
-      const double lv = t_rel / T;
-      const int k = lv >= 0 && lv < (double)POLY_CACHE_LEVELS ? (int)(lv + 0.5) : -1;
-      if (k >= 0 && k < POLY_CACHE_LEVELS) ce = D.prep_cache + ((size_t)blockIdx.x * POLY_CACHE_LEVELS + (size_t)k) * POLY_MAX_OBS + tid;
-    }
-    const unsigned long long tbits = (unsigned long long)__double_as_longlong(t_rel);
-    if (ce && ce->tag_q == cache_q && ce->tag_t == tbits) {
-      R = *ce;
-    } else {
+    if (!((level || in_lds) && R.tag_q == cache_q && R.tag_t == tbits)) {
       poly_prepare_time(D, o, T, t_rel, R);
       R.tag_t = tbits;
       R.tag_q = cache_q;
-      if (ce) *ce = R;
+      if (level) level[tid] = R;
     }
     if (poly_start_test(D, o, R, x0, y0, t_rel)) *start_hit = 1;
     atomicMax(hp_max, o.n_hp);
   }
   __syncthreads();
+  if (lds_level && tid == 0) { lds_level[0] = (unsigned long long)cache_q; lds_level[1] = tbits; }  // (read by the NEXT call, behind its barriers)
   mid_hook();
   if (cyc && tid == 0) { const unsigned long long now = __builtin_readcyclecounter(); cyc[5] += now - tc0; tc0 = now; }
   // pruning: a primitive stays within |v| T + |u| T^2 / 2 (per axis) of the node, an obstacle within its reach of
@@ -761,22 +773,61 @@ __device__ __forceinline__ void poly_collide_all(const PolyDev &D, const PolyWor
     if (keep && can_list) plist[atomicAdd(plen, 1u)] = (uint32_t)pair;
   }
   __syncthreads();
-  // items: (surviving pair, sub) with sub = slot * HP + hyperplane padded to a power of two, so that the decode is shifts
+  // items: one per (surviving pair, segment slot, hyperplane) that exists.  The surviving pairs first write their items
+  // into a dense list (upper half of uns_idx, which only uses its first n_pairs entries and its last one): a pair owns
+  // n_slots x n_hp of them (1 x n_hp for a static / linear obstacle, one for the serial fall-back) -- typically 4 to 8
+  // instead of the POLY_SLOTS x HP = 12 (padded to 16) of a rectangular index space, i.e. fewer rounds of the lanes.
+  // A list that does not fit (uniform) falls back to the rectangular space.
   const int HP = *hp_max;
+  const int n_list = can_list ? (int)*plen : n_pairs;
+  uint32_t *ilist = uns_idx + POLY_MAX_U * POLY_MAX_OBS / 2, *ilen = &uns_idx[POLY_MAX_U * POLY_MAX_OBS - 2];
+  constexpr int ICAP = POLY_MAX_U * POLY_MAX_OBS / 2 - 2;
+  const bool dense = can_list && n_pairs <= POLY_MAX_U * POLY_MAX_OBS / 2 && POLY_SLOTS <= 15 && HP <= 15;
+  if (dense) {
+    if (tid == 0) *ilen = 0u;
+    __syncthreads();
+    for (int li = tid; li < n_list; li += BLOCK) {
+      const int pair = (int)plist[li];
+      const int i = pair / n_obs, j = pair - i * n_obs;
+      if (!valid[i]) continue;
+      const PolyPrep &R = prep[j];
+      const int mode = R.mode, nh = D.obs[W.obs_off + j].n_hp;
+      const int ns_ = mode == 4 ? 1 : mode == 3 ? R.n_slots : 1, nh_ = mode == 4 ? 1 : nh;
+      const int cnt = mode == 0 ? 0 : ns_ * nh_;
+      if (cnt == 0) continue;
+      const uint32_t base = atomicAdd(ilen, (uint32_t)cnt);
+      if (base + (uint32_t)cnt <= (uint32_t)ICAP)
+        for (int s_ = 0; s_ < ns_; s_++)
+          for (int h_ = 0; h_ < nh_; h_++) ilist[base + (uint32_t)(s_ * nh_ + h_)] = ((uint32_t)li << 8) | ((uint32_t)s_ << 4) | (uint32_t)h_;
+    }
+    __syncthreads();
+  }
+  const bool use_list = dense && *ilen <= (uint32_t)ICAP;  // (uniform)
   int sub_log = 0;
   while ((1 << sub_log) < POLY_SLOTS * HP) sub_log++;
-  const int n_list = can_list ? (int)*plen : n_pairs, total = n_list << sub_log;
+  const int total = use_list ? (int)*ilen : (n_list << sub_log);
   for (int e = tid; e < total; e += BLOCK) {
-    const int li = e >> sub_log, sub = e & ((1 << sub_log) - 1);
+    int li, s, h;
+    bool first;
+    if (use_list) {
+      const uint32_t it = ilist[e];
+      li = (int)(it >> 8); s = (int)((it >> 4) & 15u); h = (int)(it & 15u);
+      first = s == 0 && h == 0;
+    } else {
+      li = e >> sub_log;
+      const int sub = e & ((1 << sub_log) - 1);
+      if (sub >= POLY_SLOTS * HP) continue;
+      s = sub / HP; h = sub - s * HP;
+      first = sub == 0;
+    }
     const int pair = can_list ? (int)plist[li] : li;
     const int i = pair / n_obs, j = pair - i * n_obs;
-    if (!valid[i] || sub >= POLY_SLOTS * HP) continue;
-    const int s = sub / HP, h = sub - s * HP;
+    if (!valid[i]) continue;
     const PolyPrep &R = prep[j];
     const PolyObs &o = D.obs[W.obs_off + j];
     const int mode = R.mode;
     if (mode == 0) continue;
-    if (mode == 4) { if (sub != 0) continue; }
+    if (mode == 4) { if (!first) continue; }
     else if (h >= o.n_hp || (mode == 3 ? s >= R.n_slots : s != 0)) continue;
     const uint32_t idx = (uint32_t)(s * HP + h);
     if (hit_idx[pair] < idx) continue;  // the reference's loop has already returned (a benign race: only saves work)

@@ -27,6 +27,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
   __shared__ PolyPrep pprep[POLY_MAX_OBS];
   __shared__ uint32_t phit_idx[POLY_MAX_U * POLY_MAX_OBS], puns_idx[POLY_MAX_U * POLY_MAX_OBS];
   __shared__ PolyWorldLds wlds;
+  __shared__ unsigned long long plevel[2];  // the (query, time level) pprep[] holds
   using V = QView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
       S.c_push = S.c_reopen = S.c_refill = S.c_evict = 0;
       S.c_hash = 0;
       punsupported = 0;
+      plevel[0] = 0ull; plevel[1] = 0ull;
       S.hp.w = P.w; S.hp.v_max = P.v_max; S.hp.heur_ignore_dynamics = P.heur_ignore_dynamics;
       S.hp.goal_control = in.goal_control;
       S.hp.goal = in.goal;
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
                                     __builtin_prefetch(Q.node(vid), 0, 3);
                                 };
         poly_collide_all<BLOCK, decltype(hook), GEN>(D, W, pcs, pvalid, P.n_u, T, t_rel, pprep, phit_idx, puns_idx, &php_max, phit, &punsupported, &pstart_hit, tid, (long long)q + 1,
-                                hook, S.cyc);
+                                hook, S.cyc, plevel);
         if (tid < P.n_u) {
           L.valid = pvalid[tid] != 0;
           L.blocked = L.valid && (pstart_hit || phit[tid]);
