@@ -438,6 +438,7 @@ def bench_c5(args):
     team.configure(pm.ACC, pm.U9, **kw)
     team.set_worlds(worlds)
     team.set_capacity(16, 1 << 21, 1 << 23, 1 << 22)
+    team.set_helpers(args.helpers if args.helpers in (-1, 0) else min(args.helpers, 15))
     world_of = np.arange(16)
     pkw = dict(eps=1.0, tol_pos=0.5, max_expand=max_expand, heur_ignore_dynamics=True)
     for _ in range(args.warmup):
@@ -471,9 +472,11 @@ def bench_c5(args):
                       "robots": 16, "n_primitives": 9},
            "expansions_per_step": n_exp, "plan_status_counts": {str(k): int(v) for k, v in enumerate(np.bincount([r.status for r in R], minlength=7))},
            "tick_ms": 1e3 * elapsed / args.steps,
-           "cycles_per_expansion_longest_robot": per_exp,
+           "cycles_per_expansion_longest_robot": {k: v for k, v in per_exp.items() if k != "lookahead_hits"},
+           "lookahead": {"helpers_per_robot": team.last_helpers(), "hit_rate_longest_robot": per_exp.get("lookahead_hits", 0.0),
+                         "note": "workgroups on the idle compute units run the collision tests of the states a search has just created; identical results"},
            "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "astar_poly_kernel<256>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
+                        "traffic": None, "kernel": "astar_poly_kernel<256,ACC>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
                         "note": "16 workgroups (one per robot): the obstacle data stays in L2 and the expansion is f64 root solving; latency bound"}}
     if args.cpu_seconds > 0:
         from oracle import refpoly

@@ -357,6 +357,12 @@ int mplx_poly_result_traj(mplx_poly *p, int32_t q, int32_t *actions, int32_t *no
 int mplx_poly_set_record(mplx_poly *p, uint32_t cap_per_query);
 int mplx_poly_result_expanded(mplx_poly *p, int32_t q, uint32_t cap, int32_t *ids, uint32_t *n);
 int mplx_poly_last_kernel_ms(const mplx_poly *p, float *ms);
+/* Look-ahead helper workgroups of mplx_poly_plan_batch (no reference counterpart: the reference runs one planner per
+ * thread of control): when every leader workgroup has one query -- the batched tick -- workgroups on the otherwise idle
+ * compute units run the collision tests of the states a search has just created, before the search pops them (the
+ * outcome is a pure function of the state: results are identical with or without).  per_leader: -1 auto, 0 off, <= 15. */
+int mplx_poly_set_helpers(mplx_poly *p, int32_t per_leader);
+int mplx_poly_last_helpers(const mplx_poly *p); /* helpers per leader of the last launch */
 /* shader-clock cycles query q of the last batch spent in [0] pop, [1] get_succ (primitives + collide), [2] look-up + commit */
 int mplx_poly_result_cycles(mplx_poly *p, int32_t q, uint64_t cyc[10]);
 

@@ -66,7 +66,7 @@ EXPORTS = [
     "mplx_lpa_counts", "mplx_lpa_result_nodes", "mplx_lpa_result_edges", "mplx_lpa_result_expanded", "mplx_lpa_last_kernel_ms",
     "mplx_poly_create", "mplx_poly_destroy", "mplx_poly_last_error", "mplx_poly_config", "mplx_poly_begin", "mplx_poly_set_world",
     "mplx_poly_add_static", "mplx_poly_add_linear", "mplx_poly_add_nonlinear", "mplx_poly_commit", "mplx_poly_get_succ_batch", "mplx_poly_set_capacity", "mplx_poly_plan_batch", "mplx_poly_result_traj",
-    "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms", "mplx_poly_result_cycles",
+    "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms", "mplx_poly_result_cycles", "mplx_poly_set_helpers", "mplx_poly_last_helpers",
     "mplx_traj_solve", "mplx_traj_sample", "mplx_traj_effort",
 ]
 
@@ -204,5 +204,7 @@ def load():
     L.mplx_poly_result_expanded.argtypes = [P, C.c_int32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
     L.mplx_poly_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float)]
     L.mplx_poly_result_cycles.argtypes = [P, C.c_int32, C.POINTER(C.c_uint64)]
+    L.mplx_poly_set_helpers.argtypes = [P, C.c_int32]
+    L.mplx_poly_last_helpers.argtypes = [P]
     _lib = L
     return L

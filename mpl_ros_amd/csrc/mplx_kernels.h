@@ -1040,10 +1040,14 @@ __device__ __forceinline__ void open_push(const QView<BLOCK, CONTROL, SM> &Q, ui
 // NK: key ints (key_len_c(CONTROL), + 1 when the state's time is part of the key); lane_cost: cost of this lane's
 // primitive (the voxel environment's cost depends on the control input only: P.ucost[tid]).
 // YAW: the state's yaw key is the (NK + 1)-th key integer, its yaw the state double before t
-template <int BLOCK, int CONTROL, class SM, int NK = key_len_c(CONTROL), bool YAW = false>
+// created(id, record index, L): called by the lane that has just created state `id` (its record is written)
+struct NoCreateHook {
+  __device__ __forceinline__ void operator()(uint32_t, uint32_t, const LaneSucc &) const {}
+};
+template <int BLOCK, int CONTROL, class SM, int NK = key_len_c(CONTROL), bool YAW = false, class CreateHook = NoCreateHook>
 // have_v0: the caller has already loaded the first table slot of the lane's key (v0_in), e.g. while other work was in flight
 __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> &Q, int tid, int q, bool act, const LaneSucc &L, unsigned long long h64, double lane_cost,
-                                                uint32_t action_tag, bool have_v0 = false, unsigned long long v0_in = 0) {
+                                                uint32_t action_tag, bool have_v0 = false, unsigned long long v0_in = 0, CreateHook created = CreateHook()) {
   using V = QView<BLOCK, CONTROL, SM>;
   const SearchParams &P = Q.P;
   SM &S = Q.S;
@@ -1134,6 +1138,7 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
     hval = hspec;
     V::h(rec) = hval;
     st_u64(&P.table[tslot], tagq | id);
+    created(id, Q.node_rec(id), L);
   }
   bool improved = false;
   double tg = 0.0;

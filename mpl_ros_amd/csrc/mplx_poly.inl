@@ -68,6 +68,11 @@ struct mplx_poly {
   // configuration
   bool have_cfg = false;
   int control = 0, n_u = 0;
+  int helpers = -1;              // look-ahead helper workgroups per leader: -1 auto (what the idle compute units allow, at most 4), 0 off, <= 15
+  unsigned long long *d_help_mask = nullptr, *d_help_pub = nullptr;
+  double *d_help_ring = nullptr;
+  size_t help_mask_n = 0;
+  int help_ring_slots = 0, last_n_help = 0;
   bool any_high_degree = false;  // an obstacle trajectory has a segment above degree two (set by mplx_poly_add_nonlinear, cleared by mplx_poly_begin)
   double dt = 1, v_max = -1, a_max = -1, j_max = -1, w = 10;
   std::vector<double> U;
@@ -137,6 +142,7 @@ extern "C" void mplx_poly_destroy(mplx_poly *p) {
   (void)hipFree(p->d_U);
   (void)hipFree(p->d_world_of);
   (void)hipFree(p->d_prep_cache);
+  (void)hipFree(p->d_help_mask); (void)hipFree(p->d_help_ring); (void)hipFree(p->d_help_pub);
   mplx_ctx_destroy(p->ctx);
   (void)hipStreamDestroy(p->stream);
   delete p;
@@ -399,15 +405,48 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   P.next_query = c->d_next;
   P.poly = poly_dev(p);
   P.poly_world = p->d_world_of;
+  // look-ahead helpers: only when every leader has exactly one query (the batched tick) and the masks fit one word
+  int n_help = 0;
+  if (p->helpers != 0 && n <= slots && p->n_u <= 31 && c->n_cus > slots) {
+    n_help = (c->n_cus - slots) / slots;
+    const int want = p->helpers < 0 ? 4 : p->helpers;  // (measured on the Team2 tick: 3 per robot already serve 99.9 % of the pops)
+    if (n_help > want) n_help = want;
+  }
+  const int grid = slots * (1 + n_help);
+  constexpr int RING_LOG = 16;
+  if (n_help > 0) {
+    const size_t recs = (size_t)P.node_chunks << NODE_CH_LOG;
+    if (p->help_mask_n < recs) {
+      (void)hipFree(p->d_help_mask);
+      p->d_help_mask = nullptr;
+      PCHK(p, hipMalloc((void **)&p->d_help_mask, sizeof(unsigned long long) * recs));
+      p->help_mask_n = recs;
+    }
+    if (p->help_ring_slots < slots) {
+      (void)hipFree(p->d_help_ring); (void)hipFree(p->d_help_pub);
+      p->d_help_ring = nullptr; p->d_help_pub = nullptr;
+      PCHK(p, hipMalloc((void **)&p->d_help_ring, sizeof(double) * 8 * ((size_t)slots << RING_LOG)));
+      PCHK(p, hipMalloc((void **)&p->d_help_pub, sizeof(unsigned long long) * (size_t)slots));
+      p->help_ring_slots = slots;
+    }
+    PCHK(p, hipMemsetAsync(p->d_help_mask, 0, sizeof(unsigned long long) * recs, c->stream));
+    PCHK(p, hipMemsetAsync(p->d_help_pub, 0, sizeof(unsigned long long) * (size_t)slots, c->stream));
+    // (the ring needs no clearing: a helper reads entry `id` only after the leader's count has passed it, and the entry
+    //  names its state)
+  }
+  P.poly.help_mask = p->d_help_mask; P.poly.help_ring = p->d_help_ring; P.poly.help_pub = p->d_help_pub;
+  P.poly.help_ring_log = RING_LOG; P.poly.n_help = n_help;
+  P.help_lead = slots;
+  p->last_n_help = n_help;
   {
     const size_t per = (size_t)mplx::POLY_CACHE_LEVELS * mplx::POLY_MAX_OBS;
-    if (p->prep_cache_slots < slots) {
+    if (p->prep_cache_slots < grid) {  // (one slice per workgroup of the launch, helpers included)
       (void)hipFree(p->d_prep_cache);
       p->d_prep_cache = nullptr;
-      PCHK(p, hipMalloc((void **)&p->d_prep_cache, sizeof(mplx::PolyPrep) * per * (size_t)slots));
-      p->prep_cache_slots = slots;
+      PCHK(p, hipMalloc((void **)&p->d_prep_cache, sizeof(mplx::PolyPrep) * per * (size_t)grid));
+      p->prep_cache_slots = grid;
     }
-    PCHK(p, hipMemsetAsync(p->d_prep_cache, 0, sizeof(mplx::PolyPrep) * per * (size_t)slots, c->stream));  // tag_q 0: empty
+    PCHK(p, hipMemsetAsync(p->d_prep_cache, 0, sizeof(mplx::PolyPrep) * per * (size_t)grid, c->stream));  // tag_q 0: empty
     P.poly.prep_cache = p->d_prep_cache;
   }
   hipStream_t st = c->stream;
@@ -419,11 +458,11 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   PCHK(p, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), st));
   PCHK(p, hipEventRecord(c->ev0, st));
   if (p->control == CTRL_JRK)
-    hipLaunchKernelGGL((mplx::astar_poly_kernel<256, CTRL_JRK, true>), dim3(slots), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((mplx::astar_poly_kernel<256, CTRL_JRK, true>), dim3(grid), dim3(256), 0, st, P);
   else if (poly_general(p))
-    hipLaunchKernelGGL((mplx::astar_poly_kernel<256, CTRL_ACC, true>), dim3(slots), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((mplx::astar_poly_kernel<256, CTRL_ACC, true>), dim3(grid), dim3(256), 0, st, P);
   else
-    hipLaunchKernelGGL((mplx::astar_poly_kernel<256, CTRL_ACC, false>), dim3(slots), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((mplx::astar_poly_kernel<256, CTRL_ACC, false>), dim3(grid), dim3(256), 0, st, P);
   PCHK(p, hipGetLastError());
   PCHK(p, hipEventRecord(c->ev1, st));
   c->last_out.resize((size_t)n);
@@ -471,3 +510,9 @@ extern "C" int mplx_poly_result_expanded(mplx_poly *p, int32_t q, uint32_t cap, 
   return r ? pfail(p, r, "%s", p->ctx->err.c_str()) : MPLX_OK;
 }
 extern "C" int mplx_poly_set_record(mplx_poly *p, uint32_t cap) { return p ? mplx_set_record(p->ctx, cap) : MPLX_ERR_ARG; }
+extern "C" int mplx_poly_set_helpers(mplx_poly *p, int32_t per_leader) {
+  if (!p || per_leader < -1 || per_leader > 15) return pfail(p, MPLX_ERR_ARG, "helpers per leader: -1 (auto), 0 (off) .. 15");
+  p->helpers = per_leader;
+  return MPLX_OK;
+}
+extern "C" int mplx_poly_last_helpers(const mplx_poly *p) { return p ? p->last_n_help : 0; }

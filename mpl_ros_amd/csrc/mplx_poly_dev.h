@@ -50,7 +50,16 @@ struct PolyDev {
   const double *cum;                                 // null, or per trajectory n_seg + 1 segment start times (cum[0] = 0, cum[k + 1] = segs[k].T + cum[k]:
                                                      // the very sums the loops below accumulate), staged with the world in LDS
   struct PolyPrep *prep_cache;                       // null, or per workgroup POLY_CACHE_LEVELS x POLY_MAX_OBS prepared obstacles (below)
+  // look-ahead by helper workgroups (mplx_poly_search.h): the collision outcome of a state -- isFree(start.pos, t) and
+  // isFree(pr, t) of its primitives -- is a pure function of the state, so workgroups on otherwise idle compute units
+  // compute it for the states a search has just created, before the search pops them
+  unsigned long long *help_mask;                     // per node-pool record: POLY_MASK_READY | start-hit / unsupported bits | hit bit per control input
+  double *help_ring;                                 // per leader: 2^help_ring_log entries of 8 doubles {id << 32 | record index, pos2, vel2, acc2, t}, indexed by state id
+  unsigned long long *help_pub;                      // per leader: states published so far | POLY_PUB_DONE
+  int32_t help_ring_log, n_help;                     // helpers per leader (0: no helpers in this launch)
 };
+constexpr unsigned long long POLY_MASK_READY = 1ull << 63, POLY_MASK_UNSUP = 1ull << 62, POLY_MASK_START = 1ull << 61;  // bits 0..30: hit of control input i
+constexpr unsigned long long POLY_PUB_DONE = 1ull << 63;
 
 // ---- Primitive1D as include/mpl_shim/mpl_basis/primitive.h writes it (left-to-right products)
 MPLX_HD double pp_p(const double *c, double t) {

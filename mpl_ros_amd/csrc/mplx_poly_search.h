@@ -28,14 +28,90 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
   __shared__ uint32_t phit_idx[POLY_MAX_U * POLY_MAX_OBS], puns_idx[POLY_MAX_U * POLY_MAX_OBS];
   __shared__ PolyWorldLds wlds;
   __shared__ unsigned long long plevel[2];  // the (query, time level) pprep[] holds
+  __shared__ unsigned long long pmask;      // (helpers) the look-ahead record of the state being expanded
+  __shared__ double hstate[8];              // (helper) the ring entry being served
+  __shared__ int32_t hgo;
   using V = QView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
-  const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
   const PolyDev &DG = P.poly;
+  const int n_help = DG.n_help, n_lead = P.help_lead;
+  // ---- helper workgroups (blockIdx >= n_lead; the host launches them only when every leader has exactly one query):
+  // helper j of leader `slot` serves the states id = 1 + j, 1 + j + n_help, ... of that leader's search as they are
+  // published -- primitives, then the collision tests, exactly what the leader would do on popping the state -- and
+  // leaves the outcome in help_mask[record].  It never writes anything else, the leader never waits for it.
+  if (n_help > 0 && (int)blockIdx.x >= n_lead) {
+    const int hidx = (int)blockIdx.x - n_lead, slot = hidx % n_lead, hj = hidx / n_lead;
+    const int q = P.order[slot];
+    const PolyWorld WG = DG.worlds[P.poly_world[q]];
+    PolyDev D;
+    PolyWorld W;
+    poly_stage_world<BLOCK>(DG, WG, wlds, tid, D, W);
+    if (tid == 0) { plevel[0] = 0ull; plevel[1] = 0ull; punsupported = 0; }
+    const unsigned long long ring_mask = (1ull << DG.help_ring_log) - 1ull;
+    const double *ring = DG.help_ring + ((size_t)slot << DG.help_ring_log) * 8;
+    unsigned long long next = 1ull + (unsigned long long)hj;
+    for (;;) {
+      if (tid == 0) {
+        int go = 0;
+        for (int spin = 0; spin < 4000000; spin++) {  // (a bound on the polls, not on time: a leader that has stopped publishing is gone)
+          const unsigned long long pv = ld_u64(&DG.help_pub[slot]);
+          const unsigned long long n = pv & ~POLY_PUB_DONE;
+          if (next < n) {
+            if (n - next > ring_mask) next += ((n - ring_mask - next + (unsigned long long)n_help - 1ull) / (unsigned long long)n_help) * (unsigned long long)n_help;  // lapped: skip
+            if (next < n) { go = 1; break; }
+          }
+          if (pv & POLY_PUB_DONE) break;
+          __builtin_amdgcn_s_sleep(32);
+        }
+        hgo = go;
+      }
+      __syncthreads();
+      if (!hgo) break;
+      if (tid < 8) hstate[tid] = ld_f64_agent(&ring[(next & ring_mask) * 8 + (unsigned long long)tid]);
+      if (tid == 0) { pstart_hit = 0; punsupported = 0; }
+      __syncthreads();
+      const unsigned long long tag = (unsigned long long)__double_as_longlong(hstate[0]);
+      if ((tag >> 32) == (next & 0xFFFFFFFFull)) {  // (uniform) the entry of state `next` (not yet overwritten by a later lap)
+        const double T = P.dt, cur_t = hstate[7], t_rel = cur_t - W.start_t;
+        if (tid < P.n_u) {
+          const double pos[2] = {hstate[1], hstate[2]}, vel[2] = {hstate[3], hstate[4]}, acc[2] = {hstate[5], hstate[6]}, u[2] = {D.U[2 * tid], D.U[2 * tid + 1]};
+          double c[2][6];
+          poly_prim_build(CONTROL, pos, vel, u, c, acc);
+          for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 6; j++) pcs[tid][i][j] = c[i][j];
+          const double ex = pp_p_auto(c[0], T), ey = pp_p_auto(c[1], T);
+          pvalid[tid] = (poly_inside(W.bbox, 4, ex, ey) && poly_validate(CONTROL, c, T, P.v_max, P.a_max, P.j_max)) ? 1 : 0;
+          phit[tid] = 0;
+        }
+        __syncthreads();
+        poly_collide_all<BLOCK, PolyNoHook, GEN>(D, W, pcs, pvalid, P.n_u, T, t_rel, pprep, phit_idx, puns_idx, &php_max, phit, &punsupported, &pstart_hit, tid, (long long)q + 1,
+                                                 PolyNoHook(), nullptr, plevel);
+        if (tid == 0) {
+          unsigned long long m = POLY_MASK_READY;
+          for (int i = 0; i < P.n_u; i++)
+            if (phit[i]) m |= 1ull << i;
+          if (pstart_hit) m |= POLY_MASK_START;
+          if (punsupported) m |= POLY_MASK_UNSUP;
+          st_u64(&DG.help_mask[(uint32_t)tag], m);
+        }
+      }
+      next += (unsigned long long)n_help;
+      __syncthreads();
+    }
+    return;
+  }
+  const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
+  bool took = false;
   for (;;) {
-    if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
-    __syncthreads();
-    const int qi = S.q_index;
+    int qi;
+    if (n_help > 0) {  // (with helpers a leader owns exactly one query: its own index)
+      qi = took ? P.nq : (int)blockIdx.x;
+      took = true;
+    } else {
+      if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
+      __syncthreads();
+      qi = S.q_index;
+    }
     if (qi >= P.nq) break;
     const int q = P.order[qi];
     const QueryIn &in = P.queries[q];
@@ -132,6 +208,9 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
           S.flag = 0;
           pstart_hit = 0;
         }
+        // (helpers) the look-ahead record of this state, if a helper has got to it: loaded now, looked at after the primitives
+        unsigned long long look = 0ull;
+        if (n_help > 0 && tid == 0) look = ld_u64(&DG.help_mask[Q.node_rec(cur)]);
         // ---- env_poly_map::get_succ(curr): S.cur[0] = pos3 vel3 ... , S.cur[0][12] = curr.t
         MPLX_TIC(tx);
         const double T = P.dt, cur_t = S.cur[0][12], t_rel = cur_t - W.start_t;
@@ -160,6 +239,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
           h64 = key_hash64(L.key, NK);
           v0 = ld_u64(&P.table[(size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask]);
         }
+        if (n_help > 0 && tid == 0) pmask = look;
         __syncthreads();
         MPLX_TOC(S, 3, tx);
         // isFree(start.pos, t) and isFree(pr, t) of all primitives against all obstacles
@@ -168,13 +248,36 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
                                   if (v0 != TBL_EMPTY && vid < CLAIM_BASE && (v0 >> 32) == ((h64 >> 48) << 16 | (unsigned long long)(uint32_t)q))
                                     __builtin_prefetch(Q.node(vid), 0, 3);
                                 };
-        poly_collide_all<BLOCK, decltype(hook), GEN>(D, W, pcs, pvalid, P.n_u, T, t_rel, pprep, phit_idx, puns_idx, &php_max, phit, &punsupported, &pstart_hit, tid, (long long)q + 1,
+        const bool looked = n_help > 0 && (pmask & POLY_MASK_READY) != 0ull;  // (uniform)
+        if (looked) {  // a helper has run the collision tests of this state: the same pure function of the state
+          const unsigned long long m = pmask;
+          if (tid < P.n_u) phit[tid] = (int32_t)((m >> tid) & 1ull);
+          if (tid == 0) {
+            if (m & POLY_MASK_START) pstart_hit = 1;
+            if (m & POLY_MASK_UNSUP) punsupported = 1;
+            S.cyc[8]++;
+          }
+          hook();
+          __syncthreads();
+        } else {
+          poly_collide_all<BLOCK, decltype(hook), GEN>(D, W, pcs, pvalid, P.n_u, T, t_rel, pprep, phit_idx, puns_idx, &php_max, phit, &punsupported, &pstart_hit, tid, (long long)q + 1,
                                 hook, S.cyc, plevel);
+        }
         if (tid < P.n_u) {
           L.valid = pvalid[tid] != 0;
           L.blocked = L.valid && (pstart_hit || phit[tid]);
         }
         const bool act = L.valid && !L.blocked;
+        // (helpers) a state this expansion creates goes into the leader's ring at once: {id | record, pos2, vel2, acc2, t}
+        const double t_next = cur_t + P.dt;
+        auto publish = [&](uint32_t id, uint32_t recx, const LaneSucc &Ls) {
+          if (n_help <= 0) return;
+          double *e = DG.help_ring + (((size_t)blockIdx.x << DG.help_ring_log) + ((size_t)id & (((size_t)1 << DG.help_ring_log) - 1))) * 8;
+          st_f64x2_agent(e + 0, __longlong_as_double((long long)(((unsigned long long)id << 32) | (unsigned long long)recx)), Ls.tn.p[0]);
+          st_f64x2_agent(e + 2, Ls.tn.p[1], Ls.tn.v[0]);
+          st_f64x2_agent(e + 4, Ls.tn.v[1], Ls.tn.a[0]);
+          st_f64x2_agent(e + 6, Ls.tn.a[1], t_next);
+        };
         {
           uint32_t tot;
           block_excl_scan<BLOCK>((L.valid ? 1u : 0u) | (act ? 1u << 10 : 0u), S, tid, tot);
@@ -203,9 +306,14 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
         }
         __syncthreads();
         if (!S.flag) {
-          commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid, q, act, L, h64, lane_cost, (uint32_t)tid, true, v0);
+          commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK, false, decltype(publish)>(Q, tid, q, act, L, h64, lane_cost, (uint32_t)tid, true, v0, publish);
         } else {
-          for (int i = 0; i < P.n_u && S.status < 0; i++) commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK>(Q, tid, q, act && tid == i, L, h64, lane_cost, (uint32_t)tid);
+          for (int i = 0; i < P.n_u && S.status < 0; i++)
+            commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, NK, false, decltype(publish)>(Q, tid, q, act && tid == i, L, h64, lane_cost, (uint32_t)tid, false, 0ull, publish);
+        }
+        if (n_help > 0 && tid < 64) {  // the ring entries of the states just created have landed (wave 0 wrote them) before the count names them
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (tid == 0) st_u64(&DG.help_pub[blockIdx.x], (unsigned long long)S.n_nodes);
         }
         __syncthreads();
         MPLX_TOC(S, 2, tc);
@@ -224,6 +332,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
       goal_id = S.cur_id;
       clear_buckets(Q, tid);
     }
+    if (n_help > 0 && tid == 0) st_u64(&DG.help_pub[blockIdx.x], POLY_PUB_DONE | (unsigned long long)S.n_nodes);  // the helpers of this leader leave
     __syncthreads();
     if (tid == 0) {  // recoverTraj + results
       QueryOut &o = P.out[q];

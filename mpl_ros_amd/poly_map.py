@@ -165,6 +165,13 @@ class PolyTeam:
     def set_capacity(self, n_slots, nodes, edges, open_log):
         self.check(self.lib.mplx_poly_set_capacity(self.h, int(n_slots), int(nodes), int(edges), int(open_log)))
 
+    def set_helpers(self, per_leader):
+        """Look-ahead helper workgroups per leader (-1 auto, 0 off): results are identical with or without."""
+        self.check(self.lib.mplx_poly_set_helpers(self.h, int(per_leader)))
+
+    def last_helpers(self):
+        return int(self.lib.mplx_poly_last_helpers(self.h))
+
     def set_record(self, cap):
         self.check(self.lib.mplx_poly_set_record(self.h, int(cap)))
 
@@ -198,7 +205,7 @@ class PolyTeam:
         """shader-clock cycles query q spent in pop / get_succ / look-up + commit"""
         cyc = (C.c_uint64 * 10)()
         self.check(self.lib.mplx_poly_result_cycles(self.h, int(q), cyc))
-        return dict(pop=int(cyc[0]), get_succ=int(cyc[1]), commit=int(cyc[2]), primitives=int(cyc[3]), start_test=int(cyc[4]), prepare=int(cyc[5]), items_lane0=int(cyc[6]), items_wait=int(cyc[7]))
+        return dict(pop=int(cyc[0]), get_succ=int(cyc[1]), commit=int(cyc[2]), primitives=int(cyc[3]), start_test=int(cyc[4]), prepare=int(cyc[5]), items_lane0=int(cyc[6]), items_wait=int(cyc[7]), lookahead_hits=int(cyc[8]))
 
     def last_kernel_ms(self):
         ms = C.c_float()

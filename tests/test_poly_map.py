@@ -260,3 +260,26 @@ def test_snp_search_is_refused_loudly():
     team.set_worlds([W])
     with pytest.raises(pm.MplxError):
         team.plan_batch([0], np.zeros((1, 9)), np.zeros((1, 9)))
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_lookahead_helpers_change_nothing_but_the_time():
+    """The Team2 tick with the look-ahead helper workgroups off, with 3 and with the automatic number per robot: every
+    result field, expansion order and path identical (the helpers only precompute a pure function of a state)."""
+    worlds, starts, goals = pm.team2_tick()
+    team = pm.PolyTeam()
+    team.configure(pm.ACC, U9, dt=0.5, v_max=2.0, a_max=1.0, w=10.0)
+    team.set_worlds(worlds)
+    team.set_capacity(16, 1 << 21, 1 << 23, 1 << 22)
+    team.set_record(1 << 16)
+    runs = {}
+    for h in (0, 3, -1):
+        team.set_helpers(h)
+        R = team.plan_batch(np.arange(16), starts, goals, max_expand=20000)
+        assert team.last_helpers() == (h if h >= 0 else 4)
+        runs[h] = [(r.status, r.n_expanded, r.n_nodes, r.n_edges, r.cost, r.expand_hash, r.traj_len) + tuple(team.traj(k)[0].tolist()) for k, r in enumerate(R)]
+        hits = [team.cycles(k)["lookahead_hits"] for k in range(16)]
+        print("helpers", h, "kernel ms", team.last_kernel_ms(), "look-ahead hits of the longest robots", sorted(hits)[-4:])
+        assert (sum(hits) > 0) == (h != 0)
+    assert runs[0] == runs[3] == runs[-1]
