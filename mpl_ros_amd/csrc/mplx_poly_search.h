@@ -409,4 +409,62 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
   }
 }
 
+
+// One successor of env_poly_map::get_succ (mirrors mplx_poly_succ)
+struct PolySuccOut {
+  double state[9];  // pos2 vel2 acc2 jrk2 t
+  double cost;      // intrinsic cost, or +inf when PolyMapUtil::isFree(pr, t) fails
+  int32_t action, valid;
+};
+
+// env_poly_map::get_succ for K nodes: one workgroup per node.  Lane i < n_u builds primitive i (end state, bounding
+// box, validate_primitive, intrinsic cost); then isFree(pr, t) of all of them against all obstacles spread over the lanes
+// below the pair level (poly_collide_all, mplx_poly_dev.h) and the start-point test isFree(start.pos, t) over the
+// obstacles; results are OR-ed in LDS.
+template <int BLOCK, bool GEN = false>
+__global__ __launch_bounds__(BLOCK) void poly_get_succ_kernel(PolyDev D, int K, const int32_t *world_of, const double *states, PolySuccOut *out, int32_t *flags) {
+  __shared__ double cs[POLY_MAX_U][2][6];
+  __shared__ int32_t valid[POLY_MAX_U], hit[POLY_MAX_U];
+  __shared__ int32_t start_hit, unsupported, hp_max;
+  __shared__ PolyPrep prep[POLY_MAX_OBS];
+  __shared__ uint32_t hit_idx[POLY_MAX_U * POLY_MAX_OBS], uns_idx[POLY_MAX_U * POLY_MAX_OBS];
+  const int tid = threadIdx.x;
+  for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    const double *st = states + 9 * (size_t)k;
+    const PolyWorld W = D.worlds[world_of[k]];
+    const double T = D.dt, t_rel = st[8] - W.start_t;
+    if (tid == 0) { start_hit = 0; unsupported = 0; }
+    if (tid < D.n_u) {
+      const double pos[2] = {st[0], st[1]}, vel[2] = {st[2], st[3]}, acc[2] = {st[4], st[5]}, jrk[2] = {st[6], st[7]}, u[2] = {D.U[2 * tid], D.U[2 * tid + 1]};
+      double c[2][6];
+      poly_prim_build(D.control, pos, vel, u, c, acc, jrk);
+      for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 6; j++) cs[tid][i][j] = c[i][j];
+      const double ex = pp_p_auto(c[0], T), ey = pp_p_auto(c[1], T);
+      valid[tid] = (poly_inside(W.bbox, 4, ex, ey) && poly_validate(D.control, c, T, D.v_max, D.a_max, D.j_max)) ? 1 : 0;
+      hit[tid] = 0;
+    }
+    __syncthreads();
+    // isFree(start.pos, t) (start = pr.evaluate(0) = the node position for every primitive) and isFree(pr, t)
+    poly_collide_all<BLOCK, PolyNoHook, GEN>(D, W, cs, valid, D.n_u, T, t_rel, prep, hit_idx, uns_idx, &hp_max, hit, &unsupported, &start_hit, tid, 0, PolyNoHook());
+    if (tid < D.n_u) {
+      PolySuccOut &o = out[(size_t)k * D.n_u + tid];
+      double c[2][6];
+      for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 6; b++) c[a][b] = cs[tid][a][b];
+      o.state[0] = pp_p_auto(c[0], T); o.state[1] = pp_p_auto(c[1], T);
+      o.state[2] = pp_v_auto(c[0], T); o.state[3] = pp_v_auto(c[1], T);
+      o.state[4] = pp_a_auto(c[0], T); o.state[5] = pp_a_auto(c[1], T);
+      o.state[6] = pp_j_auto(c[0], T); o.state[7] = pp_j_auto(c[1], T);
+      o.state[8] = st[8] + D.dt;
+      o.action = tid;
+      o.valid = valid[tid];
+      o.cost = (start_hit || hit[tid]) ? INFINITY : poly_intrinsic_cost(D.control, c, T, D.w, D.dt);
+    }
+    if (tid == 0 && unsupported) atomicOr(flags, 1);
+    __syncthreads();
+  }
+}
+
+
 }  // namespace mplx
