@@ -476,8 +476,8 @@ def bench_c5(args):
            "lookahead": {"helpers_per_robot": team.last_helpers(), "hit_rate_longest_robot": per_exp.get("lookahead_hits", 0.0),
                          "note": "workgroups on the idle compute units run the collision tests of the states a search has just created; identical results"},
            "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "astar_poly_kernel<256,ACC>", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
-                        "note": "16 workgroups (one per robot): the obstacle data stays in L2 and the expansion is f64 root solving; latency bound"}}
+                        "traffic": None, "kernel": "astar_poly_kernel<64,ACC> (leaders) + astar_poly_kernel<256,ACC> (look-ahead helpers, concurrent launch)", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
+                        "note": "16 leader workgroups (one per robot) + helper workgroups on otherwise idle compute units; the obstacle data stays in L2 and the expansion is f64 root solving; latency bound"}}
     if args.cpu_seconds > 0:
         from oracle import refpoly
         if refpoly.available():

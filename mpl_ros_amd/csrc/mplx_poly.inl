@@ -4,7 +4,7 @@
 // The kernels of this environment (poly_get_succ_kernel, astar_poly_kernel: mplx_poly_search.h) are instantiated in
 // their own translation unit, mplx_poly_launch.hip, so that the device code of libmplx.so compiles in parallel.
 bool mplx_launch_poly_get_succ(bool general, int grid, hipStream_t s, const mplx::PolyDev &D, int K, const int32_t *world_of, const double *states, mplx::PolySuccOut *out, int32_t *flags);
-bool mplx_launch_poly_search(int control, bool general, int grid, hipStream_t s, const mplx::SearchParams &P);
+bool mplx_launch_poly_search(int control, bool general, int block, int grid, hipStream_t s, const mplx::SearchParams &P);
 
 struct mplx_poly {
   int device = 0;
@@ -18,6 +18,8 @@ struct mplx_poly {
   double *d_help_ring = nullptr;
   size_t help_mask_n = 0;
   int help_ring_slots = 0, last_n_help = 0;
+  hipStream_t help_stream = nullptr;  // the helpers' launch (concurrent with the leaders' on the context's stream)
+  hipEvent_t help_ev = nullptr;
   bool any_high_degree = false;  // an obstacle trajectory has a segment above degree two (set by mplx_poly_add_nonlinear, cleared by mplx_poly_begin)
   double dt = 1, v_max = -1, a_max = -1, j_max = -1, w = 10;
   std::vector<double> U;
@@ -88,6 +90,8 @@ extern "C" void mplx_poly_destroy(mplx_poly *p) {
   (void)hipFree(p->d_world_of);
   (void)hipFree(p->d_prep_cache);
   (void)hipFree(p->d_help_mask); (void)hipFree(p->d_help_ring); (void)hipFree(p->d_help_pub);
+  if (p->help_stream) (void)hipStreamDestroy(p->help_stream);
+  if (p->help_ev) (void)hipEventDestroy(p->help_ev);
   mplx_ctx_destroy(p->ctx);
   (void)hipStreamDestroy(p->stream);
   delete p;
@@ -380,6 +384,10 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   P.poly.help_ring_log = RING_LOG; P.poly.n_help = n_help;
   P.help_lead = slots;
   p->last_n_help = n_help;
+  if (n_help > 0 && !p->help_stream) {
+    PCHK(p, hipStreamCreateWithFlags(&p->help_stream, hipStreamNonBlocking));
+    PCHK(p, hipEventCreateWithFlags(&p->help_ev, hipEventDisableTiming));
+  }
   {
     const size_t per = (size_t)mplx::POLY_CACHE_LEVELS * mplx::POLY_MAX_OBS;
     if (p->prep_cache_slots < grid) {  // (one slice per workgroup of the launch, helpers included)
@@ -399,12 +407,27 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   PCHK(p, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * (size_t)n, hipMemcpyHostToDevice, st));
   PCHK(p, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), st));
   PCHK(p, hipEventRecord(c->ev0, st));
-  mplx_launch_poly_search(p->control, poly_general(p), grid, st, P);
+  if (n_help > 0) {
+    // leaders: one 64-lane workgroup per query on the context's stream; helpers: 256-lane workgroups in a launch of
+    // their own, concurrent on a second stream (it starts behind the memsets above; a leader never waits for it)
+    PCHK(p, hipEventRecord(p->help_ev, st));
+    PCHK(p, hipStreamWaitEvent(p->help_stream, p->help_ev, 0));
+    SearchParams PH = P;
+    PH.help_lead = 0;
+    PH.poly.prep_slice0 = slots;  // (the leaders' launch owns slices 0 .. slots - 1)
+    mplx_launch_poly_search(p->control, poly_general(p), 256, slots * n_help, p->help_stream, PH);
+    PCHK(p, hipEventRecord(c->ev0, st));
+    mplx_launch_poly_search(p->control, poly_general(p), 64, slots, st, P);
+  } else {
+    mplx_launch_poly_search(p->control, poly_general(p), 256, slots, st, P);
+  }
+  (void)grid;
   PCHK(p, hipGetLastError());
   PCHK(p, hipEventRecord(c->ev1, st));
   c->last_out.resize((size_t)n);
   PCHK(p, hipMemcpyAsync(c->last_out.data(), c->d_out, sizeof(QueryOut) * (size_t)n, hipMemcpyDeviceToHost, st));
   PCHK(p, hipStreamSynchronize(st));
+  if (n_help > 0) PCHK(p, hipStreamSynchronize(p->help_stream));  // (the helpers leave when their leader has published DONE)
   PCHK(p, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
   for (int k = 0; k < n; k++) fill_result(c->last_out[(size_t)k], out[k]);
   c->last_nq = n;

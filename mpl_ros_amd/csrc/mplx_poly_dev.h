@@ -57,6 +57,7 @@ struct PolyDev {
   double *help_ring;                                 // per leader: 2^help_ring_log entries of 8 doubles {id << 32 | record index, pos2, vel2, acc2, t}, indexed by state id
   unsigned long long *help_pub;                      // per leader: states published so far | POLY_PUB_DONE
   int32_t help_ring_log, n_help;                     // helpers per leader (0: no helpers in this launch)
+  int32_t prep_slice0, pad3;                         // workgroup b of this launch owns slice prep_slice0 + b of prep_cache
 };
 constexpr unsigned long long POLY_MASK_READY = 1ull << 63, POLY_MASK_UNSUP = 1ull << 62, POLY_MASK_START = 1ull << 61;  // bits 0..30: hit of control input i
 constexpr unsigned long long POLY_PUB_DONE = 1ull << 63;
@@ -737,7 +738,7 @@ __device__ __forceinline__ void poly_collide_all(const PolyDev &D, const PolyWor
   if (D.prep_cache && T > 0 && cache_q != 0) {  // (uniform)
     const double lv = t_rel / T;
     const int k = lv >= 0 && lv < (double)POLY_CACHE_LEVELS ? (int)(lv + 0.5) : -1;
-    if (k >= 0 && k < POLY_CACHE_LEVELS) level = D.prep_cache + ((size_t)blockIdx.x * POLY_CACHE_LEVELS + (size_t)k) * POLY_MAX_OBS;
+    if (k >= 0 && k < POLY_CACHE_LEVELS) level = D.prep_cache + ((size_t)(D.prep_slice0 + (int)blockIdx.x) * POLY_CACHE_LEVELS + (size_t)k) * POLY_MAX_OBS;
   }
   const bool in_lds = lds_level && cache_q != 0 && lds_level[0] == (unsigned long long)cache_q && lds_level[1] == tbits;  // (uniform: written behind a barrier)
   if (level && !in_lds) {

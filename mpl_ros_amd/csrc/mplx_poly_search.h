@@ -34,13 +34,14 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
   using V = QView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
   const PolyDev &DG = P.poly;
-  const int n_help = DG.n_help, n_lead = P.help_lead;
-  // ---- helper workgroups (blockIdx >= n_lead; the host launches them only when every leader has exactly one query):
+  const int n_help = DG.n_help, n_lead = P.nq, first_helper = P.help_lead;
+  // ---- helper workgroups (blockIdx >= first_helper; the host launches them only when every leader has exactly one query):
   // helper j of leader `slot` serves the states id = 1 + j, 1 + j + n_help, ... of that leader's search as they are
   // published -- primitives, then the collision tests, exactly what the leader would do on popping the state -- and
   // leaves the outcome in help_mask[record].  It never writes anything else, the leader never waits for it.
-  if (n_help > 0 && (int)blockIdx.x >= n_lead) {
-    const int hidx = (int)blockIdx.x - n_lead, slot = hidx % n_lead, hj = hidx / n_lead;
+  // (the helpers may be a launch of their own -- first_helper = 0 -- so that leaders and helpers can differ in width)
+  if (n_help > 0 && (int)blockIdx.x >= first_helper) {
+    const int hidx = (int)blockIdx.x - first_helper, slot = hidx % n_lead, hj = hidx / n_lead;
     const int q = P.order[slot];
     const PolyWorld WG = DG.worlds[P.poly_world[q]];
     PolyDev D;
