@@ -350,7 +350,7 @@ def main():
                                                        "both this and the HBM fraction are low: the launch is latency-bound (serial pop chain per query)"}
         except Exception:
             pass
-        if args.cpu_seconds > 0 and mine:
+        if args.cpu_seconds > 0 and mine and world == 1:  # (the CPU baseline is a rank-0, N = 1 leg)
             # a single capped query is sampled on the CPU with a smaller cap; the GPU then repeats the query with
             # that cap (untimed) so that the parity check compares equal searches
             cpu_cap = min(max_expand, 250_000) if (args.single and max_expand > 0) else max_expand
