@@ -158,6 +158,7 @@ __device__ __forceinline__ void lpa_smem_init(const SearchParams &P, Smem<BLOCK>
 struct LpaScratch {  // (LDS) the popped entry and the expanded state's own re-insertion
   double ek, ekg;    // key of the popped entry
   uint32_t eidx;     // its OPEN-log index
+  int32_t over;      // the expansion settled an over-consistent state (its g went DOWN to rhs): see the successor update
   int32_t upush;     // the expanded state goes back into OPEN (under-consistent branch) ...
   double uk, ukg;    // ... with this key
 };
@@ -505,10 +506,12 @@ __global__ __launch_bounds__(BLOCK) void lpa_plan_kernel(SearchParams P, LpaPara
           S.cur_g = r;
           V::flags(rec) = fl | FLAG_BUILT;
           R.upush = 0;  // no push for u
+          R.over = 1;
         } else {
           // under-consistent: g = inf, then the state itself is updated (its key changed)
           V::g(rec) = INFINITY;
           S.cur_g = INFINITY;
+          R.over = 0;
           double nr = r;
           if (u != root) nr = lpa_rhs_of<V>(Q, P, rec);
           V::rhs(rec) = nr;
@@ -566,7 +569,12 @@ __global__ __launch_bounds__(BLOCK) void lpa_plan_kernel(SearchParams P, LpaPara
         char *rec = Q.node(child);
         const double g = V::g(rec), old_r = V::rhs(rec);
         double nr = old_r;
-        if (child != root) nr = lpa_rhs_of<V>(Q, P, rec);
+        // rhs(child) = min over its predecessor entries of g(pred) + cost.  The stored value is that minimum for the g
+        // values before this expansion (every change of a g is followed by this update of all successors); when the
+        // expansion LOWERED g(u) and one lane reaches the child, the new minimum is min(old, g(u) + cost of this lane's
+        // entry) -- the same f64 sum the walk over the list would form, an exact minimum either way -- so the walk
+        // (a chain of dependent HBM reads, most of an expansion's time) is only needed when g(u) went up to inf
+        if (child != root) nr = (R.over && !dup) ? lpa_min(old_r, S.cur_g + P.ucost[tid]) : lpa_rhs_of<V>(Q, P, rec);
         uint32_t fl = V::flags(rec);
         const bool was_inc = !f64_same(g, old_r);
         if (child == u) {
