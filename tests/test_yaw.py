@@ -83,12 +83,12 @@ def test_yaw_api_without_a_device():
 
 # ------------------------------------------------------------------ HIP vs oracle
 @pytest.mark.gpu
-@pytest.mark.parametrize("control,use_3d", [(orc.ACC, True), (orc.ACC, False), (orc.JRK, False), (orc.VEL, True)])
+@pytest.mark.parametrize("control,use_3d", [(orc.ACC, True), (orc.ACC, False), (orc.JRK, False), (orc.VEL, True), (orc.SNP, False)])
 def test_expand_batch_with_yaw_matches_get_succ(control, use_3d):
     grid, origin, res = util.small_map(64)
     U = mapgen.control_lattice(1.0, 1, use_3d, u_yaw=0.5)
     kw = dict(v_max=2.0, a_max=1.0, yaw_max=0.5)
-    if control == orc.JRK:
+    if control in (orc.JRK, orc.SNP):
         kw["j_max"] = 1.0
     P = util.make_oracle(grid, origin, res, control | orc.YAW, U, **kw)
     mu, pl = util.make_gpu(grid, origin, res, U, **kw)
@@ -117,7 +117,8 @@ def test_expand_batch_with_yaw_matches_get_succ(control, use_3d):
             assert g.wp.yaw == so.yaw and g.wp.t == so.t and g.wp.control == so.control == (control | orc.YAW)
             key = (orc.C.c_int32 * 16)()
             nk = orc.lib().orc_waypoint_key(orc.C.byref(so), key)
-            assert g.nkey == nk and list(g.key[:nk]) == list(key[:nk])
+            m = min(nk, 12)  # (mplx_succ.key holds 12 integers: the yaw key of an SNP state is its 13th, reported through wp.yaw)
+            assert g.nkey == nk and list(g.key[:m]) == list(key[:m])
     assert 0 < n_free <= n_valid < len(states) * nU  # the yaw constraint rejected some, passed some
 
 
@@ -142,7 +143,7 @@ def test_hip_plans_the_launch_query_with_use_yaw(simple_map):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("control,goal_yaw,yaw_max", [(orc.ACC, 1.0, 0.7), (orc.ACC, 0.0, -1.0), (orc.JRK, -2.0, 1.0), (orc.VEL, 0.5, 0.5)])
+@pytest.mark.parametrize("control,goal_yaw,yaw_max", [(orc.ACC, 1.0, 0.7), (orc.ACC, 0.0, -1.0), (orc.JRK, -2.0, 1.0), (orc.VEL, 0.5, 0.5), (orc.SNP, 0.3, 0.8)])
 def test_hip_yaw_plans_in_3d(control, goal_yaw, yaw_max):
     """81-input (x, y, z, yaw rate) lattice, start / goal yaw different (the goal's yaw key only matters to the
     heuristic's `state == goal` shortcut; reaching it is decided by the position tolerance)."""
@@ -151,7 +152,7 @@ def test_hip_yaw_plans_in_3d(control, goal_yaw, yaw_max):
     mapgen.carve_bubble(grid, (4.55, 4.05, 3.05), origin, res, 3)
     U = mapgen.control_lattice(1.0, 1, True, u_yaw=0.5)
     kw = dict(v_max=2.0, a_max=1.0, yaw_max=yaw_max, max_expand=4000)
-    if control == orc.JRK:
+    if control in (orc.JRK, orc.SNP):  # (SNP + yaw: 13 key integers, 14 state doubles -- the record's last bytes)
         kw["j_max"] = 1.0
     P = util.make_oracle(grid, origin, res, control | orc.YAW, U, **kw)
     mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=1 << 21, max_edges=1 << 23, **kw)
