@@ -59,7 +59,7 @@ __device__ __forceinline__ double lpa_min(double a, double b) { return a < b ? a
 // is_free(Primitive(state, U[action], dt)) by ONE thread, the same expressions as the sampling loop of expand_unit
 // (generic branch); also gives the successor state and its key
 template <int CONTROL>
-__device__ bool lpa_prim_free(const SearchParams &P, const double *st, int action, State &tn, int32_t *key) {
+__device__ __forceinline__ bool lpa_prim_free(const SearchParams &P, const double *st, int action, State &tn, int32_t *key) {
   constexpr int NQ = nq_c(CONTROL), ns = key_len_c(CONTROL);
   const double T = P.dt;
   double c[3][6];
@@ -98,7 +98,7 @@ __device__ bool lpa_prim_free(const SearchParams &P, const double *st, int actio
 
 // rhs of a state from its predecessor entries (state_space.h updateNode); order-independent (an exact minimum)
 template <class V, class QV>
-__device__ double lpa_rhs_of(const QV &Q, const SearchParams &P, char *rec) {
+__device__ __forceinline__ double lpa_rhs_of(const QV &Q, const SearchParams &P, char *rec) {
   double rhs = INFINITY;
   for (uint32_t e = V::pred(rec); e != NIL; e = Q.edge(e)->next) {
     const EdgeRec er = *Q.edge(e);
@@ -111,7 +111,7 @@ __device__ double lpa_rhs_of(const QV &Q, const SearchParams &P, char *rec) {
 
 // table look-up of `key` for query slot 0; returns the node id or NIL.  table / pool may be another space's.
 template <int BLOCK, int CONTROL>
-__device__ uint32_t lpa_find(const unsigned long long *table, unsigned long long mask, const char *pool, const int32_t *key, unsigned long long h64) {
+__device__ __forceinline__ uint32_t lpa_find(const unsigned long long *table, unsigned long long mask, const char *pool, const int32_t *key, unsigned long long h64) {
   constexpr int nk = key_len_c(CONTROL);
   const unsigned long long tagq = (h64 >> 48) << 48;
   size_t pos = (size_t)h64 & (size_t)mask;
