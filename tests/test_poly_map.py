@@ -283,3 +283,27 @@ def test_lookahead_helpers_change_nothing_but_the_time():
         print("helpers", h, "kernel ms", team.last_kernel_ms(), "look-ahead hits of the longest robots", sorted(hits)[-4:])
         assert (sum(hits) > 0) == (h != 0)
     assert runs[0] == runs[3] == runs[-1]
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_more_queries_than_workgroups_run_without_helpers_and_match():
+    """12 queries on 4 leader workgroups: every workgroup takes several queries one after the other, the look-ahead helpers
+    stay off (they need one query per leader), the 256-lane kernel runs its own collision tests -- same results."""
+    rng = np.random.default_rng(303)
+    dt = 0.5
+    worlds = [random_world(rng, dt=dt) for _ in range(5)]
+    team = pm.PolyTeam()
+    kw = dict(dt=dt, v_max=2.0, a_max=1.0, w=10.0)
+    team.configure(pm.ACC, U9, **kw)
+    team.set_worlds(worlds)
+    team.set_capacity(4, 1 << 20, 1 << 22, 1 << 21)
+    refs = [refpoly.RefWorld(W, pm.ACC, U9, **kw) for W in worlds]
+    n = 12
+    world_of = rng.integers(0, len(worlds), n)
+    starts, goals = np.zeros((n, 9)), np.zeros((n, 9))
+    starts[:, 0:2] = np.round(rng.uniform((0.5, -4.5), (3.0, 4.5), (n, 2)), 1)
+    starts[:, 8] = rng.integers(0, 3, n) * dt
+    goals[:, 0:2] = np.round(rng.uniform((7.0, -4.5), (9.5, 4.5), (n, 2)), 1)
+    R, n_ok = _compare_plans(team, refs, world_of, starts, goals, max_expand=3000)
+    assert team.last_helpers() == 0 and n_ok >= 3
