@@ -211,3 +211,108 @@ class PolyTeam:
         ms = C.c_float()
         self.check(self.lib.mplx_poly_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's multi-robot loop (mpl_test_node/src/robot.hpp:92-170, robot_team.hpp:33-66,366-388, multi_robot_node.cpp:
+# 95-105), host logic over any planner with a plan(world, start, goal) -> (status, actions, states) callable: the robots
+# plan once without obstacles at t = 0, ddt, 2 ddt, ..., then every loop tick set_obs(time) gives robot i the static
+# box and the 15 other robots' CURRENT trajectories as nonlinear obstacles, and a robot replans once dt has passed since
+# its last plan (with ddt = 0.01 one robot per 0.01 s tick; with ddt = 0 all sixteen in the same tick: the batched tick).
+class Robot:
+    def __init__(self, start, goal, dt):
+        self.start = np.array([start[0], start[1], 0.0, 0.0, 0, 0, 0, 0, 0.0])  # pos2 vel2 acc2 jrk2 t (t is set per plan)
+        self.goal = np.array([goal[0], goal[1], 0.0, 0.0, 0, 0, 0, 0, 0.0])
+        self.dt = dt
+        self.segs = np.zeros((0, 13))   # the primitives of the current trajectory: rows {cx[6], cy[6], T}
+        self.traj_t = -10000.0          # robot.hpp:218
+
+    def state_after_first_primitive(self):
+        """traj_.evaluate(dt_) (robot.hpp:97): Trajectory::evaluate picks the segment with taus[id] <= tau < taus[id + 1]
+        -- for tau = dt that is the second primitive at local time 0 -- or the last one at its end."""
+        n = len(self.segs)
+        if n == 0:
+            return None
+        taus = np.concatenate([[0.0], np.cumsum(self.segs[:, 12])])
+        tau = min(max(self.dt, 0.0), taus[-1])
+        for i in range(n):
+            if (taus[i] <= tau < taus[i + 1]) or i + 1 == n:
+                lt = tau - taus[i]
+                cx, cy = self.segs[i, 0:6], self.segs[i, 6:12]
+                p = [c[0] / 120 * lt * lt * lt * lt * lt + c[1] / 24 * lt * lt * lt * lt + c[2] / 6 * lt * lt * lt + c[3] / 2 * lt * lt + c[4] * lt + c[5] for c in (cx, cy)]
+                v = [c[0] / 24 * lt * lt * lt * lt + c[1] / 6 * lt * lt * lt + c[2] / 2 * lt * lt + c[3] * lt + c[4] for c in (cx, cy)]
+                return p, v
+        return None
+
+    def obstacle(self, t, max_t, shape):
+        """get_nonlinear_obstacle(t, max_t) (robot.hpp:156-170)"""
+        segs, dis = self.segs, False
+        if max_t > 0 and float(np.sum(segs[:, 12])) > max_t:
+            segs, dis = segs[: int(round(max_t / self.dt))], True
+        return NonlinearObstacle(shape, segs, start_t=t - self.traj_t, disappear_back=dis)
+
+
+class RobotTeam:
+    """HomogeneousRobotTeam<2> / Team2 (robot_team.hpp).  plan_many(worlds, starts, goals) -> list of (status, actions,
+    states (n + 1) x 9) plans the robots that are due in this tick -- with the device planner: in one launch."""
+
+    def __init__(self, layout=TEAM2, ddt=0.01, dt=0.5, traj_time=0.0, origin=(0.0, -5.0), dim=(10.0, 10.0)):
+        self.robots = [Robot(s, g, dt) for s, g in layout]
+        self.ddt, self.dt, self.traj_time, self.origin, self.dim = ddt, dt, traj_time, origin, dim
+        self.shape = rectangle(0.5)
+        self.static = []  # (the static box is added AFTER the robots' first plans: robot_team.hpp:366-388)
+        self.box = np.array([[4, 0, -1, -0.0], [6, 0, 1, 0], [5, -1, -0.0, -1], [5, 1, 0, 1]], dtype=np.float64)
+        self.plans = 0
+
+    def _world_for(self, i, time, with_obs):
+        W = PolyWorld(self.origin, self.dim)
+        if with_obs:
+            W.static = list(self.static)
+            for j, r in enumerate(self.robots):
+                if j != i:
+                    W.nonlinear.append(r.obstacle(time, self.traj_time, self.shape))
+        return W
+
+    def _adopt(self, r, time, res, U):
+        status, actions, states = res
+        if status != 0:
+            return False
+        rows = []
+        for a, s in zip(actions, states[:-1]):
+            u = U[int(a)]
+            rows.append([0, 0, 0, u[0], s[2], s[0], 0, 0, 0, u[1], s[3], s[1], self.dt])
+        r.segs = np.array(rows).reshape(-1, 13)
+        r.traj_t = time
+        self.plans += 1
+        return True
+
+    def init(self, plan_many, U):
+        """Team2::init (robot_team.hpp:366-376): robot i plans at t = i ddt, no obstacles set yet"""
+        t = 0.0
+        for i, r in enumerate(self.robots):
+            s = r.start.copy()
+            s[8] = 0.0
+            if not self._adopt(r, t, plan_many([self._world_for(i, t, False)], [s], [r.goal])[0], U):
+                return False
+            t += self.ddt
+        self.static = [StaticObstacle(self.box, (0.0, 0.0))]
+        return True
+
+    def update_decentralized(self, time, plan_many, U):
+        """set_obs(time), then every robot's plan(time) (robot_team.hpp:60-66, robot.hpp:92-133); the obstacle sets are
+        taken before anybody replans, so the robots due in this tick are independent and go to the planner together"""
+        due, worlds, starts, goals = [], [], [], []
+        for i, r in enumerate(self.robots):
+            pv = r.state_after_first_primitive()
+            if r.traj_t >= 0 and pv is not None:
+                r.start[0:2], r.start[2:4] = pv[0], pv[1]
+            if time - r.traj_t < self.dt - 1e-8 or float(np.linalg.norm(r.start[0:2] - r.goal[0:2])) < 1:
+                continue
+            s = r.start.copy()
+            s[8] = self.dt  # (start_ = traj_.evaluate(dt_) carries t = dt_: Trajectory::evaluate stamps the query time)
+            due.append(i); worlds.append(self._world_for(i, time, True)); starts.append(s); goals.append(r.goal)
+        if not due:
+            return True, []
+        res = plan_many(worlds, starts, goals)
+        ok = all(self._adopt(self.robots[i], time, rr, U) for i, rr in zip(due, res))
+        return ok, due

@@ -307,3 +307,61 @@ def test_more_queries_than_workgroups_run_without_helpers_and_match():
     goals[:, 0:2] = np.round(rng.uniform((7.0, -4.5), (9.5, 4.5), (n, 2)), 1)
     R, n_ok = _compare_plans(team, refs, world_of, starts, goals, max_expand=3000)
     assert team.last_helpers() == 0 and n_ok >= 3
+
+
+# ---------------------------------------------------------------- the reference's own multi-robot loop, several ticks
+def _device_planner(team, kw_plan):
+    def plan_many(worlds, starts, goals):
+        team.set_worlds(worlds)
+        R = team.plan_batch(np.arange(len(worlds)), np.array(starts), np.array(goals), **kw_plan)
+        out = []
+        for k, r in enumerate(R):
+            act, ids, st = team.traj(k)
+            out.append((r.status, act.copy(), st.copy()))
+        return out
+    return plan_many
+
+
+def _reference_planner(U, kw_env, kw_plan):
+    def plan_many(worlds, starts, goals):
+        out = []
+        for W, s, g in zip(worlds, starts, goals):
+            R = refpoly.RefWorld(W, pm.ACC, U, **kw_env)
+            ref = R.plan(s, g, eps=kw_plan.get("eps", 1.0), tol_pos=kw_plan.get("tol_pos", 0.5), max_expand=kw_plan.get("max_expand", -1))
+            states = np.array([R.node(int(i))[0] for i in ref["node_ids"]]).reshape(-1, 9)
+            states[:, 4:8] = 0.0  # (the device reports position, velocity and time of a path state)
+            out.append((ref["status"], np.array(ref["actions"]), states))
+        return out
+    return plan_many
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("ddt", [0.01, 0.0])
+def test_team2_decentralised_loop_over_many_ticks(ddt):
+    """multi_robot_node.cpp:95-105 with launch/multi_robot_node/test.launch (Team2, dt 0.5, v_max 2, a_max 1): Team2::init (16
+    obstacle-free plans), then the 0.01 s loop for 1.1 s of simulated time -- every robot replans twice against the others'
+    CURRENT planned trajectories.  ddt = 0.01 (the reference): one robot per tick; ddt = 0: all sixteen in the same tick (the
+    batched tick of BASELINE config 5).  The device team and a team planning through the compiled reference environment
+    must agree plan for plan (status, actions, path states) and therefore stay in the same state throughout."""
+    kw_env = dict(dt=0.5, v_max=2.0, a_max=1.0, w=10.0)
+    kw_plan = dict(tol_pos=0.5, max_expand=20000)
+    dev = pm.PolyTeam()
+    dev.configure(pm.ACC, U9, **kw_env)
+    dev.set_capacity(16, 1 << 21, 1 << 23, 1 << 22)
+    plan_dev, plan_ref = _device_planner(dev, kw_plan), _reference_planner(U9, kw_env, kw_plan)
+    A, B = pm.RobotTeam(ddt=ddt), pm.RobotTeam(ddt=ddt)
+    assert A.init(plan_dev, U9) and B.init(plan_ref, U9)
+    n_replans = 0
+    time = 0.0
+    for tick in range(110):
+        time += 0.01
+        ok_a, due_a = A.update_decentralized(time, plan_dev, U9)
+        ok_b, due_b = B.update_decentralized(time, plan_ref, U9)
+        assert ok_a == ok_b and due_a == due_b
+        n_replans += len(due_a)
+        for ra, rb in zip(A.robots, B.robots):
+            assert ra.traj_t == rb.traj_t and np.array_equal(ra.segs, rb.segs), tick
+        if not ok_a:
+            break
+    assert n_replans >= 24 and A.plans == B.plans
