@@ -88,6 +88,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # MPLX_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, RCCL broadcast of the map, run_sharded, gather)
+    # even with ONE rank -- the only way to run that path over the real "nccl" back-end on a one-GPU box (RCCL refuses two
+    # ranks on one device; tests/test_bench_multirank.py uses it next to the 2-rank gloo dry run)
+    multi = world > 1 or os.environ.get("MPLX_BENCH_FORCE_DIST") == "1"
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -99,7 +103,11 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -127,7 +135,7 @@ def main():
     t_gen = time.time() - t0
     torch.cuda.synchronize()
     t0 = time.time()
-    if world > 1:
+    if multi:
         mdist.broadcast_map(dist, map_t, meta, src=0)
         torch.cuda.synchronize()
     t_bcast = time.time() - t0
@@ -187,7 +195,7 @@ def main():
     goals = [wp(queries[i][1]) for i in mine]
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -202,7 +210,7 @@ def main():
             state["kernel_ms"] += pl.lastKernelMs()
         return [mdist.result_row(qi, r.status, r.n_expanded, r.n_nodes, r.cost, r.expand_hash, r.traj_len) for qi, r in zip(mine, res)]
 
-    sharded = world > 1 and parts is not None
+    sharded = multi and parts is not None
 
     def step():
         if sharded:  # the function tests/test_multiproc_gloo.py drives with gloo: partition -> plan -> gather -> merge
@@ -248,7 +256,7 @@ def main():
     lat = np.array([pl.queryTiming(k)[1] - pl.queryTiming(k)[0] for k in range(len(mine))]) if mine else np.zeros(0)
     per_rank = [[local_s, float(n_exp), float(len(mine))]]
     longest_ms = float(lat.max()) * 1e3 if len(lat) else 0.0
-    if world > 1:
+    if multi:
         lm = torch.tensor([longest_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(lm, op=dist.ReduceOp.MAX)
         longest_ms = float(lm.item())
@@ -285,7 +293,7 @@ def main():
         lattice = args.lattice.upper()
         if args.single:
             workload = f"C3-{lattice}: single query (2.05,..)->({queries[0][1][0]},..) on a "
-        elif args.scaling == "strong" or world == 1:
+        elif args.scaling == "strong" or not multi:
             workload = f"C4-{lattice}: {len(queries)} independent start/goal queries sharded over {world} GPU(s) ({args.shard}) on one shared "
         elif args.scaling == "weak":
             workload = f"C4-{lattice}: a stream of {len(queries)} x {world} independent start/goal queries dealt over {world} GPUs ({args.shard}; {len(queries)} per GPU) on one shared "
@@ -388,7 +396,7 @@ def main():
     # construction (a query never spans GPUs: its floor is the longest query alone); this one is what "near-linear
     # query-throughput scaling" can be read from.  One JSON line: the throughput figures ride in out["throughput"].
     thr = None
-    if world > 1 and sharded and not args.single and not args.no_throughput:
+    if multi and sharded and not args.single and not args.no_throughput:
         tq = mapgen.c4_queries(grid, origin, res, args.queries * world, rank=0)
         tparts = mdist.partition(tq, world, args.shard)
         tmine = tparts[rank]
@@ -439,7 +447,7 @@ def main():
         elif thr is not None:
             out["throughput"] = thr
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

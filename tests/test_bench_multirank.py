@@ -45,3 +45,21 @@ def test_two_ranks_sharing_one_gpu_print_one_line_with_both_phases():
     assert t["scaling"] == "strong" and t["queries_total"] == 64 and len(t["per_rank"]) == 2 and all(p["queries"] == 32 for p in t["per_rank"])
     assert sum(p["expansions_per_step"] for p in t["per_rank"]) == t["expansions_per_step"] < d["expansions_per_step"]
     assert t["tail_bound"]["longest_query_ms"] > 0 and t["ms_per_step"] >= t["tail_bound"]["longest_query_ms"] * 0.99  # a step cannot end before its longest query
+
+
+def test_one_rank_over_rccl_takes_the_multi_rank_path():
+    """The same path over the REAL back-end: backend "nccl" (= RCCL) refuses two ranks on one device, so the only way to run
+    process-group set-up, the map broadcast from a device tensor, run_sharded's barriers / all_gather and the gather of the
+    result rows through RCCL on a one-GPU box is a world of one rank (MPLX_BENCH_FORCE_DIST=1)."""
+    env = dict(os.environ, MPLX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--queries", "64", "--map", "128",
+           "--max-expand", "20000", "--max-nodes", "60000", "--cpu-seconds", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["queries_total"] == 64 and len(d["per_rank"]) == 1
+    assert d["strong"]["queries_total"] == 64 and d["strong"]["expansions_per_step"] == d["expansions_per_step"]  # one rank: the two phases hold the same stream
+    assert "RCCL" in d["config"]["parallelism"] and d["map_setup_s"]["rccl_broadcast"] >= 0
