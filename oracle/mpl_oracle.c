@@ -231,6 +231,7 @@ static void det_sincos(double x, double *sn, double *cs) {
   *sn = k == 0 ? s : k == 1 ? c : k == 2 ? -s : -c;
   *cs = k == 0 ? c : k == 1 ? -s : k == 2 ? -c : s;
 }
+void orc_det_sincos(double x, double *sn, double *cs) { det_sincos(x, sn, cs); } /* (exported for the known-answer test) */
 /* [UNVERIFIED angle normalisation of Primitive::evaluate] into [-pi, pi] by steps of 2 pi */
 static double normalize_yaw(double q) {
   const double pi = 3.141592653589793;

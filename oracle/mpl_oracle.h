@@ -118,6 +118,7 @@ void orc_primitive_build(const orc_waypoint *p, const double *u, double dt, orc_
 /* with the yaw rate of a Vec4f control input (the state carries yaw: control & ORC_YAW) */
 void orc_primitive_build_yaw(const orc_waypoint *p, const double *u, double u_yaw, double dt, orc_primitive *out);
 int orc_validate_yaw(const orc_primitive *pr, double yaw_max);
+void orc_det_sincos(double x, double *sn, double *cs); /* the fixed + - * / sequence validate_yaw evaluates sin / cos with */
 void orc_primitive_evaluate(const orc_primitive *pr, double t, orc_waypoint *out);
 double orc_primitive_max_vel(const orc_primitive *pr, int k);
 double orc_primitive_max_acc(const orc_primitive *pr, int k);

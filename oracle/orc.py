@@ -149,6 +149,7 @@ def lib():
         L.orc_validate_primitive.argtypes = [C.POINTER(Primitive), C.c_double, C.c_double, C.c_double]
         L.orc_primitive_build_yaw.argtypes = [C.POINTER(Waypoint), C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(Primitive)]
         L.orc_validate_yaw.argtypes = [C.POINTER(Primitive), C.c_double]
+        L.orc_det_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_waypoint_key.argtypes = [C.POINTER(Waypoint), C.POINTER(C.c_int32)]
         L.orc_poly_roots_above.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_double, C.POINTER(C.c_double)]
         _lib = L

@@ -186,3 +186,30 @@ def test_lpastar_over_yaw_states_is_refused(simple_map):
     pl.setLPAstar(True)
     with pytest.raises(MplxError):
         pl.plan(util.gpu_wp(SIMPLE_START, yaw=0.0), util.gpu_wp(SIMPLE_GOAL, yaw=0.0))
+
+
+def test_deterministic_sincos_is_accurate_and_validate_yaw_follows_its_definition():
+    """det_sincos (the one + - * / sequence the oracle and the device both evaluate, so that `d < cos(yaw_max)` falls the
+    same way on host and GPU) against libm over [-4 pi, 4 pi]; validate_yaw against its definition on hand-built
+    primitives: heading along the motion passes, across it fails, a resting end is not tested, yaw_max <= 0 tests nothing."""
+    L = orc.lib()
+    sn, cs = orc.C.c_double(), orc.C.c_double()
+    worst = 0.0
+    for x in np.linspace(-4 * np.pi, 4 * np.pi, 20001):
+        L.orc_det_sincos(float(x), orc.C.byref(sn), orc.C.byref(cs))
+        worst = max(worst, abs(sn.value - np.sin(x)), abs(cs.value - np.cos(x)))
+    assert worst < 3e-16
+
+    def prim(vel, u, yaw, u_yaw):
+        w = orc.waypoint((0, 0, 0), vel=vel, yaw=yaw)
+        p = orc.Primitive()
+        L.orc_primitive_build_yaw(orc.C.byref(w), (orc.C.c_double * 3)(*u), float(u_yaw), 1.0, orc.C.byref(p))
+        return p
+
+    assert L.orc_validate_yaw(orc.C.byref(prim((1, 0, 0), (0, 0, 0), 0.0, 0.0)), 0.5) == 1       # heading = direction of motion
+    assert L.orc_validate_yaw(orc.C.byref(prim((1, 0, 0), (0, 0, 0), 0.4, 0.0)), 0.5) == 1       # 0.4 rad off: inside 0.5
+    assert L.orc_validate_yaw(orc.C.byref(prim((1, 0, 0), (0, 0, 0), 0.6, 0.0)), 0.5) == 0       # 0.6 rad off: outside
+    assert L.orc_validate_yaw(orc.C.byref(prim((1, 0, 0), (0, 0, 0), 0.4, 0.2)), 0.5) == 0       # drifts to 0.6 by the end
+    assert L.orc_validate_yaw(orc.C.byref(prim((0, 0, 0), (0, 1, 0), 0.0, 0.0)), 0.5) == 0       # starts at rest (not tested), ends moving along +y with yaw 0
+    assert L.orc_validate_yaw(orc.C.byref(prim((0, 0, 0), (0, 1, 0), 1.5, 0.0)), 0.5) == 1       # ... with yaw ~ pi / 2
+    assert L.orc_validate_yaw(orc.C.byref(prim((0, 1, 0), (0, 0, 0), 0.0, 0.0)), -1.0) == 1      # no threshold
