@@ -187,7 +187,35 @@ static void check_cell_quantisation(int iters) {
   }
 }
 
+// yaw: the product's det_sincos / yaw_end_ok (mplx_math.h) against the oracle's (orc_det_sincos, orc_validate_yaw): the same
+// sequence of operations, so the validate_yaw decision falls the same way on host and device
+static void check_yaw(int iters) {
+  for (int it = 0; it < iters; it++) {
+    const double x = (it % 11 == 0) ? special((int)(rnd() % 12)) : uni(-13.0, 13.0);
+    double s0, c0, s1, c1;
+    det_sincos(x, &s0, &c0);
+    orc_det_sincos(x, &s1, &c1);
+    CHECK(same(s0, s1) && same(c0, c1), "det_sincos(%.17g)", x);
+    // one ACC primitive with a yaw channel: validate_yaw == both ends through yaw_end_ok
+    orc_waypoint w;
+    memset(&w, 0, sizeof(w));
+    w.control = ORC_ACC | ORC_YAW;
+    for (int i = 0; i < 3; i++) { w.pos[i] = uni(-2, 2); w.vel[i] = round(uni(-2, 2) * 10) / 10; }
+    w.yaw = uni(-3.1, 3.1);
+    const double u[3] = {(double)((int)(rnd() % 3) - 1), (double)((int)(rnd() % 3) - 1), 0.0}, uy = ((int)(rnd() % 3) - 1) * 0.5, T = 1.0, ymax = uni(0.1, 1.2);
+    orc_primitive pr;
+    orc_primitive_build_yaw(&w, u, uy, T, &pr);
+    double sm, cm;
+    det_sincos(ymax, &sm, &cm);
+    const double yaw1 = normalize_yaw((uy * T + 0.0) + w.yaw);
+    const bool ok = yaw_end_ok(vel_at_c<CTRL_ACC>(pr.c[0], 0.0), vel_at_c<CTRL_ACC>(pr.c[1], 0.0), normalize_yaw(w.yaw + 0.0), cm) &&
+                    yaw_end_ok(vel_at_c<CTRL_ACC>(pr.c[0], T), vel_at_c<CTRL_ACC>(pr.c[1], T), yaw1, cm);
+    CHECK(ok == (orc_validate_yaw(&pr, ymax) != 0), "validate_yaw yaw %.17g uy %g ymax %.17g", w.yaw, uy, ymax);
+  }
+}
+
 int main() {
+  check_yaw(200000);
   check_cell_quantisation(1000000);
   check_control<CTRL_VEL>(20000);
   check_control<CTRL_ACC>(20000);
