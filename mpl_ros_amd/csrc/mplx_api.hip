@@ -1064,9 +1064,9 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   HIPCHK(c, hipMemsetAsync(P.chunk_next, 0, 4 * sizeof(uint32_t), c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), c->stream));
-  // (the potential-field / search-region cost is read by the one-node kernels only)
-  // ... and so are yaw-carrying states
-  const bool spec = (c->speculation < 0 || c->speculation > 1) && !c->aux && !c->yaw;
+  // (yaw-carrying states run on the one-node kernels; a potential field / search region on the POT build of the
+  //  speculative kernel for ACC lattices of at most 32 inputs -- mplx_launch_spec decides -- without helper workgroups)
+  const bool spec = (c->speculation < 0 || c->speculation > 1) && !c->yaw;
   // Helper workgroups: a workgroup with no query (left) to lead expands the front of a running leader's OPEN list ahead
   // of time.  The launch holds one workgroup per compute unit at most, so all of them are resident together: for a
   // batch smaller than the machine the extra workgroups (blockIdx.x >= help_lead) help from the start; in a large
@@ -1074,7 +1074,7 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   int grid = slots;
   P.help_lead = slots;
   P.help_max = 0;
-  const bool help = spec && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
+  const bool help = spec && !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
                     ((P.n_u <= 31 && (P.control == CTRL_ACC || P.control == CTRL_JRK)) || (P.control == CTRL_JRK && P.n_u > 64 && P.n_u <= 128));
   if (help) {
     P.help_max = c->helpers < 0 ? 2 : c->helpers;
@@ -1149,7 +1149,8 @@ extern "C" uint64_t mplx_plan_epoch(const mplx_ctx *c) { return c ? c->plan_epoc
 extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
   if (!c || !c->have_cfg) return "";
   const int control = c->cfg.control, n_u = c->cfg.n_u;
-  const bool spec = (c->speculation < 0 || c->speculation > 1) && (control == CTRL_ACC || control == CTRL_JRK) && n_u <= 128 && !c->aux && !c->yaw;
+  const bool spec = (c->speculation < 0 || c->speculation > 1) && (control == CTRL_ACC || control == CTRL_JRK) && n_u <= 128 && !c->yaw &&
+                    (!c->aux || (control == CTRL_ACC && n_u <= 32));
   static thread_local char buf[64];
   const char *cn = control == CTRL_VEL ? "VEL" : control == CTRL_ACC ? "ACC" : control == CTRL_JRK ? "JRK" : "SNP";
   if (!spec) {
@@ -1161,9 +1162,10 @@ extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
     else if (n_u <= 64) { ul = 64; k = 4; }
     else if (c->speculation == 2) { ul = 128; k = 2; }
     else { ul = 128; k = 4; }
-    const bool help = (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 &&
+    if (c->aux) { ul = 32; k = 16; }
+    const bool help = !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 &&
                       ((ul == 32 && k == 16 && n_u <= 31) || (ul == 128 && k == 4 && control == CTRL_JRK && n_u > 64));
-    snprintf(buf, sizeof(buf), help ? "astar_spec_kernel<%d,%d,%s,help>" : "astar_spec_kernel<%d,%d,%s>", ul, k, cn);
+    snprintf(buf, sizeof(buf), c->aux ? "astar_spec_kernel<%d,%d,%s,pot>" : help ? "astar_spec_kernel<%d,%d,%s,help>" : "astar_spec_kernel<%d,%d,%s>", ul, k, cn);
   }
   return buf;
 }

@@ -222,6 +222,7 @@ struct Smem {
   unsigned long long c_expanded, c_closed, c_prims, c_succ, c_succ_finite, c_reads, c_push, c_reopen, c_refill, c_evict, c_hash;
   unsigned long long cyc[10];
   double cur_yaw[KUNITS];  // yaw of the node(s) being expanded (yaw-carrying searches)
+  __device__ __forceinline__ uint32_t *pot_scratch() { return (uint32_t *)dupset; }
 };
 
 #define MPLX_TIC(var) const unsigned long long var = __builtin_readcyclecounter()
@@ -353,12 +354,11 @@ struct NoHook {
 template <int UL, int BLOCK, int CONTROL, bool CACHE = false, bool POT = false, bool YAW = false, class SM, class Hook = NoHook>
 __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int tid, bool live_unit, LaneSucc &L, Hook after_phase1 = Hook()) {
   constexpr int NQ = nq_c(CONTROL);
-  static_assert(!POT || UL == BLOCK, "the potential sum lives in the one-unit kernels' scratch");
   const int8_t *__restrict__ aux = nullptr;
-  uint32_t *pots = nullptr;  // per-primitive potential sums: the commit's duplicate-key set is idle during the expansion
-  if constexpr (POT) {
+  uint32_t *pots = nullptr;  // per-primitive potential sums, one word per lane, in LDS that is idle during the expansion
+  if constexpr (POT) {       // (the one-unit kernels: the commit's duplicate-key set; the speculative kernels: a batch-table column)
     aux = P.map.aux;
-    pots = (uint32_t *)S.dupset;
+    pots = S.pot_scratch();
     if (aux) pots[tid] = 0;
   }
   const int ku = tid / UL, lu = tid % UL;

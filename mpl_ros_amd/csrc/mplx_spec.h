@@ -52,6 +52,9 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   uint32_t bt_leader[BT];  // smallest thread index sharing the entry (= first in commit order)
   uint32_t bt_id[BT], bt_flags[BT], bt_pred[BT], bt_dirty[BT];
   uint32_t bt_share[BT];   // lanes besides the leader that reach the entry: count << 16 | (sum of their thread indices); bit 31: a candidate of the batch
+  // (potential-field searches) the per-lane potential sums of the expansion live in bt_share, which is idle until the
+  // batch table is rebuilt after the expansion (BT >= BLOCK lanes)
+  __device__ __forceinline__ uint32_t *pot_scratch() { static_assert(BT >= UL * K, "one word per lane"); return bt_share; }
   unsigned long long bt_tslot[BT];
   double bt_g[BT], bt_h[BT];
   int32_t lane_key[UL * K][NK];
@@ -171,7 +174,7 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
     EdgeRec *e = Q.edge(eidx);
     e->parent = S.cand_id[kc];
     e->next = chain_next;
-    e->action = (uint32_t)lu;
+    e->action = (uint32_t)lu | (L.pot << EDGE_POT_SHIFT);  // control input | potential sum of the primitive's samples (0 without a potential field)
     if (PAR) {
       if (write_pred) V::pred(Q.node(id)) = eidx;  // nobody else modifies this state in the batch
     } else {
@@ -452,8 +455,12 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
   }
 }
 
-template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false>
+// POT: the auxiliary map (potential field / search region, MapDev::aux) is read next to the occupancy and the edge cost is
+// ucost + pot_weight * (sum of the potential over the primitive's samples): per lane, carried in the predecessor record
+// like in the one-node kernel.  Without helper workgroups (their cache rows carry no potential sums).
+template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false, bool POT = false>
 __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
+  static_assert(!(HELP && POT), "the look-ahead cache rows carry no potential sums");
   constexpr int BLOCK = UL * K;
   using SM = SmemSpec<UL, K, CONTROL, BTN, NCAP_>;
   constexpr int BT = SM::BT;
@@ -906,7 +913,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         // its voxels are sampled (a blocked successor wastes one load), consumed after the batch table is built
         unsigned long long h64 = 0, v0 = TBL_EMPTY;
         size_t pos0 = 0;
-        expand_unit<UL, BLOCK, CONTROL, HELP>(P, S, tid, live_unit, L, [&](const LaneSucc &l) {
+        expand_unit<UL, BLOCK, CONTROL, HELP, POT>(P, S, tid, live_unit, L, [&](const LaneSucc &l) {
           if (l.valid && !l.blocked) {
             h64 = key_hash64(l.key, nk);
             pos0 = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
@@ -1096,7 +1103,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         if (act) {
           const bool nw = S.bt_id[my_slot] == NIL;
           const double hv = S.bt_h[my_slot];
-          pre.tg = S.cand_g[ku] + P.ucost[lu];
+          pre.tg = S.cand_g[ku] + ((POT && P.map.aux) ? P.ucost[lu] + P.pot_weight * (double)L.pot : P.ucost[lu]);
           pre.pf = pre.tg + P.eps * hv;
           if (pre.pf != pre.pf) pre.pf = INFINITY;
           // a state created by this batch gets an id above every existing one: ties on (f, g) never favour it
@@ -1312,12 +1319,13 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           for (uint32_t e = V::pred(Q.node(node)); e != NIL; e = Q.edge(e)->next) {
             const EdgeRec er = *Q.edge(e);
             double gp = V::g(Q.node(er.parent));
-            double rhs = gp + P.ucost[er.action];
+            const double ec = (POT && P.map.aux) ? P.ucost[er.action & EDGE_ACTION_MASK] + P.pot_weight * (double)(er.action >> EDGE_POT_SHIFT) : P.ucost[er.action & EDGE_ACTION_MASK];
+            double rhs = gp + ec;
             if (rhs < min_rhs || (rhs == min_rhs && gp >= min_g)) { min_rhs = rhs; min_g = gp; best = e; }
           }
           if (best == NIL) { ok = false; break; }
           if (len >= MAX_TRAJ) { too_long = true; break; }
-          ta[len] = (int32_t)Q.edge(best)->action;
+          ta[len] = (int32_t)(Q.edge(best)->action & EDGE_ACTION_MASK);
           node = Q.edge(best)->parent;
           len++;
           tn[len] = (int32_t)node;

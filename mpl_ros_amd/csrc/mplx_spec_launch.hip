@@ -16,8 +16,15 @@ static void launch_spec(int control, int grid, hipStream_t s, const SearchParams
 }
 
 // speculation: -1 / >1 = widest variant for the lattice; 8, 4, 2 = narrower variants (A/B measurements)
+// P.map.aux (potential field / search region): the POT build of the <= 32-input ACC variant (the distance-map planner's
+// lattices); anything else with an auxiliary map is left to the one-node kernel (return false)
 bool mplx_launch_spec(int speculation, int grid, hipStream_t s, const SearchParams &P) {
   if (!(P.control == CTRL_ACC || P.control == CTRL_JRK) || P.n_u > 128) return false;  // built for the reference's lattices
+  if (P.map.aux) {
+    if (P.control != CTRL_ACC || P.n_u > 32) return false;
+    hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024, false, true>), dim3(grid), dim3(512), 0, s, P);
+    return true;
+  }
   if (P.n_u <= 32 && speculation == 8)
     launch_spec<64, 8, 512, 512>(P.control, grid, s, P);     // 8 units of one wave each
   else if (P.n_u <= 32)

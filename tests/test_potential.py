@@ -149,7 +149,15 @@ def test_hip_distance_map_planner_flow_matches_the_oracle():
     assert n_pot > 20  # the potential term really is in play
     r, c = util.compare_plan(Q, p2, (START, (0, 0, 0)), (GOAL,), orc.ACC)
     assert r.status == 0 and r.cost > P.traj_cost
-    assert p2.kernelName().startswith("astar_kernel")  # the cost terms are read by the one-node kernel
+    assert p2.kernelName() == "astar_spec_kernel<32,16,ACC,pot>"  # the POT build of the speculative kernel (9-input ACC lattice)
+    p2.plan(util.gpu_wp(START, vel=(0, 0, 0)), util.gpu_wp(GOAL))  # (a second launch: the first one pays the code load)
+    ms_spec = p2.lastKernelMs()
+    p2.setSpeculation(0)  # ... and the one-node kernel: the same search, whole state space
+    r1, _ = util.compare_plan(Q, p2, (START, (0, 0, 0)), (GOAL,), orc.ACC)
+    assert p2.kernelName().startswith("astar_kernel<") and (r1.cost, r1.n_expanded, r1.expand_hash) == (r.cost, r.n_expanded, r.expand_hash)
+    p2.plan(util.gpu_wp(START, vel=(0, 0, 0)), util.gpu_wp(GOAL))
+    print(f"potential-field plan, {r.n_expanded} expansions: speculative kernel {ms_spec:.3f} ms, one-node kernel {p2.lastKernelMs():.3f} ms")
+    p2.setSpeculation(-1)
     # getSearchRegion / getPotentialCloud
     a = Q.aux_map()[0]
     reg = p2.getSearchRegion()
