@@ -12,6 +12,11 @@ using namespace mplx;
 // Returns false when no helper-capable variant exists for the configuration.
 bool mplx_launch_spec_help(int grid, hipStream_t s, const SearchParams &P) {
   if (!(P.control == CTRL_ACC || P.control == CTRL_JRK) || !P.boxes) return false;
+#ifdef MPLX_ONLY_ACC  // (A/B builds of the 27-input ACC kernel only: tools/build_kernel_variant.sh)
+  if (P.control != CTRL_ACC || P.n_u > 31) return false;
+  hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024, true>), dim3(grid), dim3(512), 0, s, P);
+  return true;
+#else
   if (P.control == CTRL_JRK && P.n_u > 64 && P.n_u <= 128) {
     hipLaunchKernelGGL((astar_spec_kernel<128, 4, CTRL_JRK, 1024, 1024, true>), dim3(grid), dim3(512), 0, s, P);
     return true;
@@ -22,4 +27,5 @@ bool mplx_launch_spec_help(int grid, hipStream_t s, const SearchParams &P) {
   else
     hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_JRK, 1024, 1024, true>), dim3(grid), dim3(512), 0, s, P);
   return true;
+#endif
 }

@@ -225,8 +225,30 @@ struct Smem {
   __device__ __forceinline__ uint32_t *pot_scratch() { return (uint32_t *)dupset; }
 };
 
+// Per-phase cycle counters of the search kernels (mplx_result_cycles): s_memtime + a 64-bit LDS add on thread 0 at every
+// phase boundary sit on the serial chain of a query (about eight per batch, ~1 k cycles of 41 k), so the product build
+// leaves them out and reports zeros for the time fields (the event counts -- batches, look-ahead hits -- stay);
+// -DMPLX_PHASE_TIMERS=1 (tools/build_variant.sh timers) puts them back.
+#ifndef MPLX_PHASE_TIMERS
+#define MPLX_PHASE_TIMERS 0
+#endif
+#if MPLX_PHASE_TIMERS || defined(MPLX_LOOKUP_TIMERS) || defined(MPLX_FINE_TIMERS)
 #define MPLX_TIC(var) const unsigned long long var = __builtin_readcyclecounter()
 #define MPLX_TOC(S, k, var) do { if (threadIdx.x == 0) (S).cyc[k] += __builtin_readcyclecounter() - (var); } while (0)
+#else
+#define MPLX_TIC(var) [[maybe_unused]] constexpr unsigned long long var = 0ull
+#define MPLX_TOC(S, k, var) do { } while (0)
+#endif
+
+// The value, made opaque to the optimiser (no instruction).  The search kernels sit at their register limit, and the
+// compiler hoists the LDS addresses of small per-lane arrays (&S.x[tid]: one add) out of the batch loop, then spills them:
+// every use became a scratch load plus s_waitcnt vmcnt(0) -- a wait for everything the wave has in flight -- on the serial
+// chain of a query (five in a row in the batch set-up, four in the cut evaluation: ~2 k cycles each section).  An index
+// that went through here is recomputed where it is used instead.
+__device__ __forceinline__ int opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 
 template <int BLOCK, class SM>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, SM &S, int tid, uint32_t &total) {
@@ -342,6 +364,12 @@ struct LaneSucc {
 struct NoHook {
   __device__ __forceinline__ void operator()(const LaneSucc &) const {}
 };
+// control input `lu`, axis `ax`: from LDS in the kernels that stage the lattice there (SmemSpec::u_lds: P.U is a global
+// load at the head of every expansion otherwise -- an L2 round trip on a query's serial chain), from P.U elsewhere
+template <class SM>
+__device__ __forceinline__ auto lane_u(const SM &S, const SearchParams &, int lu, int ax, int) -> decltype((void)S.u_lds, double()) { return S.u_lds[ax][lu]; }
+template <class SM>
+__device__ __forceinline__ double lane_u(const SM &, const SearchParams &P, int lu, int ax, long) { return P.U[3 * lu + ax]; }
 // `after_phase1(L)` runs once the successor state and key of the lane's primitive are known (L.valid),
 // before the voxel sampling: the caller can start memory traffic that depends on the key only.
 // CACHE: units whose S.hc_row is non-zero take validity / blocked flags from the look-ahead cache entry
@@ -375,9 +403,8 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
   uint32_t my_cnt = 0, my_pairs = 0;
   if (live_unit && lu < P.n_u) {
     double c[3][6];
-    const double *u = P.U + 3 * lu;
 #pragma unroll
-    for (int ax = 0; ax < 3; ax++) prim_build_axis(CONTROL, S.cur[ku][ax], S.cur[ku][3 + ax], S.cur[ku][6 + ax], S.cur[ku][9 + ax], u[ax], c[ax]);
+    for (int ax = 0; ax < 3; ax++) prim_build_axis(CONTROL, S.cur[ku][ax], S.cur[ku][3 + ax], S.cur[ku][6 + ax], S.cur[ku][9 + ax], lane_u(S, P, lu, ax, 0), c[ax]);
 #pragma unroll
     for (int ax = 0; ax < 3; ax++) {
       L.tn.p[ax] = pos_at_c<CONTROL>(c[ax], T);

@@ -24,6 +24,21 @@
 #define MPLX_T2(S, k, var) do { } while (0)
 #endif
 
+// Switches of the leader's batch loop (tools/build_kernel_variant.sh builds A/B variants with -DMPLX_X_...=0); the values
+// here are the product configuration.
+#ifndef MPLX_X_LDS_CONST
+#define MPLX_X_LDS_CONST 1    // control inputs, edge costs in LDS; goal test against the LDS copy of the goal
+#endif
+#ifndef MPLX_X_EARLY_SETUP
+#define MPLX_X_EARLY_SETUP 1  // next batch's set-up (resets, chunk capacity, helper announcement) inside the end-of-batch bookkeeping
+#endif
+#ifndef MPLX_X_EARLY_ROW
+#define MPLX_X_EARLY_ROW 1    // look-ahead cache row (heuristics, voxel-read count) requested as soon as the row is known
+#endif
+#ifndef MPLX_X_EARLY_CLEAR
+#define MPLX_X_EARLY_CLEAR 1  // batch table cleared by the idle waves of the end-of-batch bookkeeping
+#endif
+
 namespace mplx {
 
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain
@@ -82,6 +97,10 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   uint32_t n_work;
   uint32_t work[WISH];          // pool indices of the node records to expand ahead of time
   unsigned long long wish_l[WISH];
+#if MPLX_X_LDS_CONST
+  double u_lds[3][UL];   // P.U by axis (expand_unit: lane_u)
+  double ucost_lds[UL];  // P.ucost
+#endif
 #ifdef MPLX_LOOKUP_TIMERS
   unsigned long long cyc2[24];
   unsigned long long cycw[16][4];
@@ -473,6 +492,10 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   fill_uq<BLOCK, CONTROL>(P, S, tid);
+#if MPLX_X_LDS_CONST
+  for (int i = tid; i < 3 * P.n_u; i += BLOCK) S.u_lds[i % 3][i / 3] = P.U[i];
+  for (int i = tid; i < P.n_u; i += BLOCK) S.ucost_lds[i] = P.ucost[i];
+#endif
   if (tid == 0) {
     unsigned long long pw = 1ull;
     for (int e = 0; e < 17; e++) { S.hpow[e] = pw; pw *= 0x100000001B3ull; }
@@ -590,6 +613,69 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       // stored at the top of the NEXT iteration -- nothing walks a far list before that -- so the round trip
       // overlaps the end-of-batch bookkeeping instead of being waited for
       uint32_t pend_idx = NIL, pend_old = NIL;
+#if MPLX_X_EARLY_SETUP
+      // Set-up of a batch, run inside the end-of-batch bookkeeping of the batch before it (and once before the first):
+      // the workgroup is waiting for thread 0's counters there anyway, so the resets (wave 0, after its own reads of what
+      // they reset), the chunk capacity for everything the batch can create (one pool per wave 1-3) and the sampling of
+      // the helper flag (an agent-scope load, every eighth batch) cost nothing on the chain, and the barrier that used
+      // to follow them at the head of the batch is gone.  Pool exhaustion is noticed one barrier earlier than before and
+      // ends the query at the same point (nothing of the batch that lacked room was ever committed).
+      auto batch_setup = [&](unsigned long long n_expanded_now) {
+        if (tid < K) {
+          const int t = opaque(tid);
+          S.cand_live[t] = 0;
+          S.unit_seq[t] = 0;
+          S.cur_slot[t] = NIL;
+          S.u_succ[t] = S.u_fin[t] = S.u_reads[t] = 0;
+          S.u_goal[t] = 0;
+          S.u_cut[t] = K;
+          if constexpr (HELP) S.hc_row[t] = 0;
+        }
+        if (tid == 0) {
+          if (S.status < 0) S.cyc[7]++;  // batches
+          S.n_cand = 0;
+          S.cut_at = K;
+          S.batch_dep = 0;
+          S.any_shared = 0;
+          S.dep_cause = 0;
+          if constexpr (HELP) {
+            // announce the wish list written during the batch that just ended (complete: a __syncthreads() lies between)
+            if (S.helped && S.box_seq) {
+              HelpBox *box = P.boxes + blockIdx.x;
+              st_u64(&box->n_expanded, n_expanded_now);
+              st_u64(&box->seq, ((unsigned long long)P.epoch << 32) | (S.box_seq + 1ull));
+            }
+          }
+        } else if ((tid & 63) == 0 && tid < 256) {  // chunk capacity for everything the batch can create: one pool per wave
+          const uint32_t room = (uint32_t)(K * P.n_u + K);
+          bool ok;
+          if (tid == 64)
+            ok = ensure_chunks(S.node_tbl, S.node_chunks, S.n_nodes + room, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks);
+          else if (tid == 128)
+            ok = ensure_chunks(S.edge_tbl, S.edge_chunks, S.n_edges + room, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks);
+          else
+            ok = ensure_chunks(S.open_tbl, S.open_chunks, S.n_log + room, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
+          if (!ok && S.status < 0) S.status = 4;  // MPLX_PLAN_POOL_FULL
+          if constexpr (HELP) {  // (thread 0 increments the batch count next to this read: two consecutive values, so that one is seen)
+            if (tid == 64 && (S.cyc[7] & 7ull) <= 1ull) S.helped = ld_u32(&(P.boxes + blockIdx.x)->helpers) != 0u;
+          }
+        }
+#if MPLX_X_EARLY_CLEAR
+        if constexpr (!POT) {  // the batch table, by the upper half of the workgroup (idle here)
+          if (tid >= BLOCK / 2) {
+            for (int i = opaque(tid - BLOCK / 2); i < BT; i += BLOCK / 2) {
+              S.bt_hash[i] = 0ull;
+              S.bt_leader[i] = NIL;
+              S.bt_dirty[i] = 0;
+              S.bt_share[i] = 0;
+            }
+          }
+        }
+#endif
+      };
+      batch_setup(0ull);
+      __syncthreads();
+#endif
       for (;;) {
         if (pend_idx != NIL) {
           Q.open(pend_idx)->next = pend_old;
@@ -626,6 +712,22 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         }
         MPLX_T2(S, 16, t3);
         // ---- 1. the K smallest OPEN entries, in order
+#if MPLX_X_EARLY_SETUP
+        // (the batch's set-up -- resets, chunk capacity, helper announcement -- was done by the end-of-batch bookkeeping
+        // of the previous batch, or by the prologue: batch_setup below; no barrier here)
+#ifdef MPLX_HELP_DEBUG
+        if (HELP && tid == 0) {  // longest time between two batch starts of this slot, when (since the query began), of which query, helped or not
+          HelpBox *box = P.boxes + blockIdx.x;
+          const unsigned long long now = wall_clock64(), gap = now - S.dbg_t;
+          S.dbg_t = now;
+          if (gap > S.dbg_gap) { S.dbg_gap = gap; S.dbg_when = ((now - t_begin) << 1) | (S.helped ? 1ull : 0ull); }
+          if (gap > 1000000ull) {  // > 10 ms: leave a record right away
+            if (gap > box->pad1[0]) { box->pad1[0] = gap; box->pad1[1] = S.dbg_when; box->pad1[2] = (unsigned long long)q; box->pad1[3] = S.cyc[7]; }
+          }
+        }
+#endif
+        MPLX_T2(S, 17, t3);
+#else
         if (tid == 0) {
           S.cyc[7]++;  // batches
           S.n_cand = 0;
@@ -675,6 +777,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         }
         __syncthreads();
         MPLX_T2(S, 17, t3);
+#endif
         // Look-ahead cache records of the LIKELY candidates, issued before the ranking so that their (agent-scope,
         // always-missing) loads overlap it: the head of the sorted prefix is almost always what the ranking selects
         // (fresh pushes rarely enter the top K); a candidate that turns out different is looked up in 2a as before.
@@ -845,7 +948,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             if (S.helped && tid < WISH) {
               unsigned long long v = ~0ull;
               if ((uint32_t)tid < n - kc) v = ((unsigned long long)(uint32_t)q << 48) | (unsigned long long)Q.node_rec(S.near_id[tid]);
-              st_u64(&(P.boxes + blockIdx.x)->wish[S.box_seq & 1ull][tid], v);
+              st_u64(&(P.boxes + blockIdx.x)->wish[S.box_seq & 1ull][opaque(tid)], v);
               if (tid == 0) S.box_seq++;
             }
           }
@@ -876,12 +979,13 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
           live_unit = __double_as_longlong(rg) == __double_as_longlong(S.cand_g[ku]) && !(fl & FLAG_CLOSED);
           if (live_unit) {
-            if (lu <= ns) S.cur[ku][lu < ns ? lu : 12] = sval;
-            if (lu >= ns && lu < 12) S.cur[ku][lu] = 0.0;
-            if (lu < nk) S.cur_key[ku][lu] = kval;
-            if (lu == 0) {
-              S.cand_live[ku] = 1;
-              S.cand_fl[ku] = fl;
+            const int ko = opaque(ku), lo = opaque(lu);
+            if (lo <= ns) S.cur[ko][lo < ns ? lo : 12] = sval;
+            if (lo >= ns && lo < 12) S.cur[ko][lo] = 0.0;
+            if (lo < nk) S.cur_key[ko][lo] = kval;
+            if (lo == 0) {
+              S.cand_live[ko] = 1;
+              S.cand_fl[ko] = fl;
             }
           }
         }
@@ -890,7 +994,11 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         if (live_unit && lu == 0) {  // goal test of the candidate (applied when, and if, it is committed)
           State sgoal;
           for (int i = 0; i < 12; i++) ((double *)&sgoal)[i] = S.cur[ku][i];
+#if MPLX_X_LDS_CONST
+          S.u_goal[ku] = (S.cur[ku][12] >= P.t_max || is_goal_state(sgoal, S.hp.goal, S.hp.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) ? 1 : 0;
+#else
           S.u_goal[ku] = (S.cur[ku][12] >= P.t_max || is_goal_state(sgoal, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) ? 1 : 0;
+#endif
         }
         if constexpr (HELP) {
           // did a helper expand this node ahead of time?  The entry must be of THIS state: the helper's hash of the
@@ -904,6 +1012,22 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
         }
         unit_sync<UL>();
+        // the helper's row of a cached candidate -- the heuristics of its successors, the voxel-read count -- is asked
+        // for now (agent-scope loads: always a trip to memory) so that it travels during the expansion; used in 2b / 2c
+        [[maybe_unused]] double h_row = 0.0;
+        [[maybe_unused]] unsigned long long reads_row = 0ull;
+#if MPLX_X_EARLY_ROW
+        if constexpr (HELP) {
+          const uint32_t rp1 = live_unit ? S.hc_row[ku] : 0u;
+          if (rp1) {
+            const double *row = P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL);
+            bool want = lu < P.n_u && P.eps != 0.0;
+            if constexpr (UL <= 64) want = want && (((S.hc_valid[ku] & ~S.hc_blocked[ku]) >> lu) & 1u);
+            if (want) h_row = ld_f64_agent(&row[cache_h_slot(UL, lu)]);
+            if (lu == 0) reads_row = ld_u64((const unsigned long long *)&row[cache_reads_slot(UL)]);
+          }
+        }
+#endif
         MPLX_T2(S, 21, t3);
         MPLX_TOC(S, 0, tp);
         // ---- 2b. expand all live units concurrently
@@ -929,7 +1053,11 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             S.u_succ[ku] = tot & 0x3FFu;
             S.u_fin[ku] = tot >> 10;
             if (HELP && S.hc_row[ku] != 0u)  // voxel reads of the expansion as the helper counted them (slot 31 of its row)
+#if MPLX_X_EARLY_ROW
+              S.u_reads[ku] = (uint32_t)reads_row;
+#else
               S.u_reads[ku] = (uint32_t)ld_u64((const unsigned long long *)&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)]);
+#endif
             else
               S.u_reads[ku] = treads;
           }
@@ -940,11 +1068,16 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         MPLX_TIC(tc);
         [[maybe_unused]] unsigned long long t2 = __builtin_readcyclecounter();
         int my_slot = 0;
-        for (int i = tid; i < BT; i += BLOCK) {
-          S.bt_hash[i] = 0ull;
-          S.bt_leader[i] = NIL;
-          S.bt_dirty[i] = 0;
-          S.bt_share[i] = 0;
+        // (the table was cleared by the idle waves of the previous batch's bookkeeping -- batch_setup -- unless the
+        // expansion borrowed a column for the potential sums)
+        constexpr bool CLEAR_HERE = !(MPLX_X_EARLY_SETUP && MPLX_X_EARLY_CLEAR) || POT;
+        if constexpr (CLEAR_HERE) {
+          for (int i = tid; i < BT; i += BLOCK) {
+            S.bt_hash[i] = 0ull;
+            S.bt_leader[i] = NIL;
+            S.bt_dirty[i] = 0;
+            S.bt_share[i] = 0;
+          }
         }
         if (act) {
 #pragma unroll
@@ -955,7 +1088,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         if ((tid & 63) == 0) S.cycw[tid >> 6][0] += __builtin_readcyclecounter() - tx;
         unsigned long long tw = 0;
 #endif
-        __syncthreads();
+        if constexpr (CLEAR_HERE) __syncthreads();
         MPLX_T2(S, 0, t2);
         if (act) {
           const unsigned long long hv = h64 | 1ull;
@@ -1015,7 +1148,11 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
               // look-ahead cache hit: the heuristic of this successor is in the helper's row (written before the
               // cache record was, read after it)
               if (HELP && S.hc_row[ku] != 0u)
+#if MPLX_X_EARLY_ROW
+                hspec = h_row;
+#else
                 hspec = ld_f64_agent(&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * cache_row_doubles(UL) + cache_h_slot(UL, lu)]);
+#endif
               else
                 hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
             }
@@ -1103,7 +1240,12 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         if (act) {
           const bool nw = S.bt_id[my_slot] == NIL;
           const double hv = S.bt_h[my_slot];
-          pre.tg = S.cand_g[ku] + ((POT && P.map.aux) ? P.ucost[lu] + P.pot_weight * (double)L.pot : P.ucost[lu]);
+#if MPLX_X_LDS_CONST
+          const double uc = S.ucost_lds[lu];
+#else
+          const double uc = P.ucost[lu];
+#endif
+          pre.tg = S.cand_g[ku] + ((POT && P.map.aux) ? uc + P.pot_weight * (double)L.pot : uc);
           pre.pf = pre.tg + P.eps * hv;
           if (pre.pf != pre.pf) pre.pf = INFINITY;
           // a state created by this batch gets an id above every existing one: ties on (f, g) never favour it
@@ -1154,7 +1296,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           // (every wave evaluates this redundantly: lane k holds unit k, ballots make the result uniform)
           int st_after = -1;
           {
-            const int l = tid & 63;
+            const int l = opaque(tid & 63);
             const bool inb = l < K && l < n_cand;
             const bool lvk = inb && S.cand_live[inb ? l : 0] != 0;
             const int uck = lvk ? S.u_cut[l] : K;
@@ -1185,7 +1327,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
               n_commit = __popcll(livem);
             }
           }
-          const bool mine = ku < k_stop && S.cand_live[ku < K ? ku : 0];
+          const bool mine = ku < k_stop && S.cand_live[opaque(ku)];
           if (mine && lu == 0) V::flags(Q.node(S.cand_id[ku])) = S.cand_fl[ku] | FLAG_CLOSED;
           MPLX_T2(S, 8, t2);
           __syncthreads();  // everyone has read status / u_cut before they change
@@ -1244,7 +1386,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         __syncthreads();
         MPLX_T2(S, 12, t2);
         if (tid < 64) {  // counters of the committed units, in commit order; lane k holds unit k
-          const int l = tid;
+          const int l = opaque(tid);
           const bool inb = l < K && l < n_cand && S.cand_live[l < K ? l : 0] != 0;
           const bool done = inb && l < k_stop;
           const bool back = inb && l >= k_stop && S.status < 0;  // behind a cut: returns to OPEN untouched
@@ -1286,6 +1428,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             if (!parallel_commit) S.cyc[8]++;  // batches that needed the unit-by-unit commit
           }
         }
+#if MPLX_X_EARLY_SETUP
+        batch_setup(S.c_expanded);  // (thread 0 reads back what it has just written; nobody else uses the argument)
+#endif
         __syncthreads();
         MPLX_T2(S, 13, t2);
         MPLX_TOC(S, 6, to);
