@@ -413,9 +413,12 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
       L.tn.j[ax] = jrk_at_c<CONTROL>(c[ax], T);
     }
     state_key_c<CONTROL>(L.tn, L.key);
-    bool same = true;
+    // (key comparisons are written without short circuit everywhere: `a && b` makes the compiler wait for each word of
+    // the other key -- an LDS or memory round trip -- before it asks for the next)
+    uint32_t kdiff = 0;
 #pragma unroll
-    for (int i = 0; i < key_len_c(CONTROL); i++) same = same && (L.key[i] == S.cur_key[ku][i]);
+    for (int i = 0; i < key_len_c(CONTROL); i++) kdiff |= (uint32_t)(L.key[i] ^ S.cur_key[ku][i]);
+    bool same = kdiff == 0u;
     bool yaw_ok = true;
     if constexpr (YAW) {
       static_assert(UL == BLOCK, "yaw-carrying states are expanded by the one-unit kernels");
@@ -1118,10 +1121,11 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
         const double rg = V::g(r), rh = V::h(r);
         const uint32_t rfl = V::flags(r), rpred = V::pred(r);
         const int32_t *kk = V::key(r);
-        bool eq = true;
+        uint32_t kd = 0;
 #pragma unroll
-        for (int i = 0; i < nk; i++) eq = eq && (kk[i] == L.key[i]);
-        if constexpr (YAW) eq = eq && kk[nk] == L.yaw_key;
+        for (int i = 0; i < nk; i++) kd |= (uint32_t)(kk[i] ^ L.key[i]);
+        if constexpr (YAW) kd |= (uint32_t)(kk[nk] ^ L.yaw_key);
+        const bool eq = kd == 0u;
         if (eq) {
           role = 1; id = vid; rec = r;
           old_g = rg; hval = rh; fl = rfl; old_pred = rpred;

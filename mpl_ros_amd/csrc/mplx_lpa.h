@@ -121,10 +121,10 @@ __device__ __forceinline__ uint32_t lpa_find(const unsigned long long *table, un
     const uint32_t vid = (uint32_t)v;
     if (vid < CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
       const int32_t *kk = (const int32_t *)(pool + (size_t)vid * rec_bytes(CONTROL) + 24);
-      bool eq = true;
+      uint32_t kd = 0;
 #pragma unroll
-      for (int i = 0; i < nk; i++) eq = eq && kk[i] == key[i];
-      if (eq) return vid;
+      for (int i = 0; i < nk; i++) kd |= (uint32_t)(kk[i] ^ key[i]);
+      if (kd == 0u) return vid;
     }
     pos = (pos + 1) & (size_t)mask;
   }
@@ -268,10 +268,10 @@ __device__ __forceinline__ void lpa_link(const QView<BLOCK, CONTROL> &Q, const L
       const uint32_t vid = (uint32_t)v;
       if (vid < CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
         const int32_t *kk = V::key(Q.node(vid));
-        bool eq = true;
+        uint32_t kd = 0;
 #pragma unroll
-        for (int i = 0; i < nk; i++) eq = eq && (kk[i] == L.key[i]);
-        if (eq) { role = 1; id = vid; break; }
+        for (int i = 0; i < nk; i++) kd |= (uint32_t)(kk[i] ^ L.key[i]);
+        if (kd == 0u) { role = 1; id = vid; break; }
       }
       pos = (pos + 1) & mask;
     }

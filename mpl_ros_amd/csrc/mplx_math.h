@@ -649,9 +649,9 @@ MPLX_HD double cal_heur(const HeurParams &hp, int control, const State &s) {
 // get_heur: 0 when the state's key equals the goal's key
 MPLX_HD double get_heur(const HeurParams &hp, int control, const State &s, const int32_t *key, int nkey) {
   if ((control & 15) == (hp.goal_control & 15) && nkey == hp.goal_nkey) {
-    bool eq = true;
-    for (int i = 0; i < nkey; i++) eq = eq && (key[i] == hp.goal_key[i]);
-    if (eq) return 0.0;
+    uint32_t diff = 0;  // (no short circuit: a chain of dependent LDS reads on the device otherwise)
+    for (int i = 0; i < nkey; i++) diff |= (uint32_t)(key[i] ^ hp.goal_key[i]);
+    if (diff == 0u) return 0.0;
   }
   return cal_heur(hp, control, s);
 }

@@ -80,6 +80,7 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   unsigned long long hpow[17];  // powers of the expansion-hash multiplier (0x100000001B3^e mod 2^64), filled once per workgroup
   double app_f[256], app_g[256];
   uint32_t app_id[256], app_rank[256];
+  uint32_t csum[2][UL * K / 64];  // per-wave totals of the parallel commit's workgroup scan, alternating between batches
   int32_t batch_dep;  // units interact through a state one of them MODIFIES -> ordered, unit-by-unit commit
   int32_t any_shared; // some state is reached by two lanes (they only append predecessor edges unless batch_dep)
   int32_t dep_cause;  // (debug statistics) 1 shared successor, 2 candidate is a successor, 4 a sharer modifies the state
@@ -122,7 +123,7 @@ struct LanePre {   // per-lane values of the ordered commit that do not depend o
 
 template <int UL, int K, int CONTROL, bool PAR, bool HELP, class SM, class V>
 __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, int q, int kc, bool active, int my_slot, int k_stop,
-                                                  const LaneSucc &L, double hspec, const LanePre &pre, uint32_t &pend_idx, uint32_t &pend_old) {
+                                                  const LaneSucc &L, double hspec, const LanePre &pre, uint32_t &pend_idx, uint32_t &pend_old, int par = 0) {
   constexpr int BLOCK = UL * K;
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   const SearchParams &P = Q.P;
@@ -149,7 +150,26 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
   // (unit, lane) order = the order the unit-by-unit loop would assign
   uint32_t total;
   const uint32_t packed = (isnew ? 1u : 0u) | (active ? 1u << 10 : 0u) | (improved ? 1u << 20 : 0u);
-  const uint32_t sc = PAR ? block_excl_scan<BLOCK>(packed, S, tid, total) : unit_excl_scan<UL, BLOCK>(packed, S, tid, total);
+  uint32_t sc;
+  if constexpr (PAR) {
+    // workgroup scan with ONE barrier: the per-wave totals go to the half of csum this batch owns (the other half may
+    // still be read by a wave that is late leaving the previous batch's scan -- many barriers ago)
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t x = wave_incl_sum<64>(packed);
+    if (lane == 63) S.csum[par][opaque(wave)] = x;
+    lds_barrier();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) {
+      const uint32_t t = S.csum[par][w];
+      if (w < wave) base += t;
+      tot += t;
+    }
+    total = tot;
+    sc = base + x - packed;
+  } else {
+    sc = unit_excl_scan<UL, BLOCK>(packed, S, tid, total);
+  }
   const uint32_t base_nodes = S.n_nodes, base_edges = S.n_edges, base_log = S.n_log;
   uint32_t chain_next = old_pred;
   bool write_pred = true;
@@ -613,6 +633,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       // stored at the top of the NEXT iteration -- nothing walks a far list before that -- so the round trip
       // overlaps the end-of-batch bookkeeping instead of being waited for
       uint32_t pend_idx = NIL, pend_old = NIL;
+      uint32_t batch_no = 0;  // (parity: which half of csum the batch's commit scan uses)
 #if MPLX_X_EARLY_SETUP
       // Set-up of a batch, run inside the end-of-batch bookkeeping of the batch before it (and once before the first):
       // the workgroup is waiting for thread 0's counters there anyway, so the resets (wave 0, after its own reads of what
@@ -621,32 +642,27 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       // to follow them at the head of the batch is gone.  Pool exhaustion is noticed one barrier earlier than before and
       // ends the query at the same point (nothing of the batch that lacked room was ever committed).
       auto batch_setup = [&](unsigned long long n_expanded_now) {
-        if (tid < K) {
-          const int t = opaque(tid);
-          S.cand_live[t] = 0;
-          S.unit_seq[t] = 0;
-          S.cur_slot[t] = NIL;
-          S.u_succ[t] = S.u_fin[t] = S.u_reads[t] = 0;
-          S.u_goal[t] = 0;
-          S.u_cut[t] = K;
-          if constexpr (HELP) S.hc_row[t] = 0;
-        }
-        if (tid == 0) {
-          if (S.status < 0) S.cyc[7]++;  // batches
-          S.n_cand = 0;
-          S.cut_at = K;
-          S.batch_dep = 0;
-          S.any_shared = 0;
-          S.dep_cause = 0;
-          if constexpr (HELP) {
-            // announce the wish list written during the batch that just ended (complete: a __syncthreads() lies between)
-            if (S.helped && S.box_seq) {
-              HelpBox *box = P.boxes + blockIdx.x;
-              st_u64(&box->n_expanded, n_expanded_now);
-              st_u64(&box->seq, ((unsigned long long)P.epoch << 32) | (S.box_seq + 1ull));
+        // (the per-unit words -- cand_live, unit_seq, cur_slot, u_goal, u_cut, hc_row -- are reset by each unit's first
+        // lane in 2a, before anybody reads them; u_succ / u_fin / u_reads are written by every unit after the expansion)
+        if ((tid & 63) == 0 && tid >= 64 && tid < 256) {  // (thread 0 is busy with the counters: the other waves' first lanes)
+          if (tid == 64) {
+            if (S.status < 0) S.cyc[7]++;  // batches
+            S.n_cand = 0;
+            S.cut_at = K;
+            S.batch_dep = 0;
+            S.any_shared = 0;
+            S.dep_cause = 0;
+            if constexpr (HELP) {
+              // announce the wish list written during the batch that just ended (complete: a __syncthreads() lies
+              // between); the expansion count is the helpers' hint for choosing whom to serve (one batch old here)
+              if (S.helped && S.box_seq) {
+                HelpBox *box = P.boxes + blockIdx.x;
+                st_u64(&box->n_expanded, n_expanded_now);
+                st_u64(&box->seq, ((unsigned long long)P.epoch << 32) | (S.box_seq + 1ull));
+              }
             }
           }
-        } else if ((tid & 63) == 0 && tid < 256) {  // chunk capacity for everything the batch can create: one pool per wave
+          // chunk capacity for everything the batch can create: one pool per wave
           const uint32_t room = (uint32_t)(K * P.n_u + K);
           bool ok;
           if (tid == 64)
@@ -656,8 +672,8 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           else
             ok = ensure_chunks(S.open_tbl, S.open_chunks, S.n_log + room, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
           if (!ok && S.status < 0) S.status = 4;  // MPLX_PLAN_POOL_FULL
-          if constexpr (HELP) {  // (thread 0 increments the batch count next to this read: two consecutive values, so that one is seen)
-            if (tid == 64 && (S.cyc[7] & 7ull) <= 1ull) S.helped = ld_u32(&(P.boxes + blockIdx.x)->helpers) != 0u;
+          if constexpr (HELP) {  // (the helper flag: an agent-scope load, every eighth batch)
+            if (tid == 192 && (S.cyc[7] & 7ull) <= 1ull) S.helped = ld_u32(&(P.boxes + blockIdx.x)->helpers) != 0u;
           }
         }
 #if MPLX_X_EARLY_CLEAR
@@ -690,6 +706,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         }
         MPLX_TIC(tp);
         [[maybe_unused]] unsigned long long t3 = __builtin_readcyclecounter();
+        batch_no++;
         if (S.n_near == 0) {
           __syncthreads();
           if (!refill(Q, tid)) {
@@ -957,12 +974,28 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         // ---- 2a. fetch the candidates' records; drop stale entries (improved or closed since pushed)
         bool live_unit = false;
         [[maybe_unused]] unsigned long long hc_a = 0, hc_b = 0;
+#if MPLX_X_EARLY_SETUP
+        if (lu == 0) {  // the unit's words of the batch (a live unit sets cand_live below: same lane, program order)
+          const int ko = opaque(ku);
+          S.cand_live[ko] = 0;
+          S.unit_seq[ko] = 0;
+          S.cur_slot[ko] = NIL;
+          S.u_goal[ko] = 0;
+          S.u_cut[ko] = K;
+          if constexpr (HELP) S.hc_row[ko] = 0;
+        }
+#endif
         if (ku < n_cand) {
           const uint32_t cid = S.cand_id[ku];
           double rg = pf_g, sval = pf_s;
           uint32_t fl = pf_fl;
           int32_t kval = pf_k;
           hc_a = pf_a; hc_b = pf_b;
+          // [Two ways of sparing this fetch were measured and lost (round 3): handing the other units' prefetched records
+          // over through LDS -- one fresh push among the first K shifts every later candidate by one unit -- costs more in
+          // the selection (the stage write waits for the look-ahead cache words before its last barrier: +0.5 k cycles)
+          // than the arrival skew it removes (-0.4 k); keeping the records of the states a batch creates in LDS for the
+          // next batch's candidates: +1 %.]
           if (cid != pf_id) {  // (uniform per unit) not the prefetched entry: fetch it now
             char *rec = Q.node(cid);
             rg = V::g(rec);
@@ -1115,10 +1148,10 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         if (act) {
           const uint32_t leader = S.bt_leader[my_slot];
           if (leader != (uint32_t)tid) {
-            bool eq = true;
+            uint32_t kd = 0;
 #pragma unroll
-            for (int i = 0; i < nk; i++) eq = eq && (S.lane_key[leader][i] == L.key[i]);
-            if (!eq) S.status = 5;                                    // 64-bit key-hash collision inside a batch
+            for (int i = 0; i < nk; i++) kd |= (uint32_t)(S.lane_key[leader][i] ^ L.key[i]);
+            if (kd != 0u) S.status = 5;                                    // 64-bit key-hash collision inside a batch
             // a state reached from two lanes of the batch: harmless while both only append a predecessor
             // edge (decided once g is known); three lanes on one state take the ordered path
             if (atomicAdd(&S.bt_share[my_slot], 0x10000u + (uint32_t)tid) != 0u) S.batch_dep = 1;
@@ -1180,14 +1213,21 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
               first = false;
               const uint32_t vid = (uint32_t)v;
               if (vid < CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
-                char *r = Q.node(vid);
-                const double rg = V::g(r), rh = V::h(r);
-                const uint32_t rfl = V::flags(r), rpred = V::pred(r);
-                const int32_t *kk = V::key(r);
-                bool eq = true;
+                // the record's hot line in 16-byte words, all asked for at once: g | h | flags pred key[0..1] | key[2..] ...
+                const uint4 *r4 = (const uint4 *)Q.node(vid);
+                constexpr int NW4 = (24 + 4 * nk + 15) / 16;
+                uint32_t w[4 * NW4];
 #pragma unroll
-                for (int i = 0; i < nk; i++) eq = eq && (kk[i] == L.key[i]);
-                if (eq) {
+                for (int j = 0; j < NW4; j++) {
+                  const uint4 x = r4[j];
+                  w[4 * j] = x.x; w[4 * j + 1] = x.y; w[4 * j + 2] = x.z; w[4 * j + 3] = x.w;
+                }
+                uint32_t kd = 0;
+#pragma unroll
+                for (int i = 0; i < nk; i++) kd |= w[6 + i] ^ (uint32_t)L.key[i];
+                const double rg = __hiloint2double((int)w[1], (int)w[0]), rh = __hiloint2double((int)w[3], (int)w[2]);
+                const uint32_t rfl = w[4], rpred = w[5];
+                if (kd == 0u) {
                   S.bt_id[my_slot] = vid;
                   S.bt_g[my_slot] = rg;
                   S.bt_h[my_slot] = rh;
@@ -1251,8 +1291,10 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           // a state created by this batch gets an id above every existing one: ties on (f, g) never favour it
           const uint32_t pid = nw ? 0xFFFFFFFFu : S.bt_id[my_slot];
           pre.code = classify(S, P.bucket_width, pre.pf, pre.tg, pid);
-          {  // candidates are in ascending order: "my entry precedes candidate k2" is monotone in k2
-            int lo = ku + 1, hi = n_cand;
+          // candidates are in ascending order: "my entry precedes candidate k2" is monotone in k2; most entries precede
+          // none (one look at the last candidate), and a wave whose lanes all see that skips the search
+          if (ku + 1 < n_cand && entry_less(pre.pf, pre.tg, pid, S.cand_f[n_cand - 1], S.cand_g[n_cand - 1], S.cand_id[n_cand - 1])) {
+            int lo = ku + 1, hi = n_cand - 1;  // (precedes the last one: the answer is in [ku + 1, n_cand - 1])
             while (lo < hi) {
               const int mid = (lo + hi) >> 1;
               if (entry_less(pre.pf, pre.tg, pid, S.cand_f[mid], S.cand_g[mid], S.cand_id[mid])) hi = mid; else lo = mid + 1;
@@ -1332,7 +1374,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           MPLX_T2(S, 8, t2);
           __syncthreads();  // everyone has read status / u_cut before they change
           MPLX_T2(S, 9, t2);
-          spec_commit_lanes<UL, K, CONTROL, true, HELP>(Q, S, tid, q, ku, act && mine, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
+          spec_commit_lanes<UL, K, CONTROL, true, HELP>(Q, S, tid, q, ku, act && mine, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old, (int)(batch_no & 1u));
           if (tid == 0 && st_after >= 0) S.status = st_after;
           MPLX_T2(S, 10, t2);
         }
