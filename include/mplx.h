@@ -192,7 +192,7 @@ int mplx_set_speculation(mplx_ctx *ctx, int32_t mode);
  * One launch, at most one workgroup per compute unit: in a batch larger than the machine the leading workgroups
  * turn into helpers as they run out of queries; a batch smaller than the machine is launched with extra
  * workgroups that help from the start (up to per_leader for every query).
- * per_leader: -1 auto (2), 0 off, 2.  reserved: workgroups that never lead, for a batch larger than the machine:
+ * per_leader: -1 auto (2), 0 off, 2..4 (the helpers of one leader split its list by record index).  reserved: workgroups that never lead, for a batch larger than the machine:
  * they help, from the start, the queries predicted longest (earliest in the launch order = longest straight-line
  * distance); 0 none, -1 auto (one eighth of the compute units when the batch holds at least twice as many queries
  * as the machine has compute units and max_expand is 0 or at least 200 000, i.e. one query can outlast the rest).

@@ -687,7 +687,7 @@ extern "C" int mplx_set_speculation(mplx_ctx *c, int32_t mode) {
   return MPLX_OK;
 }
 extern "C" int mplx_set_helpers(mplx_ctx *c, int32_t per_leader, int32_t reserved, uint64_t cache_rows) {
-  if (!c || !(per_leader == -1 || per_leader == 0 || per_leader == 2)) return fail(c, MPLX_ERR_ARG, "helpers per leader: -1 (auto), 0 (off) or 2");
+  if (!c || !(per_leader == -1 || per_leader == 0 || (per_leader >= 2 && per_leader <= 4))) return fail(c, MPLX_ERR_ARG, "helpers per leader: -1 (auto), 0 (off) or 2..4");
   c->helpers = per_leader;
   c->help_reserved = reserved;
   c->help_rows = cache_rows;

@@ -335,7 +335,8 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
       const uint32_t rec = (uint32_t)(v & 0xFFFFFFFFFFFFull);
       if (ok && P.help_max > 1) {
         const uint32_t m = ld_u32(&B->helpers);
-        if (__popc(m) > 1) ok = (int)(rec & 1u) == S.help_idx;  // two helpers: split by record parity
+        const int nh = __popc(m);  // several helpers: split by record index (this helper's rank among those attached)
+        if (nh > 1) ok = (int)(rec % (uint32_t)nh) == __popc(m & ((1u << S.help_idx) - 1u));
       }
       if (ok) ok = (uint32_t)ld_u64((const unsigned long long *)&P.cache_c[rec]) == 0u;
       const unsigned long long mk = __ballot(ok);
