@@ -77,6 +77,7 @@ struct mplx_ctx {
   double last_dt = 0;
   std::vector<double> last_U;
   uint64_t plan_epoch = 0;  // bumped by every mplx_plan / mplx_plan_batch
+  bool help_cache_filled = false;  // (MPLX_DEBUG_KEEP_CACHE) a launch has left its look-ahead cache behind
   uint64_t map_epoch = 0, last_map_epoch = 0;  // bumped whenever the grid changes (build_bricks); value at the last plan
   std::vector<QueryOut> last_out;
   QueryOut *d_out = nullptr;
@@ -1090,7 +1091,12 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
     grid = std::max(P.help_lead, std::min(P.help_lead * (P.help_max + 1), c->n_cus));
     HIPCHK(c, hipMemsetAsync(P.boxes, 0, sizeof(HelpBox) * ((size_t)c->pool_slots + 1024), c->stream));
     c->dbg_boxes = P.boxes;
-    HIPCHK(c, hipMemsetAsync(P.cache_c, 0, sizeof(CacheRec) * ((size_t)P.node_chunks << NODE_CH_LOG), c->stream));
+    // (diagnostic, tools/tail_probe.py: MPLX_DEBUG_KEEP_CACHE=1 keeps the look-ahead cache of the previous launch -- the
+    // same query planned again then finds an entry for every node, the fresh ones included: the time without any miss)
+    static const bool keep_cache = getenv("MPLX_DEBUG_KEEP_CACHE") != nullptr;
+    const bool kept = keep_cache && c->help_cache_filled;
+    if (!kept) HIPCHK(c, hipMemsetAsync(P.cache_c, 0, sizeof(CacheRec) * ((size_t)P.node_chunks << NODE_CH_LOG), c->stream));
+    c->help_cache_filled = true;
     // launch epoch: every word the helpers poll is tagged with it, so nothing left over from the previous launch
     // can be mistaken for progress of this one
     c->help_epoch++;
@@ -1098,6 +1104,8 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
     P.epoch = c->help_epoch;
     c->help_done_init = (unsigned long long)P.epoch << 32;
     HIPCHK(c, hipMemsetAsync(P.cache_next, 0, HELP_CTR_WORDS * sizeof(uint32_t), c->stream));
+    if (keep_cache && kept)  // the kept records name rows of the previous launch: new rows go behind them
+      HIPCHK(c, hipMemcpyAsync(P.cache_next, &c->help_ctr_back[0], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(P.done_word, &c->help_done_init, 8, hipMemcpyHostToDevice, c->stream));
   } else {
     P.boxes = nullptr;

@@ -331,7 +331,7 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
     // ---- the announced list -> the entries that are mine and still missing
     if (tid < WISH) {
       const unsigned long long v = ld_u64(&B->wish[((uint32_t)last_seq - 2u) & 1u][tid]);
-      bool ok = v != ~0ull && (uint32_t)(v >> 48) == q;
+      bool ok = v != ~0ull && (uint32_t)(v >> 48) == (q & 0xFFFFu);  // (16 bits of the query index: enough to tell a stale list from the running query's)
       const uint32_t rec = (uint32_t)(v & 0xFFFFFFFFFFFFull);
       if (ok && P.help_max > 1) {
         const uint32_t m = ld_u32(&B->helpers);
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             // by the seq store at the start of the NEXT batch, so no wait for these stores is needed here.
             if (S.helped && tid < WISH) {
               unsigned long long v = ~0ull;
-              if ((uint32_t)tid < n - kc) v = ((unsigned long long)(uint32_t)q << 48) | (unsigned long long)Q.node_rec(S.near_id[tid]);
+              if ((uint32_t)tid < n - kc) v = ((unsigned long long)((uint32_t)q & 0xFFFFu) << 48) | (unsigned long long)Q.node_rec(S.near_id[tid]);
               st_u64(&(P.boxes + blockIdx.x)->wish[S.box_seq & 1ull][opaque(tid)], v);
               if (tid == 0) S.box_seq++;
             }
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         // the helper's row of a cached candidate -- the heuristics of its successors, the voxel-read count -- is asked
         // for now (agent-scope loads: always a trip to memory) so that it travels during the expansion; used in 2b / 2c
         [[maybe_unused]] double h_row = 0.0;
-        [[maybe_unused]] unsigned long long reads_row = 0ull;
+        [[maybe_unused]] uint32_t reads_row = 0u;  // (32 bits asked for: a 64-bit load whose upper half is dead makes the compiler wait for it at once, to reuse the register)
 #if MPLX_X_EARLY_ROW
         if constexpr (HELP) {
           const uint32_t rp1 = live_unit ? S.hc_row[ku] : 0u;
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             bool want = lu < P.n_u && P.eps != 0.0;
             if constexpr (UL <= 64) want = want && (((S.hc_valid[ku] & ~S.hc_blocked[ku]) >> lu) & 1u);
             if (want) h_row = ld_f64_agent(&row[cache_h_slot(UL, lu)]);
-            if (lu == 0) reads_row = ld_u64((const unsigned long long *)&row[cache_reads_slot(UL)]);
+            if (lu == 0) reads_row = ld_u32((const uint32_t *)&row[cache_reads_slot(UL)]);
           }
         }
 #endif
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             S.u_fin[ku] = tot >> 10;
             if (HELP && S.hc_row[ku] != 0u)  // voxel reads of the expansion as the helper counted them (slot 31 of its row)
 #if MPLX_X_EARLY_ROW
-              S.u_reads[ku] = (uint32_t)reads_row;
+              S.u_reads[ku] = reads_row;
 #else
               S.u_reads[ku] = (uint32_t)ld_u64((const unsigned long long *)&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)]);
 #endif

@@ -161,7 +161,7 @@ def test_c4_batch_sample_matches_the_oracle(map512, lattice):
 @pytest.mark.parametrize("nq", [1, 40, 600])
 def test_helpers_leave_every_result_unchanged(nq):
     """Helper workgroups (mplx_set_helpers): a batch smaller than the machine gets extra workgroups that help from the
-    start, a larger one has its leaders turn into helpers as the queries run out; off / on / a reserved share must give
+    start, a larger one has its leaders turn into helpers as the queries run out; off / on / a reserved share / four per leader must give
     identical plans -- counters, expansion-order hash, cost, path -- and the first few are replayed on the CPU oracle."""
     grid, origin, res, start, goal, _ = mapgen.benchmark_map(128)
     grid = np.ascontiguousarray(grid)
@@ -174,7 +174,7 @@ def test_helpers_leave_every_result_unchanged(nq):
     G = [util.gpu_wp(g, control=orc.ACC) for s, g in queries]
     runs = {}
     gc.collect()
-    for name, (per, reserved) in {"off": (0, -1), "on": (2, -1), "reserved": (2, 64)}.items():
+    for name, (per, reserved) in {"off": (0, -1), "on": (2, -1), "reserved": (2, 64), "four": (4, -1)}.items():
         mu, pl = util.make_gpu(grid, origin, res, U, n_slots=min(nq, 1024), max_nodes=pools["nodes"], max_edges=pools["edges"], max_log=pools["log"], **kw)
         pl.setHelpers(per, reserved)
         R = pl.planBatch(S, G)
@@ -190,7 +190,7 @@ def test_helpers_leave_every_result_unchanged(nq):
             assert hits == 0
         del mu, pl, R
         gc.collect()  # (the context and its pools go with the planner)
-    assert runs["on"] == runs["off"] and runs["reserved"] == runs["off"]
+    assert runs["on"] == runs["off"] and runs["reserved"] == runs["off"] and runs["four"] == runs["off"]  # (four: the helpers of a leader split its list four ways)
     sample = list(range(min(nq, 4)))
     cpu = _cpu_replay(grid, origin, res, orc.ACC, U, kw, queries, sample)
     for i in sample:
