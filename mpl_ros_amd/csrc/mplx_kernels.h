@@ -185,6 +185,9 @@ struct Smem {
   // part that only depends on the control input (per query) and the part that only depends on the
   // node being expanded (per unit): no per-primitive staging
   double uq[3][BLOCK / KUNITS];  // q[0] of control input i per axis: U[i][ax] / {1, 2, 6, 24}
+  // the control inputs by axis and their edge costs (fill_uq): P.U / P.ucost are global loads at the head of every
+  // expansion / before every commit otherwise -- an L2 round trip on a query's serial chain (lane_u)
+  double u_lds[3][BLOCK / KUNITS], ucost_lds[BLOCK / KUNITS];
   double qn[KUNITS][3][5];       // q[1..] of the node per axis
   double dts[BLOCK];
   // per unit: flattened sample e -> (primitive << 8) | sample index; 12 samples per lane of the unit
@@ -654,7 +657,9 @@ __device__ __forceinline__ void fill_uq(const SearchParams &P, SM &S, int tid) {
     prim_build_axis(CONTROL, 0.0, 0.0, 0.0, 0.0, P.U[3 * pi + ax], c0);
     pack_q_c<CONTROL>(c0, qc);
     S.uq[ax][pi] = qc[0];
+    S.u_lds[ax][pi] = P.U[3 * pi + ax];
   }
+  for (int i = tid; i < P.n_u; i += BLOCK) S.ucost_lds[i] = P.ucost[i];
 }
 
 // ------------------------------------------------------------------ expand_kernel (unit-test entry)
@@ -1291,8 +1296,8 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL), NKY = nk + (YAW ? 1 : 0), EX = YAW ? 1 : 0;
   // is_goal with the yaw tolerance of a yaw-carrying search
   auto goal_reached = [&](const State &s, double yaw, const QueryIn &in) {
-    bool g = is_goal_state(s, in.goal, in.goal_control & 15, P.tol_pos, P.tol_vel, P.tol_acc);
-    if (YAW && g && P.tol_yaw >= 0) g = fabs(yaw - in.goal_yaw) <= P.tol_yaw;
+    bool g = is_goal_state(s, S.hp.goal, S.hp.goal_control & 15, P.tol_pos, P.tol_vel, P.tol_acc);  // (the LDS copy of the goal)
+    if (YAW && g && P.tol_yaw >= 0) g = fabs(yaw - S.hp.goal_yaw) <= P.tol_yaw;
     return g;
   };
   fill_uq<BLOCK, CONTROL>(P, S, tid);
@@ -1450,7 +1455,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         }
         __syncthreads();
         // edge cost: J + w dt of the control input, plus the potential term when a potential map exists
-        const double lane_cost = act ? (P.map.aux ? P.ucost[tid] + P.pot_weight * (double)L.pot : P.ucost[tid]) : 0.0;
+        const double lane_cost = act ? (P.map.aux ? S.ucost_lds[tid] + P.pot_weight * (double)L.pot : S.ucost_lds[tid]) : 0.0;
         const uint32_t action_tag = (uint32_t)tid | (L.pot << EDGE_POT_SHIFT);
         if (!S.flag) {
           commit_parallel<BLOCK, CONTROL, Smem<BLOCK>, nk, YAW>(Q, tid, q, act, L, h64, lane_cost, action_tag);

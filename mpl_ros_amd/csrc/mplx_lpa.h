@@ -574,7 +574,7 @@ __global__ __launch_bounds__(BLOCK) void lpa_plan_kernel(SearchParams P, LpaPara
         // expansion LOWERED g(u) and one lane reaches the child, the new minimum is min(old, g(u) + cost of this lane's
         // entry) -- the same f64 sum the walk over the list would form, an exact minimum either way -- so the walk
         // (a chain of dependent HBM reads, most of an expansion's time) is only needed when g(u) went up to inf
-        if (child != root) nr = (R.over && !dup) ? lpa_min(old_r, S.cur_g + P.ucost[tid]) : lpa_rhs_of<V>(Q, P, rec);
+        if (child != root) nr = (R.over && !dup) ? lpa_min(old_r, S.cur_g + S.ucost_lds[tid]) : lpa_rhs_of<V>(Q, P, rec);
         uint32_t fl = V::flags(rec);
         const bool was_inc = !f64_same(g, old_r);
         if (child == u) {
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(BLOCK) void lpa_subtree_kernel(SearchParams P, LpaP
       push = false;
       if (!go || child == NIL) return;
       char *rec = Q.node(child);
-      const double tentative = gu + P.ucost[tid];
+      const double tentative = gu + S.ucost_lds[tid];
       if (tentative < V::rhs(rec)) {
         V::rhs(rec) = tentative;
         uint32_t fl = V::flags(rec) | FLAG_OPENED;

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
   __shared__ unsigned long long pmask;      // (helpers) the look-ahead record of the state being expanded
   __shared__ double hstate[8];              // (helper) the ring entry being served
   __shared__ int32_t hgo;
+  __shared__ double pU[POLY_MAX_U][2];      // the control inputs (D.U is a global load at the head of every expansion otherwise)
   using V = QView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
   const PolyDev &DG = P.poly;
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
     PolyDev D;
     PolyWorld W;
     poly_stage_world<BLOCK>(DG, WG, wlds, tid, D, W);
+    if (tid < P.n_u) { pU[tid][0] = D.U[2 * tid]; pU[tid][1] = D.U[2 * tid + 1]; }  // (read after the __syncthreads() that follow)
     if (tid == 0) { plevel[0] = 0ull; plevel[1] = 0ull; punsupported = 0; }
     const unsigned long long ring_mask = (1ull << DG.help_ring_log) - 1ull;
     const double *ring = DG.help_ring + ((size_t)slot << DG.help_ring_log) * 8;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
       if ((tag >> 32) == (next & 0xFFFFFFFFull)) {  // (uniform) the entry of state `next` (not yet overwritten by a later lap)
         const double T = P.dt, cur_t = hstate[7], t_rel = cur_t - W.start_t;
         if (tid < P.n_u) {
-          const double pos[2] = {hstate[1], hstate[2]}, vel[2] = {hstate[3], hstate[4]}, acc[2] = {hstate[5], hstate[6]}, u[2] = {D.U[2 * tid], D.U[2 * tid + 1]};
+          const double pos[2] = {hstate[1], hstate[2]}, vel[2] = {hstate[3], hstate[4]}, acc[2] = {hstate[5], hstate[6]}, u[2] = {pU[tid][0], pU[tid][1]};
           double c[2][6];
           poly_prim_build(CONTROL, pos, vel, u, c, acc);
           for (int i = 0; i < 2; i++)
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
     PolyDev D;
     PolyWorld W;
     poly_stage_world<BLOCK>(DG, WG, wlds, tid, D, W);
+    if (tid < P.n_u) { pU[tid][0] = D.U[2 * tid]; pU[tid][1] = D.U[2 * tid + 1]; }  // (read after the __syncthreads() that follow)
     for (int i = tid; i < 2 * NB; i += BLOCK) S.cnt[0][i] = 0;
     if (tid == 0) {
       S.n_near = 0; S.n_nodes = 0; S.n_edges = 0; S.n_log = 0;
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
         L.valid = false; L.blocked = false; L.reads = 0;
         double lane_cost = 0.0;
         if (tid < P.n_u) {
-          const double pos[2] = {S.cur[0][0], S.cur[0][1]}, vel[2] = {S.cur[0][3], S.cur[0][4]}, acc[2] = {S.cur[0][6], S.cur[0][7]}, u[2] = {D.U[2 * tid], D.U[2 * tid + 1]};
+          const double pos[2] = {S.cur[0][0], S.cur[0][1]}, vel[2] = {S.cur[0][3], S.cur[0][4]}, acc[2] = {S.cur[0][6], S.cur[0][7]}, u[2] = {pU[tid][0], pU[tid][1]};
           double c[2][6];
           poly_prim_build(CONTROL, pos, vel, u, c, acc);
           for (int i = 0; i < 2; i++)
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
         if (tid == 0) {
           State s;
           for (int i = 0; i < 12; i++) ((double *)&s)[i] = S.cur[0][i];
-          if (S.cur[0][12] >= P.t_max || is_goal_state(s, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc))
+          if (S.cur[0][12] >= P.t_max || is_goal_state(s, S.hp.goal, S.hp.goal_control, P.tol_pos, P.tol_vel, P.tol_acc))  // (the LDS copy of the goal)
             S.status = 0;
           else if (P.max_expand > 0 && S.c_expanded >= (unsigned long long)P.max_expand)
             S.status = 3;

@@ -98,10 +98,6 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   uint32_t n_work;
   uint32_t work[WISH];          // pool indices of the node records to expand ahead of time
   unsigned long long wish_l[WISH];
-#if MPLX_X_LDS_CONST
-  double u_lds[3][UL];   // P.U by axis (expand_unit: lane_u)
-  double ucost_lds[UL];  // P.ucost
-#endif
 #ifdef MPLX_LOOKUP_TIMERS
   unsigned long long cyc2[24];
   unsigned long long cycw[16][4];
@@ -513,10 +509,6 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   fill_uq<BLOCK, CONTROL>(P, S, tid);
-#if MPLX_X_LDS_CONST
-  for (int i = tid; i < 3 * P.n_u; i += BLOCK) S.u_lds[i % 3][i / 3] = P.U[i];
-  for (int i = tid; i < P.n_u; i += BLOCK) S.ucost_lds[i] = P.ucost[i];
-#endif
   if (tid == 0) {
     unsigned long long pw = 1ull;
     for (int e = 0; e < 17; e++) { S.hpow[e] = pw; pw *= 0x100000001B3ull; }
@@ -1212,6 +1204,11 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
                 v = old;
               }
               first = false;
+              // A claim with this query's tag seen through the compute unit's L1 may be a STALE copy of a slot that has
+              // long held its final entry (the line was fetched between the claiming compare-and-swap and the agent-scope
+              // store of the entry, which does not update the L1 copy): taken at face value the probe would move on and
+              // create the state a second time.  Look again past the L1 before believing it.
+              if ((uint32_t)v >= CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) v = ld_u64(&P.table[pos]);
               const uint32_t vid = (uint32_t)v;
               if (vid < CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
                 // the record's hot line in 16-byte words, all asked for at once: g | h | flags pred key[0..1] | key[2..] ...

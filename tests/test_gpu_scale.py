@@ -87,6 +87,26 @@ def test_c3_single_query_jrk_512_full_cap(map512):
           f"kernel {pl.lastKernelMs():.0f} ms")
 
 
+def test_c3_repeated_plans_are_identical(map512):
+    """The BASELINE C3 query (helper-assisted 125-input kernel, 2 000 000 expansions) planned three times: every result
+    word must repeat.  A race between a leader's waves, or between a leader and its helpers, shows here as a different
+    state count or expansion-order hash -- this is how the stale-claim hazard of the table probe was found (a slot's
+    claim seen through the compute unit's L1 after the slot had received its entry made the leader create a state twice,
+    in about half of the runs once the control inputs no longer churned the L1; mplx_spec.h: the look-up re-reads a claim
+    with the query's tag past the L1)."""
+    grid, origin, res, start, goal = map512
+    U = mapgen.control_lattice(1.0, 2, True)
+    kw = dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=2_000_000)
+    pools = mapgen.c4_pools(True, 1, 2_000_000)
+    mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=pools["nodes"], max_edges=pools["edges"], max_log=pools["log"], **kw)
+    seen = set()
+    for it in range(3):
+        pl.plan(util.gpu_wp(start, control=orc.JRK), util.gpu_wp(goal, control=orc.JRK))
+        r = pl.getResult()
+        seen.add((r.status, r.n_expanded, r.expand_hash, r.n_nodes, r.n_edges, r.voxel_reads, r.n_succ, r.n_succ_finite))
+    assert len(seen) == 1, seen
+
+
 def _cpu_replay(grid, origin, res, control, U, kw, queries, idx, threads=16):
     """Plan queries[i] for i in idx on the oracle; returns {i: dict of results}.  One shared read-only map."""
     out, lock, todo = {}, threading.Lock(), list(idx)
