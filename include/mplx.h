@@ -371,7 +371,9 @@ int mplx_poly_result_cycles(mplx_poly *p, int32_t q, uint64_t cyc[10]);
 int mplx_result_timing(mplx_ctx *ctx, int q, double *t_begin_s, double *t_end_s, int32_t *slot);
 /* shader-clock cycles query q spent in: [0] pop (incl. refill), [1] expand (primitives + voxels),
  * [2] successor look-up (+ commit in the one-node kernel), [3] near-set eviction, [4] refill,
- * [5] coarse-bucket activation, [6] ordered commit; counts: [7] batches, [8] batches committed unit by unit */
+ * [5] coarse-bucket activation, [6] ordered commit; counts: [7] batches, [8] batches committed unit by unit,
+ * [9] candidates served from the look-ahead cache.  [0]..[6] are zero in the product build of the library (the timers
+ * sit on a query's serial chain; built with -DMPLX_PHASE_TIMERS=1 -- tools/build_variant.sh timers -- they are filled) */
 int mplx_result_cycles(mplx_ctx *ctx, int q, uint64_t cyc[10]);
 /* duration (ms, HIP events on the context's stream) of the last search / expand kernel launch */
 int mplx_last_kernel_ms(const mplx_ctx *ctx, float *ms);

@@ -27,12 +27,17 @@ __device__ __forceinline__ void st_u64(unsigned long long *p, unsigned long long
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // state-table probe: a workgroup-scope load is a PLAIN load on gfx950 (non-tgsplit mode): it may hit in this compute
-// unit's vector L1 and in the XCD's L2.  Why that is safe for a table shared by queries on other XCDs: a slot of this
-// query is only ever written by this workgroup -- the hardware keeps a compute unit's L1 coherent with its own stores
-// and atomics (write-through + the atomic's returning path), which is all "workgroup scope" promises when the whole
-// workgroup lives on one compute unit; a stale EMPTY is caught by the claiming compare-and-swap (executed at the memory
-// side), a stale foreign entry just moves the probe on.  The assumption breaks if the library is ever built with
-// -mtgsplit (workgroups split over compute units) or if the claim stops being an atomic: see the guard below.
+// unit's vector L1 and in the XCD's L2.  A slot of this query is only ever written by this workgroup, and it only goes
+// EMPTY -> claim (compare-and-swap, executed at the memory side) -> entry (agent-scope store), never back; neither write
+// updates the L1 copy of the line, so what a probe sees through the L1 may be one step behind:
+//   * a stale EMPTY is caught by the claiming compare-and-swap, which returns what the slot really holds;
+//   * a stale CLAIM of a slot that has its entry (the line was fetched between the two writes and survived in the L1)
+//     would move the probe on and make the leader create the state a second time: the look-up re-reads a claim that
+//     carries the query's tag with an agent-scope load before believing it (mplx_spec.h; round 3 -- it took the control
+//     inputs moving to LDS, which stopped the churn of the L1, for this to show: the helper-assisted 125-input search then
+//     created 3..120 duplicate states in half of its runs);
+//   * a foreign entry, stale or not, just moves the probe on.
+// The scheme needs the whole workgroup on one compute unit (one L1): see the guard below.
 #if defined(__gfx950__) && defined(__AMDGCN_TGSPLIT__)
 #error "libmplx assumes one workgroup = one compute unit (do not build with -mtgsplit): ld_u64_probe relies on it"
 #endif

@@ -5,7 +5,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 V=${1:-timers}
 case $V in
-  timers) DEF=-DMPLX_LOOKUP_TIMERS ;;
+  timers) DEF="-DMPLX_LOOKUP_TIMERS -DMPLX_PHASE_TIMERS=1" ;;
   helpdbg) DEF=-DMPLX_HELP_DEBUG ;;
   *) echo "unknown variant $V"; exit 2 ;;
 esac
