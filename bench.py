@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--max-nodes", type=int, default=0, help="mean states per query used to size the shared pools")
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="CPU-baseline sample budget of the N-thread leg (0 disables both legs)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the N-thread CPU leg (0 = all cores, at most 64)")
-    ap.add_argument("--helpers", type=int, default=-1, help="helper workgroups per leading workgroup: -1 auto (2), 0 off, 2")
+    ap.add_argument("--helpers", type=int, default=-1, help="helper workgroups per leading workgroup: -1 auto (4; 2 for the 125-input lattice), 0 off, 2..4")
     ap.add_argument("--help-reserved", type=int, default=-1, help="workgroups that only ever help (-1 auto)")
     ap.add_argument("--config", choices=["c4", "c5"], default="c4",
                     help="c4 (default): the query batch on the voxel map; c5: BASELINE config 5 -- one decentralised replanning tick of 16 robots "

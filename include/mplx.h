@@ -192,9 +192,11 @@ int mplx_set_speculation(mplx_ctx *ctx, int32_t mode);
  * One launch, at most one workgroup per compute unit: in a batch larger than the machine the leading workgroups
  * turn into helpers as they run out of queries; a batch smaller than the machine is launched with extra
  * workgroups that help from the start (up to per_leader for every query).
- * per_leader: -1 auto (2), 0 off, 2..4 (the helpers of one leader split its list by record index).  reserved: workgroups that never lead, for a batch larger than the machine:
+ * per_leader: -1 auto (4 for lattices of at most 31 inputs, 2 for the 65..128-input jerk lattices), 0 off, 2..4 (the
+ * helpers of one leader split its list by record index).  reserved: workgroups that never lead, for a batch larger than the machine:
  * they help, from the start, the queries predicted longest (earliest in the launch order = longest straight-line
- * distance); 0 none, -1 auto (one eighth of the compute units when the batch holds at least twice as many queries
+ * distance); 0 none, -1 auto (helpers for 1/16 of the compute units' worth of leaders -- 16 x per_leader workgroups on
+ * 256 compute units -- when the batch holds at least twice as many queries
  * as the machine has compute units and max_expand is 0 or at least 200 000, i.e. one query can outlast the rest).
  * cache_rows: rows of the heuristic cache (0 auto).  Used by the speculative kernels for lattices
  * of at most 31 inputs and for the 65..128-input jerk lattices.  The leader never waits for a helper; a helper

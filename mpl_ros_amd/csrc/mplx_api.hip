@@ -1078,15 +1078,20 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   const bool help = spec && !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
                     ((P.n_u <= 31 && (P.control == CTRL_ACC || P.control == CTRL_JRK)) || (P.control == CTRL_JRK && P.n_u > 64 && P.n_u <= 128));
   if (help) {
-    P.help_max = c->helpers < 0 ? 2 : c->helpers;
+    // auto: four helpers per leader for the lattices of at most 31 inputs (the capped query of the C4 batch alone: 1.95 s
+    // with two, 1.89 s with four), two for the 65..128-input jerk lattices (no gain from more)
+    P.help_max = c->helpers < 0 ? (P.n_u <= 31 ? 4 : 2) : c->helpers;
     P.help_lead = std::min(slots, c->n_cus);  // (one workgroup of these kernels fills a compute unit: more would only wait)
     // a share of the machine that never leads: its workgroups help, from the start, the queries predicted longest
     // (the launch order is longest straight-line distance first; a batch lasts as long as its longest query).
-    // auto: one eighth of the compute units when the batch is at least twice the machine AND a single query may run
-    // long (no expansion cap, or a cap of at least 200 000: with short capped queries every workgroup is worth more
-    // leading -- the 125-input jerk batch capped at 20 000 loses 11 % to a reserved share)
+    // auto: helpers for one sixteenth of the compute units' worth of leaders (16 leaders x helpers per leader on 256
+    // compute units: 32 workgroups with two per leader, 64 with four) when the batch is at least twice the machine AND a
+    // single query may run long (no expansion cap, or a cap of at least 200 000: with short capped queries every workgroup
+    // is worth more leading -- the 125-input jerk batch capped at 20 000 loses 11 % to a reserved share).  Measured on the
+    // C4-ACC batch (helpers per leader x reserved): 2 x 32: 2.190 s, 3 x 48: 2.166 s, 4 x 64: 2.151 s; 4 x 32 and 3 x 32
+    // (fewer leaders covered: the capped query, 13th in the launch order, goes unhelped until the queue drains): 2.24 / 2.27 s
     const bool long_queries = P.max_expand <= 0 || P.max_expand >= 200000;
-    const int reserved = c->help_reserved >= 0 ? c->help_reserved : (nq >= 2 * c->n_cus && long_queries ? c->n_cus / 8 : 0);
+    const int reserved = c->help_reserved >= 0 ? c->help_reserved : (nq >= 2 * c->n_cus && long_queries ? std::max(1, c->n_cus / 16) * P.help_max : 0);
     if (reserved > 0 && slots + reserved > c->n_cus) P.help_lead = std::max(1, c->n_cus - reserved);
     grid = std::max(P.help_lead, std::min(P.help_lead * (P.help_max + 1), c->n_cus));
     HIPCHK(c, hipMemsetAsync(P.boxes, 0, sizeof(HelpBox) * ((size_t)c->pool_slots + 1024), c->stream));

@@ -584,7 +584,7 @@ class VoxelMapPlanner:
         ctx.check(ctx.lib.mplx_set_speculation(ctx.h, int(mode)))
 
     def setHelpers(self, per_leader=-1, reserved=-1, cache_rows=0):
-        """Helper workgroups (look-ahead expansion on idle compute units).  per_leader: -1 auto (= 2), 0 off, 2..4 (several
+        """Helper workgroups (look-ahead expansion on idle compute units).  per_leader: -1 auto (4; 2 for the 65..128-input jerk lattices), 0 off, 2..4 (several
         helpers of one leader split its wish list by record index); reserved: workgroups that never lead (-1 auto); cache_rows: 0 auto."""
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_helpers(ctx.h, int(per_leader), int(reserved), int(cache_rows)))
