@@ -121,6 +121,7 @@ class MapUtil {
   }
   /// the device context planners attach to (not part of the reference API)
   mplx_ctx *ctx() { ensure_ctx(); return ctx_; }
+  bool has_ctx() const { return ctx_ != nullptr; }  // (a destructor must not create one)
 
  private:
   void ensure_ctx() {  // constructors stay free of HIP work: global planner objects are legal (map_replanner_node.cpp:14-15)

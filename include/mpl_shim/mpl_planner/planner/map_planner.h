@@ -18,9 +18,17 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstdint>
 
 namespace MPL {
+
+/// ids of the planner objects of this process, never reused (the owner tag of a context's auxiliary map); the Python
+/// wrapper's ids have bit 63 set
+inline uint64_t next_planner_id() {
+  static std::atomic<uint64_t> n{1};
+  return n.fetch_add(1);
+}
 
 /// env_map<Dim>: the voxel / occupancy-map environment.  Its expansion IS the device's: get_succ runs the
 /// get_succ kernel for the one node (mplx_expand_batch), is_free asks the device map.
@@ -37,7 +45,8 @@ class env_map : public env_base<Dim> {
     mplx_waypoint c = mplx_waypoint();
     for (int i = 0; i < Dim; i++) { c.pos[i] = curr.pos(i); c.vel[i] = curr.vel(i); c.acc[i] = curr.acc(i); c.jrk[i] = curr.jrk(i); }
     c.t = curr.t;
-    c.control = (int32_t)curr.control & 15;
+    c.yaw = curr.yaw;                           // (read by the device when the context is configured with MPLX_YAW)
+    c.control = (int32_t)curr.control & 31;
     std::vector<mplx_succ> out((size_t)n_u);
     if (mplx_expand_batch(map_util_->ctx(), 1, &c, out.data()) != MPLX_OK) {  // needs the planner set-up on the context: MapPlanner::plan / configure
       printf(ANSI_COLOR_RED "[env_map] %s\n" ANSI_COLOR_RESET, mplx_last_error(map_util_->ctx()));
@@ -48,6 +57,7 @@ class env_map : public env_base<Dim> {
       Waypoint<Dim> tn(curr.control);
       for (int k = 0; k < Dim; k++) { tn.pos(k) = out[i].wp.pos[k]; tn.vel(k) = out[i].wp.vel[k]; tn.acc(k) = out[i].wp.acc[k]; tn.jrk(k) = out[i].wp.jrk[k]; }
       tn.t = out[i].wp.t;
+      tn.yaw = out[i].wp.yaw;
       succ.push_back(tn);
       succ_cost.push_back(out[i].cost);
       action_idx.push_back(i);
@@ -70,7 +80,13 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   MapPlanner(bool verbose) : Base(verbose) {
     if (planner_verbose_) printf(ANSI_COLOR_CYAN "[MapPlanner] PLANNER VERBOSE ON (mplx back-end)\n" ANSI_COLOR_RESET);
   }
-  ~MapPlanner() { if (lpa_) mplx_lpa_destroy(lpa_); }  // (before the MapUtil / context it plans on: map_util_ is a member)
+  ~MapPlanner() {  // (before the MapUtil / context it plans on: map_util_ is a member)
+    if (lpa_) mplx_lpa_destroy(lpa_);
+    if (map_util_ && map_util_->has_ctx()) {  // this planner's cost terms must not outlive it on the shared context
+      uint64_t token = 0;
+      if (mplx_aux_token(map_util_->ctx(), 0, 0, &token) == MPLX_OK && token == id_) mplx_potential_clear(map_util_->ctx());
+    }
+  }
   MapPlanner(const MapPlanner &) = delete;
   MapPlanner &operator=(const MapPlanner &) = delete;
   void setMapUtil(const std::shared_ptr<MapUtil<Dim>> &map_util) {
@@ -247,9 +263,9 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   /// ones (cost inf upstream), re-derived on request by mplx_result_blocked; getExpandedEdges()
   /// (map_replanner_node.cpp:100-102) keeps the edges that enter an expanded (closed) node
   /// [UNVERIFIED selection rules: upstream bodies not vendored]
-  vec_E<Primitive<Dim>> getValidPrimitives() const { return edge_primitives(false); }
+  vec_E<Primitive<Dim>> getValidPrimitives() const { return edge_primitives(false, false); }
   vec_E<Primitive<Dim>> getAllPrimitives() const {
-    vec_E<Primitive<Dim>> prs = edge_primitives(false);
+    vec_E<Primitive<Dim>> prs = edge_primitives(false, true);
     uint64_t n = 0, n_all = 0;
     if (lpa_mode()) return prs;  // (the LPA* state space keeps its blocked entries as flagged predecessor entries: already in prs)
     if (!own_results() || mplx_result_blocked(map_util_->ctx(), nullptr, nullptr, 0, &n, &n_all) != MPLX_OK || n == 0) return prs;
@@ -267,7 +283,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     if (!own_results()) return 0;
     return mplx_result_blocked(map_util_->ctx(), nullptr, nullptr, 0, &n, &n_all) == MPLX_OK ? (size_t)n_all : (size_t)res_.n_nodes;
   }
-  vec_E<Primitive<Dim>> getExpandedEdges() const { return edge_primitives(true); }
+  vec_E<Primitive<Dim>> getExpandedEdges() const { return edge_primitives(true, false); }
   const mplx_result &getResult() const { return res_; }
 
  protected:
@@ -304,23 +320,28 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     if (lpa_mode()) return mplx_lpa_result_nodes(lpa_, n, coords.data(), nullptr, nullptr, nullptr, closed ? closed->data() : nullptr, nullptr, nullptr) == MPLX_OK;
     return mplx_result_nodes(map_util_->ctx(), n, coords.data(), nullptr, nullptr, closed ? closed->data() : nullptr, nullptr) == MPLX_OK;
   }
-  bool edges(std::vector<int32_t> &child, std::vector<int32_t> &parent, std::vector<int32_t> &action) const {
+  /// blocked (may be null): per entry, its primitive is not free in the current map -- only an LPA* state space keeps
+  /// such entries (flagged, cost inf); the A* state space stores finite arrivals only (all zeros)
+  bool edges(std::vector<int32_t> &child, std::vector<int32_t> &parent, std::vector<int32_t> &action, std::vector<int32_t> *blocked = nullptr) const {
     const size_t n = (size_t)res_.n_edges;
     if (!own_results()) return false;
     child.resize(n ? n : 1); parent.resize(n ? n : 1); action.resize(n ? n : 1);
+    if (blocked) blocked->assign(n ? n : 1, 0);
     uint64_t m = 0;
-    if ((lpa_mode() ? mplx_lpa_result_edges(lpa_, child.data(), parent.data(), action.data(), nullptr, n, &m)
+    if ((lpa_mode() ? mplx_lpa_result_edges(lpa_, child.data(), parent.data(), action.data(), blocked ? blocked->data() : nullptr, n, &m)
                     : mplx_result_edges(map_util_->ctx(), child.data(), parent.data(), action.data(), n, &m)) != MPLX_OK) return false;
     child.resize((size_t)m); parent.resize((size_t)m); action.resize((size_t)m);
+    if (blocked) blocked->resize((size_t)m);
     return true;
   }
-  vec_E<Primitive<Dim>> edge_primitives(bool into_closed_only) const {
+  vec_E<Primitive<Dim>> edge_primitives(bool into_closed_only, bool with_blocked) const {
     vec_E<Primitive<Dim>> prs;
     std::vector<mplx_waypoint> coords;
-    std::vector<int32_t> closed, child, parent, action;
-    if (!nodes(coords, &closed) || !edges(child, parent, action)) return prs;
+    std::vector<int32_t> closed, child, parent, action, blocked;
+    if (!nodes(coords, &closed) || !edges(child, parent, action, &blocked)) return prs;
     for (size_t e = 0; e < child.size(); e++) {
       if (into_closed_only && !closed[(size_t)child[e]]) continue;
+      if (!with_blocked && blocked[e]) continue;  // (LPA*) an entry whose primitive passes through an obstacle: cost inf
       prs.push_back(primitive_of(coords[(size_t)parent[e]], action[e]));
     }
     return prs;
@@ -418,7 +439,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
     mplx_ctx *ctx = map_util_->ctx();
     uint64_t token = 0;
     mplx_aux_token(ctx, 0, 0, &token);
-    const uint64_t me = (uint64_t)(uintptr_t)this;
+    const uint64_t me = id_;  // (never the address: a planner allocated where a dead one lived would pass for the owner)
     if (!has_region_ && !has_pot_) {
       if (token != 0 && token != me) mplx_potential_clear(ctx);  // another planner's cost terms must not leak into this plan
       return true;
@@ -446,6 +467,7 @@ class MapPlanner : public PlannerBase<Dim, Waypoint<Dim>> {
   uint64_t epoch_ = 0;  // mplx_plan_epoch of this planner's last plan()
   Control::Control control_ = Control::ACC;
   uint32_t record_cap_ = 1u << 20;
+  const uint64_t id_ = next_planner_id();  // owner tag of the auxiliary map on the shared context (mplx_aux_token)
   void refuse(const char *what) {
     printf(ANSI_COLOR_RED "[MapPlanner] %s: not supported by the mplx back-end; plan() will fail\n" ANSI_COLOR_RESET, what);
     this->unsupported_ = true;

@@ -210,6 +210,7 @@ static int set_map_meta(mplx_ctx *c, const int32_t dim[3], const double origin[3
   if (c->aux && (dim[0] != c->dim[0] || dim[1] != c->dim[1] || dim[2] != c->dim[2])) {  // another grid: the auxiliary map goes
     (void)hipFree(c->aux);
     c->aux = nullptr;
+    c->aux_token = 0;  // nobody's any more: the planner that built it must build it again (its token would say "still mine")
   }
   for (int i = 0; i < 3; i++) {
     c->dim[i] = dim[i];

@@ -237,7 +237,13 @@ extern "C" int mplx_lpa_plan(mplx_lpa *l, const mplx_waypoint *start, const mplx
     l->valid = false;
     l->traj_len = 0;
   }
-  if (l->st.valid) {
+  // Pool exhaustion ends the launch in the middle of an expansion (the expanded state is already marked built, its
+  // successors are not all linked): the space is not reusable -- the next plan() starts a fresh one, as after a failed
+  // update (lpa_update).  The result of THIS call (status MPLX_PLAN_POOL_FULL) still says what happened.
+  if (l->last_out.status == MPLX_PLAN_POOL_FULL) {
+    l->valid = false;
+    l->traj_len = 0;
+  } else if (l->st.valid) {
     l->valid = true;
     l->cfg = c->cfg;
     l->U = c->U;

@@ -508,18 +508,30 @@ class VoxelMapPlanner:
         self._aux_dirty = True
         self._apply_aux()
 
+    _aux_ids = iter(range(1, 1 << 62))
+
+    def _aux_id(self):
+        """This planner's owner tag for the context's auxiliary map: never reused (not id(self)); bit 63 tells the Python
+        wrapper's tags from the C++ shim's."""
+        if getattr(self, "_aux_id_v", None) is None:
+            self._aux_id_v = (1 << 63) | next(VoxelMapPlanner._aux_ids)
+        return self._aux_id_v
+
     def _has_aux(self):
         return getattr(self, "_region", None) is not None or getattr(self, "_pot_call", None) is not None
 
     def _apply_aux(self):
         """Make the context's auxiliary map this planner's: region first, then the potential (which keeps the region)."""
         ctx = self._ctx()
-        owner = getattr(ctx, "aux_owner", None)
-        mine = owner is not None and owner() is self
+        # the owner tag lives on the context itself (mplx_aux_token): the library resets it whenever it drops the auxiliary
+        # map (another grid, mplx_potential_clear), so "still mine" can never outlive the map it refers to
+        tok = C.c_uint64(0)
+        ctx.check(ctx.lib.mplx_aux_token(ctx.h, 0, 0, C.byref(tok)))
+        me = self._aux_id()
+        mine = tok.value == me
         if not self._has_aux():
-            if owner is not None and not mine:
+            if tok.value != 0 and not mine:
                 ctx.check(ctx.lib.mplx_potential_clear(ctx.h))  # another planner's cost terms must not leak into this plan
-                ctx.aux_owner = None
             return
         if mine and not getattr(self, "_aux_dirty", True):
             return
@@ -537,7 +549,7 @@ class VoxelMapPlanner:
         if call is not None:
             pos, rng = call
             ctx.check(ctx.lib.mplx_potential_update(ctx.h, d3(self._pot_radius), d3(pos), d3(rng), 1))
-        ctx.aux_owner = weakref.ref(self)
+        ctx.check(ctx.lib.mplx_aux_token(ctx.h, me, 1, None))
         self._aux_dirty = False
 
     def _aux_cloud(self, which):
