@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--config", choices=["c4", "c5"], default="c4",
                     help="c4 (default): the query batch on the voxel map; c5: BASELINE config 5 -- one decentralised replanning tick of 16 robots "
                          "(Team2) through the moving-obstacle planner, batched in one launch")
+    ap.add_argument("--c5-capped", action="store_true",
+                    help="--config c5: round 3's variant (distance heuristic, max_expand 20000) instead of the reference's planner parameters")
     ap.add_argument("--no-throughput", action="store_true",
                     help="N > 1, strong scaling: skip the additional throughput phase (a 1024 x N query stream through the same sharded path)")
     ap.add_argument("--dump-queries", default="", help="write per-query expansions / device timing of the last step to this JSON file")
@@ -462,7 +464,11 @@ def bench_c5(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     worlds, starts, goals = pm.team2_tick(dt=0.5, t_now=1.0, traj_time=4.0)
-    max_expand = args.max_expand if args.max_expand > 0 else 20000
+    # Planner parameters = the reference's (robot.hpp:109-122: setVmax / setAmax / setDt / setTol(0.5) / setU and nothing else,
+    # i.e. the dynamics-aware heuristic and no expansion cap).  --c5-capped: round 3's variant (distance heuristic,
+    # max_expand 20 000), which the default run reports as the labelled extra `capped_variant`.
+    ref_params = not args.c5_capped
+    max_expand = args.max_expand if args.max_expand > 0 else (-1 if ref_params else 20000)
     kw = dict(dt=0.5, v_max=2.0, a_max=1.0, w=10.0)
     team = pm.PolyTeam()
     team.configure(pm.ACC, pm.U9, **kw)
@@ -470,7 +476,7 @@ def bench_c5(args):
     team.set_capacity(16, 1 << 21, 1 << 23, 1 << 22)
     team.set_helpers(args.helpers if args.helpers in (-1, 0) else min(args.helpers, 15))
     world_of = np.arange(16)
-    pkw = dict(eps=1.0, tol_pos=0.5, max_expand=max_expand, heur_ignore_dynamics=True)
+    pkw = dict(eps=1.0, tol_pos=0.5, max_expand=max_expand, heur_ignore_dynamics=not ref_params)
     for _ in range(args.warmup):
         team.plan_batch(world_of, starts, goals, **pkw)
     torch.cuda.synchronize()
@@ -498,7 +504,9 @@ def bench_c5(args):
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": "C5: one decentralised replanning tick of the 16 robots of Team2 (robot_team.hpp:275-353), each against the 15 others' "
                                   "trajectories (4 s horizon) + the static box, moving-obstacle planner (env_poly_map), 9-primitive acc lattice, dt 0.5 "
-                                  f"v_max 2 a_max 1 tol 0.5, distance heuristic, max_expand {max_expand}; all 16 searches in one launch",
+                                  "v_max 2 a_max 1 tol 0.5, " + ("the reference's planner parameters (robot.hpp:109-122): dynamics-aware heuristic, no expansion cap"
+                                                                 if ref_params and max_expand <= 0 else
+                                                                 f"{'dynamics-aware' if ref_params else 'distance'} heuristic, max_expand {max_expand}") + "; all 16 searches in one launch",
                       "robots": 16, "n_primitives": 9},
            "expansions_per_step": n_exp, "plan_status_counts": {str(k): int(v) for k, v in enumerate(np.bincount([r.status for r in R], minlength=7))},
            "tick_ms": 1e3 * elapsed / args.steps,
@@ -514,7 +522,8 @@ def bench_c5(args):
             t0 = time.perf_counter()
             n_cpu, bad = 0, 0
             for r in range(16):
-                ref = refpoly.RefWorld(worlds[r], pm.ACC, pm.U9, **kw).plan(starts[r], goals[r], eps=1.0, tol_pos=0.5, max_expand=max_expand)
+                ref = refpoly.RefWorld(worlds[r], pm.ACC, pm.U9, **kw).plan(starts[r], goals[r], eps=1.0, tol_pos=0.5, max_expand=max_expand,
+                                                                            heur_ignore_dynamics=not ref_params)
                 n_cpu += len(ref["expanded"])
                 act, ids, _ = team.traj(r)
                 ok = ref["status"] == R[r].status and len(ref["expanded"]) == R[r].n_expanded and ref["n_nodes"] == R[r].n_nodes
@@ -527,6 +536,19 @@ def bench_c5(args):
                                              "compiled from its own headers, driven by the restated best-first loop (GraphSearch is not vendored)",
                                    "tick_ms": 1e3 * cpu_s}
             out["parity_sample"] = {"queries": 16, "mismatches": bad, "checked": "status, n_expanded, n_nodes, cost (bit-exact f64), actions, node ids"}
+    if ref_params and args.max_expand <= 0:  # labelled extra: round 3's capped variant of the same tick (not the line's value)
+        ckw = dict(eps=1.0, tol_pos=0.5, max_expand=20000, heur_ignore_dynamics=True)
+        team.plan_batch(world_of, starts, goals, **ckw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            team.set_worlds(worlds)
+            Rc = team.plan_batch(world_of, starts, goals, **ckw)
+        torch.cuda.synchronize()
+        ce = time.perf_counter() - t0
+        out["capped_variant"] = {"note": "NOT the reference's parameters: distance heuristic (setHeurIgnoreDynamics(true)) and max_expand 20 000, round 3's C5 line",
+                                 "tick_ms": 1e3 * ce / args.steps, "expansions_per_step": int(sum(r.n_expanded for r in Rc)),
+                                 "plan_status_counts": {str(k): int(v) for k, v in enumerate(np.bincount([r.status for r in Rc], minlength=7))}}
     print(json.dumps(out), flush=True)
 
 

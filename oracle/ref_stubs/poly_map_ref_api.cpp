@@ -109,12 +109,23 @@ int refpoly_get_succ(void *h, const double *state, int control, double *succ, do
 
 // ---- best-first search over the reference environment (GraphSearch::Astar restated, see the header comment).
 // Total order of OPEN: (f, g, creation id); goal test after the expansion; max_expand then empty-OPEN.
-// heur: w * |dp|_inf / v_max (heur_ignore_dynamics form; v_max <= 0: w * |dp|_inf) -- the time-keyed PolyMap states
-// use the distance bound (the dynamics-aware closed forms are pinned elsewhere), is_goal: |dp|_inf <= tol_pos.
+// heur_mode != 0: w * |dp|_inf / v_max (setHeurIgnoreDynamics(true); v_max <= 0: w * |dp|_inf).
+// heur_mode == 0: the dynamics-aware env_base::cal_heur -- what the reference's robots plan with (robot.hpp:109-122 sets
+// neither setHeurIgnoreDynamics nor setMaxNum).  Its closed forms live in the CPU oracle (oracle/mpl_oracle.c cal_heur,
+// pinned against a numerical optimal-control solve in tests/test_oracle_kat.py); this library does not link the oracle:
+// the caller hands over the address of orc_heuristic and an orc_planner configured with the same w / v_max / goal
+// (refpoly_set_heuristic), and the search calls through it with the state's z components zero.
+// is_goal: |dp|_inf <= tol_pos.
 struct PNode { Waypoint2D coord; double g, h; int closed, opened; std::vector<int> pred, pact; std::vector<double> pcost; };
 static std::vector<int> g_exp, g_traj_nodes, g_traj_act;
 static std::vector<PNode> g_nodes;
 static double g_cost;
+typedef double (*orc_heur_fn)(const void *planner, const void *waypoint);
+static orc_heur_fn g_heur_fn = nullptr;
+static const void *g_heur_planner = nullptr;
+// layout of orc_waypoint (oracle/mpl_oracle.h); restated here so that this file needs nothing of the oracle's but the call
+struct OrcWaypoint { double pos[3], vel[3], acc[3], jrk[3]; double yaw, t; int32_t control, enable_t; };
+void refpoly_set_heuristic(void *fn, const void *planner) { g_heur_fn = (orc_heur_fn)fn; g_heur_planner = planner; }
 int refpoly_plan(void *h, const double *start, const double *goal, int control, double eps, double tol_pos, int max_expand, int heur_mode) {
   Ref *r = (Ref *)h;
   g_nodes.clear(); g_exp.clear(); g_traj_nodes.clear(); g_traj_act.clear();
@@ -124,10 +135,18 @@ int refpoly_plan(void *h, const double *start, const double *goal, int control, 
   if (!r->env->is_free(s.pos)) return 2;  // PlannerBase::plan: ENV_->is_free(start.pos) = inside the bounding box (env_poly_map.h:33)
   const double v_max = r->env->v_max_, w = r->env->w_;
   auto heur = [&](const Waypoint2D &x) {
+    if (heur_mode == 0) {  // dynamics-aware: the oracle's cal_heur (states are time-keyed: never equal to the goal key)
+      OrcWaypoint o = OrcWaypoint();
+      for (int i = 0; i < 2; i++) { o.pos[i] = x.pos(i); o.vel[i] = x.vel(i); o.acc[i] = x.acc(i); o.jrk[i] = x.jrk(i); }
+      o.t = x.t;
+      o.control = control;
+      o.enable_t = 1;
+      return g_heur_fn(g_heur_planner, &o);
+    }
     const double d = std::max(std::fabs(x.pos(0) - g.pos(0)), std::fabs(x.pos(1) - g.pos(1)));
-    (void)heur_mode;
     return v_max > 0 ? w * d / v_max : w * d;
   };
+  if (heur_mode == 0 && !g_heur_fn) return -1;  // refpoly_set_heuristic first
   auto is_goal = [&](const Waypoint2D &x) { return std::max(std::fabs(x.pos(0) - g.pos(0)), std::fabs(x.pos(1) - g.pos(1))) <= tol_pos; };
   if (is_goal(s)) { g_cost = 0; return 0; }
   std::map<std::vector<int>, int> table;

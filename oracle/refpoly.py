@@ -36,6 +36,7 @@ def lib():
         L.refpoly_get_succ.argtypes = [P, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.refpoly_plan.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int, D, D, C.c_int, C.c_int]
         L.refpoly_traj_cost.restype = D
+        L.refpoly_set_heuristic.argtypes = [C.c_void_p, C.c_void_p]
         L.refpoly_get_expanded.argtypes = [C.c_void_p]
         L.refpoly_get_traj.argtypes = [C.c_void_p, C.c_void_p]
         L.refpoly_get_node.argtypes = [C.c_int, C.c_void_p, C.POINTER(D), C.POINTER(D)]
@@ -59,6 +60,8 @@ class RefWorld:
             L.refpoly_add_nonlinear(self.h, len(o.poly), o.poly.ctypes.data, len(o.segs), o.segs.ctypes.data, self.control, o.start_t,
                                     int(o.disappear_front), int(o.disappear_back))
         self.U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, 2)
+        self.env_kw = dict(dt=float(dt), v_max=float(v_max), a_max=float(a_max), j_max=float(j_max), w=float(w))
+        self.goal_control = None  # control kind of the goal waypoint (None: that of the search states, as robot.hpp builds it)
         L.refpoly_set_env(self.h, len(self.U), self.U.ctypes.data, float(dt), float(v_max), float(a_max), float(j_max), float(w))
 
     def __del__(self):
@@ -74,9 +77,27 @@ class RefWorld:
         k = self.L.refpoly_get_succ(self.h, s.ctypes.data, self.control, succ.ctypes.data, cost.ctypes.data, act.ctypes.data)
         return succ[:k], cost[:k], act[:k]
 
-    def plan(self, start, goal, eps=1.0, tol_pos=0.5, max_expand=-1):
+    def plan(self, start, goal, eps=1.0, tol_pos=0.5, max_expand=-1, heur_ignore_dynamics=True):
+        """Best-first search through the reference environment.  heur_ignore_dynamics=False (what robot.hpp:109-122 plans with:
+        it calls neither setHeurIgnoreDynamics nor setMaxNum): the dynamics-aware heuristic, evaluated by the CPU oracle's
+        orc_heuristic on an orc planner configured with this world's w / v_max and the goal."""
         s = np.ascontiguousarray(start, dtype=np.float64); g = np.ascontiguousarray(goal, dtype=np.float64)
-        st = self.L.refpoly_plan(self.h, s.ctypes.data, g.ctypes.data, self.control, float(eps), float(tol_pos), int(max_expand), 0)
+        keep = None
+        if not heur_ignore_dynamics:
+            from . import orc
+            U3 = np.zeros((len(self.U), 3)); U3[:, :2] = self.U
+            keep = orc.Planner()
+            keep.set_config(self.control, U3, dt=self.env_kw["dt"], v_max=self.env_kw["v_max"], a_max=self.env_kw["a_max"], j_max=self.env_kw["j_max"],
+                            w=self.env_kw["w"], eps=eps, tol_pos=tol_pos, heur_ignore_dynamics=False)
+            gw = orc.Waypoint()
+            gw.pos[0], gw.pos[1] = g[0], g[1]
+            gw.vel[0], gw.vel[1] = g[2], g[3]
+            gw.acc[0], gw.acc[1] = g[4], g[5]
+            gw.control = self.goal_control if self.goal_control is not None else self.control
+            keep.set_goal(gw)
+            self.L.refpoly_set_heuristic(C.cast(keep.L.orc_heuristic, C.c_void_p), keep.h)
+        st = self.L.refpoly_plan(self.h, s.ctypes.data, g.ctypes.data, self.control, float(eps), float(tol_pos), int(max_expand), 1 if heur_ignore_dynamics else 0)
+        del keep
         ne, nl = self.L.refpoly_num_expanded(), self.L.refpoly_traj_len()
         ids = np.zeros(max(ne, 1), dtype=np.int32)
         self.L.refpoly_get_expanded(ids.ctypes.data)

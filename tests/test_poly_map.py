@@ -122,7 +122,8 @@ def _compare_plans(team, refs, world_of, starts, goals, compare_acc=False, **kw)
     R = team.plan_batch(world_of, starts, goals, **kw)
     n_ok = 0
     for k, w in enumerate(world_of):
-        ref = refs[w].plan(starts[k], goals[k], eps=kw.get("eps", 1.0), tol_pos=kw.get("tol_pos", 0.5), max_expand=kw.get("max_expand", -1))
+        ref = refs[w].plan(starts[k], goals[k], eps=kw.get("eps", 1.0), tol_pos=kw.get("tol_pos", 0.5), max_expand=kw.get("max_expand", -1),
+                           heur_ignore_dynamics=kw.get("heur_ignore_dynamics", True))
         r = R[k]
         assert r.status == ref["status"], (k, r.status, ref["status"])
         assert r.n_expanded == len(ref["expanded"]) and r.n_nodes == ref["n_nodes"], (k, r.n_expanded, len(ref["expanded"]), r.n_nodes, ref["n_nodes"])
@@ -181,6 +182,51 @@ def test_team2_tick_plans_match():
     R, n_ok = _compare_plans(team, refs, np.arange(16), starts, goals, max_expand=20000)
     print("Team2 tick:", [(r.status, int(r.n_expanded)) for r in R], "kernel ms", team.last_kernel_ms())
     assert n_ok >= 12
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_team2_tick_plans_match_under_the_reference_parameters():
+    """The same tick planned the way the reference plans it: robot.hpp:109-122 calls neither setHeurIgnoreDynamics nor
+    setMaxNum, i.e. the dynamics-aware heuristic (env_base::cal_heur, ACC state -> ACC goal at rest) and no expansion cap.
+    Every robot finds its trajectory (16 / 0); the device against the search over the compiled reference environment with
+    the CPU oracle's heuristic, bit-exact as above."""
+    worlds, starts, goals = pm.team2_tick()
+    team = pm.PolyTeam()
+    kw = dict(dt=0.5, v_max=2.0, a_max=1.0, w=10.0)
+    team.configure(pm.ACC, U9, **kw)
+    team.set_worlds(worlds)
+    team.set_capacity(16, 1 << 21, 1 << 23, 1 << 22)
+    refs = [refpoly.RefWorld(W, pm.ACC, U9, **kw) for W in worlds]
+    R, n_ok = _compare_plans(team, refs, np.arange(16), starts, goals, max_expand=-1, heur_ignore_dynamics=False)
+    print("Team2 tick, reference parameters:", [(r.status, int(r.n_expanded)) for r in R], "kernel ms", team.last_kernel_ms())
+    assert n_ok == 16
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("seed", range(2))
+def test_random_world_plans_match_with_the_dynamics_aware_heuristic(seed):
+    """Random worlds, default (dynamics-aware) heuristic, goals at rest and moving goals, no cap unless a search runs away."""
+    rng = np.random.default_rng(900 + seed)
+    dt = 0.5
+    worlds = [random_world(rng, dt=dt) for _ in range(8)]
+    team = pm.PolyTeam()
+    kw = dict(dt=dt, v_max=2.0, a_max=1.0, w=10.0)
+    team.configure(pm.ACC, U9, **kw)
+    team.set_worlds(worlds)
+    team.set_capacity(16, 1 << 20, 1 << 22, 1 << 21)
+    refs = [refpoly.RefWorld(W, pm.ACC, U9, **kw) for W in worlds]
+    n = 12
+    world_of = rng.integers(0, len(worlds), n)
+    starts, goals = np.zeros((n, 9)), np.zeros((n, 9))
+    starts[:, 0:2] = np.round(rng.uniform((0.5, -4.5), (3.0, 4.5), (n, 2)), 1)
+    starts[:, 2:4] = np.round(rng.uniform(-1, 1, (n, 2)), 1)
+    starts[:, 8] = rng.integers(0, 3, n) * dt
+    goals[:, 0:2] = np.round(rng.uniform((7.0, -4.5), (9.5, 4.5), (n, 2)), 1)
+    goals[n // 2:, 2:4] = np.round(rng.uniform(-1, 1, (n - n // 2, 2)), 1)  # (half of the goals carry a velocity)
+    R, n_ok = _compare_plans(team, refs, world_of, starts, goals, max_expand=20000, heur_ignore_dynamics=False)
+    assert n_ok >= 6
 
 
 # ---------------------------------------------------------------- beyond VEL / ACC (round 3): the general solve()
@@ -327,7 +373,8 @@ def _reference_planner(U, kw_env, kw_plan):
         out = []
         for W, s, g in zip(worlds, starts, goals):
             R = refpoly.RefWorld(W, pm.ACC, U, **kw_env)
-            ref = R.plan(s, g, eps=kw_plan.get("eps", 1.0), tol_pos=kw_plan.get("tol_pos", 0.5), max_expand=kw_plan.get("max_expand", -1))
+            ref = R.plan(s, g, eps=kw_plan.get("eps", 1.0), tol_pos=kw_plan.get("tol_pos", 0.5), max_expand=kw_plan.get("max_expand", -1),
+                         heur_ignore_dynamics=kw_plan.get("heur_ignore_dynamics", True))
             states = np.array([R.node(int(i))[0] for i in ref["node_ids"]]).reshape(-1, 9)
             states[:, 4:8] = 0.0  # (the device reports position, velocity and time of a path state)
             out.append((ref["status"], np.array(ref["actions"]), states))
@@ -337,15 +384,17 @@ def _reference_planner(U, kw_env, kw_plan):
 
 @pytest.mark.gpu
 @needs_ref
-@pytest.mark.parametrize("ddt", [0.01, 0.0])
-def test_team2_decentralised_loop_over_many_ticks(ddt):
+@pytest.mark.parametrize("ddt,ref_params", [(0.01, False), (0.0, False), (0.0, True)])
+def test_team2_decentralised_loop_over_many_ticks(ddt, ref_params):
     """multi_robot_node.cpp:95-105 with launch/multi_robot_node/test.launch (Team2, dt 0.5, v_max 2, a_max 1): Team2::init (16
     obstacle-free plans), then the 0.01 s loop for 1.1 s of simulated time -- every robot replans twice against the others'
     CURRENT planned trajectories.  ddt = 0.01 (the reference): one robot per tick; ddt = 0: all sixteen in the same tick (the
     batched tick of BASELINE config 5).  The device team and a team planning through the compiled reference environment
     must agree plan for plan (status, actions, path states) and therefore stay in the same state throughout."""
     kw_env = dict(dt=0.5, v_max=2.0, a_max=1.0, w=10.0)
-    kw_plan = dict(tol_pos=0.5, max_expand=20000)
+    # ref_params: what robot.hpp:109-122 sets -- the dynamics-aware heuristic, no expansion cap; else round 3's capped
+    # distance-heuristic variant
+    kw_plan = dict(tol_pos=0.5, max_expand=-1, heur_ignore_dynamics=False) if ref_params else dict(tol_pos=0.5, max_expand=20000)
     dev = pm.PolyTeam()
     dev.configure(pm.ACC, U9, **kw_env)
     dev.set_capacity(16, 1 << 21, 1 << 23, 1 << 22)
