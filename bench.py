@@ -70,9 +70,11 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the N-thread CPU leg (0 = all cores, at most 64)")
     ap.add_argument("--helpers", type=int, default=-1, help="helper workgroups per leading workgroup: -1 auto (4; 2 for the 125-input lattice), 0 off, 2..4")
     ap.add_argument("--help-reserved", type=int, default=-1, help="workgroups that only ever help (-1 auto)")
-    ap.add_argument("--config", choices=["c4", "c5"], default="c4",
+    ap.add_argument("--config", choices=["c4", "c5", "lpa"], default="c4",
                     help="c4 (default): the query batch on the voxel map; c5: BASELINE config 5 -- one decentralised replanning tick of 16 robots "
-                         "(Team2) through the moving-obstacle planner, batched in one launch")
+                         "(Team2) through the moving-obstacle planner, batched in one launch; lpa: the replanning cycle of map_replanner_node.cpp "
+                         "(plan, obstacle on the path -> updateBlockedNodes, removed -> updateClearedNodes, getSubStateSpace(1)) on the --map^3 map, "
+                         "LPA* repair time next to a fresh device A*")
     ap.add_argument("--c5-capped", action="store_true",
                     help="--config c5: round 3's variant (distance heuristic, max_expand 20000) instead of the reference's planner parameters")
     ap.add_argument("--no-throughput", action="store_true",
@@ -83,6 +85,8 @@ def main():
         args.queries = 1
     if args.config == "c5":
         return bench_c5(args)
+    if args.config == "lpa":
+        return bench_lpa(args)
 
     import torch
     import torch.distributed as dist
@@ -549,6 +553,119 @@ def bench_c5(args):
         out["capped_variant"] = {"note": "NOT the reference's parameters: distance heuristic (setHeurIgnoreDynamics(true)) and max_expand 20 000, round 3's C5 line",
                                  "tick_ms": 1e3 * ce / args.steps, "expansions_per_step": int(sum(r.n_expanded for r in Rc)),
                                  "plan_status_counts": {str(k): int(v) for k, v in enumerate(np.bincount([r.status for r in Rc], minlength=7))}}
+    print(json.dumps(out), flush=True)
+
+
+def bench_lpa(args):
+    """Incremental replanning at BASELINE C2 size: the cycle of map_replanner_node.cpp:175-255 on the 256^3
+    random-box map (--map), 27-input lattice.  replan_planner_ (setLPAstar(true): the state space stays in HBM between
+    plan() calls) next to planner_ (a fresh A* on the same shared MapUtil, the speculative kernel with its helpers) after
+    every step; both costs must agree.  One "step" of the line = one whole cycle; value = the LPA* repair after the obstacle
+    landed on the path (kernel ms), the number the replanner exists for."""
+    import torch
+    from mpl_ros_amd import mapgen
+    from mpl_ros_amd.planner import ACC, VoxelMapPlanner, VoxelMapUtil, Waypoint3D
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    n = args.map if args.map != 512 else 256
+    grid, origin, res, start, goal, _ = mapgen.benchmark_map(n)
+    U = mapgen.control_lattice(1.0, 1, True)
+    mu = VoxelMapUtil(0)
+
+    def set_map(g):
+        dz, dy, dx = g.shape
+        mu.setMap(origin, (dx, dy, dz), g.ravel(), res)
+
+    set_map(grid)
+
+    def planner(lpa):
+        pl = VoxelMapPlanner(False)
+        pl.setMapUtil(mu)
+        pl.setVmax(2.0); pl.setAmax(1.0); pl.setDt(1.0); pl.setU(U); pl.setTol(0.5)
+        pl.setCapacity(1, 1 << 19, 1 << 21, 1 << 22)
+        pl.setLPAstar(lpa)
+        return pl
+
+    def wp(p, v=(0, 0, 0)):
+        w = Waypoint3D(ACC)
+        w.pos, w.vel = np.array(p, dtype=np.float64), np.array(v, dtype=np.float64)
+        return w
+
+    def box_on(grid_now, center, half=2):
+        c = [int(round((center[i] - origin[i]) / res - 0.5)) for i in range(3)]  # MapUtil::floatToInt
+        cells = []
+        for dz in range(-half, half + 1):
+            for dy in range(-half, half + 1):
+                for dx in range(-half, half + 1):
+                    x, y, z = c[0] + dx, c[1] + dy, c[2] + dz
+                    if 0 <= x < n and 0 <= y < n and 0 <= z < n and grid_now[z, y, x] == 0:
+                        cells.append((x, y, z))
+        return cells
+
+    rows = []
+
+    def cycle():
+        a, l = planner(False), planner(True)
+        s, g = wp(start), wp(goal)
+        out = []
+
+        def both(label):
+            t0 = time.perf_counter()
+            ok_l = l.plan(s, g)
+            wl = (time.perf_counter() - t0) * 1e3
+            rl, kl = l.getResult(), l.lastKernelMs()
+            t0 = time.perf_counter()
+            ok_a = a.plan(s, g)
+            wa = (time.perf_counter() - t0) * 1e3
+            ra, ka = a.getResult(), a.lastKernelMs()
+            assert ok_l and ok_a and rl.cost == ra.cost, (label, rl.cost, ra.cost)
+            out.append({"step": label, "lpa_ms": kl, "fresh_ms": ka, "lpa_wall_ms": wl, "fresh_wall_ms": wa,
+                        "lpa_expansions": int(rl.n_expanded), "fresh_expansions": int(ra.n_expanded), "cost": rl.cost})
+
+        both("first plan")
+        tr = l.getTraj()
+        wps = tr.getWaypoints()
+        cells = box_on(grid, tuple(wps[len(wps) // 2].pos))
+        g2 = grid.copy()
+        for x, y, z in cells:
+            g2[z, y, x] = 100
+        set_map(g2)
+        t0 = time.perf_counter()
+        nb = l.updateBlockedNodes(cells)
+        upd_b = (time.perf_counter() - t0) * 1e3
+        both("obstacle on the path (updateBlockedNodes)")
+        out[-1]["update_ms"], out[-1]["entries_changed"] = upd_b, nb
+        set_map(grid)
+        t0 = time.perf_counter()
+        nc = l.updateClearedNodes(cells)
+        upd_c = (time.perf_counter() - t0) * 1e3
+        both("obstacle removed (updateClearedNodes)")
+        out[-1]["update_ms"], out[-1]["entries_changed"] = upd_c, nc
+        tr = l.getTraj()
+        t0 = time.perf_counter()
+        l.getSubStateSpace(1)
+        sub = (time.perf_counter() - t0) * 1e3
+        w1 = tr.getWaypoints()[1]
+        s = wp(tuple(w1.pos), tuple(w1.vel))
+        both("one primitive ahead (getSubStateSpace(1))")
+        out[-1]["update_ms"] = sub
+        return out
+
+    for _ in range(args.warmup):
+        cycle()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows = cycle()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rep = rows[1]
+    out = {"metric": "plan_wall_time_ms", "value": rep["lpa_ms"], "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"LPA* replanning cycle of map_replanner_node.cpp:175-255 on the {n}^3 random-box voxel map (BASELINE C2 query, 27-primitive acc lattice, dt 1 "
+                                  "v_max 2 a_max 1 tol 0.5): plan, a 5^3-voxel obstacle on the middle of the path, removed again, one primitive ahead; value = kernel ms of the "
+                                  "LPA* repair after the obstacle landed; `cycle` lists every step next to a fresh device A* (speculative kernel + helpers) on the same map"},
+           "cycle": rows, "lpa_vs_fresh_after_obstacle": rep["fresh_ms"] / max(rep["lpa_ms"], 1e-9)}
     print(json.dumps(out), flush=True)
 
 

@@ -271,3 +271,131 @@ def test_lpastar_replanning_cycles_do_not_exhaust_the_pools():
     assert cycles >= 5
     ss = l.lpaStateSpace()
     assert ss["n_nodes"] <= 4 * first["n_nodes"] and ss["n_edges"] <= 4 * first["n_edges"]
+
+
+# ---------------------------------------------------------------- round 4: LPA* on 3-D voxel maps
+# The scenario of map_replanner_node.cpp:175-255 on a 3-D map with the 27-input lattice: plan; an obstacle (a cube of
+# voxels: what addCloudCallback's inflated cloud amounts to in 3-D) lands on the middle of the current trajectory
+# (updateBlockedNodes); it is removed again (updateClearedNodes); the robot moves one primitive ahead (getSubStateSpace(1)).
+KW3 = dict(v_max=2.0, a_max=1.0, tol_pos=0.5)
+
+
+def box_cells(P, center, half):
+    """free cells of the (2 half + 1)^3 cube around the cell of `center` (P: a scratch oracle holding the current map)"""
+    c = P.float_to_int(center)
+    out = []
+    for dz in range(-half, half + 1):
+        for dy in range(-half, half + 1):
+            for dx in range(-half, half + 1):
+                cc = (c[0] + dx, c[1] + dy, c[2] + dz)
+                if P.cell_state(cc) == 0:
+                    out.append(cc)
+    return out
+
+
+def scenario_3d(name):
+    if name == "skir":  # the reference's one surviving 3-D map and its launch query (launch/map_planner_node/test.launch.skir)
+        d = np.load(os.path.join(ROOT, "tests", "golden", "skir_map.npz"))
+        return d["grid"].copy(), tuple(d["origin"].tolist()), float(d["res"]), (5.5, 5.5, 0.5), (1.0, 0.0, 0.0), (1.5, 1.5, 5.5)
+    grid, origin, res, start, goal, _ = mapgen.benchmark_map(256)  # BASELINE C2: 256^3 random boxes, 31 309 expansions to the goal
+    return grid, origin, res, start, (0.0, 0.0, 0.0), goal
+
+
+def test_oracle_lpastar_equals_fresh_astar_on_a_3d_map():
+    grid, origin, res, start, sv, goal = scenario_3d("skir")
+    U = mapgen.control_lattice(1.0, 1, True)
+    A = util.make_oracle(grid, origin, res, orc.ACC, U, **KW3)
+    L = util.make_oracle(grid, origin, res, orc.ACC, U, **KW3)
+    L.set_lpastar(True)
+    so, go = orc.waypoint(start, vel=sv), orc.waypoint(goal)
+    assert A.plan(so, go) == L.plan(so, go) == orc.OK and A.traj_cost == L.traj_cost
+    cost0, n0 = L.traj_cost, L.lpa_iterations()
+    tr = L.traj()
+    cells = box_cells(A, tuple(tr["wps"][tr["n"] // 2].pos), 2)
+    g2 = grid.copy()
+    for x, y, z in cells:
+        g2[z, y, x] = 100
+    for P in (A, L):
+        P.set_map(g2, origin, res)
+    assert L.update_blocked(cells) > 0
+    L.reset_counters()
+    assert A.plan(so, go) == L.plan(so, go) == orc.OK and A.traj_cost == L.traj_cost > cost0
+    assert 0 < L.lpa_iterations() < len(A.expanded()[0])
+    for P in (A, L):
+        P.set_map(grid, origin, res)
+    assert L.update_cleared(cells) > 0
+    L.reset_counters()
+    assert A.plan(so, go) == L.plan(so, go) == orc.OK and A.traj_cost == L.traj_cost == cost0
+    assert L.lpa_iterations() < n0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["skir", "c2_256"])
+def test_hip_lpastar_on_3d_maps_bit_exact_and_equal_to_fresh_astar(name):
+    """LPA* replayed on the skir 3-D map and on the 256^3 random-box map of BASELINE C2 (27-input lattice): the HIP LPA*
+    against the oracle's bit for bit (expansion order, every state's g / rhs / flags, every predecessor entry with its
+    blocked flag, trajectory), and after every repair cost == a fresh device A* on the edited map.  Prints the kernel time
+    of the repair next to the fresh A*'s."""
+    from mpl_ros_amd.planner import VoxelMapPlanner
+    grid, origin, res, start, sv, goal = scenario_3d(name)
+    U = mapgen.control_lattice(1.0, 1, True)
+    scratch = util.make_oracle(grid, origin, res, orc.ACC, U, **KW3)
+    L = util.make_oracle(grid, origin, res, orc.ACC, U, **KW3)
+    L.set_lpastar(True)
+    big = name != "skir"
+    caps = dict(max_nodes=1 << 18, max_edges=1 << 20, max_log=1 << 20) if big else {}
+    mu, a = util.make_gpu(grid, origin, res, U, **KW3, **caps)
+    l = VoxelMapPlanner(False)
+    l.setMapUtil(mu)
+    l.setVmax(2.0); l.setAmax(1.0); l.setDt(1.0); l.setU(U); l.setTol(0.5)
+    l.setCapacity(1, 1 << 18, 1 << 20, 1 << 21) if big else l.setCapacity(1, 1 << 16, 1 << 18, 1 << 18)
+    l.setLPAstar(True)
+    go, gg = orc.waypoint(goal), util.gpu_wp(goal)
+    times = []
+
+    def replan(label, so, sg):
+        L.reset_counters()
+        sl = L.plan(so, go)
+        ok_l = l.plan(sg, gg)
+        rl = l.getResult()
+        lpa_ms = l.lastKernelMs()
+        assert ok_l == (sl == orc.OK)
+        compare_lpa(L, l, rl, sl)
+        ok_a = a.plan(sg, gg)
+        ra = a.getResult()
+        assert ok_a == ok_l and rl.cost == ra.cost  # LPA* cost == fresh A* cost on the same (edited) map
+        times.append((label, int(rl.n_expanded), round(lpa_ms, 3), int(ra.n_expanded), round(a.lastKernelMs(), 3)))
+        return rl, ra
+
+    def set_maps(g):
+        scratch.set_map(g, origin, res)
+        L.set_map(g, origin, res)
+        dz, dy, dx = g.shape
+        mu.setMap(origin, (dx, dy, dz), g.ravel(), res)
+
+    so, sg = orc.waypoint(start, vel=sv), util.gpu_wp(start, vel=sv)
+    rl0, ra0 = replan("first plan", so, sg)
+    assert l.initialized() and rl0.n_expanded == ra0.n_expanded
+    cost0 = rl0.cost
+    tr = L.traj()
+    cells = box_cells(scratch, tuple(tr["wps"][tr["n"] // 2].pos), 2)
+    g2 = grid.copy()
+    for x, y, z in cells:
+        g2[z, y, x] = 100
+    set_maps(g2)
+    nb = L.update_blocked(cells)
+    assert l.updateBlockedNodes(cells) == nb > 0
+    rl1, ra1 = replan("box on the path", so, sg)
+    assert rl1.cost >= cost0 and 0 < rl1.n_expanded < ra1.n_expanded
+    set_maps(grid)
+    nc = L.update_cleared(cells)
+    assert l.updateClearedNodes(cells) == nc > 0
+    rl2, ra2 = replan("box removed", so, sg)
+    assert rl2.cost == cost0 and rl2.n_expanded < ra2.n_expanded
+    tg = l.getTraj()
+    L.sub_state_space(1)
+    l.getSubStateSpace(1)
+    w1 = tg.getWaypoints()[1]
+    rl3, ra3 = replan("one primitive ahead", orc.waypoint(tuple(w1.pos), vel=tuple(w1.vel)), util.gpu_wp(tuple(w1.pos), vel=tuple(w1.vel)))
+    assert rl3.n_expanded < ra3.n_expanded and rl3.cost < cost0
+    print(f"LPA* on {name}: (step, LPA* expansions, LPA* kernel ms, fresh A* expansions, fresh A* kernel ms)", times)
