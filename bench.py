@@ -79,6 +79,12 @@ def main():
                     help="--config c5: round 3's variant (distance heuristic, max_expand 20000) instead of the reference's planner parameters")
     ap.add_argument("--no-throughput", action="store_true",
                     help="N > 1, strong scaling: skip the additional throughput phase (a 1024 x N query stream through the same sharded path)")
+    ap.add_argument("--stream", type=int, default=-1,
+                    help="N = 1, C4 batch: batches of the additional streamed leg (mplx_stream: two batches in flight on two lanes of the same map replica; "
+                         "every result compared with the blocking step's); -1 auto = max(steps, 6), 0 off")
+    ap.add_argument("--stream-depth", type=int, default=2, help="lanes of the streamed leg (each holds a batch's pools: two fit 288 GB at C4 size)")
+    ap.add_argument("--stream-helper-limit", type=int, default=32,
+                    help="streamed leg: workgroups of a batch that stay on as helpers once its queue is empty (the others leave their compute unit to the next batch)")
     ap.add_argument("--dump-queries", default="", help="write per-query expansions / device timing of the last step to this JSON file")
     args = ap.parse_args()
     if args.single:
@@ -369,6 +375,9 @@ def main():
                                                        "both this and the HBM fraction are low: the launch is latency-bound (serial pop chain per query)"}
         except Exception:
             pass
+        n_stream = args.stream if args.stream >= 0 else max(args.steps, 6)
+        if n_stream > 0 and world == 1 and not multi and not args.single and mine:
+            out["stream"] = stream_leg(args, pl, starts, goals, results, n_stream, control, jrk, max_expand, alg)
         if args.cpu_seconds > 0 and mine and world == 1:  # (the CPU baseline is a rank-0, N = 1 leg)
             # a single capped query is sampled on the CPU with a smaller cap; the GPU then repeats the query with
             # that cap (untimed) so that the parity check compares equal searches
@@ -554,6 +563,79 @@ def bench_c5(args):
                                  "tick_ms": 1e3 * ce / args.steps, "expansions_per_step": int(sum(r.n_expanded for r in Rc)),
                                  "plan_status_counts": {str(k): int(v) for k, v in enumerate(np.bincount([r.status for r in Rc], minlength=7))}}
     print(json.dumps(out), flush=True)
+
+
+def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, max_expand, alg_bytes_per_batch):
+    """Steady-state query throughput with several batches in flight (include/mplx.h mplx_stream_*; north_star: "many independent
+    start/goal queries ... shard one-query-per-stream").  The blocking step above lasts as long as its longest query -- one
+    serial pop chain on one compute unit -- while most of the machine idles; here `depth` lanes (own HIP stream, own pools)
+    share the map replica and batch n + 1's workgroups take the compute units batch n's tail no longer needs.  The same
+    1024-query batch is submitted n_batches times; EVERY result of EVERY batch is compared with the blocking step's
+    (which the CPU leg below parity-samples).  Reported: expansions/s over the wall time of the whole stream, per-batch
+    latency (submit -> done), and the algorithmic-bytes rate."""
+    import ctypes as C
+    import torch
+    from mpl_ros_amd import _capi, mapgen
+    nq = len(starts)
+    key = lambda r: (r.status, r.traj_len, r.cost, r.n_expanded, r.n_nodes, r.n_edges, r.n_succ_finite, r.voxel_reads, r.expand_hash)
+    want = [key(r) for r in ref_results]
+    exp_per_batch = sum(r.n_expanded for r in ref_results)
+    pl.releasePools()  # the blocking leg's pools (~ 130 GB at C4 size) make room for the lanes'
+    depth = max(1, args.stream_depth)
+    caps = mapgen.c4_pools(jrk, max(nq, 256), max_expand, per_q=args.max_nodes or (420_000 if not jrk else 0))
+    st = pl.stream(depth)
+    # a lane = one workgroup per compute unit, all of them leading (no reserved helper share); when a batch's queue is empty
+    # at most --stream-helper-limit of its workgroups stay on to help its longest queries, the others exit
+    st.configure(min(nq, 256), caps["nodes"], caps["edges"], caps["log"], args.helpers, 0, 1 << 24, args.stream_helper_limit)
+    S = (_capi.Waypoint * nq)(*[w.to_c() for w in starts])
+    G = (_capi.Waypoint * nq)(*[w.to_c() for w in goals])
+    mism = 0
+
+    def collect(t):
+        nonlocal mism
+        R = st.wait(t)
+        bad = sum(1 for r, w in zip(R, want) if key(r) != w)
+        mism += bad
+        return R
+
+    for t in [st.submit_c(S, G, nq) for _ in range(depth)]:  # warm-up: allocates the lanes' pools
+        collect(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inflight, lat, done_at, submitted, kernel_ms = [], [], [], 0, []
+    while submitted < n_batches or inflight:
+        while submitted < n_batches and len(inflight) < depth:
+            inflight.append((st.submit_c(S, G, nq), time.perf_counter()))
+            submitted += 1
+        progressed = False
+        for item in list(inflight):
+            t, ts = item
+            if st.done(t):
+                now = time.perf_counter()
+                collect(t)
+                kernel_ms.append(st.lastKernelMs())
+                lat.append(now - ts)
+                done_at.append(now - t0)
+                inflight.remove(item)
+                progressed = True
+        if not progressed:
+            time.sleep(0.0005)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    st.close()
+    gaps = np.diff([0.0] + sorted(done_at))
+    return {"value": exp_per_batch * n_batches / wall, "unit": "expansions/s", "batches": n_batches, "depth": depth, "wall_s": wall,
+            "ms_per_batch": 1e3 * wall / n_batches, "steady_state_ms_per_batch": 1e3 * float(np.median(gaps[1:])) if len(gaps) > 2 else None,
+            "batch_latency_ms": {"mean": 1e3 * float(np.mean(lat)), "min": 1e3 * float(np.min(lat)), "max": 1e3 * float(np.max(lat))},
+            "kernel_ms_per_batch": {"mean": float(np.mean(kernel_ms)), "max": float(np.max(kernel_ms))},
+            "helper_limit": args.stream_helper_limit,
+            "parity": {"batches_checked": n_batches + depth, "queries_per_batch": nq, "mismatches_vs_blocking_step": mism,
+                       "checked": "status, traj_len, cost (bit-exact f64), n_expanded, n_nodes, n_edges, n_succ_finite, voxel_reads, expand_hash of every query of every batch"},
+            "roofline": {"achieved": alg_bytes_per_batch * n_batches / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg_bytes_per_batch * n_batches / wall / 1e9 / HBM_PEAK_GBS,
+                         "note": "algorithmic bytes of all batches / wall time of the stream (launches overlap: a per-launch duration would count shared time twice)"},
+            "workload": f"the same {nq}-query batch submitted {n_batches} times, {depth} in flight on {depth} lanes of one map replica (mplx_stream); "
+                        "submit -> done latency per batch beside the throughput"}
 
 
 def bench_lpa(args):

@@ -221,6 +221,36 @@ int mplx_plan(mplx_ctx *ctx, const mplx_waypoint *start, const mplx_waypoint *go
 /* nq independent queries on the shared map, one workgroup per in-flight query */
 int mplx_plan_batch(mplx_ctx *ctx, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals, mplx_result *out);
 
+/* ---- streamed batches (north star: "many independent start/goal queries ... shard one-query-per-stream"; the independence
+ *      of the queries: robot_team.hpp:60-66, every robot plans on its own).  mplx_plan_batch is submit + wait.  submit()
+ *      returns once the batch is launched on the context's stream; wait() blocks until it is finished and hands out the
+ *      results (the getters below then answer for it).  One batch may be outstanding per context. ---- */
+int mplx_plan_batch_submit(mplx_ctx *ctx, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals);
+int mplx_plan_batch_wait(mplx_ctx *ctx, mplx_result *out /* nq records; may be NULL */);
+int mplx_plan_batch_done(mplx_ctx *ctx); /* 1: wait() will not block, 0: still running, < 0: error */
+/* Several batches in flight: an mplx_stream holds `depth` lanes -- contexts of their own (HIP stream, pools, result buffers)
+ * on ctx's map replica (adopted, not copied) and planner set-up.  submit() launches on a free lane (MPLX_ERR_ARG when every
+ * lane is busy) and returns a ticket; wait(ticket) collects it; *lane_ctx (may be NULL) is the context that answers
+ * mplx_result_traj / mplx_result_timing for that batch until the lane is submitted to again.  A query is a serial pop chain
+ * on one compute unit: while the longest queries of batch n finish, the workgroups of batch n + 1 run on the rest of the
+ * machine.  mplx_stream_configure: pools and helper policy of every lane (helper_limit: see mplx_set_helper_limit).
+ * Destroy the stream before ctx. */
+typedef struct mplx_stream mplx_stream;
+int mplx_stream_create(mplx_ctx *ctx, int depth, mplx_stream **out);
+void mplx_stream_destroy(mplx_stream *s);
+const char *mplx_stream_last_error(const mplx_stream *s);
+int mplx_stream_depth(const mplx_stream *s);
+int mplx_stream_configure(mplx_stream *s, int32_t n_slots, uint64_t total_nodes, uint64_t total_edges, uint64_t total_open_log,
+                          int32_t helpers_per_leader, int32_t helpers_reserved, uint64_t cache_rows, int32_t helper_limit);
+int mplx_stream_submit(mplx_stream *s, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals, int64_t *ticket);
+int mplx_stream_done(mplx_stream *s, int64_t ticket);
+int mplx_stream_wait(mplx_stream *s, int64_t ticket, mplx_result *out, mplx_ctx **lane_ctx);
+/* At most `limit` workgroups of a launch stay on as helpers once its query queue is empty (-1: all of them, the default
+ * of a blocking batch); the others exit, so that the next batch's workgroups get their compute units. */
+int mplx_set_helper_limit(mplx_ctx *ctx, int32_t limit);
+/* Free the context's device pools and batch buffers (re-created by its next plan): hands the memory to other contexts. */
+int mplx_release_pools(mplx_ctx *ctx);
+
 /* ---- results of query q of the last plan / plan_batch ---- */
 /* getTraj(): prs[traj_len] primitives, wps[traj_len+1] waypoints, actions[traj_len]; NULLs allowed */
 int mplx_result_traj(mplx_ctx *ctx, int q, mplx_primitive *prs, mplx_waypoint *wps, int32_t *actions, int32_t *node_ids);

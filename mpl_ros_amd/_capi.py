@@ -68,6 +68,9 @@ EXPORTS = [
     "mplx_poly_add_static", "mplx_poly_add_linear", "mplx_poly_add_nonlinear", "mplx_poly_commit", "mplx_poly_get_succ_batch", "mplx_poly_set_capacity", "mplx_poly_plan_batch", "mplx_poly_result_traj",
     "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms", "mplx_poly_result_cycles", "mplx_poly_set_helpers", "mplx_poly_last_helpers",
     "mplx_traj_solve", "mplx_traj_sample", "mplx_traj_effort",
+    "mplx_plan_batch_submit", "mplx_plan_batch_wait", "mplx_plan_batch_done", "mplx_set_helper_limit", "mplx_release_pools",
+    "mplx_stream_create", "mplx_stream_destroy", "mplx_stream_last_error", "mplx_stream_depth", "mplx_stream_configure",
+    "mplx_stream_submit", "mplx_stream_done", "mplx_stream_wait",
 ]
 
 
@@ -206,5 +209,20 @@ def load():
     L.mplx_poly_result_cycles.argtypes = [P, C.c_int32, C.POINTER(C.c_uint64)]
     L.mplx_poly_set_helpers.argtypes = [P, C.c_int32]
     L.mplx_poly_last_helpers.argtypes = [P]
+    L.mplx_plan_batch_submit.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(Waypoint)]
+    L.mplx_plan_batch_wait.argtypes = [P, C.POINTER(Result)]
+    L.mplx_plan_batch_done.argtypes = [P]
+    L.mplx_set_helper_limit.argtypes = [P, C.c_int32]
+    L.mplx_release_pools.argtypes = [P]
+    L.mplx_stream_create.argtypes = [P, C.c_int, C.POINTER(P)]
+    L.mplx_stream_destroy.argtypes = [P]
+    L.mplx_stream_destroy.restype = None
+    L.mplx_stream_last_error.argtypes = [P]
+    L.mplx_stream_last_error.restype = C.c_char_p
+    L.mplx_stream_depth.argtypes = [P]
+    L.mplx_stream_configure.argtypes = [P, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32, C.c_uint64, C.c_int32]
+    L.mplx_stream_submit.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(Waypoint), C.POINTER(C.c_int64)]
+    L.mplx_stream_done.argtypes = [P, C.c_int64]
+    L.mplx_stream_wait.argtypes = [P, C.c_int64, C.POINTER(Result), C.POINTER(P)]
     _lib = L
     return L

@@ -95,6 +95,14 @@ struct mplx_ctx {
   uint32_t help_stats[4] = {0, 0, 0, 0};
   uint32_t help_ctr_back[HELP_CTR_WORDS] = {};
   bool help_stats_pending = false;  // last batch: cache rows used, queries done, helpers that gave up on a stopped leader, helpers that found every leader served
+  // streamed batches (mplx_plan_batch_submit / _wait): the batch launched on this context's stream and not yet collected.
+  // The host-side sources of its asynchronous uploads live here until then.
+  bool pending = false;
+  int pend_nq = 0;
+  bool pend_help = false;
+  std::vector<QueryIn> pend_in;
+  std::vector<int32_t> pend_order;
+  int help_limit = -1;  // workgroups of a launch that may turn into helpers once the query queue is empty (-1: all of them)
 };
 
 static int fail(mplx_ctx *c, int code, const char *fmt, ...) {
@@ -1012,15 +1020,20 @@ static void fill_result(const QueryOut &o, mplx_result &r) {
   r.n_refill = o.n_refill; r.n_evict = o.n_evict; r.expand_hash = o.expand_hash;
 }
 
-extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals, mplx_result *out) {
+// First half of a batch: marshal the queries, reset the per-batch device state, launch the search on the context's stream.
+// Nothing here waits for the device; the uploads' host-side sources stay alive in the context (pend_in / pend_order)
+// until plan_batch_finish() has synchronised.
+static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals) {
   int r = check_ready(c);
   if (r) return r;
-  if (nq <= 0 || !starts || !goals || !out) return fail(c, MPLX_ERR_ARG, "bad argument");
+  if (nq <= 0 || !starts || !goals) return fail(c, MPLX_ERR_ARG, "bad argument");
+  if (c->pending) return fail(c, MPLX_ERR_ARG, "a submitted batch is still outstanding on this context (mplx_plan_batch_wait first)");
   HIPCHK(c, hipSetDevice(c->device));
   const int slots = nq < c->n_slots ? nq : c->n_slots;
   if ((r = ensure_pools(c, slots)) != MPLX_OK) return r;
   if ((r = ensure_batch(c, nq)) != MPLX_OK) return r;
-  std::vector<QueryIn> in(nq);
+  std::vector<QueryIn> &in = c->pend_in;
+  in.assign((size_t)nq, QueryIn{});
   for (int i = 0; i < nq; i++) {
     if (starts[i].enable_t) return fail(c, MPLX_ERR_ARG, "enable_t is not supported by the voxel-map environment");
     if (!control_ok(goals[i].control & ~MPLX_YAW)) return fail(c, MPLX_ERR_ARG, "bad goal control");
@@ -1037,7 +1050,8 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   if (nq >= 0xFFFF) return fail(c, MPLX_ERR_ARG, "at most 65534 queries per batch");
   // launch order: longest expected search first (straight-line distance), so the tail of the batch
   // is made of short queries
-  std::vector<int32_t> order(nq);
+  std::vector<int32_t> &order = c->pend_order;
+  order.assign((size_t)nq, 0);
   {
     std::vector<std::pair<double, int32_t>> key(nq);
     for (int i = 0; i < nq; i++) {
@@ -1076,6 +1090,7 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   int grid = slots;
   P.help_lead = slots;
   P.help_max = 0;
+  P.help_limit = c->help_limit;
   const bool help = spec && !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
                     ((P.n_u <= 31 && (P.control == CTRL_ACC || P.control == CTRL_JRK)) || (P.control == CTRL_JRK && P.n_u > 64 && P.n_u <= 128));
   if (help) {
@@ -1134,8 +1149,20 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-  if (launched) {
-    HIPCHK(c, hipMemcpyAsync(c->help_ctr_back, P.cache_next, HELP_CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  c->pending = true;
+  c->pend_nq = nq;
+  c->pend_help = launched;
+  return MPLX_OK;
+}
+
+// Second half: wait for the launch, read the results back.
+static int plan_batch_finish(mplx_ctx *c, mplx_result *out) {
+  if (!c->pending) return fail(c, MPLX_ERR_ARG, "no submitted batch on this context");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int nq = c->pend_nq;
+  c->pending = false;  // (whatever happens below, the batch is not outstanding any more)
+  if (c->pend_help) {
+    HIPCHK(c, hipMemcpyAsync(c->help_ctr_back, c->pools.cache_next, HELP_CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     c->help_stats_pending = true;
   } else {
     memset(c->help_stats, 0, sizeof(c->help_stats));
@@ -1145,7 +1172,8 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   HIPCHK(c, hipMemcpyAsync(c->last_out.data(), c->d_out, sizeof(QueryOut) * nq, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
-  for (int i = 0; i < nq; i++) fill_result(c->last_out[i], out[i]);
+  if (out)
+    for (int i = 0; i < nq; i++) fill_result(c->last_out[i], out[i]);
   c->last_nq = nq;
   c->last_single = (nq == 1);
   c->last_control = c->cfg.control;
@@ -1155,6 +1183,156 @@ extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts,
   c->last_Uyaw = c->Uyaw;
   c->last_map_epoch = c->map_epoch;
   c->plan_epoch++;
+  return MPLX_OK;
+}
+
+extern "C" int mplx_plan_batch(mplx_ctx *c, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals, mplx_result *out) {
+  if (!out) return fail(c, MPLX_ERR_ARG, "bad argument");
+  int r = plan_batch_launch(c, nq, starts, goals);
+  if (r) return r;
+  return plan_batch_finish(c, out);
+}
+
+// ---- streamed batches: the asynchronous pair of mplx_plan_batch.  submit() returns as soon as the batch is launched on
+// the context's stream; wait() blocks until it has finished and hands out the results (mplx_result_traj etc. then answer
+// for it).  One batch may be outstanding per context: several batches in flight = several contexts sharing one map
+// replica (mplx_map_set_device on the same device pointer), which is what mplx_stream_* below packages.
+extern "C" int mplx_plan_batch_submit(mplx_ctx *c, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals) {
+  return plan_batch_launch(c, nq, starts, goals);
+}
+extern "C" int mplx_plan_batch_wait(mplx_ctx *c, mplx_result *out) {
+  if (!c) return MPLX_ERR_ARG;
+  return plan_batch_finish(c, out);
+}
+extern "C" int mplx_plan_batch_done(mplx_ctx *c) {  // 1: wait() will not block; 0: still running; < 0: error
+  if (!c) return MPLX_ERR_ARG;
+  if (!c->pending) return 1;
+  if (hipSetDevice(c->device) != hipSuccess) return MPLX_ERR_HIP;
+  const hipError_t e = hipStreamQuery(c->stream);
+  return e == hipSuccess ? 1 : e == hipErrorNotReady ? 0 : fail(c, MPLX_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
+}
+extern "C" int mplx_set_helper_limit(mplx_ctx *c, int32_t limit) {
+  if (!c) return MPLX_ERR_ARG;
+  c->help_limit = limit < 0 ? -1 : limit;
+  return MPLX_OK;
+}
+// give the pools back to the device allocator (they are re-created by the next plan): lets a caller hand the memory to
+// other contexts -- a stream's lanes -- without destroying this one
+extern "C" int mplx_release_pools(mplx_ctx *c) {
+  if (!c) return MPLX_ERR_ARG;
+  if (c->pending) return fail(c, MPLX_ERR_ARG, "a submitted batch is still outstanding on this context");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_pools(c);
+  free_batch(c);
+  c->last_nq = 0;
+  c->last_single = false;
+  return MPLX_OK;
+}
+
+// ---- mplx_stream: `depth` lanes (contexts of their own: stream, pools, result buffers) on the parent context's map replica
+// and planner set-up.  submit() launches a batch on a free lane and returns a ticket; wait(ticket) collects it.  While
+// the longest queries of batch n still run (a query is a serial pop chain: one compute unit plus its helpers), the
+// workgroups of batch n + 1 take the compute units batch n no longer needs.  North star: "many independent start/goal
+// queries ... shard one-query-per-stream"; the independence that licenses it: robot_team.hpp:60-66.
+struct mplx_stream {
+  mplx_ctx *parent = nullptr;
+  std::vector<mplx_ctx *> lanes;
+  std::vector<int64_t> ticket_of;   // ticket outstanding on each lane (-1: free)
+  int64_t next_ticket = 0;
+  std::string err;
+};
+static int sfail(mplx_stream *s, int code, const char *msg) {
+  if (s) s->err = msg ? msg : "";
+  return code;
+}
+extern "C" const char *mplx_stream_last_error(const mplx_stream *s) { return s ? s->err.c_str() : ""; }
+extern "C" void mplx_stream_destroy(mplx_stream *s) {
+  if (!s) return;
+  for (mplx_ctx *l : s->lanes) mplx_ctx_destroy(l);
+  delete s;
+}
+extern "C" int mplx_stream_create(mplx_ctx *parent, int depth, mplx_stream **out) {
+  if (!parent || !out || depth < 1 || depth > 8) return fail(parent, MPLX_ERR_ARG, "bad argument (depth 1..8)");
+  *out = nullptr;
+  int r = check_ready(parent);
+  if (r) return r;
+  mplx_stream *s = new mplx_stream();
+  s->parent = parent;
+  for (int k = 0; k < depth; k++) {
+    mplx_ctx *l = nullptr;
+    r = mplx_ctx_create(parent->device, &l);
+    if (r == MPLX_OK) {
+      s->lanes.push_back(l);
+      r = mplx_map_set_device(l, parent->map, parent->dim, parent->origin, parent->res);  // the parent's replica, adopted: no copy
+    }
+    if (r == MPLX_OK) {
+      mplx_config cfg = parent->cfg;
+      cfg.control = parent->cfg.control | (parent->yaw ? MPLX_YAW : 0);
+      cfg.U = parent->U.data();
+      cfg.U_yaw = parent->yaw ? parent->Uyaw.data() : nullptr;
+      r = mplx_planner_config(l, &cfg);
+    }
+    if (r == MPLX_OK) {
+      l->n_slots = parent->n_slots; l->cap_nodes = parent->cap_nodes; l->cap_edges = parent->cap_edges; l->cap_log = parent->cap_log;
+      l->bucket_width = parent->bucket_width; l->speculation = parent->speculation;
+      l->helpers = parent->helpers; l->help_reserved = parent->help_reserved; l->help_rows = parent->help_rows; l->help_limit = parent->help_limit;
+    }
+    if (r != MPLX_OK) {
+      if (l) parent->err = l->err.empty() ? g_create_error : l->err;
+      mplx_stream_destroy(s);
+      return r;
+    }
+  }
+  s->ticket_of.assign((size_t)depth, -1);
+  *out = s;
+  return MPLX_OK;
+}
+// per-lane knobs (the lanes copy the parent's at creation): pool capacities and helper policy of every lane
+extern "C" int mplx_stream_configure(mplx_stream *s, int32_t n_slots, uint64_t total_nodes, uint64_t total_edges, uint64_t total_open_log,
+                                     int32_t helpers_per_leader, int32_t helpers_reserved, uint64_t cache_rows, int32_t helper_limit) {
+  if (!s) return MPLX_ERR_ARG;
+  for (mplx_ctx *l : s->lanes) {
+    if (l->pending) return sfail(s, MPLX_ERR_ARG, "a lane has a batch outstanding");
+    mplx_set_capacity(l, n_slots, total_nodes, total_edges, total_open_log);
+    int r = mplx_set_helpers(l, helpers_per_leader, helpers_reserved, cache_rows);
+    if (r) return sfail(s, r, l->err.c_str());
+    mplx_set_helper_limit(l, helper_limit);
+  }
+  return MPLX_OK;
+}
+extern "C" int mplx_stream_depth(const mplx_stream *s) { return s ? (int)s->lanes.size() : 0; }
+extern "C" int mplx_stream_submit(mplx_stream *s, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals, int64_t *ticket) {
+  if (!s || !ticket) return MPLX_ERR_ARG;
+  for (size_t k = 0; k < s->lanes.size(); k++) {
+    if (s->ticket_of[k] >= 0) continue;
+    int r = plan_batch_launch(s->lanes[k], nq, starts, goals);
+    if (r) return sfail(s, r, s->lanes[k]->err.c_str());
+    s->ticket_of[k] = *ticket = s->next_ticket++;
+    return MPLX_OK;
+  }
+  return sfail(s, MPLX_ERR_ARG, "every lane of the stream has a batch outstanding (mplx_stream_wait for one first)");
+}
+// the lane a ticket runs on (-1: unknown / already collected): its context answers mplx_result_traj etc. after wait()
+static int stream_lane_of(const mplx_stream *s, int64_t ticket) {
+  for (size_t k = 0; k < s->lanes.size(); k++)
+    if (s->ticket_of[k] == ticket) return (int)k;
+  return -1;
+}
+extern "C" int mplx_stream_done(mplx_stream *s, int64_t ticket) {
+  if (!s) return MPLX_ERR_ARG;
+  const int k = stream_lane_of(s, ticket);
+  if (k < 0) return sfail(s, MPLX_ERR_ARG, "no such ticket");
+  return mplx_plan_batch_done(s->lanes[(size_t)k]);
+}
+extern "C" int mplx_stream_wait(mplx_stream *s, int64_t ticket, mplx_result *out, mplx_ctx **lane_ctx) {
+  if (!s) return MPLX_ERR_ARG;
+  const int k = stream_lane_of(s, ticket);
+  if (k < 0) return sfail(s, MPLX_ERR_ARG, "no such ticket");
+  s->ticket_of[(size_t)k] = -1;
+  int r = plan_batch_finish(s->lanes[(size_t)k], out);
+  if (lane_ctx) *lane_ctx = s->lanes[(size_t)k];  // valid until the lane's next submit: trajectories, timings of this batch
+  if (r) return sfail(s, r, s->lanes[(size_t)k]->err.c_str());
   return MPLX_OK;
 }
 

@@ -715,11 +715,19 @@ __global__ __launch_bounds__(BLOCK) void lpa_plan_kernel(SearchParams P, LpaPara
 // mode 0: updateBlockedNodes -- entries whose primitive is no longer free get EDGE_BLOCKED
 // mode 1: updateClearedNodes -- blocked entries that are free again lose the flag; logged blocked successors whose
 //         primitive is free now become entries (in log order, creating the state when it does not exist yet)
-// then rhs (and the open / closed flags) of every state whose entries changed is recomputed.  One workgroup.
+// then rhs (and the open / closed flags) of every state whose entries changed is recomputed.
+// Three passes, launched one after the other on the planner's stream (round 4: the one-workgroup version took 56 ms for
+// the 350 000 entries of the BASELINE C2 state space -- seven times the repair it prepares):
+//   pass 0  every predecessor entry (and, mode 1, every entry of the blocked log) re-sampled against the current map --
+//           independent of each other, grid-stride over as many workgroups as the launch has; changed entries flag their
+//           state (FLAG_DIRTY, a memory-side atomic) and are counted into st->n_changed (zeroed by the host)
+//   pass 1  (mode 1) the freed log entries become predecessor entries IN LOG ORDER (ids of the states they create and
+//           the order of the entries are results): one thread
+//   pass 2  updateNode of the flagged states, grid-stride again
+// The passes are separate launches: what pass 0 writes (entry flags, state flags) is read by other workgroups in pass 2.
 template <int BLOCK, int CONTROL>
-__global__ __launch_bounds__(BLOCK) void lpa_update_kernel(SearchParams P, LpaParams A, int mode) {
+__global__ __launch_bounds__(BLOCK) void lpa_update_kernel(SearchParams P, LpaParams A, int mode, int pass) {
   __shared__ Smem<BLOCK> S;
-  __shared__ unsigned long long s_changed;
   using V = LView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
   const QView<BLOCK, CONTROL> Q{P, S, P.bkt_head};
@@ -728,7 +736,6 @@ __global__ __launch_bounds__(BLOCK) void lpa_update_kernel(SearchParams P, LpaPa
   __syncthreads();
   LpaState *st = A.st;
   if (tid == 0) {
-    s_changed = 0;
     S.n_nodes = st->n_nodes;
     S.n_edges = st->n_edges;
     S.hp.w = P.w; S.hp.v_max = P.v_max; S.hp.heur_ignore_dynamics = P.heur_ignore_dynamics;
@@ -738,37 +745,42 @@ __global__ __launch_bounds__(BLOCK) void lpa_update_kernel(SearchParams P, LpaPa
   }
   __syncthreads();
   const uint32_t n_edges0 = S.n_edges, root = st->root_id;
-  uint32_t n_blocked = st->n_blocked;
-  // ---- predecessor entries
-  unsigned long long mine = 0;
-  for (uint32_t e = tid; e < n_edges0; e += BLOCK) {
-    EdgeRec *er = Q.edge(e);
-    const uint32_t a = er->action;
-    const bool was_blocked = (a & EDGE_BLOCKED) != 0;
-    if (was_blocked != (mode == 1)) continue;
-    State tn;
-    int32_t key[MAX_KEY];
-    const bool free_ = lpa_prim_free<CONTROL>(P, V::state(Q.node(er->parent)), (int)(a & ~EDGE_BLOCKED), tn, key);
-    if (free_ == (mode == 1)) {
-      er->action = mode == 1 ? (a & ~EDGE_BLOCKED) : (a | EDGE_BLOCKED);
-      const uint32_t child = lpa_find<BLOCK, CONTROL>(P.table, P.table_mask, P.node_pool, key, key_hash64(key, nk));
-      if (child != NIL) atomicOr(&V::flags(Q.node(child)), FLAG_DIRTY);
-      mine++;
-    }
-  }
-  if (mine) atomicAdd(&s_changed, mine);
-  __syncthreads();
-  // ---- the blocked log (mode 1): evaluate in parallel, convert in log order
-  if (mode == 1) {
-    for (uint32_t b = tid; b < n_blocked; b += BLOCK) {
-      uint2 le = A.blocked_log[b];
-      if (le.y & LOG_CONVERTED) continue;
+  const uint32_t n_blocked = st->n_blocked;
+  const uint32_t gtid = blockIdx.x * BLOCK + (uint32_t)tid, gstride = gridDim.x * BLOCK;
+  if (pass == 0) {
+    // ---- predecessor entries
+    unsigned long long mine = 0;
+    for (uint32_t e = gtid; e < n_edges0; e += gstride) {
+      EdgeRec *er = Q.edge(e);
+      const uint32_t a = er->action;
+      const bool was_blocked = (a & EDGE_BLOCKED) != 0;
+      if (was_blocked != (mode == 1)) continue;
       State tn;
       int32_t key[MAX_KEY];
-      if (lpa_prim_free<CONTROL>(P, V::state(Q.node(le.x)), (int)(le.y & 0xFFFFu), tn, key)) A.blocked_log[b].y = le.y | LOG_FREE_NOW;
+      const bool free_ = lpa_prim_free<CONTROL>(P, V::state(Q.node(er->parent)), (int)(a & ~EDGE_BLOCKED), tn, key);
+      if (free_ == (mode == 1)) {
+        er->action = mode == 1 ? (a & ~EDGE_BLOCKED) : (a | EDGE_BLOCKED);
+        const uint32_t child = lpa_find<BLOCK, CONTROL>(P.table, P.table_mask, P.node_pool, key, key_hash64(key, nk));
+        if (child != NIL) atomicOr(&V::flags(Q.node(child)), FLAG_DIRTY);
+        mine++;
+      }
     }
-    __syncthreads();
-    if (tid == 0) {
+    if (mine) atomicAdd(&st->n_changed, mine);
+    // ---- the blocked log (mode 1): evaluated here, converted in log order by pass 1
+    if (mode == 1) {
+      for (uint32_t b = gtid; b < n_blocked; b += gstride) {
+        uint2 le = A.blocked_log[b];
+        if (le.y & LOG_CONVERTED) continue;
+        State tn;
+        int32_t key[MAX_KEY];
+        if (lpa_prim_free<CONTROL>(P, V::state(Q.node(le.x)), (int)(le.y & 0xFFFFu), tn, key)) A.blocked_log[b].y = le.y | LOG_FREE_NOW;
+      }
+    }
+    return;
+  }
+  if (pass == 1) {
+    if (tid == 0 && blockIdx.x == 0) {
+      unsigned long long converted = 0;
       for (uint32_t b = 0; b < n_blocked && S.status < 0; b++) {
         uint2 le = A.blocked_log[b];
         if (!(le.y & LOG_FREE_NOW) || (le.y & LOG_CONVERTED)) continue;
@@ -809,14 +821,17 @@ __global__ __launch_bounds__(BLOCK) void lpa_update_kernel(SearchParams P, LpaPa
         V::pred(rec) = eidx;
         V::flags(rec) |= FLAG_DIRTY;
         A.blocked_log[b].y = (le.y & ~LOG_FREE_NOW) | LOG_CONVERTED;
-        s_changed++;
+        converted++;
       }
+      st->n_nodes = S.n_nodes;
+      st->n_edges = S.n_edges;
+      st->n_changed = S.status == 4 ? ~0ull : st->n_changed + converted;  // (~0: pool full -- the host drops the space)
     }
-    __syncthreads();
+    return;
   }
-  // ---- updateNode of the states whose entries changed (no OPEN here: the next plan rebuilds it)
+  // ---- pass 2: updateNode of the states whose entries changed (no OPEN here: the next plan rebuilds it)
   const uint32_t n_nodes = S.n_nodes;
-  for (uint32_t i = tid; i < n_nodes; i += BLOCK) {
+  for (uint32_t i = gtid; i < n_nodes; i += gstride) {
     char *rec = Q.node(i);
     uint32_t fl = V::flags(rec);
     if (!(fl & FLAG_DIRTY)) continue;
@@ -830,13 +845,6 @@ __global__ __launch_bounds__(BLOCK) void lpa_update_kernel(SearchParams P, LpaPa
     else if ((fl & FLAG_OPENED) && !(fl & FLAG_CLOSED))
       fl |= FLAG_CLOSED;
     V::flags(rec) = fl;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    st->n_nodes = S.n_nodes;
-    st->n_edges = S.n_edges;
-    st->n_changed = s_changed;
-    if (S.status == 4) st->n_changed = ~0ull;  // pool full
   }
 }
 

@@ -4,7 +4,7 @@
 // map_replanner_node.cpp:415,427) never touches it.  Kernels: mplx_lpa.h.
 
 namespace mplx { struct LpaParams; }
-bool mplx_launch_lpa(int what, int mode, hipStream_t s, const mplx::SearchParams &P, const mplx::LpaParams &A);
+bool mplx_launch_lpa(int what, int mode, hipStream_t s, const mplx::SearchParams &P, const mplx::LpaParams &A, int pass = 0, int grid = 1);
 #include "mplx_lpa.h"
 
 struct LpaSpace {
@@ -277,7 +277,13 @@ static int lpa_update(mplx_lpa *l, int mode, int n_cells, const int32_t *cells, 
   SearchParams P;
   LpaParams A;
   lpa_params(l, l->cur, P, A);
-  if (!mplx_launch_lpa(1, mode, c->stream, P, A)) return lfail(l, MPLX_ERR_ARG, "lattice too wide for LPA*");
+  // three passes (mplx_lpa.h): entries re-sampled by the whole machine, log entries converted in order by one thread,
+  // the touched states' rhs recomputed by the whole machine
+  LCHK(l, hipMemsetAsync(&A.st->n_changed, 0, sizeof(unsigned long long), c->stream));
+  const int wide = std::max(1, 4 * c->n_cus);
+  if (!mplx_launch_lpa(1, mode, c->stream, P, A, 0, wide)) return lfail(l, MPLX_ERR_ARG, "lattice too wide for LPA*");
+  if (mode == 1) mplx_launch_lpa(1, mode, c->stream, P, A, 1, 1);
+  mplx_launch_lpa(1, mode, c->stream, P, A, 2, wide);
   LCHK(l, hipGetLastError());
   LCHK(l, hipMemcpyAsync(&l->st, A.st, sizeof(LpaState), hipMemcpyDeviceToHost, c->stream));
   LCHK(l, hipStreamSynchronize(c->stream));

@@ -7,10 +7,10 @@
 using namespace mplx;
 
 template <int BLOCK>
-static void launch_lpa(int what, int control, hipStream_t s, const SearchParams &P, const LpaParams &A, int mode) {
+static void launch_lpa(int what, int control, hipStream_t s, const SearchParams &P, const LpaParams &A, int mode, int pass, int grid) {
 #define MPLX_LPA_CASE(C)                                                                                                   \
   if (what == 0) hipLaunchKernelGGL((lpa_plan_kernel<BLOCK, C>), dim3(1), dim3(BLOCK), 0, s, P, A);                        \
-  else if (what == 1) hipLaunchKernelGGL((lpa_update_kernel<BLOCK, C>), dim3(1), dim3(BLOCK), 0, s, P, A, mode);           \
+  else if (what == 1) hipLaunchKernelGGL((lpa_update_kernel<BLOCK, C>), dim3(grid), dim3(BLOCK), 0, s, P, A, mode, pass); \
   else hipLaunchKernelGGL((lpa_subtree_kernel<BLOCK, C>), dim3(1), dim3(BLOCK), 0, s, P, A);
   switch (control) {
     case CTRL_VEL: MPLX_LPA_CASE(CTRL_VEL) break;
@@ -21,10 +21,11 @@ static void launch_lpa(int what, int control, hipStream_t s, const SearchParams 
 #undef MPLX_LPA_CASE
 }
 
-// what: 0 ComputeShortestPath, 1 map edit (mode 0 blocked / 1 cleared), 2 getSubStateSpace.  false: lattice too wide.
-bool mplx_launch_lpa(int what, int mode, hipStream_t s, const SearchParams &P, const LpaParams &A) {
+// what: 0 ComputeShortestPath, 1 map edit (mode 0 blocked / 1 cleared; pass 0..2 of lpa_update_kernel on `grid` workgroups),
+// 2 getSubStateSpace.  false: lattice too wide.
+bool mplx_launch_lpa(int what, int mode, hipStream_t s, const SearchParams &P, const LpaParams &A, int pass, int grid) {
   if (P.n_u > 128) return false;
-  if (P.n_u <= 64) launch_lpa<64>(what, P.control, s, P, A, mode);
-  else launch_lpa<128>(what, P.control, s, P, A, mode);
+  if (P.n_u <= 64) launch_lpa<64>(what, P.control, s, P, A, mode, pass, grid);
+  else launch_lpa<128>(what, P.control, s, P, A, mode, pass, grid);
   return true;
 }

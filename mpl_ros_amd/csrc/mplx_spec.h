@@ -412,7 +412,9 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
     if (tid == 0) {
       // leave when every query is done or the cache is full, when there has been nobody to help for a while, or
       // when the leader just served stopped making progress (helper_serve sets help_quit)
-      const bool expired = S.help_quit || S.help_idle > HELP_IDLE_ROUNDS;
+      // (with a helper limit -- streamed batches -- a helper that finds nobody to serve leaves after ~3 ms instead of ~50: its
+      // compute unit is wanted by the next batch)
+      const bool expired = S.help_quit || S.help_idle > (P.help_limit >= 0 ? 64 : HELP_IDLE_ROUNDS);
       if (S.help_quit) atomicAdd(P.cache_next + 2, 1u);  // (diagnostics) helpers that left a leader that had stopped
       else if (expired) atomicAdd(P.cache_next + 3, 1u);  // (diagnostics) helpers that found every leader served
       const unsigned long long dw = ld_u64(P.done_word);
@@ -1566,9 +1568,12 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       if (tid == 0) {
         S.help_idle = 0;
         S.help_quit = 0;
+        // streamed batches: at most help_limit workgroups of the launch stay on as helpers; the others exit here, and the
+        // workgroups of the next batch (another launch, another stream) take their compute units
+        S.flag = (P.help_limit >= 0 && atomicAdd(P.cache_next + 4, 1u) >= (uint32_t)P.help_limit) ? 1 : 0;
       }
       __syncthreads();
-      helper_loop<UL, K, CONTROL>(P, S, tid);
+      if (!S.flag) helper_loop<UL, K, CONTROL>(P, S, tid);
     }
   }
 }

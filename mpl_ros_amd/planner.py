@@ -710,6 +710,54 @@ class VoxelMapPlanner:
         self._epoch = ctx.lib.mplx_plan_epoch(ctx.h)
         return self._results
 
+    # ---- streamed batches (include/mplx.h: mplx_plan_batch_submit / _wait, mplx_stream_*)
+    def planBatchSubmit(self, starts, goals):
+        """First half of planBatch: returns once the batch is launched on the context's stream."""
+        ctx = self._ctx()
+        self._configure(starts[0].control)
+        self._apply_aux()
+        n = len(starts)
+        S = (_capi.Waypoint * n)(*[s.to_c() for s in starts])
+        G = (_capi.Waypoint * n)(*[g.to_c() for g in goals])
+        ctx.check(ctx.lib.mplx_plan_batch_submit(ctx.h, n, S, G))
+        self._pending_n = n
+
+    def planBatchDone(self):
+        ctx = self._ctx()
+        rc = ctx.lib.mplx_plan_batch_done(ctx.h)
+        if rc < 0:
+            ctx.check(rc)
+        return rc == 1
+
+    def planBatchWait(self):
+        ctx = self._ctx()
+        n = self._pending_n
+        R = (_capi.Result * n)()
+        ctx.check(ctx.lib.mplx_plan_batch_wait(ctx.h, R))
+        self._results = [R[i] for i in range(n)]
+        self._result = self._results[0]
+        self._epoch = ctx.lib.mplx_plan_epoch(ctx.h)
+        return self._results
+
+    def setHelperLimit(self, limit):
+        """At most `limit` workgroups of a launch stay on as helpers once its query queue is empty (-1: all)."""
+        ctx = self._ctx()
+        ctx.check(ctx.lib.mplx_set_helper_limit(ctx.h, int(limit)))
+
+    def releasePools(self):
+        """Give the context's device pools back (re-created by the next plan): room for a stream's lanes."""
+        ctx = self._ctx()
+        ctx.check(ctx.lib.mplx_release_pools(ctx.h))
+
+    def stream(self, depth=2):
+        """A PlanStream of `depth` lanes on this planner's map replica and set-up (the planner must be configured:
+        plan once, or call configure(control))."""
+        return PlanStream(self, depth)
+
+    def configure(self, control):
+        self._configure(control)
+        self._apply_aux()
+
     def lastKernelMs(self):
         ctx = self._ctx()
         ms = C.c_float()
@@ -910,6 +958,84 @@ class VoxelMapPlanner:
 # the 2-D lattice is the 3-D path with z frozen -- one layer of voxels whose centre plane is z = 0,
 # control inputs (ux, uy, 0).  Every z term of the polynomial, key, cost and heuristic arithmetic is
 # an exact +0.0, so states, keys, costs and the expansion order equal those of a genuinely 2-D run.
+class PlanStream:
+    """Host mirror of mplx_stream: several query batches in flight on one map replica.  While the longest queries of
+    batch n still run (a query is a serial pop chain on one compute unit), the workgroups of batch n + 1 take the rest
+    of the machine.  submit() -> ticket, done(ticket), wait(ticket) -> results (+ the lane's trajectories / timings until
+    that lane is submitted to again)."""
+
+    def __init__(self, planner, depth=2):
+        self._pl = planner
+        self._ctx = planner._ctx()
+        self.lib = self._ctx.lib
+        h = C.c_void_p()
+        self._ctx.check(self.lib.mplx_stream_create(self._ctx.h, int(depth), C.byref(h)))
+        self.h = h
+        self.depth = int(depth)
+        self._n = {}
+        self._lane = {}
+
+    def close(self):
+        if self.h is not None:
+            self.lib.mplx_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise MplxError(f"mplx_stream: {self.lib.mplx_stream_last_error(self.h).decode()} (rc {rc})")
+        return rc
+
+    def configure(self, n_slots=0, max_nodes=0, max_edges=0, max_open_log=0, helpers=-1, reserved=-1, cache_rows=0, helper_limit=-1):
+        self._check(self.lib.mplx_stream_configure(self.h, n_slots, max_nodes, max_edges, max_open_log, helpers, reserved, cache_rows, helper_limit))
+
+    def submit(self, starts, goals):
+        n = len(starts)
+        S = (_capi.Waypoint * n)(*[s.to_c() for s in starts])
+        G = (_capi.Waypoint * n)(*[g.to_c() for g in goals])
+        return self.submit_c(S, G, n)
+
+    def submit_c(self, S, G, n):
+        """submit with pre-marshalled ctypes arrays (a steady stream re-uses them)"""
+        t = C.c_int64(-1)
+        self._check(self.lib.mplx_stream_submit(self.h, n, S, G, C.byref(t)))
+        self._n[t.value] = n
+        return t.value
+
+    def done(self, ticket):
+        return self._check(self.lib.mplx_stream_done(self.h, int(ticket))) == 1
+
+    def wait(self, ticket):
+        n = self._n.pop(int(ticket))
+        R = (_capi.Result * n)()
+        lane = C.c_void_p()
+        self._check(self.lib.mplx_stream_wait(self.h, int(ticket), R, C.byref(lane)))
+        self._last_lane = lane
+        return [R[i] for i in range(n)]
+
+    def lastKernelMs(self):
+        ms = C.c_float()
+        self.lib.mplx_last_kernel_ms(self._last_lane, C.byref(ms))
+        return ms.value
+
+    def queryTiming(self, q=0):
+        b, e, sl = C.c_double(), C.c_double(), C.c_int32()
+        self.lib.mplx_result_timing(self._last_lane, q, C.byref(b), C.byref(e), C.byref(sl))
+        return b.value, e.value, sl.value
+
+    def trajActions(self, q, traj_len):
+        """actions of query q's trajectory in the batch last waited for"""
+        act = (C.c_int32 * max(int(traj_len), 1))()
+        if traj_len > 0:
+            self.lib.mplx_result_traj(self._last_lane, q, None, None, act, None)
+        return np.array(act[:int(traj_len)], dtype=np.int32)
+
+
 class Waypoint2D(Waypoint3D):
     """Waypoint<2>: only the first two components of pos/vel/acc/jrk are meaningful."""
 

@@ -1,0 +1,78 @@
+"""Streamed query batches (include/mplx.h: mplx_plan_batch_submit / _wait, mplx_stream_*): several batches in flight on one map
+replica.  north_star: "many independent start/goal queries (multi-robot, replanning) shard one-query-per-stream"; the
+reference's own statement of the independence is robot_team.hpp:60-66 (every robot plans on its own).  What is checked: a
+batch gives the same results -- every field, every query, the trajectories -- whether it runs alone and blocking, or
+overlapped with other batches on other lanes, with or without a helper limit."""
+import numpy as np
+import pytest
+
+from mpl_ros_amd import mapgen
+from oracle import orc
+from tests import util
+
+KW = dict(v_max=2.0, a_max=1.0, tol_pos=0.5)
+
+
+def _queries(grid, origin, res, n, seed):
+    rng = mapgen.SplitMix64(seed)
+    return mapgen.random_queries(grid, origin, res, n, rng, min_dist=3.0)
+
+
+def _tuple(r):
+    return (r.status, r.traj_len, r.cost, r.n_expanded, r.n_closed, r.n_nodes, r.n_edges, r.n_succ, r.n_succ_finite, r.voxel_reads, r.n_push, r.n_reopen,
+            r.expand_hash)
+
+
+@pytest.mark.gpu
+def test_submit_wait_is_plan_batch_and_a_stream_overlaps_batches_without_changing_them():
+    grid, origin, res = util.small_map(64, seed=11)
+    U = mapgen.control_lattice(1.0, 1, True)
+    mu, pl = util.make_gpu(grid, origin, res, U, n_slots=64, max_nodes=1 << 21, max_edges=1 << 23, max_log=1 << 22, max_expand=30000, **KW)
+    sets = [_queries(grid, origin, res, 40, 100 + k) for k in range(3)]
+    wps = [([util.gpu_wp(s) for s, _ in qs], [util.gpu_wp(g) for _, g in qs]) for qs in sets]
+    # blocking reference runs (the path the parity suite checks against the CPU oracle); one query of each is re-checked here
+    ref, ref_act = [], []
+    for S, G in wps:
+        R = pl.planBatch(S, G)
+        ref.append([_tuple(r) for r in R])
+        ref_act.append([pl.getTraj(q).actions.copy() for q in range(len(S))])
+    P = util.make_oracle(grid, origin, res, orc.ACC, U, max_expand=30000, **KW)
+    s0, g0 = sets[0][0]
+    st = P.plan(orc.waypoint(s0), orc.waypoint(g0))
+    assert st == ref[0][0][0] and util.expand_hash(P.expanded()[0]) == ref[0][0][-1]
+    # the asynchronous pair on the planner's own context
+    pl.planBatchSubmit(*wps[1])
+    R = pl.planBatchWait()
+    assert [_tuple(r) for r in R] == ref[1]
+    assert all(np.array_equal(pl.getTraj(q).actions, ref_act[1][q]) for q in range(len(R)))
+    # a second submit before the wait is refused, and leaves the outstanding batch intact
+    pl.planBatchSubmit(*wps[2])
+    with pytest.raises(Exception):
+        pl.planBatchSubmit(*wps[0])
+    assert [_tuple(r) for r in pl.planBatchWait()] == ref[2]
+    # a stream of two lanes: twelve batches, two in flight at any time, with and without a helper limit
+    for limit in (-1, 2):
+        st = pl.stream(2)
+        st.configure(64, 1 << 21, 1 << 23, 1 << 22, -1, 0, 0, limit)
+        order = [k % 3 for k in range(12)]
+        inflight, seen = [], 0
+        for k in order:
+            if len(inflight) == 2:
+                t, kk = inflight.pop(0)
+                R = st.wait(t)
+                assert [_tuple(r) for r in R] == ref[kk], (limit, seen)
+                for q in (0, 7, 39):
+                    assert np.array_equal(st.trajActions(q, R[q].traj_len), ref_act[kk][q])
+                seen += 1
+            inflight.append((st.submit(*wps[k]), k))
+        with pytest.raises(Exception):  # every lane busy
+            st.submit(*wps[0])
+        for t, kk in inflight:
+            assert [_tuple(r) for r in st.wait(t)] == ref[kk]
+            seen += 1
+        assert seen == 12
+        st.close()
+    # the planner's own context still plans (its pools were not touched by the lanes)
+    assert [_tuple(r) for r in pl.planBatch(*wps[0])] == ref[0]
+    pl.releasePools()
+    assert [_tuple(r) for r in pl.planBatch(*wps[0])] == ref[0]
