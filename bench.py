@@ -79,6 +79,9 @@ def main():
                     help="--config c5: round 3's variant (distance heuristic, max_expand 20000) instead of the reference's planner parameters")
     ap.add_argument("--no-throughput", action="store_true",
                     help="N > 1, strong scaling: skip the additional throughput phase (a 1024 x N query stream through the same sharded path)")
+    ap.add_argument("--throughput", type=int, default=0,
+                    help="1: the two-workgroups-per-compute-unit instantiation of the search kernel (mplx_set_throughput) for the blocking steps AND the streamed leg; "
+                         "0 (default): blocking steps on the 16-unit kernel; -1: blocking steps on the 16-unit kernel, streamed leg on the throughput instantiation")
     ap.add_argument("--stream", type=int, default=-1,
                     help="N = 1, C4 batch: batches of the additional streamed leg (mplx_stream: two batches in flight on two lanes of the same map replica; "
                          "every result compared with the blocking step's); -1 auto = max(steps, 6), 0 off")
@@ -197,6 +200,7 @@ def main():
     pl.setMaxNum(max_expand)
     pl.setCapacity(min(slots, n_local), caps["nodes"], caps["edges"], caps["log"])
     pl.setHelpers(args.helpers, args.help_reserved)
+    pl.setThroughput(1 if args.throughput > 0 else 0)
 
     def wp(p):
         w = Waypoint3D(control)
@@ -581,6 +585,7 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
     want = [key(r) for r in ref_results]
     exp_per_batch = sum(r.n_expanded for r in ref_results)
     pl.releasePools()  # the blocking leg's pools (~ 130 GB at C4 size) make room for the lanes'
+    pl.setThroughput(1 if args.throughput != 0 else 0)  # (the lanes copy the planner's setting)
     depth = max(1, args.stream_depth)
     caps = mapgen.c4_pools(jrk, max(nq, 256), max_expand, per_q=args.max_nodes or (420_000 if not jrk else 0))
     st = pl.stream(depth)
@@ -590,12 +595,17 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
     S = (_capi.Waypoint * nq)(*[w.to_c() for w in starts])
     G = (_capi.Waypoint * nq)(*[w.to_c() for w in goals])
     mism = 0
+    mism_detail = []
 
     def collect(t):
         nonlocal mism
         R = st.wait(t)
-        bad = sum(1 for r, w in zip(R, want) if key(r) != w)
-        mism += bad
+        for qi, (r, w) in enumerate(zip(R, want)):
+            if key(r) != w:
+                mism += 1
+                if len(mism_detail) < 8:
+                    mism_detail.append({"ticket": int(t), "query": qi, "got": [float(x) if isinstance(x, float) else int(x) for x in key(r)],
+                                        "want": [float(x) if isinstance(x, float) else int(x) for x in w], "timing": list(st.queryTiming(qi))})
         return R
 
     for t in [st.submit_c(S, G, nq) for _ in range(depth)]:  # warm-up: allocates the lanes' pools
@@ -628,8 +638,8 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
             "ms_per_batch": 1e3 * wall / n_batches, "steady_state_ms_per_batch": 1e3 * float(np.median(gaps[1:])) if len(gaps) > 2 else None,
             "batch_latency_ms": {"mean": 1e3 * float(np.mean(lat)), "min": 1e3 * float(np.min(lat)), "max": 1e3 * float(np.max(lat))},
             "kernel_ms_per_batch": {"mean": float(np.mean(kernel_ms)), "max": float(np.max(kernel_ms))},
-            "helper_limit": args.stream_helper_limit,
-            "parity": {"batches_checked": n_batches + depth, "queries_per_batch": nq, "mismatches_vs_blocking_step": mism,
+            "helper_limit": args.stream_helper_limit, "kernel": pl.kernelName(),
+            "parity": {"batches_checked": n_batches + depth, "queries_per_batch": nq, "mismatches_vs_blocking_step": mism, "mismatch_detail": mism_detail,
                        "checked": "status, traj_len, cost (bit-exact f64), n_expanded, n_nodes, n_edges, n_succ_finite, voxel_reads, expand_hash of every query of every batch"},
             "roofline": {"achieved": alg_bytes_per_batch * n_batches / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes_per_batch * n_batches / wall / 1e9 / HBM_PEAK_GBS,

@@ -245,6 +245,11 @@ int mplx_stream_configure(mplx_stream *s, int32_t n_slots, uint64_t total_nodes,
 int mplx_stream_submit(mplx_stream *s, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals, int64_t *ticket);
 int mplx_stream_done(mplx_stream *s, int64_t ticket);
 int mplx_stream_wait(mplx_stream *s, int64_t ticket, mplx_result *out, mplx_ctx **lane_ctx);
+/* Throughput instantiation of the search kernel (mode 1; 0 = off, the default): two 256-lane workgroups per compute unit, eight
+ * expansion units each, instead of one 512-lane workgroup of sixteen -- for batches / streams of many queries (a compute
+ * unit's two queries hide each other's barriers and memory round trips); one query alone on the machine is faster without.
+ * Exists for ACC lattices of at most 31 inputs (BASELINE C4); other configurations ignore the setting.  Same results. */
+int mplx_set_throughput(mplx_ctx *ctx, int32_t mode);
 /* At most `limit` workgroups of a launch stay on as helpers once its query queue is empty (-1: all of them, the default
  * of a blocking batch); the others exit, so that the next batch's workgroups get their compute units. */
 int mplx_set_helper_limit(mplx_ctx *ctx, int32_t limit);

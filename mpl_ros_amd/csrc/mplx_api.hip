@@ -102,6 +102,7 @@ struct mplx_ctx {
   bool pend_help = false;
   std::vector<QueryIn> pend_in;
   std::vector<int32_t> pend_order;
+  int throughput = 0;   // 1: two-workgroups-per-compute-unit instantiation of the speculative kernel where one exists (ACC lattices of <= 31 inputs)
   int help_limit = -1;  // workgroups of a launch that may turn into helpers once the query queue is empty (-1: all of them)
 };
 
@@ -803,6 +804,7 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   if (och < 1) och = 1;
   // chunk ids are 16 bits in the kernels' LDS chunk tables: 2.1 G nodes / 4.3 G edges / 2.1 G log records
   if (nch > 0xFFFFull || ech > 0xFFFFull || och > 0xFFFFull) return fail(c, MPLX_ERR_ARG, "capacity too large (more than 65535 chunks in a pool)");
+  if ((nch << NODE_CH_LOG) > (1ull << 30)) return fail(c, MPLX_ERR_ARG, "capacity too large (more than 2^30 states: the state table is indexed with 32 bits)");
   const uint64_t T = next_pow2(4ull * (nch << NODE_CH_LOG));  // load factor <= 0.25: the slowest lane of a batch sets the pace, and its probe chain is a chain of HBM round trips
   int r;
 #define PA(ptr, cnt) if ((r = pool_alloc(c, &(ptr), (cnt))) != MPLX_OK) { free_pools(c); return r; }
@@ -813,6 +815,7 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   PA(P.bkt_head, (size_t)slots * 2 * NB * NSUB);
   HIPCHK(c, hipMemsetAsync(P.bkt_head, 0xFF, sizeof(uint32_t) * (size_t)slots * 2 * NB * NSUB, c->stream));  // all heads NIL; queries leave them so
   PA(P.chunk_next, 4);
+  PA(P.tbl_spill, (size_t)slots * (MAX_NODE_CH + MAX_EDGE_CH + MAX_OPEN_CH));  // chunk-table entries beyond the LDS window (throughput kernel)
   P.boxes = nullptr; P.cache_c = nullptr; P.cache_h = nullptr; P.cache_next = nullptr; P.done_word = nullptr; P.cache_rows = 0;
   if (c->helpers != 0) {  // look-ahead cache of the helper workgroups (used by the speculative kernels, lattices <= 31 inputs)
     // rows of the heuristic cache: a quarter of the state capacity (a node is expanded ahead of time at most once),
@@ -1087,6 +1090,12 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
   // of time.  The launch holds one workgroup per compute unit at most, so all of them are resident together: for a
   // batch smaller than the machine the extra workgroups (blockIdx.x >= help_lead) help from the start; in a large
   // batch the leaders turn into helpers as they run out of queries.
+  // throughput instantiation: two 256-lane workgroups per compute unit (27-input ACC lattices): a compute unit's two queries
+  // hide each other's barriers and memory round trips; a query alone on the machine is slower on it (8 expansion units
+  // instead of 16), so it is the caller's choice (mplx_set_throughput) -- streams of large batches want it
+  const bool tp = c->throughput > 0 && spec && !c->aux && P.control == CTRL_ACC && P.n_u <= 31 && (c->speculation < 0 || c->speculation >= 16);
+  P.throughput = tp ? 1 : 0;
+  const int n_wg = c->n_cus * (tp ? 2 : 1);  // workgroups of the search kernel the machine holds at once
   int grid = slots;
   P.help_lead = slots;
   P.help_max = 0;
@@ -1097,7 +1106,7 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
     // auto: four helpers per leader for the lattices of at most 31 inputs (the capped query of the C4 batch alone: 1.95 s
     // with two, 1.89 s with four), two for the 65..128-input jerk lattices (no gain from more)
     P.help_max = c->helpers < 0 ? (P.n_u <= 31 ? 4 : 2) : c->helpers;
-    P.help_lead = std::min(slots, c->n_cus);  // (one workgroup of these kernels fills a compute unit: more would only wait)
+    P.help_lead = std::min(slots, n_wg);  // (the machine holds n_wg workgroups of these kernels: more would only wait)
     // a share of the machine that never leads: its workgroups help, from the start, the queries predicted longest
     // (the launch order is longest straight-line distance first; a batch lasts as long as its longest query).
     // auto: helpers for one sixteenth of the compute units' worth of leaders (16 leaders x helpers per leader on 256
@@ -1108,8 +1117,8 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
     // (fewer leaders covered: the capped query, 13th in the launch order, goes unhelped until the queue drains): 2.24 / 2.27 s
     const bool long_queries = P.max_expand <= 0 || P.max_expand >= 200000;
     const int reserved = c->help_reserved >= 0 ? c->help_reserved : (nq >= 2 * c->n_cus && long_queries ? std::max(1, c->n_cus / 16) * P.help_max : 0);
-    if (reserved > 0 && slots + reserved > c->n_cus) P.help_lead = std::max(1, c->n_cus - reserved);
-    grid = std::max(P.help_lead, std::min(P.help_lead * (P.help_max + 1), c->n_cus));
+    if (reserved > 0 && slots + reserved > n_wg) P.help_lead = std::max(1, n_wg - reserved);
+    grid = std::max(P.help_lead, std::min(P.help_lead * (P.help_max + 1), n_wg));
     HIPCHK(c, hipMemsetAsync(P.boxes, 0, sizeof(HelpBox) * ((size_t)c->pool_slots + 1024), c->stream));
     c->dbg_boxes = P.boxes;
     // (diagnostic, tools/tail_probe.py: MPLX_DEBUG_KEEP_CACHE=1 keeps the look-ahead cache of the previous launch -- the
@@ -1137,8 +1146,8 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
     launched = mplx_launch_spec_help(grid, c->stream, P);
   }
   if (!launched) {
-    grid = slots;
-    P.help_lead = slots;
+    grid = tp ? std::min(slots, n_wg) : slots;
+    P.help_lead = grid;
   }
   if (!launched && !(spec && mplx_launch_spec(c->speculation, grid, c->stream, P))) {
     switch (pick_block(P.n_u)) {
@@ -1211,6 +1220,11 @@ extern "C" int mplx_plan_batch_done(mplx_ctx *c) {  // 1: wait() will not block;
   const hipError_t e = hipStreamQuery(c->stream);
   return e == hipSuccess ? 1 : e == hipErrorNotReady ? 0 : fail(c, MPLX_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
 }
+extern "C" int mplx_set_throughput(mplx_ctx *c, int32_t mode) {
+  if (!c) return MPLX_ERR_ARG;
+  c->throughput = mode > 0 ? 1 : 0;
+  return MPLX_OK;
+}
 extern "C" int mplx_set_helper_limit(mplx_ctx *c, int32_t limit) {
   if (!c) return MPLX_ERR_ARG;
   c->help_limit = limit < 0 ? -1 : limit;
@@ -1277,6 +1291,7 @@ extern "C" int mplx_stream_create(mplx_ctx *parent, int depth, mplx_stream **out
       l->n_slots = parent->n_slots; l->cap_nodes = parent->cap_nodes; l->cap_edges = parent->cap_edges; l->cap_log = parent->cap_log;
       l->bucket_width = parent->bucket_width; l->speculation = parent->speculation;
       l->helpers = parent->helpers; l->help_reserved = parent->help_reserved; l->help_rows = parent->help_rows; l->help_limit = parent->help_limit;
+      l->throughput = parent->throughput;
     }
     if (r != MPLX_OK) {
       if (l) parent->err = l->err.empty() ? g_create_error : l->err;
@@ -1355,9 +1370,12 @@ extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
     else if (c->speculation == 2) { ul = 128; k = 2; }
     else { ul = 128; k = 4; }
     if (c->aux) { ul = 32; k = 16; }
+    const bool tp = c->throughput > 0 && !c->aux && control == CTRL_ACC && n_u <= 31 && (c->speculation < 0 || c->speculation >= 16);
+    if (tp) { ul = 32; k = 8; }
     const bool help = !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 &&
-                      ((ul == 32 && k == 16 && n_u <= 31) || (ul == 128 && k == 4 && control == CTRL_JRK && n_u > 64));
-    snprintf(buf, sizeof(buf), c->aux ? "astar_spec_kernel<%d,%d,%s,pot>" : help ? "astar_spec_kernel<%d,%d,%s,help>" : "astar_spec_kernel<%d,%d,%s>", ul, k, cn);
+                      ((ul == 32 && (k == 16 || tp) && n_u <= 31) || (ul == 128 && k == 4 && control == CTRL_JRK && n_u > 64));
+    snprintf(buf, sizeof(buf), c->aux ? "astar_spec_kernel<%d,%d,%s,pot>" : tp ? (help ? "astar_spec_kernel<%d,%d,%s,help,2-per-CU>" : "astar_spec_kernel<%d,%d,%s,2-per-CU>") :
+                                help ? "astar_spec_kernel<%d,%d,%s,help>" : "astar_spec_kernel<%d,%d,%s>", ul, k, cn);
   }
   return buf;
 }

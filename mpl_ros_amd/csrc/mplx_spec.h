@@ -50,8 +50,9 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int UL, int K, int CONTROL, int BTN, int NCAP_>
-struct SmemSpec : Smem<UL * K, K, NCAP_> {
+// TP (throughput instantiation): a quarter of the chunk tables resident in LDS, the rest in HBM (QView::spill)
+template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool TP = false>
+struct SmemSpec : Smem<UL * K, K, NCAP_, TP ? MAX_NODE_CH / 4 : MAX_NODE_CH, TP ? MAX_EDGE_CH / 4 : MAX_EDGE_CH, TP ? MAX_OPEN_CH / 4 : MAX_OPEN_CH> {
   static constexpr int BLOCK = UL * K, BT = BTN, NK = key_len_c(CONTROL);
   // candidates in pop order
   double cand_f[K], cand_g[K];
@@ -70,7 +71,7 @@ struct SmemSpec : Smem<UL * K, K, NCAP_> {
   // (potential-field searches) the per-lane potential sums of the expansion live in bt_share, which is idle until the
   // batch table is rebuilt after the expansion (BT >= BLOCK lanes)
   __device__ __forceinline__ uint32_t *pot_scratch() { static_assert(BT >= UL * K, "one word per lane"); return bt_share; }
-  unsigned long long bt_tslot[BT];
+  uint32_t bt_tslot[BT];  // slot of the state table claimed for a new state (the host keeps tables at <= 2^32 slots)
   double bt_g[BT], bt_h[BT];
   int32_t lane_key[UL * K][NK];
   int32_t u_goal[K];  // candidate k satisfies the goal test (evaluated ahead of its commit)
@@ -496,11 +497,15 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
 // POT: the auxiliary map (potential field / search region, MapDev::aux) is read next to the occupancy and the edge cost is
 // ucost + pot_weight * (sum of the potential over the primitive's samples): per lane, carried in the predecessor record
 // like in the one-node kernel.  Without helper workgroups (their cache rows carry no potential sums).
-template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false, bool POT = false>
+// TP: the throughput instantiation -- two workgroups per compute unit (<= 80 KB of LDS each: the chunk tables' resident window
+// is a quarter, the rest spills to HBM), for batches of many queries where a compute unit's two workgroups -- two
+// independent queries -- hide each other's barriers and memory round trips.
+template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false, bool POT = false, bool TP = false>
 __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
   static_assert(!(HELP && POT), "the look-ahead cache rows carry no potential sums");
   constexpr int BLOCK = UL * K;
-  using SM = SmemSpec<UL, K, CONTROL, BTN, NCAP_>;
+  using SM = SmemSpec<UL, K, CONTROL, BTN, NCAP_, TP>;
+  static_assert(!TP || sizeof(SM) <= 80 * 1024, "two workgroups of the throughput instantiation must fit the 160 KB of a compute unit");
   constexpr int BT = SM::BT;
   __shared__ SM S;
   using V = QView<BLOCK, CONTROL, SM>;
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
   // HELP: workgroups with no query left to lead turn into helpers (helper_loop above); a leader publishes the front
   // of its OPEN list and picks up the look-ahead cache entries they leave.  Compiled out of the plain variant (the
   // kernel sits at the register limit).
-  const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
+  const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB, TP ? P.tbl_spill + (size_t)blockIdx.x * (MAX_NODE_CH + MAX_EDGE_CH + MAX_OPEN_CH) : nullptr};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   fill_uq<BLOCK, CONTROL>(P, S, tid);
   if (tid == 0) {
@@ -581,8 +586,8 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       }
       S.tmp_d0 = cost0;
       if (S.status < 0) {
-        bool ok = ensure_chunks(S.node_tbl, S.node_chunks, 1, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks) &&
-                  ensure_chunks(S.open_tbl, S.open_chunks, 1, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
+        bool ok = Q.ensure_nodes(1) &&
+                  Q.ensure_open(1);
         if (!ok) S.status = 4;
       }
     }
@@ -661,11 +666,11 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           const uint32_t room = (uint32_t)(K * P.n_u + K);
           bool ok;
           if (tid == 64)
-            ok = ensure_chunks(S.node_tbl, S.node_chunks, S.n_nodes + room, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks);
+            ok = Q.ensure_nodes(S.n_nodes + room);
           else if (tid == 128)
-            ok = ensure_chunks(S.edge_tbl, S.edge_chunks, S.n_edges + room, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks);
+            ok = Q.ensure_edges(S.n_edges + room);
           else
-            ok = ensure_chunks(S.open_tbl, S.open_chunks, S.n_log + room, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
+            ok = Q.ensure_open(S.n_log + room);
           if (!ok && S.status < 0) S.status = 4;  // MPLX_PLAN_POOL_FULL
           if constexpr (HELP) {  // (the helper flag: an agent-scope load, every eighth batch)
             if (tid == 192 && (S.cyc[7] & 7ull) <= 1ull) S.helped = ld_u32(&(P.boxes + blockIdx.x)->helpers) != 0u;
@@ -771,11 +776,11 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           const uint32_t room = (uint32_t)(K * P.n_u + K);
           bool ok;
           if (tid == 0)
-            ok = ensure_chunks(S.node_tbl, S.node_chunks, S.n_nodes + room, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks);
+            ok = Q.ensure_nodes(S.n_nodes + room);
           else if (tid == 64)
-            ok = ensure_chunks(S.edge_tbl, S.edge_chunks, S.n_edges + room, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks);
+            ok = Q.ensure_edges(S.n_edges + room);
           else
-            ok = ensure_chunks(S.open_tbl, S.open_chunks, S.n_log + room, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks);
+            ok = Q.ensure_open(S.n_log + room);
           if (!ok) S.status = 4;  // MPLX_PLAN_POOL_FULL
         }
         if (tid < K) {
@@ -1196,7 +1201,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
                 first = false;
                 if (old == TBL_EMPTY) {
                   S.bt_id[my_slot] = NIL;  // new state; created when its first sharer commits
-                  S.bt_tslot[my_slot] = (unsigned long long)pos;
+                  S.bt_tslot[my_slot] = (uint32_t)pos;
                   S.bt_h[my_slot] = hspec;  // of the leader's state = the state the node will be created with
                   S.bt_g[my_slot] = INFINITY;
                   S.bt_flags[my_slot] = 0;
@@ -1555,9 +1560,9 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
 #endif
     }
     for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)
-      P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? S.node_tbl[i] : NIL;
+      P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? Q.node_chunk(i) : NIL;
     for (uint32_t i = tid; i < (uint32_t)MAX_EDGE_CH; i += BLOCK)
-      P.edge_tables[(size_t)q * MAX_EDGE_CH + i] = i < S.edge_chunks ? S.edge_tbl[i] : NIL;
+      P.edge_tables[(size_t)q * MAX_EDGE_CH + i] = i < S.edge_chunks ? Q.edge_chunk(i) : NIL;
     if constexpr (HELP) {
       if (tid == 0) atomicAdd(P.done_word, 1ull);
     }

@@ -25,6 +25,10 @@ bool mplx_launch_spec(int speculation, int grid, hipStream_t s, const SearchPara
     hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024, false, true>), dim3(grid), dim3(512), 0, s, P);
     return true;
   }
+  if (P.throughput && P.n_u <= 32 && P.control == CTRL_ACC) {  // throughput instantiation without helper workgroups
+    hipLaunchKernelGGL((astar_spec_kernel<32, 8, CTRL_ACC, 512, 512, false, false, true>), dim3(grid), dim3(256), 0, s, P);
+    return true;
+  }
   if (P.n_u <= 32 && speculation == 8)
     launch_spec<64, 8, 512, 512>(P.control, grid, s, P);     // 8 units of one wave each
   else if (P.n_u <= 32)
