@@ -91,6 +91,8 @@ struct VecD {
   const decimal_t &operator()(int i) const { return v[i]; }
   int size() const { return (int)v.size(); }
   int rows() const { return (int)v.size(); }
+  decimal_t lpNormInf() const { decimal_t m = 0; for (double e : v) m = std::fabs(e) > m ? std::fabs(e) : m; return m; }
+  template <int P> decimal_t lpNorm() const { return lpNormInf(); }  // only lpNorm<Eigen::Infinity> is used in-tree (robot_team.hpp:158)
 };
 }  // namespace mplx_shim
 template <typename T> using vec_E = std::vector<T>;

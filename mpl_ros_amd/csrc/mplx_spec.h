@@ -500,8 +500,10 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
 // TP: the throughput instantiation -- two workgroups per compute unit (<= 80 KB of LDS each: the chunk tables' resident window
 // is a quarter, the rest spills to HBM), for batches of many queries where a compute unit's two workgroups -- two
 // independent queries -- hide each other's barriers and memory round trips.
+// (second launch bound = waves per SIMD the register allocation must leave room for: a 256-lane workgroup alone would be given
+// the whole 512-entry register file -- arch VGPRs plus AGPRs as spill space -- and a second workgroup could not join it)
 template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false, bool POT = false, bool TP = false>
-__global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
+__global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchParams P) {
   static_assert(!(HELP && POT), "the look-ahead cache rows carry no potential sums");
   constexpr int BLOCK = UL * K;
   using SM = SmemSpec<UL, K, CONTROL, BTN, NCAP_, TP>;

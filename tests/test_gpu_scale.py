@@ -178,6 +178,45 @@ def test_c4_batch_sample_matches_the_oracle(map512, lattice):
           f"batch {ne.sum()} expansions in {pl.lastKernelMs():.0f} ms")
 
 
+def test_c4_acc_batch_repeats_blocking_and_streamed(map512):
+    """Repeatability at bench size (DESIGN: memory-ordering contract): the 1024-query C4-ACC batch planned
+    twice blocking (sixteen-unit kernel, reserved helpers), twice on the two-per-compute-unit instantiation, and four times
+    through a two-lane stream with a helper limit (helpers attach and leave in the middle of queries, two launches share
+    the machine): all 1024 result tuples of every run must be identical.  No oracle involved: any race between a leader's
+    waves, a leader and its helpers, or two launches shows as a differing state count / order hash."""
+    grid, origin, res, _, _ = map512
+    grid = np.ascontiguousarray(grid)
+    nq, cap = 1024, 2_000_000
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5, max_expand=cap)
+    queries = mapgen.c4_queries(grid, origin, res, nq, rank=0)
+    pools = mapgen.c4_pools(False, nq, cap, per_q=420_000)
+    mu, pl = util.make_gpu(grid, origin, res, U, n_slots=1024, max_nodes=pools["nodes"], max_edges=pools["edges"], max_log=pools["log"], **kw)
+    S = [util.gpu_wp(s) for s, g in queries]
+    G = [util.gpu_wp(g) for s, g in queries]
+    word = lambda r: (r.status, r.traj_len, r.cost, r.n_expanded, r.n_nodes, r.n_edges, r.n_succ_finite, r.voxel_reads, r.n_push, r.expand_hash)
+    ref = [word(r) for r in pl.planBatch(S, G)]
+    ms0 = pl.lastKernelMs()
+    assert [word(r) for r in pl.planBatch(S, G)] == ref
+    pl.setThroughput(1)
+    assert [word(r) for r in pl.planBatch(S, G)] == ref
+    ms_tp = pl.lastKernelMs()
+    pl.setThroughput(0)
+    pl.releasePools()
+    st = pl.stream(2)
+    st.configure(256, pools["nodes"], pools["edges"], pools["log"], -1, 0, 1 << 24, 32)
+    tickets = [st.submit(S, G), st.submit(S, G)]
+    bad = 0
+    for k in range(4):
+        t = tickets.pop(0)
+        bad += sum(1 for r, w in zip(st.wait(t), ref) if word(r) != w)
+        if k < 2:
+            tickets.append(st.submit(S, G))
+    st.close()
+    print(f"C4-ACC repeat: blocking {ms0:.0f} ms, two-per-CU {ms_tp:.0f} ms, 4 streamed batches, mismatching tuples {bad}")
+    assert bad == 0
+
+
 @pytest.mark.parametrize("nq", [1, 40, 600])
 def test_helpers_leave_every_result_unchanged(nq):
     """Helper workgroups (mplx_set_helpers): a batch smaller than the machine gets extra workgroups that help from the

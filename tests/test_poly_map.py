@@ -325,6 +325,9 @@ def test_lookahead_helpers_change_nothing_but_the_time():
         R = team.plan_batch(np.arange(16), starts, goals, max_expand=20000)
         assert team.last_helpers() == (h if h >= 0 else 4)
         runs[h] = [(r.status, r.n_expanded, r.n_nodes, r.n_edges, r.cost, r.expand_hash, r.traj_len) + tuple(team.traj(k)[0].tolist()) for k, r in enumerate(R)]
+        for _ in range(2):  # repeatability of each configuration (leader rings, help masks: DESIGN's memory-ordering contract): three runs, equal
+            R2 = team.plan_batch(np.arange(16), starts, goals, max_expand=20000)
+            assert [(r.status, r.n_expanded, r.n_nodes, r.n_edges, r.cost, r.expand_hash, r.traj_len) for r in R2] == [t[:7] for t in runs[h]], h
         hits = [team.cycles(k)["lookahead_hits"] for k in range(16)]
         print("helpers", h, "kernel ms", team.last_kernel_ms(), "look-ahead hits of the longest robots", sorted(hits)[-4:])
         assert (sum(hits) > 0) == (h != 0)

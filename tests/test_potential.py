@@ -152,6 +152,13 @@ def test_hip_distance_map_planner_flow_matches_the_oracle():
     assert p2.kernelName() == "astar_spec_kernel<32,16,ACC,pot>"  # the POT build of the speculative kernel (9-input ACC lattice)
     p2.plan(util.gpu_wp(START, vel=(0, 0, 0)), util.gpu_wp(GOAL))  # (a second launch: the first one pays the code load)
     ms_spec = p2.lastKernelMs()
+    # repeatability of the POT kernel (DESIGN: memory-ordering contract): the same plan five times, every result word equal
+    word = lambda x: (x.status, x.cost, x.n_expanded, x.expand_hash, x.n_nodes, x.n_edges, x.voxel_reads, x.n_succ, x.n_succ_finite, x.n_push)
+    again = set()
+    for _ in range(5):
+        p2.plan(util.gpu_wp(START, vel=(0, 0, 0)), util.gpu_wp(GOAL))
+        again.add(word(p2.getResult()))
+    assert again == {word(r)}
     p2.setSpeculation(0)  # ... and the one-node kernel: the same search, whole state space
     r1, _ = util.compare_plan(Q, p2, (START, (0, 0, 0)), (GOAL,), orc.ACC)
     assert p2.kernelName().startswith("astar_kernel<") and (r1.cost, r1.n_expanded, r1.expand_hash) == (r.cost, r.n_expanded, r.expand_hash)
