@@ -427,8 +427,11 @@ __global__ __launch_bounds__(BLOCK) void lpa_plan_kernel(SearchParams P, LpaPara
   bool searched = false;
   if (S.status < 0) {
     searched = true;
-    // ---- OPEN = the inconsistent states, rebuilt from the pool (L1)
+    // ---- OPEN = the inconsistent states, rebuilt from the pool (L1); the same pass finds the goal state to follow (L7):
+    //      the settled (consistent, finite g) state of the goal REGION with the smallest (key, g, id)
     const uint32_t n0 = S.n_nodes;
+    double gk = INFINITY, gg = INFINITY;
+    uint32_t gi = 0xFFFFFFFFu, gpos = NIL;  // (gpos != NIL: this thread holds a candidate)
     for (uint32_t base = 0; base < n0; base += BLOCK) {
       while (S.n_near + (uint32_t)BLOCK > (uint32_t)NC) {
         evict_half(Q, tid);
@@ -441,6 +444,15 @@ __global__ __launch_bounds__(BLOCK) void lpa_plan_kernel(SearchParams P, LpaPara
         char *rec = Q.node(i);
         g = V::g(rec); r = V::rhs(rec); h = V::h(rec);
         inc = !f64_same(g, r);
+        if (!inc && g < INFINITY) {  // settled: inside the goal region?
+          const double *st = V::state(rec);
+          State sg;
+          for (int k = 0; k < 12; k++) ((double *)&sg)[k] = k < ns ? st[k] : 0.0;
+          if (st[ns] >= P.t_max || is_goal_state(sg, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) {
+            const double k = g + P.eps * h;
+            if (gpos == NIL || entry_less(k, g, i, gk, gg, gi)) { gk = k; gg = g; gi = i; gpos = 0u; }
+          }
+        }
       }
       uint32_t tot;
       const uint32_t sc = block_excl_scan<BLOCK>(inc ? 1u : 0u, S, tid, tot);
@@ -456,6 +468,19 @@ __global__ __launch_bounds__(BLOCK) void lpa_plan_kernel(SearchParams P, LpaPara
       if (tid == 0) {
         S.n_log = base_log + tot;
         S.c_push += tot;
+      }
+      __syncthreads();
+    }
+    {  // L7: the workgroup's best settled goal-region state, if any, replaces the last plan's goal state
+      const bool have = wave_min_entry(gpos != NIL, gk, gg, gi, gpos);
+      if ((tid & 63) == 0) { S.red_f[tid >> 6] = gk; S.red_g[tid >> 6] = gg; S.red_id[tid >> 6] = gi; S.red_pos[tid >> 6] = have ? 0u : NIL; }
+      __syncthreads();
+      if (tid == 0) {
+        double bk = INFINITY, bg = INFINITY;
+        uint32_t bi = NIL;
+        for (int w = 0; w < BLOCK / 64; w++)
+          if (S.red_pos[w] != NIL && (bi == NIL || entry_less(S.red_f[w], S.red_g[w], S.red_id[w], bk, bg, bi))) { bk = S.red_f[w]; bg = S.red_g[w]; bi = S.red_id[w]; }
+        if (bi != NIL) s_gid = bi;
       }
       __syncthreads();
     }
@@ -621,7 +646,8 @@ __global__ __launch_bounds__(BLOCK) void lpa_plan_kernel(SearchParams P, LpaPara
         S.c_push += tot + extra;
         State s;
         for (int i = 0; i < 12; i++) ((double *)&s)[i] = S.cur[0][i];
-        if (S.cur[0][12] >= P.t_max || is_goal_state(s, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) s_gid = u;
+        // (L7: a state popped under-consistent has g = inf now: no goal state to follow)
+        if (S.cur_g < INFINITY && (S.cur[0][12] >= P.t_max || is_goal_state(s, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc))) s_gid = u;
         if (P.max_expand > 0 && S.c_expanded >= (unsigned long long)P.max_expand) S.status = 3;
         // (safety net: LPA* expands a state at most twice per call; never spin on the device)
         else if (S.c_expanded > 8ull * ((unsigned long long)P.node_chunks << NODE_CH_LOG) + 1024ull) S.status = 5;

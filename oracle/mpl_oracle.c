@@ -25,6 +25,8 @@
 #define ORC_HASH_RES_YAW 0.1
 
 /* ------------------------------------------------------------------ small helpers */
+/* [UNVERIFIED Q1 of mpl_oracle.h] upstream is recalled to call std::pow(t, n) here; equal at t = 1, possibly one ulp apart at
+ * the interior sample times of cubic / quartic terms */
 static double pw(double t, int n) { /* t^n by repeated multiplication, left to right */
   double r = t;
   for (int i = 1; i < n; i++) r = r * t;

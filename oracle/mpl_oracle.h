@@ -57,6 +57,24 @@
  *   D8  env_base::cal_heur with v_max <= 0 ("unlimited"): the |dp|_inf / v_max arrival-time bound is dropped
  *       (t_bar = 0; heur_ignore_dynamics returns w |dp|_inf) instead of dividing by a non-positive number.
  *       Believed to equal upstream's `v_max_ > 0` guard; UNVERIFIED.
+ *
+ * OPEN QUESTIONS -- places where a reviewer's recollection of upstream differs from this restatement and neither can be
+ * checked against source (the submodule is empty); listed so that they are the first things diffed when it is available.
+ * They are NOT known deviations: each is tagged [UNVERIFIED Qn] at the line it applies to; the HIP product follows this file.
+ *   Q1  Primitive1D::p / v / a / j(t): upstream is recalled to raise t to its powers with std::pow(t, n); here --
+ *       and on the device -- the powers are repeated multiplications (t * t * t ...).  Identical at t = dt = 1 (every end
+ *       state of BASELINE C1-C4) and wherever pow's result is the correctly rounded product chain; at the interior sample
+ *       times i dt / n of a JRK primitive (cubic / quartic terms) the two can differ in the last ulp of a position, which
+ *       matters only if the position sits within an ulp of a voxel boundary.  No cell index in any committed fixture
+ *       depends on it as far as the analytic pins (tests/test_oracle_kat.py) can tell; unpinned either way.
+ *   Q2  potential mask (P1 of mpl_oracle_pot.inc): upstream is recalled to normalise the distance by the INTEGER radius
+ *       rn = ceil(r / res) in cells (d = |n| / rn per axis), this file normalises by the metric radius (n res / r).  The
+ *       two agree when r is a multiple of res (1.5 / 0.1 in distance_map_planner_node.cpp:187 -- up to the rounding of
+ *       1.5 / 0.1); they differ for other radii.
+ *   Q3  traverse cost of the potential (P3): upstream is recalled to walk t in [0, T) in steps of dt_sample and to scale
+ *       the summed potential by that step (an approximate line integral), this file sums the potential over the n + 1
+ *       collision samples unscaled.  The weight the reference passes (10) then means different things in the two forms;
+ *       path shape under a potential field is therefore NOT claimed to match upstream, only the restatement.
  */
 #ifndef MPL_ORACLE_H
 #define MPL_ORACLE_H

@@ -399,3 +399,72 @@ def test_hip_lpastar_on_3d_maps_bit_exact_and_equal_to_fresh_astar(name):
     rl3, ra3 = replan("one primitive ahead", orc.waypoint(tuple(w1.pos), vel=tuple(w1.vel)), util.gpu_wp(tuple(w1.pos), vel=tuple(w1.vel)))
     assert rl3.n_expanded < ra3.n_expanded and rl3.cost < cost0
     print(f"LPA* on {name}: (step, LPA* expansions, LPA* kernel ms, fresh A* expansions, fresh A* kernel ms)", times)
+
+
+# ---------------------------------------------------------------- round 4: the goal is a region (choice L7)
+# tests/golden/lpa_goal_region_case.npz: a 40 x 40 cell world found by a random search for "LPA* != fresh A*" (5951 replans
+# agree since).  Four single-cell edits near the goal: a cheaper state G1 of the goal region appears, then its own cell is
+# occupied.  Following only the last plan's goal state, the search ran G1 to g = inf and came back with another state of the
+# region at cost 56 although the settled state a fresh A* returns (cost 67, smaller key) was sitting in the pool.
+GOAL_REGION_EDITS = [(36, 37, False), (28, 28, True), (27, 27, True), (30, 30, False)]  # (x, y, was occupied)
+
+
+def _goal_region_case():
+    grid = np.load(os.path.join(ROOT, "tests", "golden", "lpa_goal_region_case.npz"))["grid"].copy()
+    return grid, (0.0, 0.0, 0.0), 0.25, (1.125, 1.125, 0.125), (8.125, 8.125, 0.125)
+
+
+def test_oracle_lpastar_follows_the_best_settled_state_of_the_goal_region():
+    grid, origin, res, start, goal = _goal_region_case()
+    U = mapgen.control_lattice(1.0, 1, False)
+    A = util.make_oracle(grid, origin, res, orc.ACC, U, **KW3)
+    L = util.make_oracle(grid, origin, res, orc.ACC, U, **KW3)
+    L.set_lpastar(True)
+    so, go = orc.waypoint(start), orc.waypoint(goal)
+    assert A.plan(so, go) == L.plan(so, go) == orc.OK and A.traj_cost == L.traj_cost
+    costs = []
+    for cx, cy, occ in GOAL_REGION_EDITS:
+        grid[0, cy, cx] = 0 if occ else 100
+        for P in (A, L):
+            P.set_map(grid, origin, res)
+        (L.update_cleared if occ else L.update_blocked)([(cx, cy, 0)])
+        assert A.plan(so, go) == L.plan(so, go) == orc.OK and A.traj_cost == L.traj_cost
+        costs.append(L.traj_cost)
+    assert costs == [67.0, 58.0, 56.0, 67.0]
+
+
+@pytest.mark.gpu
+def test_hip_lpastar_goal_region_case_matches_the_oracle_and_a_fresh_astar():
+    from mpl_ros_amd.planner import VoxelMapPlanner
+    grid, origin, res, start, goal = _goal_region_case()
+    U = mapgen.control_lattice(1.0, 1, False)
+    L = util.make_oracle(grid, origin, res, orc.ACC, U, **KW3)
+    L.set_lpastar(True)
+    mu, a = util.make_gpu(grid, origin, res, U, **KW3)
+    l = VoxelMapPlanner(False)
+    l.setMapUtil(mu)
+    l.setVmax(2.0); l.setAmax(1.0); l.setDt(1.0); l.setU(U); l.setTol(0.5)
+    l.setCapacity(1, 1 << 16, 1 << 18, 1 << 18)
+    l.setLPAstar(True)
+    so, go, sg, gg = orc.waypoint(start), orc.waypoint(goal), util.gpu_wp(start), util.gpu_wp(goal)
+
+    def both():
+        L.reset_counters()
+        sl = L.plan(so, go)
+        assert l.plan(sg, gg) == (sl == orc.OK)
+        compare_lpa(L, l, l.getResult(), sl)
+        assert a.plan(sg, gg) and a.getResult().cost == l.getResult().cost
+        return l.getResult().cost
+
+    costs = [both()]
+    for cx, cy, occ in GOAL_REGION_EDITS:
+        grid[0, cy, cx] = 0 if occ else 100
+        L.set_map(grid, origin, res)
+        dz, dy, dx = grid.shape
+        mu.setMap(origin, (dx, dy, dz), grid.ravel(), res)
+        if occ:
+            assert l.updateClearedNodes([(cx, cy, 0)]) == L.update_cleared([(cx, cy, 0)])
+        else:
+            assert l.updateBlockedNodes([(cx, cy, 0)]) == L.update_blocked([(cx, cy, 0)])
+        costs.append(both())
+    assert costs == [67.0, 67.0, 58.0, 56.0, 67.0]
