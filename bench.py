@@ -79,9 +79,9 @@ def main():
                     help="--config c5: round 3's variant (distance heuristic, max_expand 20000) instead of the reference's planner parameters")
     ap.add_argument("--no-throughput", action="store_true",
                     help="N > 1, strong scaling: skip the additional throughput phase (a 1024 x N query stream through the same sharded path)")
-    ap.add_argument("--throughput", type=int, default=0,
-                    help="1: the two-workgroups-per-compute-unit instantiation of the search kernel (mplx_set_throughput) for the blocking steps AND the streamed leg; "
-                         "0 (default): blocking steps on the 16-unit kernel; -1: blocking steps on the 16-unit kernel, streamed leg on the throughput instantiation")
+    ap.add_argument("--two-per-cu", action="store_true",
+                    help="measurement only (DESIGN.md, round 4): two 256-lane workgroups of eight expansion units per compute unit instead of one 512-lane workgroup "
+                         "of sixteen, without helper workgroups (use with --helpers 0 --max-expand 20000 --stream 0): no gain, not a product configuration")
     ap.add_argument("--stream", type=int, default=-1,
                     help="N = 1, C4 batch: batches of the additional streamed leg (mplx_stream: two batches in flight on two lanes of the same map replica; "
                          "every result compared with the blocking step's); -1 auto = max(steps, 6), 0 off")
@@ -200,7 +200,8 @@ def main():
     pl.setMaxNum(max_expand)
     pl.setCapacity(min(slots, n_local), caps["nodes"], caps["edges"], caps["log"])
     pl.setHelpers(args.helpers, args.help_reserved)
-    pl.setThroughput(1 if args.throughput > 0 else 0)
+    if args.two_per_cu:
+        pl.setSpeculation(82)
 
     def wp(p):
         w = Waypoint3D(control)
@@ -585,7 +586,6 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
     want = [key(r) for r in ref_results]
     exp_per_batch = sum(r.n_expanded for r in ref_results)
     pl.releasePools()  # the blocking leg's pools (~ 130 GB at C4 size) make room for the lanes'
-    pl.setThroughput(1 if args.throughput != 0 else 0)  # (the lanes copy the planner's setting)
     depth = max(1, args.stream_depth)
     caps = mapgen.c4_pools(jrk, max(nq, 256), max_expand, per_q=args.max_nodes or (420_000 if not jrk else 0))
     st = pl.stream(depth)

@@ -184,7 +184,8 @@ int mplx_planner_config(mplx_ctx *ctx, const mplx_config *cfg);
  * queries of one batch -- states, predecessor records, OPEN-log entries (0 = keep current) */
 int mplx_set_capacity(mplx_ctx *ctx, int32_t n_slots, uint64_t total_nodes, uint64_t total_edges, uint64_t total_open_log);
 /* speculative multi-node expansion (results are identical either way): -1 auto (on when
- * n_u <= 128), 0 = sequential kernel (one node per iteration), 2 = on */
+ * n_u <= 128), 0 = sequential kernel (one node per iteration), 2 = on; 8 / 82: measurement variants (eight expansion units;
+ * 82: two 256-lane workgroups per compute unit, no helper workgroups -- measured in round 4, no gain) */
 int mplx_set_speculation(mplx_ctx *ctx, int32_t mode);
 /* Helper workgroups: a workgroup with no query (left) to lead expands the front of a running query's OPEN list
  * ahead of time (get_succ and successor heuristics are pure functions of the node, the map and the goal) and
@@ -245,11 +246,6 @@ int mplx_stream_configure(mplx_stream *s, int32_t n_slots, uint64_t total_nodes,
 int mplx_stream_submit(mplx_stream *s, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals, int64_t *ticket);
 int mplx_stream_done(mplx_stream *s, int64_t ticket);
 int mplx_stream_wait(mplx_stream *s, int64_t ticket, mplx_result *out, mplx_ctx **lane_ctx);
-/* Throughput instantiation of the search kernel (mode 1; 0 = off, the default): two 256-lane workgroups per compute unit, eight
- * expansion units each, instead of one 512-lane workgroup of sixteen -- for batches / streams of many queries (a compute
- * unit's two queries hide each other's barriers and memory round trips); one query alone on the machine is faster without.
- * Exists for ACC lattices of at most 31 inputs (BASELINE C4); other configurations ignore the setting.  Same results. */
-int mplx_set_throughput(mplx_ctx *ctx, int32_t mode);
 /* At most `limit` workgroups of a launch stay on as helpers once its query queue is empty (-1: all of them, the default
  * of a blocking batch); the others exit, so that the next batch's workgroups get their compute units. */
 int mplx_set_helper_limit(mplx_ctx *ctx, int32_t limit);

@@ -68,7 +68,7 @@ EXPORTS = [
     "mplx_poly_add_static", "mplx_poly_add_linear", "mplx_poly_add_nonlinear", "mplx_poly_commit", "mplx_poly_get_succ_batch", "mplx_poly_set_capacity", "mplx_poly_plan_batch", "mplx_poly_result_traj",
     "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms", "mplx_poly_result_cycles", "mplx_poly_set_helpers", "mplx_poly_last_helpers",
     "mplx_traj_solve", "mplx_traj_sample", "mplx_traj_effort",
-    "mplx_plan_batch_submit", "mplx_plan_batch_wait", "mplx_plan_batch_done", "mplx_set_helper_limit", "mplx_release_pools", "mplx_set_throughput",
+    "mplx_plan_batch_submit", "mplx_plan_batch_wait", "mplx_plan_batch_done", "mplx_set_helper_limit", "mplx_release_pools",
     "mplx_stream_create", "mplx_stream_destroy", "mplx_stream_last_error", "mplx_stream_depth", "mplx_stream_configure",
     "mplx_stream_submit", "mplx_stream_done", "mplx_stream_wait",
 ]
@@ -214,7 +214,6 @@ def load():
     L.mplx_plan_batch_done.argtypes = [P]
     L.mplx_set_helper_limit.argtypes = [P, C.c_int32]
     L.mplx_release_pools.argtypes = [P]
-    L.mplx_set_throughput.argtypes = [P, C.c_int32]
     L.mplx_stream_create.argtypes = [P, C.c_int, C.POINTER(P)]
     L.mplx_stream_destroy.argtypes = [P]
     L.mplx_stream_destroy.restype = None

@@ -102,7 +102,6 @@ struct mplx_ctx {
   bool pend_help = false;
   std::vector<QueryIn> pend_in;
   std::vector<int32_t> pend_order;
-  int throughput = 0;   // 1: two-workgroups-per-compute-unit instantiation of the speculative kernel where one exists (ACC lattices of <= 31 inputs)
   int help_limit = -1;  // workgroups of a launch that may turn into helpers once the query queue is empty (-1: all of them)
 };
 
@@ -1090,17 +1089,15 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
   // of time.  The launch holds one workgroup per compute unit at most, so all of them are resident together: for a
   // batch smaller than the machine the extra workgroups (blockIdx.x >= help_lead) help from the start; in a large
   // batch the leaders turn into helpers as they run out of queries.
-  // throughput instantiation: two 256-lane workgroups per compute unit (27-input ACC lattices): a compute unit's two queries
-  // hide each other's barriers and memory round trips; a query alone on the machine is slower on it (8 expansion units
-  // instead of 16), so it is the caller's choice (mplx_set_throughput) -- streams of large batches want it
-  const bool tp = c->throughput > 0 && spec && !c->aux && P.control == CTRL_ACC && P.n_u <= 31 && (c->speculation < 0 || c->speculation >= 16);
-  P.throughput = tp ? 1 : 0;
+  // (measurement only: mplx_set_speculation(ctx, 82) = two 256-lane workgroups per compute unit, no helper workgroups -- see
+  //  mplx_spec_launch.hip; measured, no gain, selected by no product configuration)
+  const bool tp = c->speculation == 82 && spec && !c->aux && P.control == CTRL_ACC && P.n_u <= 31;
   const int n_wg = c->n_cus * (tp ? 2 : 1);  // workgroups of the search kernel the machine holds at once
   int grid = slots;
   P.help_lead = slots;
   P.help_max = 0;
   P.help_limit = c->help_limit;
-  const bool help = spec && !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
+  const bool help = spec && !tp && !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
                     ((P.n_u <= 31 && (P.control == CTRL_ACC || P.control == CTRL_JRK)) || (P.control == CTRL_JRK && P.n_u > 64 && P.n_u <= 128));
   if (help) {
     // auto: four helpers per leader for the lattices of at most 31 inputs (the capped query of the C4 batch alone: 1.95 s
@@ -1220,11 +1217,6 @@ extern "C" int mplx_plan_batch_done(mplx_ctx *c) {  // 1: wait() will not block;
   const hipError_t e = hipStreamQuery(c->stream);
   return e == hipSuccess ? 1 : e == hipErrorNotReady ? 0 : fail(c, MPLX_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(e));
 }
-extern "C" int mplx_set_throughput(mplx_ctx *c, int32_t mode) {
-  if (!c) return MPLX_ERR_ARG;
-  c->throughput = mode > 0 ? 1 : 0;
-  return MPLX_OK;
-}
 extern "C" int mplx_set_helper_limit(mplx_ctx *c, int32_t limit) {
   if (!c) return MPLX_ERR_ARG;
   c->help_limit = limit < 0 ? -1 : limit;
@@ -1291,7 +1283,6 @@ extern "C" int mplx_stream_create(mplx_ctx *parent, int depth, mplx_stream **out
       l->n_slots = parent->n_slots; l->cap_nodes = parent->cap_nodes; l->cap_edges = parent->cap_edges; l->cap_log = parent->cap_log;
       l->bucket_width = parent->bucket_width; l->speculation = parent->speculation;
       l->helpers = parent->helpers; l->help_reserved = parent->help_reserved; l->help_rows = parent->help_rows; l->help_limit = parent->help_limit;
-      l->throughput = parent->throughput;
     }
     if (r != MPLX_OK) {
       if (l) parent->err = l->err.empty() ? g_create_error : l->err;
@@ -1370,11 +1361,11 @@ extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
     else if (c->speculation == 2) { ul = 128; k = 2; }
     else { ul = 128; k = 4; }
     if (c->aux) { ul = 32; k = 16; }
-    const bool tp = c->throughput > 0 && !c->aux && control == CTRL_ACC && n_u <= 31 && (c->speculation < 0 || c->speculation >= 16);
+    const bool tp = c->speculation == 82 && !c->aux && control == CTRL_ACC && n_u <= 31;  // (measurement-only variant)
     if (tp) { ul = 32; k = 8; }
-    const bool help = !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 &&
-                      ((ul == 32 && (k == 16 || tp) && n_u <= 31) || (ul == 128 && k == 4 && control == CTRL_JRK && n_u > 64));
-    snprintf(buf, sizeof(buf), c->aux ? "astar_spec_kernel<%d,%d,%s,pot>" : tp ? (help ? "astar_spec_kernel<%d,%d,%s,help,2-per-CU>" : "astar_spec_kernel<%d,%d,%s,2-per-CU>") :
+    const bool help = !tp && !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 &&
+                      ((ul == 32 && k == 16 && n_u <= 31) || (ul == 128 && k == 4 && control == CTRL_JRK && n_u > 64));
+    snprintf(buf, sizeof(buf), c->aux ? "astar_spec_kernel<%d,%d,%s,pot>" : tp ? "astar_spec_kernel<%d,%d,%s,2-per-CU>" :
                                 help ? "astar_spec_kernel<%d,%d,%s,help>" : "astar_spec_kernel<%d,%d,%s>", ul, k, cn);
   }
   return buf;

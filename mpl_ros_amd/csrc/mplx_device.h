@@ -153,7 +153,6 @@ struct SearchParams {
   uint32_t epoch;                 // launch counter of the context
   int32_t help_lead;              // workgroups blockIdx.x < help_lead lead queries (and own the boxes [0, help_lead)); the others only help
   int32_t help_max;               // helpers per leader (0 or 2..4)
-  int32_t throughput;             // 1: the launch uses the throughput instantiation (two workgroups per compute unit)
   int32_t help_limit;             // workgroups of the launch that may turn into helpers once the query queue is empty (-1: no limit);
                                   // counted in cache_next[4].  Streamed batches: the rest exit and leave their compute unit to the next batch
   // moving-obstacle environment (astar_poly_kernel): the worlds and the world of each query

@@ -22,11 +22,6 @@ bool mplx_launch_spec_help(int grid, hipStream_t s, const SearchParams &P) {
     return true;
   }
   if (P.n_u > 31) return false;
-  if (P.throughput) {  // two 256-lane workgroups per compute unit, eight expansion units each (ACC lattices; the host asks for no other)
-    if (P.control != CTRL_ACC) return false;
-    hipLaunchKernelGGL((astar_spec_kernel<32, 8, CTRL_ACC, 512, 512, true, false, true>), dim3(grid), dim3(256), 0, s, P);
-    return true;
-  }
   if (P.control == CTRL_ACC)
     hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024, true>), dim3(grid), dim3(512), 0, s, P);
   else

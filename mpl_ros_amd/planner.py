@@ -744,11 +744,6 @@ class VoxelMapPlanner:
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_helper_limit(ctx.h, int(limit)))
 
-    def setThroughput(self, mode):
-        """1: the two-workgroups-per-compute-unit instantiation of the search kernel (batches / streams of many queries)."""
-        ctx = self._ctx()
-        ctx.check(ctx.lib.mplx_set_throughput(ctx.h, int(mode)))
-
     def releasePools(self):
         """Give the context's device pools back (re-created by the next plan): room for a stream's lanes."""
         ctx = self._ctx()
