@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--stream-depth", type=int, default=2, help="lanes of the streamed leg (each holds a batch's pools: two fit 288 GB at C4 size)")
     ap.add_argument("--stream-helper-limit", type=int, default=32,
                     help="streamed leg: workgroups of a batch that stay on as helpers once its queue is empty (the others leave their compute unit to the next batch)")
+    ap.add_argument("--stream-reserved", type=int, default=0, help="streamed leg: workgroups of every lane's launch that never lead (help from the start)")
     ap.add_argument("--dump-queries", default="", help="write per-query expansions / device timing of the last step to this JSON file")
     args = ap.parse_args()
     if args.single:
@@ -591,7 +592,7 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
     st = pl.stream(depth)
     # a lane = one workgroup per compute unit, all of them leading (no reserved helper share); when a batch's queue is empty
     # at most --stream-helper-limit of its workgroups stay on to help its longest queries, the others exit
-    st.configure(min(nq, 256), caps["nodes"], caps["edges"], caps["log"], args.helpers, 0, 1 << 24, args.stream_helper_limit)
+    st.configure(min(nq, 256), caps["nodes"], caps["edges"], caps["log"], args.helpers, args.stream_reserved, 1 << 24, args.stream_helper_limit)
     S = (_capi.Waypoint * nq)(*[w.to_c() for w in starts])
     G = (_capi.Waypoint * nq)(*[w.to_c() for w in goals])
     mism = 0
@@ -638,7 +639,7 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
             "ms_per_batch": 1e3 * wall / n_batches, "steady_state_ms_per_batch": 1e3 * float(np.median(gaps[1:])) if len(gaps) > 2 else None,
             "batch_latency_ms": {"mean": 1e3 * float(np.mean(lat)), "min": 1e3 * float(np.min(lat)), "max": 1e3 * float(np.max(lat))},
             "kernel_ms_per_batch": {"mean": float(np.mean(kernel_ms)), "max": float(np.max(kernel_ms))},
-            "helper_limit": args.stream_helper_limit, "kernel": pl.kernelName(),
+            "helper_limit": args.stream_helper_limit, "reserved": args.stream_reserved, "kernel": pl.kernelName(),
             "parity": {"batches_checked": n_batches + depth, "queries_per_batch": nq, "mismatches_vs_blocking_step": mism, "mismatch_detail": mism_detail,
                        "checked": "status, traj_len, cost (bit-exact f64), n_expanded, n_nodes, n_edges, n_succ_finite, voxel_reads, expand_hash of every query of every batch"},
             "roofline": {"achieved": alg_bytes_per_batch * n_batches / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
