@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--stream-depth", type=int, default=2, help="lanes of the streamed leg (each holds a batch's pools: two fit 288 GB at C4 size)")
     ap.add_argument("--stream-helper-limit", type=int, default=32,
                     help="streamed leg: workgroups of a batch that stay on as helpers once its queue is empty (the others leave their compute unit to the next batch)")
+    ap.add_argument("--stream-split", type=int, default=1,
+                    help="streamed leg: every batch is submitted as this many tickets (alternate queries of the longest-first order, so every part holds the same mix); "
+                         "the lanes are sized for a part, so --stream-depth can grow with it (2 parts x 4 lanes fit where 1 x 2 do)")
     ap.add_argument("--stream-reserved", type=int, default=0, help="streamed leg: workgroups of every lane's launch that never lead (help from the start)")
     ap.add_argument("--dump-queries", default="", help="write per-query expansions / device timing of the last step to this JSON file")
     args = ap.parse_args()
@@ -588,45 +591,57 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
     exp_per_batch = sum(r.n_expanded for r in ref_results)
     pl.releasePools()  # the blocking leg's pools (~ 130 GB at C4 size) make room for the lanes'
     depth = max(1, args.stream_depth)
-    caps = mapgen.c4_pools(jrk, max(nq, 256), max_expand, per_q=args.max_nodes or (420_000 if not jrk else 0))
+    split = max(1, args.stream_split)
+    # the parts of a batch: alternate queries of the launch order (longest straight-line distance first, what the planner sorts
+    # by), so that every part is the same mix of long and short queries
+    order = sorted(range(nq), key=lambda i: -float(np.sum((starts[i].pos - goals[i].pos) ** 2)))
+    parts = [order[k::split] for k in range(split)]
+    n_part = max(len(p) for p in parts)
+    caps = mapgen.c4_pools(jrk, max(n_part, 256), max_expand, per_q=args.max_nodes or ((420_000 if split == 1 else 450_000) if not jrk else 0))
     st = pl.stream(depth)
-    # a lane = one workgroup per compute unit, all of them leading (no reserved helper share); when a batch's queue is empty
-    # at most --stream-helper-limit of its workgroups stay on to help its longest queries, the others exit
-    st.configure(min(nq, 256), caps["nodes"], caps["edges"], caps["log"], args.helpers, args.stream_reserved, 1 << 24, args.stream_helper_limit)
-    S = (_capi.Waypoint * nq)(*[w.to_c() for w in starts])
-    G = (_capi.Waypoint * nq)(*[w.to_c() for w in goals])
+    # a lane = one workgroup per compute unit, all of them leading (no reserved helper share unless asked); when a batch's queue
+    # is empty at most --stream-helper-limit of its workgroups stay on to help its longest queries, the others exit
+    st.configure(min(n_part, 256), caps["nodes"], caps["edges"], caps["log"], args.helpers, args.stream_reserved, 1 << 24, args.stream_helper_limit)
+    SG = [((_capi.Waypoint * len(p))(*[starts[i].to_c() for i in p]), (_capi.Waypoint * len(p))(*[goals[i].to_c() for i in p]), p) for p in parts]
     mism = 0
     mism_detail = []
 
-    def collect(t):
+    def collect(t, part):
         nonlocal mism
         R = st.wait(t)
-        for qi, (r, w) in enumerate(zip(R, want)):
-            if key(r) != w:
+        for k, r in enumerate(R):
+            qi = part[k]
+            if key(r) != want[qi]:
                 mism += 1
                 if len(mism_detail) < 8:
                     mism_detail.append({"ticket": int(t), "query": qi, "got": [float(x) if isinstance(x, float) else int(x) for x in key(r)],
-                                        "want": [float(x) if isinstance(x, float) else int(x) for x in w], "timing": list(st.queryTiming(qi))})
+                                        "want": [float(x) if isinstance(x, float) else int(x) for x in want[qi]], "timing": list(st.queryTiming(k))})
         return R
 
-    for t in [st.submit_c(S, G, nq) for _ in range(depth)]:  # warm-up: allocates the lanes' pools
-        collect(t)
+    jobs = [(b, k) for b in range(n_batches) for k in range(split)]  # (batch, part) in submission order
+    for t, k in [(st.submit_c(SG[k % split][0], SG[k % split][1], len(SG[k % split][2])), k % split) for k in range(depth)]:  # warm-up: allocates the lanes' pools
+        collect(t, SG[k][2])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    inflight, lat, done_at, submitted, kernel_ms = [], [], [], 0, []
-    while submitted < n_batches or inflight:
-        while submitted < n_batches and len(inflight) < depth:
-            inflight.append((st.submit_c(S, G, nq), time.perf_counter()))
+    inflight, submitted, kernel_ms = [], 0, []
+    first_submit, last_done, left = {}, {}, {b: split for b in range(n_batches)}
+    while submitted < len(jobs) or inflight:
+        while submitted < len(jobs) and len(inflight) < depth:
+            b, k = jobs[submitted]
+            now = time.perf_counter()
+            first_submit.setdefault(b, now)
+            inflight.append((st.submit_c(SG[k][0], SG[k][1], len(SG[k][2])), b, k))
             submitted += 1
         progressed = False
         for item in list(inflight):
-            t, ts = item
+            t, b, k = item
             if st.done(t):
                 now = time.perf_counter()
-                collect(t)
+                collect(t, SG[k][2])
                 kernel_ms.append(st.lastKernelMs())
-                lat.append(now - ts)
-                done_at.append(now - t0)
+                left[b] -= 1
+                if left[b] == 0:
+                    last_done[b] = now
                 inflight.remove(item)
                 progressed = True
         if not progressed:
@@ -634,19 +649,20 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     st.close()
-    gaps = np.diff([0.0] + sorted(done_at))
-    return {"value": exp_per_batch * n_batches / wall, "unit": "expansions/s", "batches": n_batches, "depth": depth, "wall_s": wall,
+    lat = [last_done[b] - first_submit[b] for b in range(n_batches)]
+    gaps = np.diff([0.0] + sorted(last_done[b] - t0 for b in range(n_batches)))
+    return {"value": exp_per_batch * n_batches / wall, "unit": "expansions/s", "batches": n_batches, "depth": depth, "split": split, "wall_s": wall,
             "ms_per_batch": 1e3 * wall / n_batches, "steady_state_ms_per_batch": 1e3 * float(np.median(gaps[1:])) if len(gaps) > 2 else None,
             "batch_latency_ms": {"mean": 1e3 * float(np.mean(lat)), "min": 1e3 * float(np.min(lat)), "max": 1e3 * float(np.max(lat))},
-            "kernel_ms_per_batch": {"mean": float(np.mean(kernel_ms)), "max": float(np.max(kernel_ms))},
+            "kernel_ms_per_ticket": {"mean": float(np.mean(kernel_ms)), "max": float(np.max(kernel_ms))},
             "helper_limit": args.stream_helper_limit, "reserved": args.stream_reserved, "kernel": pl.kernelName(),
-            "parity": {"batches_checked": n_batches + depth, "queries_per_batch": nq, "mismatches_vs_blocking_step": mism, "mismatch_detail": mism_detail,
+            "parity": {"batches_checked": n_batches, "warmup_tickets_checked": depth, "queries_per_batch": nq, "mismatches_vs_blocking_step": mism, "mismatch_detail": mism_detail,
                        "checked": "status, traj_len, cost (bit-exact f64), n_expanded, n_nodes, n_edges, n_succ_finite, voxel_reads, expand_hash of every query of every batch"},
             "roofline": {"achieved": alg_bytes_per_batch * n_batches / wall / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": alg_bytes_per_batch * n_batches / wall / 1e9 / HBM_PEAK_GBS,
                          "note": "algorithmic bytes of all batches / wall time of the stream (launches overlap: a per-launch duration would count shared time twice)"},
-            "workload": f"the same {nq}-query batch submitted {n_batches} times, {depth} in flight on {depth} lanes of one map replica (mplx_stream); "
-                        "submit -> done latency per batch beside the throughput"}
+            "workload": f"the same {nq}-query batch submitted {n_batches} times" + (f", each as {split} tickets of {n_part} queries (alternate queries of the longest-first order)" if split > 1 else "") +
+                        f"; {depth} tickets in flight on {depth} lanes of one map replica (mplx_stream); submit -> done latency per batch beside the throughput"}
 
 
 def bench_lpa(args):
