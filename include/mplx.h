@@ -249,7 +249,8 @@ int mplx_stream_wait(mplx_stream *s, int64_t ticket, mplx_result *out, mplx_ctx 
 /* At most `limit` workgroups of a launch stay on as helpers once its query queue is empty (-1: all of them, the default
  * of a blocking batch); the others exit, so that the next batch's workgroups get their compute units. */
 int mplx_set_helper_limit(mplx_ctx *ctx, int32_t limit);
-/* Free the context's device pools and batch buffers (re-created by its next plan): hands the memory to other contexts. */
+/* Free the context's device pools (re-created by its next plan): hands the memory to other contexts, e.g. a stream's lanes.
+ * The last batch's results and trajectories stay readable; the state-space dumps of a single plan do not. */
 int mplx_release_pools(mplx_ctx *ctx);
 
 /* ---- results of query q of the last plan / plan_batch ---- */

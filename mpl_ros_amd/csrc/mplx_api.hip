@@ -1229,10 +1229,8 @@ extern "C" int mplx_release_pools(mplx_ctx *c) {
   if (c->pending) return fail(c, MPLX_ERR_ARG, "a submitted batch is still outstanding on this context");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  free_pools(c);
-  free_batch(c);
-  c->last_nq = 0;
-  c->last_single = false;
+  free_pools(c);  // (the per-query result buffers stay: status / cost / trajectories of the last batch remain readable; the
+                  //  state-space dumps -- mplx_result_nodes / _edges / _blocked -- need the pools and now fail loudly)
   return MPLX_OK;
 }
 

@@ -21,7 +21,13 @@ pass stream/trace "$STREAM" --kernel-trace --stats
 pass stream/pmc_fetch "$STREAM" --pmc FETCH_SIZE
 pass stream/pmc_write "$STREAM" --pmc WRITE_SIZE
 pass stream/pmc_sq1 "$STREAM" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES
+# (c) the bulk phase alone: every query capped at 20 000 expansions, no helper workgroups -- 256 compute units busy, no tail
+BULK="python $ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --stream 0 --max-expand 20000 --helpers 0"
+mkdir -p "$OUT/bulk"
+pass bulk/pmc_sq1 "$BULK" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES
+pass bulk/pmc_sq2 "$BULK" --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_SALU
 cd - > /dev/null
+python profiles/summarize_rocprof.py "$OUT/bulk" > "$OUT/summary_bulk.txt" 2>&1
 python profiles/summarize_rocprof.py "$OUT/block" > "$OUT/summary_block.txt" 2>&1
 python profiles/summarize_rocprof.py "$OUT/stream" > "$OUT/summary_stream.txt" 2>&1
 find "$OUT" -name "*.db" -delete
