@@ -387,6 +387,13 @@ def main():
         n_stream = args.stream if args.stream >= 0 else max(args.steps, 6)
         if n_stream > 0 and world == 1 and not multi and not args.single and mine:
             out["stream"] = stream_leg(args, pl, starts, goals, results, n_stream, control, jrk, max_expand, alg)
+            try:  # HBM traffic per streamed launch from the committed counter passes of the same leg (tools/profile_r04.sh)
+                trs = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("stream")
+                if trs and args.lattice == "acc" and len(mine) == 1024 and n == 512 and args.stream_split == 1:
+                    out["stream"]["roofline"]["traffic_per_batch"] = (trs["FETCH_SIZE_KB"] + trs["WRITE_SIZE_KB"]) * 1024.0
+                    out["stream"]["roofline"]["traffic_source"] = trs["profile"]
+            except Exception:
+                pass
         if args.cpu_seconds > 0 and mine and world == 1:  # (the CPU baseline is a rank-0, N = 1 leg)
             # a single capped query is sampled on the CPU with a smaller cap; the GPU then repeats the query with
             # that cap (untimed) so that the parity check compares equal searches
