@@ -235,7 +235,9 @@ int mplx_plan_batch_done(mplx_ctx *ctx); /* 1: wait() will not block, 0: still r
  * mplx_result_traj / mplx_result_timing for that batch until the lane is submitted to again.  A query is a serial pop chain
  * on one compute unit: while the longest queries of batch n finish, the workgroups of batch n + 1 run on the rest of the
  * machine.  mplx_stream_configure: pools and helper policy of every lane (helper_limit: see mplx_set_helper_limit).
- * Destroy the stream before ctx. */
+ * The lanes take ctx's planner set-up when the stream is created and follow ctx's MAP: after the map was edited (setMap,
+ * dilate, a VoxelGrid hand-over) the next submit makes every lane adopt it again -- with a batch still in flight that
+ * submit fails (MPLX_ERR_ARG: wait first; a running batch must not lose its map).  Destroy the stream before ctx. */
 typedef struct mplx_stream mplx_stream;
 int mplx_stream_create(mplx_ctx *ctx, int depth, mplx_stream **out);
 void mplx_stream_destroy(mplx_stream *s);

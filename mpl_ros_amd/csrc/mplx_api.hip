@@ -1244,6 +1244,7 @@ struct mplx_stream {
   std::vector<mplx_ctx *> lanes;
   std::vector<int64_t> ticket_of;   // ticket outstanding on each lane (-1: free)
   int64_t next_ticket = 0;
+  uint64_t map_epoch = 0;           // the parent's map generation the lanes have adopted
   std::string err;
 };
 static int sfail(mplx_stream *s, int code, const char *msg) {
@@ -1289,7 +1290,22 @@ extern "C" int mplx_stream_create(mplx_ctx *parent, int depth, mplx_stream **out
     }
   }
   s->ticket_of.assign((size_t)depth, -1);
+  s->map_epoch = parent->map_epoch;
   *out = s;
+  return MPLX_OK;
+}
+// The lanes plan on the PARENT's map buffer.  When the parent's map changed since they adopted it (setMap / dilate / a
+// VoxelGrid hand-over: another buffer, or other contents and another bitmap), every lane adopts it again -- which needs
+// all of them idle: a batch in flight would be reading a buffer the parent may have freed.
+static int stream_follow_map(mplx_stream *s) {
+  if (s->parent->map_epoch == s->map_epoch) return MPLX_OK;
+  for (mplx_ctx *l : s->lanes)
+    if (l->pending) return sfail(s, MPLX_ERR_ARG, "the parent context's map changed while batches of the stream are in flight: wait for them before editing the map");
+  for (mplx_ctx *l : s->lanes) {
+    int r = mplx_map_set_device(l, s->parent->map, s->parent->dim, s->parent->origin, s->parent->res);
+    if (r) return sfail(s, r, l->err.c_str());
+  }
+  s->map_epoch = s->parent->map_epoch;
   return MPLX_OK;
 }
 // per-lane knobs (the lanes copy the parent's at creation): pool capacities and helper policy of every lane
@@ -1308,6 +1324,8 @@ extern "C" int mplx_stream_configure(mplx_stream *s, int32_t n_slots, uint64_t t
 extern "C" int mplx_stream_depth(const mplx_stream *s) { return s ? (int)s->lanes.size() : 0; }
 extern "C" int mplx_stream_submit(mplx_stream *s, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals, int64_t *ticket) {
   if (!s || !ticket) return MPLX_ERR_ARG;
+  int rm = stream_follow_map(s);
+  if (rm) return rm;
   for (size_t k = 0; k < s->lanes.size(); k++) {
     if (s->ticket_of[k] >= 0) continue;
     int r = plan_batch_launch(s->lanes[k], nq, starts, goals);

@@ -973,7 +973,7 @@ class PlanStream:
         self.h = h
         self.depth = int(depth)
         self._n = {}
-        self._lane = {}
+        self._last_lane = None  # context of the lane last waited for (answers trajectories / timings of that batch)
 
     def close(self):
         if self.h is not None:

@@ -72,6 +72,22 @@ def test_submit_wait_is_plan_batch_and_a_stream_overlaps_batches_without_changin
             seen += 1
         assert seen == 12
         st.close()
+    # the lanes follow the parent's map: edit it (dilate) between batches and the next submit plans on the edited map; with a
+    # batch in flight the submit that would have to re-adopt the map is refused
+    st = pl.stream(2)
+    st.configure(64, 1 << 21, 1 << 23, 1 << 22, -1, 0, 0, 4)
+    assert [_tuple(r) for r in st.wait(st.submit(*wps[0]))] == ref[0]
+    t_busy = st.submit(*wps[1])
+    mu.dilate([(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0)])
+    with pytest.raises(Exception):
+        st.submit(*wps[2])
+    st.wait(t_busy)
+    dil = [_tuple(r) for r in st.wait(st.submit(*wps[0]))]
+    assert dil == [_tuple(r) for r in pl.planBatch(*wps[0])] and dil != ref[0]
+    st.close()
+    dz, dy, dx = grid.shape
+    mu.setMap(origin, (dx, dy, dz), grid.ravel(), res)
+    mu.freeUnknown()
     # the planner's own context still plans (its pools were not touched by the lanes)
     assert [_tuple(r) for r in pl.planBatch(*wps[0])] == ref[0]
     pl.releasePools()
