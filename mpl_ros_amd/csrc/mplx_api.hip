@@ -920,6 +920,8 @@ static void launch_expand(int control, int grid, hipStream_t s, const SearchPara
 bool mplx_launch_spec(int speculation, int grid, hipStream_t s, const mplx::SearchParams &P);
 // helper-assisted variant (mplx_help_launch.hip): leaders on s, helper workgroups on hs
 bool mplx_launch_spec_help(int grid, hipStream_t s, const mplx::SearchParams &P);
+// yaw-carrying states (mplx_yaw_launch.hip): ACC / JRK lattices of at most 128 inputs; false: none for the configuration
+bool mplx_launch_spec_yaw(int grid, hipStream_t s, const mplx::SearchParams &P);
 
 static int check_ready(mplx_ctx *c) {
   if (!c) return MPLX_ERR_ARG;
@@ -1146,7 +1148,11 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
     grid = tp ? std::min(slots, n_wg) : slots;
     P.help_lead = grid;
   }
-  if (!launched && !(spec && mplx_launch_spec(c->speculation, grid, c->stream, P))) {
+  // yaw-carrying states: the YAW build of the speculative kernel where one exists (ACC / JRK lattices of at most 128 inputs,
+  // no auxiliary map), else the one-node kernel below
+  bool launched_any = launched;
+  if (!launched_any && c->yaw && (c->speculation < 0 || c->speculation > 1)) launched_any = mplx_launch_spec_yaw(grid, c->stream, P);
+  if (!launched_any && !(spec && mplx_launch_spec(c->speculation, grid, c->stream, P))) {
     switch (pick_block(P.n_u)) {
       case 64: launch_astar<64>(P.control, c->yaw, slots, c->stream, P); break;
       case 128: launch_astar<128>(P.control, c->yaw, slots, c->stream, P); break;
@@ -1367,6 +1373,10 @@ extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
                     (!c->aux || (control == CTRL_ACC && n_u <= 32));
   static thread_local char buf[64];
   const char *cn = control == CTRL_VEL ? "VEL" : control == CTRL_ACC ? "ACC" : control == CTRL_JRK ? "JRK" : "SNP";
+  if (c->yaw && (c->speculation < 0 || c->speculation > 1) && (control == CTRL_ACC || control == CTRL_JRK) && n_u <= 128 && !c->aux) {
+    snprintf(buf, sizeof(buf), "astar_spec_kernel<%d,%d,%s,yaw>", n_u <= 32 ? 32 : n_u <= 64 ? 64 : 128, n_u <= 32 ? 16 : 4, cn);
+    return buf;
+  }
   if (!spec) {
     snprintf(buf, sizeof(buf), c->yaw ? "astar_kernel<%d,%s,yaw>" : "astar_kernel<%d,%s>", pick_block(n_u), cn);
   } else {

@@ -432,8 +432,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
     for (int i = 0; i < key_len_c(CONTROL); i++) kdiff |= (uint32_t)(L.key[i] ^ S.cur_key[ku][i]);
     bool same = kdiff == 0u;
     bool yaw_ok = true;
-    if constexpr (YAW) {
-      static_assert(UL == BLOCK, "yaw-carrying states are expanded by the one-unit kernels");
+    if constexpr (YAW) {  // (one-unit kernels, and the YAW builds of the speculative kernel: S.cur_yaw is per unit)
       const double yaw0 = S.cur_yaw[ku], uy = P.U_yaw ? P.U_yaw[lu] : 0.0;
       L.yaw = normalize_yaw((uy * T + 0.0) + yaw0);  // the VEL-type yaw channel evaluated at T, normalised like evaluate()
       L.yaw_key = (int32_t)round(L.yaw / KEY_RES_YAW);

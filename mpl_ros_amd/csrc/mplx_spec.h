@@ -51,9 +51,11 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // TP (throughput instantiation): a quarter of the chunk tables resident in LDS, the rest in HBM (QView::spill)
-template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool TP = false>
+// YAW: yaw-carrying states -- one more key integer (round(yaw / 0.1)) behind the control kind's own
+template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool TP = false, bool YAW = false>
 struct SmemSpec : Smem<UL * K, K, NCAP_, TP ? MAX_NODE_CH / 4 : MAX_NODE_CH, TP ? MAX_EDGE_CH / 4 : MAX_EDGE_CH, TP ? MAX_OPEN_CH / 4 : MAX_OPEN_CH> {
-  static constexpr int BLOCK = UL * K, BT = BTN, NK = key_len_c(CONTROL);
+  static constexpr int BLOCK = UL * K, BT = BTN, NK = key_len_c(CONTROL) + (YAW ? 1 : 0);
+  static_assert(NK <= MAX_KEY, "yaw-carrying SNP states (13 key integers) stay on the one-node kernel");
   // candidates in pop order
   double cand_f[K], cand_g[K];
   uint32_t cand_id[K], cand_idx[K], cand_pos[K];
@@ -118,7 +120,7 @@ struct LanePre {   // per-lane values of the ordered commit that do not depend o
   int cut;         // first later candidate such an entry would precede (K if none)
 };
 
-template <int UL, int K, int CONTROL, bool PAR, bool HELP, class SM, class V>
+template <int UL, int K, int CONTROL, bool PAR, bool HELP, bool YAW, class SM, class V>
 __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, int q, int kc, bool active, int my_slot, int k_stop,
                                                   const LaneSucc &L, double hspec, const LanePre &pre, uint32_t &pend_idx, uint32_t &pend_old, int par = 0) {
   constexpr int BLOCK = UL * K;
@@ -188,6 +190,7 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
       int32_t *kk = V::key(rec);
 #pragma unroll
       for (int i = 0; i < nk; i++) kk[i] = L.key[i];
+      if constexpr (YAW) kk[nk] = L.yaw_key;
       double *st = V::state(rec);
       if constexpr (HELP) {  // helper workgroups on other compute units read the state: agent-scope (write-through) stores,
         // 16 bytes at a time (the state starts on a 64-byte boundary of the record)
@@ -199,7 +202,12 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
 #pragma unroll
         for (int i = 0; i < ns; i++) st[i] = i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3];
       }
-      st[ns] = S.cur[kc][12] + P.dt;
+      if constexpr (YAW) {  // the state's yaw sits between the control kind's own doubles and t (the one-node kernel's layout)
+        st[ns] = L.yaw;
+        st[ns + 1] = S.cur[kc][12] + P.dt;
+      } else {
+        st[ns] = S.cur[kc][12] + P.dt;
+      }
       V::h(rec) = hspec;
       S.bt_id[my_slot] = id;
       S.bt_h[my_slot] = hspec;
@@ -502,11 +510,16 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
 // independent queries -- hide each other's barriers and memory round trips.
 // (second launch bound = waves per SIMD the register allocation must leave room for: a 256-lane workgroup alone would be given
 // the whole 512-entry register file -- arch VGPRs plus AGPRs as spill space -- and a second workgroup could not join it)
-template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false, bool POT = false, bool TP = false>
+// YAW (round 4): yaw-carrying states (use_yaw lattices, map_planner_node.cpp:119-139,165) on the speculative kernel: one more
+// key integer and one more state double through candidate fetch, batch table, table look-up and creation; the rules are the
+// one-node kernel's (astar_kernel<..., YAW>: successor yaw and validate_yaw in expand_unit, heuristic of the yaw-less search
+// unless the yaw keys differ from the goal's, optional yaw tolerance in the goal test).  Without helper workgroups.
+template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false, bool POT = false, bool TP = false, bool YAW = false>
 __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchParams P) {
   static_assert(!(HELP && POT), "the look-ahead cache rows carry no potential sums");
+  static_assert(!(YAW && (HELP || POT)), "yaw-carrying searches run without helpers and without an auxiliary map");
   constexpr int BLOCK = UL * K;
-  using SM = SmemSpec<UL, K, CONTROL, BTN, NCAP_, TP>;
+  using SM = SmemSpec<UL, K, CONTROL, BTN, NCAP_, TP, YAW>;
   static_assert(!TP || sizeof(SM) <= 80 * 1024, "two workgroups of the throughput instantiation must fit the 160 KB of a compute unit");
   constexpr int BT = SM::BT;
   __shared__ SM S;
@@ -517,6 +530,25 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
   // kernel sits at the register limit).
   const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB, TP ? P.tbl_spill + (size_t)blockIdx.x * (MAX_NODE_CH + MAX_EDGE_CH + MAX_OPEN_CH) : nullptr};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
+  constexpr int NKY = nk + (YAW ? 1 : 0), EX = YAW ? 1 : 0;  // key integers / extra state doubles (the yaw) of a record
+  // key of a lane's successor incl. the yaw key, its 64-bit hash
+  auto lane_hash = [&](const LaneSucc &l) {
+    if constexpr (YAW) {
+      int32_t kk[MAX_KEY + 1];
+#pragma unroll
+      for (int i = 0; i < nk; i++) kk[i] = l.key[i];
+      kk[nk] = l.yaw_key;
+      return key_hash64(kk, NKY);
+    } else {
+      return key_hash64(l.key, nk);
+    }
+  };
+  // is_goal with the optional yaw tolerance of a yaw-carrying search (astar_kernel's goal_reached)
+  auto goal_reached = [&](const State &s, double yaw) {
+    bool g = is_goal_state(s, S.hp.goal, S.hp.goal_control & 15, P.tol_pos, P.tol_vel, P.tol_acc);
+    if (YAW && g && P.tol_yaw >= 0) g = fabs(yaw - S.hp.goal_yaw) <= P.tol_yaw;
+    return g;
+  };
   fill_uq<BLOCK, CONTROL>(P, S, tid);
   if (tid == 0) {
     unsigned long long pw = 1ull;
@@ -572,6 +604,8 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
       S.hp.goal_control = in.goal_control;
       S.hp.goal = in.goal;
       S.hp.goal_nkey = state_key(in.goal_control, in.goal, S.hp.goal_key);
+      S.hp.goal_yaw = in.goal_yaw;
+      S.hp.goal_yaw_key = (int32_t)round(in.goal_yaw / KEY_RES_YAW);
       int32_t c[3];
       bool free_ = true;
       for (int ax = 0; ax < 3; ax++) {
@@ -582,7 +616,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
       double cost0 = INFINITY;
       if (!free_)
         S.status = 2;
-      else if (in.start_t >= P.t_max || is_goal_state(in.start, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) {
+      else if (in.start_t >= P.t_max || goal_reached(in.start, in.start_yaw)) {
         S.status = 0;
         cost0 = 0.0;
       }
@@ -599,21 +633,25 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
       searched = true;
       // ---- start node (id 0)
       if (tid == 0) {
-        int32_t key[MAX_KEY];
+        int32_t key[MAX_KEY + 1];
         state_key_c<CONTROL>(in.start, key);
+        const int32_t ykey = (int32_t)round(in.start_yaw / KEY_RES_YAW);
+        if (YAW) key[nk] = ykey;
         char *rec = Q.node(0);
-        for (int i = 0; i < nk; i++) V::key(rec)[i] = key[i];
+        for (int i = 0; i < NKY; i++) V::key(rec)[i] = key[i];
         const double *src = (const double *)&in.start;
         for (int i = 0; i < ns; i++) {
           if constexpr (HELP) st_f64_agent(&V::state(rec)[i], src[i]); else V::state(rec)[i] = src[i];
         }
-        V::state(rec)[ns] = in.start_t;
-        double h = P.eps == 0.0 ? 0.0 : get_heur(S.hp, CONTROL, in.start, key, nk);
+        if (YAW) V::state(rec)[ns] = in.start_yaw;
+        V::state(rec)[ns + EX] = in.start_t;
+        double h = 0.0;
+        if (P.eps != 0.0) h = (YAW && ykey != S.hp.goal_yaw_key) ? cal_heur(S.hp, CONTROL, in.start) : get_heur(S.hp, CONTROL, in.start, key, nk);
         V::h(rec) = h;
         V::g(rec) = 0.0;
         V::flags(rec) = FLAG_OPENED;
         V::pred(rec) = NIL;
-        const unsigned long long h64 = key_hash64(key, nk);
+        const unsigned long long h64 = key_hash64(key, NKY);
         const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
         size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
         for (;;) {
@@ -812,8 +850,8 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           char *prec = Q.node(pf_id);
           pf_g = V::g(prec);
           pf_fl = V::flags(prec);
-          if (lu <= ns) pf_s = V::state(prec)[lu];
-          if (lu < nk) pf_k = V::key(prec)[lu];
+          if (lu <= ns + EX) pf_s = V::state(prec)[lu];
+          if (lu < NKY) pf_k = V::key(prec)[lu];
           if constexpr (HELP) {
             if (S.helped && lu == UL - 1) {
               const unsigned long long *cr = (const unsigned long long *)&P.cache_c[Q.node_rec(pf_id)];
@@ -1002,8 +1040,8 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
             char *rec = Q.node(cid);
             rg = V::g(rec);
             fl = V::flags(rec);
-            if (lu <= ns) sval = V::state(rec)[lu];
-            if (lu < nk) kval = V::key(rec)[lu];
+            if (lu <= ns + EX) sval = V::state(rec)[lu];
+            if (lu < NKY) kval = V::key(rec)[lu];
             if constexpr (HELP) {
               if (S.helped && lu == UL - 1) {
                 const unsigned long long *cr = (const unsigned long long *)&P.cache_c[Q.node_rec(cid)];
@@ -1015,9 +1053,11 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           live_unit = __double_as_longlong(rg) == __double_as_longlong(S.cand_g[ku]) && !(fl & FLAG_CLOSED);
           if (live_unit) {
             const int ko = opaque(ku), lo = opaque(lu);
-            if (lo <= ns) S.cur[ko][lo < ns ? lo : 12] = sval;
+            if (lo < ns) S.cur[ko][lo] = sval;
+            if (YAW && lo == ns) S.cur_yaw[ko] = sval;
+            if (lo == ns + EX) S.cur[ko][12] = sval;
             if (lo >= ns && lo < 12) S.cur[ko][lo] = 0.0;
-            if (lo < nk) S.cur_key[ko][lo] = kval;
+            if (lo < NKY) S.cur_key[ko][lo] = kval;
             if (lo == 0) {
               S.cand_live[ko] = 1;
               S.cand_fl[ko] = fl;
@@ -1030,9 +1070,9 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           State sgoal;
           for (int i = 0; i < 12; i++) ((double *)&sgoal)[i] = S.cur[ku][i];
 #if MPLX_X_LDS_CONST
-          S.u_goal[ku] = (S.cur[ku][12] >= P.t_max || is_goal_state(sgoal, S.hp.goal, S.hp.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) ? 1 : 0;
+          S.u_goal[ku] = (S.cur[ku][12] >= P.t_max || goal_reached(sgoal, YAW ? S.cur_yaw[ku] : 0.0)) ? 1 : 0;
 #else
-          S.u_goal[ku] = (S.cur[ku][12] >= P.t_max || is_goal_state(sgoal, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc)) ? 1 : 0;
+          S.u_goal[ku] = (S.cur[ku][12] >= P.t_max || goal_reached(sgoal, YAW ? S.cur_yaw[ku] : 0.0)) ? 1 : 0;
 #endif
         }
         if constexpr (HELP) {
@@ -1072,9 +1112,9 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         // its voxels are sampled (a blocked successor wastes one load), consumed after the batch table is built
         unsigned long long h64 = 0, v0 = TBL_EMPTY;
         size_t pos0 = 0;
-        expand_unit<UL, BLOCK, CONTROL, HELP, POT>(P, S, tid, live_unit, L, [&](const LaneSucc &l) {
+        expand_unit<UL, BLOCK, CONTROL, HELP, POT, YAW>(P, S, tid, live_unit, L, [&](const LaneSucc &l) {
           if (l.valid && !l.blocked) {
-            h64 = key_hash64(l.key, nk);
+            h64 = lane_hash(l);
             pos0 = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
             v0 = ld_u64_probe(&P.table[pos0]);
           }
@@ -1117,6 +1157,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         if (act) {
 #pragma unroll
           for (int i = 0; i < nk; i++) S.lane_key[tid][i] = L.key[i];
+          if constexpr (YAW) S.lane_key[tid][nk] = L.yaw_key;
         }
         MPLX_T2(S, 14, t2);
 #ifdef MPLX_LOOKUP_TIMERS
@@ -1153,6 +1194,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
             uint32_t kd = 0;
 #pragma unroll
             for (int i = 0; i < nk; i++) kd |= (uint32_t)(S.lane_key[leader][i] ^ L.key[i]);
+            if constexpr (YAW) kd |= (uint32_t)(S.lane_key[leader][nk] ^ L.yaw_key);
             if (kd != 0u) S.status = 5;                                    // 64-bit key-hash collision inside a batch
             // a state reached from two lanes of the batch: harmless while both only append a predecessor
             // edge (decided once g is known); three lanes on one state take the ordered path
@@ -1188,8 +1230,8 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
 #else
                 hspec = ld_f64_agent(&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * cache_row_doubles(UL) + cache_h_slot(UL, lu)]);
 #endif
-              else
-                hspec = get_heur(S.hp, CONTROL, L.tn, L.key, nk);
+              else  // (get_heur is 0 when the state's key equals the goal's: with yaw the yaw key is part of that comparison)
+                hspec = (YAW && L.yaw_key != S.hp.goal_yaw_key) ? cal_heur(S.hp, CONTROL, L.tn) : get_heur(S.hp, CONTROL, L.tn, L.key, nk);
             }
             MPLX_T2(S, 3, t2);
 #ifdef MPLX_LOOKUP_TIMERS
@@ -1222,7 +1264,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
               if (vid < CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
                 // the record's hot line in 16-byte words, all asked for at once: g | h | flags pred key[0..1] | key[2..] ...
                 const uint4 *r4 = (const uint4 *)Q.node(vid);
-                constexpr int NW4 = (24 + 4 * nk + 15) / 16;
+                constexpr int NW4 = (24 + 4 * NKY + 15) / 16;
                 uint32_t w[4 * NW4];
 #pragma unroll
                 for (int j = 0; j < NW4; j++) {
@@ -1232,6 +1274,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
                 uint32_t kd = 0;
 #pragma unroll
                 for (int i = 0; i < nk; i++) kd |= w[6 + i] ^ (uint32_t)L.key[i];
+                if constexpr (YAW) kd |= w[6 + nk] ^ (uint32_t)L.yaw_key;
                 const double rg = __hiloint2double((int)w[1], (int)w[0]), rh = __hiloint2double((int)w[3], (int)w[2]);
                 const uint32_t rfl = w[4], rpred = w[5];
                 if (kd == 0u) {
@@ -1254,7 +1297,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         // does a candidate itself appear among the successors of the batch?  (its closed flag must
         // reach the units committed after it)
         if (lu == 0 && live_unit) {
-          const unsigned long long hk = key_hash64(S.cur_key[ku], nk);
+          const unsigned long long hk = key_hash64(S.cur_key[ku], NKY);
           const unsigned long long hv = hk | 1ull;
           int sl = (int)(hk >> 7) & (BT - 1);
           for (;;) {
@@ -1381,7 +1424,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           MPLX_T2(S, 8, t2);
           __syncthreads();  // everyone has read status / u_cut before they change
           MPLX_T2(S, 9, t2);
-          spec_commit_lanes<UL, K, CONTROL, true, HELP>(Q, S, tid, q, ku, act && mine, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old, (int)(batch_no & 1u));
+          spec_commit_lanes<UL, K, CONTROL, true, HELP, YAW>(Q, S, tid, q, ku, act && mine, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old, (int)(batch_no & 1u));
           if (tid == 0 && st_after >= 0) S.status = st_after;
           MPLX_T2(S, 10, t2);
         }
@@ -1409,10 +1452,10 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           }
           if (S.cur_slot[k] != NIL) lds_barrier();  // (uniform) its closed flag must precede its own successors' relax
           if (!S.unit_seq[k]) {
-            spec_commit_lanes<UL, K, CONTROL, false, HELP>(Q, S, tid, q, k, act && ku == k, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
+            spec_commit_lanes<UL, K, CONTROL, false, HELP, YAW>(Q, S, tid, q, k, act && ku == k, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
           } else {
             for (int i = 0; i < P.n_u; i++) {
-              spec_commit_lanes<UL, K, CONTROL, false, HELP>(Q, S, tid, q, k, act && ku == k && lu == i, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
+              spec_commit_lanes<UL, K, CONTROL, false, HELP, YAW>(Q, S, tid, q, k, act && ku == k && lu == i, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old);
               lds_barrier();
             }
           }
@@ -1534,7 +1577,8 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           for (int i = 0; i <= len; i++) {
             const double *st = V::state(Q.node((uint32_t)tn[i]));
             for (int k = 0; k < 12; k++) ts[i * 13 + k] = k < ns ? st[k] : 0.0;
-            ts[i * 13 + 12] = st[ns];
+            ts[i * 13 + 12] = st[ns + EX];
+            if (YAW && P.traj_yaw) P.traj_yaw[(size_t)q * (MAX_TRAJ + 1) + i] = st[ns];
           }
         } else {
           status = 1;

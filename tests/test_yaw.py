@@ -131,7 +131,14 @@ def test_hip_plans_the_launch_query_with_use_yaw(simple_map):
     mu, pl = util.make_gpu(grid, origin, res, U, **kw)
     r, c = util.compare_plan(P, pl, (SIMPLE_START, (0, 0, 0)), (SIMPLE_GOAL,), orc.ACC, yaw=(0.0, 0.0))
     assert (r.status, r.cost, r.n_expanded) == (0, 128.0, 1108)
-    assert pl.kernelName() == "astar_kernel<64,ACC,yaw>"
+    assert pl.kernelName() == "astar_spec_kernel<32,16,ACC,yaw>"  # round 4: the YAW build of the speculative kernel (27-input lattice)
+    ms_spec = pl.lastKernelMs()
+    pl.setSpeculation(0)  # ... and the one-node kernel: the same search, whole state space
+    r1, _ = util.compare_plan(P, pl, (SIMPLE_START, (0, 0, 0)), (SIMPLE_GOAL,), orc.ACC, yaw=(0.0, 0.0))
+    assert pl.kernelName() == "astar_kernel<64,ACC,yaw>" and (r1.cost, r1.n_expanded, r1.expand_hash, r1.n_nodes) == (r.cost, r.n_expanded, r.expand_hash, r.n_nodes)
+    print(f"yaw plan, {r.n_expanded} expansions: speculative kernel {ms_spec:.3f} ms, one-node kernel {pl.lastKernelMs():.3f} ms")
+    pl.setSpeculation(-1)
+    r, c = util.compare_plan(P, pl, (SIMPLE_START, (0, 0, 0)), (SIMPLE_GOAL,), orc.ACC, yaw=(0.0, 0.0))
     # the state space's states carry their yaw
     coords = pl._nodes()[0]
     for i in (0, 1, r.n_nodes // 2, r.n_nodes - 1):

@@ -10,6 +10,6 @@ S=$ROOT/mpl_ros_amd/csrc
 O=$ROOT/build_tmp
 mkdir -p $O
 /opt/rocm/bin/hipcc $F -c -o $O/kv_$N.o $S/mplx_help_launch.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libmplx_$N.so $S/mplx_api.o $S/mplx_spec_launch.o $O/kv_$N.o $S/mplx_lpa_launch.o $S/mplx_poly_launch.o $S/mplx_host.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libmplx_$N.so $S/mplx_api.o $S/mplx_spec_launch.o $O/kv_$N.o $S/mplx_yaw_launch.o $S/mplx_lpa_launch.o $S/mplx_poly_launch.o $S/mplx_host.o
 rm -f $O/kv_$N.o
 ls -la $O/libmplx_$N.so

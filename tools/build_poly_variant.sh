@@ -9,6 +9,6 @@ S=$ROOT/mpl_ros_amd/csrc
 O=$ROOT/build_tmp
 mkdir -p $O
 /opt/rocm/bin/hipcc $F -c -o $O/pv_$N.o $S/mplx_poly_launch.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libmplx_$N.so $S/mplx_api.o $S/mplx_spec_launch.o $S/mplx_help_launch.o $S/mplx_lpa_launch.o $O/pv_$N.o $S/mplx_host.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libmplx_$N.so $S/mplx_api.o $S/mplx_spec_launch.o $S/mplx_help_launch.o $S/mplx_yaw_launch.o $S/mplx_lpa_launch.o $O/pv_$N.o $S/mplx_host.o
 rm -f $O/pv_$N.o
 ls -la $O/libmplx_$N.so
