@@ -386,7 +386,10 @@ def main():
             pass
         n_stream = args.stream if args.stream >= 0 else max(args.steps, 6)
         if n_stream > 0 and world == 1 and not multi and not args.single and mine:
-            out["stream"] = stream_leg(args, pl, starts, goals, results, n_stream, control, jrk, max_expand, alg)
+            try:
+                out["stream"] = stream_leg(args, pl, starts, goals, results, n_stream, control, jrk, max_expand, alg)
+            except Exception as e:  # (e.g. the lanes' pools do not fit next to something else on the device: the blocking line stands on its own)
+                out["stream"] = {"error": f"{type(e).__name__}: {e}"}
             try:  # HBM traffic per streamed launch from the committed counter passes of the same leg (tools/profile_r04.sh)
                 trs = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("stream")
                 if trs and args.lattice == "acc" and len(mine) == 1024 and n == 512 and args.stream_split == 1:

@@ -1369,8 +1369,7 @@ extern "C" uint64_t mplx_plan_epoch(const mplx_ctx *c) { return c ? c->plan_epoc
 extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
   if (!c || !c->have_cfg) return "";
   const int control = c->cfg.control, n_u = c->cfg.n_u;
-  const bool spec = (c->speculation < 0 || c->speculation > 1) && (control == CTRL_ACC || control == CTRL_JRK) && n_u <= 128 && !c->yaw &&
-                    (!c->aux || (control == CTRL_ACC && n_u <= 32));
+  const bool spec = (c->speculation < 0 || c->speculation > 1) && (control == CTRL_ACC || control == CTRL_JRK) && n_u <= 128 && !c->yaw;
   static thread_local char buf[64];
   const char *cn = control == CTRL_VEL ? "VEL" : control == CTRL_ACC ? "ACC" : control == CTRL_JRK ? "JRK" : "SNP";
   if (c->yaw && (c->speculation < 0 || c->speculation > 1) && (control == CTRL_ACC || control == CTRL_JRK) && n_u <= 128 && !c->aux) {
@@ -1386,7 +1385,7 @@ extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
     else if (n_u <= 64) { ul = 64; k = 4; }
     else if (c->speculation == 2) { ul = 128; k = 2; }
     else { ul = 128; k = 4; }
-    if (c->aux) { ul = 32; k = 16; }
+    if (c->aux) { ul = n_u <= 32 ? 32 : 128; k = n_u <= 32 ? 16 : 4; }
     const bool tp = c->speculation == 82 && !c->aux && control == CTRL_ACC && n_u <= 31;  // (measurement-only variant)
     if (tp) { ul = 32; k = 8; }
     const bool help = !tp && !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 &&

@@ -16,13 +16,18 @@ static void launch_spec(int control, int grid, hipStream_t s, const SearchParams
 }
 
 // speculation: -1 / >1 = widest variant for the lattice; 8, 4, 2 = narrower variants (A/B measurements)
-// P.map.aux (potential field / search region): the POT build of the <= 32-input ACC variant (the distance-map planner's
-// lattices); anything else with an auxiliary map is left to the one-node kernel (return false)
+// P.map.aux (potential field / search region): the POT builds (round 3: the <= 32-input ACC variant, the distance-map planner's
+// lattices; round 4: JRK states and lattices up to 128 inputs as well)
 bool mplx_launch_spec(int speculation, int grid, hipStream_t s, const SearchParams &P) {
   if (!(P.control == CTRL_ACC || P.control == CTRL_JRK) || P.n_u > 128) return false;  // built for the reference's lattices
-  if (P.map.aux) {
-    if (P.control != CTRL_ACC || P.n_u > 32) return false;
-    hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024, false, true>), dim3(grid), dim3(512), 0, s, P);
+  if (P.map.aux) {  // POT builds: the 16-unit kernel for lattices of at most 32 inputs, four 128-lane units up to 128 inputs
+    if (P.n_u <= 32) {
+      if (P.control == CTRL_ACC) hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024, false, true>), dim3(grid), dim3(512), 0, s, P);
+      else hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_JRK, 1024, 1024, false, true>), dim3(grid), dim3(512), 0, s, P);
+    } else {
+      if (P.control == CTRL_ACC) hipLaunchKernelGGL((astar_spec_kernel<128, 4, CTRL_ACC, 1024, 1024, false, true>), dim3(grid), dim3(512), 0, s, P);
+      else hipLaunchKernelGGL((astar_spec_kernel<128, 4, CTRL_JRK, 1024, 1024, false, true>), dim3(grid), dim3(512), 0, s, P);
+    }
     return true;
   }
   // `speculation == 82` (measurement only, round 4): two 256-lane workgroups of eight expansion units per compute unit instead of one

@@ -213,3 +213,32 @@ def test_hip_potential_in_3d_with_a_range():
     assert np.array_equal(out, a.ravel()) and ((a > 0) & (a < 100)).sum() > 100
     r, c = util.compare_plan(P, pl, ((1.05, 1.05, 1.05), (0, 0, 0)), ((3.55, 3.55, 3.05),), orc.ACC)
     assert r.status == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("control,num,kernel", [(orc.JRK, 1, "astar_spec_kernel<32,16,JRK,pot>"), (orc.ACC, 2, "astar_spec_kernel<128,4,ACC,pot>"),
+                                                (orc.JRK, 2, "astar_spec_kernel<128,4,JRK,pot>")])
+def test_hip_potential_beyond_the_small_acc_lattices_runs_on_the_speculative_kernel(control, num, kernel):
+    """Round 4: the POT builds of the speculative kernel for JRK states and for lattices up to 128 inputs (27 / 125 inputs
+    here) -- the same cost terms, whole plans and state spaces against the oracle, and against the one-node kernel."""
+    grid, origin, res = util.small_map(48, seed=21, occupancy=0.05)
+    mapgen.carve_bubble(grid, (1.05, 1.05, 1.05), origin, res, 3)
+    mapgen.carve_bubble(grid, (3.55, 3.55, 3.05), origin, res, 3)
+    U = mapgen.control_lattice(1.0, num, True)
+    kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5, max_expand=3000)
+    if control == orc.JRK:
+        kw["j_max"] = 1.0
+    P = util.make_oracle(grid, origin, res, control, U, **kw)
+    P.set_potential_weights(3.0, 0)
+    P.update_potential_map((0.4, 0.4, 0.3), (2.0, 2.0, 2.0), (1.5, 1.5, 1.0))
+    mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=1 << 21, max_edges=1 << 23, **kw)
+    pl.setPotentialRadius((0.4, 0.4, 0.3)); pl.setPotentialWeight(3.0); pl.setPotentialMapRange((1.5, 1.5, 1.0))
+    pl.updatePotentialMap((2.0, 2.0, 2.0))
+    start = ((1.05, 1.05, 1.05), (0, 0, 0), (0, 0, 0))
+    r, c = util.compare_plan(P, pl, start, ((3.55, 3.55, 3.05),), control)
+    assert pl.kernelName() == kernel and r.n_expanded > 20
+    ms_spec = pl.lastKernelMs()
+    pl.setSpeculation(0)
+    r1, _ = util.compare_plan(P, pl, start, ((3.55, 3.55, 3.05),), control)
+    assert pl.kernelName().startswith("astar_kernel<") and (r1.status, r1.cost, r1.n_expanded, r1.expand_hash, r1.n_nodes) == (r.status, r.cost, r.n_expanded, r.expand_hash, r.n_nodes)
+    print(f"potential plan {kernel}: {r.n_expanded} expansions, {ms_spec:.2f} ms; one-node kernel {pl.lastKernelMs():.2f} ms")
