@@ -805,11 +805,29 @@ __global__ __launch_bounds__(BLOCK) void lpa_update_kernel(SearchParams P, LpaPa
     return;
   }
   if (pass == 1) {
-    if (tid == 0 && blockIdx.x == 0) {
-      unsigned long long converted = 0;
-      for (uint32_t b = 0; b < n_blocked && S.status < 0; b++) {
+    // the freed entries are few among a log of hundreds of thousands: the workgroup scans the log BLOCK entries at a time
+    // (one coalesced load each, a ballot), thread 0 converts the marked ones in log order (the serial walk of the whole log
+    // by one thread took 37 ms on the C2 state space)
+    __shared__ unsigned long long s_mark[BLOCK / 64];
+    __shared__ unsigned long long s_conv;
+    if (blockIdx.x != 0) return;
+    if (tid == 0) s_conv = 0;
+    for (uint32_t base = 0; base < n_blocked; base += BLOCK) {
+      const uint32_t bi = base + (uint32_t)tid;
+      bool want = false;
+      if (bi < n_blocked) {
+        const uint2 lv = A.blocked_log[bi];
+        want = (lv.y & LOG_FREE_NOW) && !(lv.y & LOG_CONVERTED);
+      }
+      const unsigned long long mk = __ballot(want);
+      if ((tid & 63) == 0) s_mark[tid >> 6] = mk;
+      __syncthreads();
+      if (tid == 0) {
+       unsigned long long converted = 0;
+       for (int wv = 0; wv < BLOCK / 64 && S.status < 0; wv++)
+        for (unsigned long long rest = s_mark[wv]; rest != 0ull && S.status < 0; rest &= rest - 1ull) {
+        const uint32_t b = base + (uint32_t)wv * 64u + (uint32_t)(__ffsll((long long)rest) - 1);
         uint2 le = A.blocked_log[b];
-        if (!(le.y & LOG_FREE_NOW) || (le.y & LOG_CONVERTED)) continue;
         const int action = (int)(le.y & 0xFFFFu);
         State tn;
         int32_t key[MAX_KEY];
@@ -848,10 +866,16 @@ __global__ __launch_bounds__(BLOCK) void lpa_update_kernel(SearchParams P, LpaPa
         V::flags(rec) |= FLAG_DIRTY;
         A.blocked_log[b].y = (le.y & ~LOG_FREE_NOW) | LOG_CONVERTED;
         converted++;
+        }
+       s_conv += converted;
       }
+      __syncthreads();
+      if (S.status >= 0) break;  // (uniform: pool full)
+    }
+    if (tid == 0) {
       st->n_nodes = S.n_nodes;
       st->n_edges = S.n_edges;
-      st->n_changed = S.status == 4 ? ~0ull : st->n_changed + converted;  // (~0: pool full -- the host drops the space)
+      st->n_changed = S.status == 4 ? ~0ull : st->n_changed + s_conv;  // (~0: pool full -- the host drops the space)
     }
     return;
   }
