@@ -19,3 +19,4 @@ timeout 100 python bench.py --config c5 --steps 3 --warmup 1 > $OUT/bench_c5.jso
 timeout 60 python bench.py --config lpa --steps 2 --warmup 1 > $OUT/bench_lpa.json 2> $OUT/bench_lpa.err; head -c 300 $OUT/bench_lpa.json; echo
 timeout 120 python bench.py --single --lattice jrk --steps 1 --warmup 1 --cpu-seconds 0 > $OUT/bench_c3.json 2> $OUT/bench_c3.err; head -c 300 $OUT/bench_c3.json; echo
 tools/profile_r04.sh $TAG/prof
+timeout 330 python tools/full_parity_c4.py $OUT/full_parity_c4.json > $OUT/full_parity.log 2>&1; tail -n 1 $OUT/full_parity.log | cut -c1-600
