@@ -34,6 +34,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_T0 = time.perf_counter()
+
+
+def _log(msg):
+    """Progress on stderr (stdout carries the ONE JSON line): where a run that is cut off by an outer timeout had got to."""
+    print(f"[bench +{time.perf_counter() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured)
 
 
@@ -244,6 +252,8 @@ def main():
         import faulthandler
         import signal
         faulthandler.register(signal.SIGUSR1, all_threads=True)
+    if rank == 0:
+        _log(f"map and planner ready; {args.warmup} warm-up + {args.steps} timed steps of {len(mine)} queries")
     for _ in range(args.warmup):
         step()
         if os.environ.get("MPLX_BENCH_TRACE"):
@@ -258,8 +268,10 @@ def main():
     barrier()
     state["kernel_ms"] = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i_step in range(args.steps):
         step()
+        if rank == 0 and (i_step + 1) % 5 == 0:
+            _log(f"step {i_step + 1} of {args.steps}")
         if os.environ.get("MPLX_BENCH_TRACE"):
             Tq = np.array([pl.queryTiming(k) for k in range(len(mine))])
             late = np.argsort(-Tq[:, 1])[:4]
@@ -268,6 +280,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     local_s = elapsed
+    if rank == 0:
+        _log(f"timed steps done: {1e3 * elapsed / args.steps:.1f} ms per step")
     results, kernel_ms = state["results"], state["kernel_ms"]
 
     n_exp = sum(r.n_expanded for r in results)
@@ -384,19 +398,6 @@ def main():
                                                        "both this and the HBM fraction are low: the launch is latency-bound (serial pop chain per query)"}
         except Exception:
             pass
-        n_stream = args.stream if args.stream >= 0 else max(args.steps, 6)
-        if n_stream > 0 and world == 1 and not multi and not args.single and mine:
-            try:
-                out["stream"] = stream_leg(args, pl, starts, goals, results, n_stream, control, jrk, max_expand, alg)
-            except Exception as e:  # (e.g. the lanes' pools do not fit next to something else on the device: the blocking line stands on its own)
-                out["stream"] = {"error": f"{type(e).__name__}: {e}"}
-            try:  # HBM traffic per streamed launch from the committed counter passes of the same leg (tools/profile_r04.sh)
-                trs = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("stream")
-                if trs and args.lattice == "acc" and len(mine) == 1024 and n == 512 and args.stream_split == 1:
-                    out["stream"]["roofline"]["traffic_per_batch"] = (trs["FETCH_SIZE_KB"] + trs["WRITE_SIZE_KB"]) * 1024.0
-                    out["stream"]["roofline"]["traffic_source"] = trs["profile"]
-            except Exception:
-                pass
         if args.cpu_seconds > 0 and mine and world == 1:  # (the CPU baseline is a rank-0, N = 1 leg)
             # a single capped query is sampled on the CPU with a smaller cap; the GPU then repeats the query with
             # that cap (untimed) so that the parity check compares equal searches
@@ -406,8 +407,12 @@ def main():
                 pl.setMaxNum(cpu_cap)
                 par_results = pl.planBatch(starts, goals)
             gpu_exp = [r.n_expanded for r in par_results]
+            _log(f"CPU baseline leg (budget {args.cpu_seconds:.0f} s)")
             nthr = 1 if args.single else (args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 64))
-            out["cpu_baseline"] = cpu_baseline(grid, origin, res, control, U, cpu_cap, [queries[i] for i in mine], gpu_exp, args.cpu_seconds, nthr)
+            try:
+                out["cpu_baseline"] = cpu_baseline(grid, origin, res, control, U, cpu_cap, [queries[i] for i in mine], gpu_exp, args.cpu_seconds, nthr)
+            except Exception as e:  # (a worker process that died, no gcc ...: the GPU line is still printed, the failure is named)
+                out["cpu_baseline"] = {"value": None, "unit": "expansions/s", "cores": nthr, "kind": "port", "sample": "", "error": f"{type(e).__name__}: {e}", "_per_query": {}}
             # the CPU sample doubles as a full-size parity check of the GPU results (checker only): expansion
             # order hash, states created, path cost and the path's actions of every sampled query must be identical
             pq = out["cpu_baseline"].pop("_per_query")
@@ -423,8 +428,33 @@ def main():
             out["parity_sample"] = {"queries": len(pq), "mismatches": len(bad), "checked": "expand_hash, n_expanded, n_nodes, cost (bit-exact f64), actions"}
             if bad:
                 out["parity_sample"]["first_bad_query"] = int(bad[0])
+            _log(f"CPU baseline done: {(out['cpu_baseline']['value'] or 0.0) / 1e6:.2f} M expansions/s on {nthr} cores; parity {len(pq)} queries, {len(bad)} mismatches")
             if cpu_cap != max_expand:
                 out["cpu_baseline"]["sample"] += f"; CPU run and the GPU parity run capped at {cpu_cap} expansions"
+        # the streamed leg comes last: it frees the blocking leg's pools, and if a lane stops answering (deadline in stream_leg)
+        # the line is printed with what the blocking and CPU legs measured and the process leaves without waiting for the device
+        n_stream = args.stream if args.stream >= 0 else max(args.steps, 6)
+        if n_stream > 0 and world == 1 and not multi and not args.single and mine:
+            _log(f"streamed leg: {n_stream} batches, {args.stream_depth} in flight")
+            try:
+                out["stream"] = stream_leg(args, pl, starts, goals, results, n_stream, control, jrk, max_expand, alg)
+                _log(f"streamed leg done: {out['stream']['value'] / 1e6:.1f} M expansions/s, {out['stream']['parity']['mismatches_vs_blocking_step']} mismatches")
+            except StreamStalled as e:
+                out["stream"] = {"error": f"{e}", "stalled": True}
+                _log(f"streamed leg STALLED: {e}")
+                print(json.dumps(out), flush=True)
+                sys.stderr.flush()
+                os._exit(0)  # (a launch that never ends cannot be cancelled; do not let interpreter teardown wait on it)
+            except Exception as e:  # (e.g. the lanes' pools do not fit next to something else on the device: the blocking line stands on its own)
+                out["stream"] = {"error": f"{type(e).__name__}: {e}"}
+                _log(f"streamed leg failed: {out['stream']['error']}")
+            try:  # HBM traffic per streamed launch from the committed counter passes of the same leg (tools/profile_r04.sh)
+                trs = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("stream")
+                if trs and args.lattice == "acc" and len(mine) == 1024 and n == 512 and args.stream_split == 1:
+                    out["stream"]["roofline"]["traffic_per_batch"] = (trs["FETCH_SIZE_KB"] + trs["WRITE_SIZE_KB"]) * 1024.0
+                    out["stream"]["roofline"]["traffic_source"] = trs["profile"]
+            except Exception:
+                pass
     # ---- N > 1, strong scaling: the SAME command also measures query throughput -- a stream of 1024 x N queries dealt by the
     # same run_sharded (every rank then holds what one GPU holds at N = 1).  The strong line above is tail-bound by
     # construction (a query never spans GPUs: its floor is the longest query alone); this one is what "near-linear
@@ -584,6 +614,10 @@ def bench_c5(args):
     print(json.dumps(out), flush=True)
 
 
+class StreamStalled(RuntimeError):
+    """No ticket of the streamed leg completed within the deadline (the launches cannot be cancelled)."""
+
+
 def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, max_expand, alg_bytes_per_batch):
     """Steady-state query throughput with several batches in flight (include/mplx.h mplx_stream_*; north_star: "many independent
     start/goal queries ... shard one-query-per-stream").  The blocking step above lasts as long as its longest query -- one
@@ -611,10 +645,21 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
     st = pl.stream(depth)
     # a lane = one workgroup per compute unit, all of them leading (no reserved helper share unless asked); when a batch's queue
     # is empty at most --stream-helper-limit of its workgroups stay on to help its longest queries, the others exit
-    st.configure(min(n_part, 256), caps["nodes"], caps["edges"], caps["log"], args.helpers, args.stream_reserved, 1 << 24, args.stream_helper_limit)
+    # (diagnostic: MPLX_BENCH_LANE_SLOTS = workgroups of a lane's launch; 128 x 2 lanes = all of them resident at once)
+    st.configure(min(n_part, int(os.environ.get("MPLX_BENCH_LANE_SLOTS", "256"))), caps["nodes"], caps["edges"], caps["log"], args.helpers, args.stream_reserved, 1 << 24, args.stream_helper_limit)
     SG = [((_capi.Waypoint * len(p))(*[starts[i].to_c() for i in p]), (_capi.Waypoint * len(p))(*[goals[i].to_c() for i in p]), p) for p in parts]
     mism = 0
     mism_detail = []
+
+    # a batch takes 2 - 4 s at C4 size: a minute without a single completion means a lane no longer answers
+    stall_s = float(os.environ.get("MPLX_BENCH_STREAM_STALL_S", "60"))
+
+    def wait_done(t, what):
+        t_w = time.perf_counter()
+        while not st.done(t):
+            if time.perf_counter() - t_w > stall_s:
+                raise StreamStalled(f"{what}: ticket {int(t)} not done after {stall_s:.0f} s")
+            time.sleep(0.0005)
 
     def collect(t, part):
         nonlocal mism
@@ -630,9 +675,11 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
 
     jobs = [(b, k) for b in range(n_batches) for k in range(split)]  # (batch, part) in submission order
     for t, k in [(st.submit_c(SG[k % split][0], SG[k % split][1], len(SG[k % split][2])), k % split) for k in range(depth)]:  # warm-up: allocates the lanes' pools
+        wait_done(t, "warm-up")
         collect(t, SG[k][2])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t_progress = t0
     inflight, submitted, kernel_ms = [], 0, []
     first_submit, last_done, left = {}, {}, {b: split for b in range(n_batches)}
     while submitted < len(jobs) or inflight:
@@ -654,7 +701,11 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
                     last_done[b] = now
                 inflight.remove(item)
                 progressed = True
+                t_progress = now
         if not progressed:
+            if time.perf_counter() - t_progress > stall_s:
+                raise StreamStalled(f"{len(last_done)} of {n_batches} batches done, tickets {[int(i[0]) for i in inflight]} in flight: none completed in {stall_s:.0f} s "
+                                    f"({mism} mismatches so far)")
             time.sleep(0.0005)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0

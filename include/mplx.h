@@ -158,7 +158,8 @@ int mplx_map_cloud(mplx_ctx *ctx, int which, double *pts, uint64_t cap, uint64_t
  *      distance_map_planner_node.cpp:185-193,199,218-224,231).  One auxiliary int8 map per context next to the grid:
  *      0..100 = potential of the voxel, < 0 = outside the search region.  While it exists, a primitive with a sample
  *      outside the region is blocked and a free primitive costs J + w dt + potential_weight * (sum of the potential over
- *      its collision samples); plans run on the one-node kernel.  [Upstream's implementation is un-vendored: semantics
+ *      its collision samples); ACC / JRK lattices of at most 128 inputs plan on the POT builds of the speculative kernel, the
+ *      rest on the one-node kernel.  [Upstream's implementation is un-vendored: semantics
  *      P1-P3 of DESIGN.md, restated for the tests' CPU checker.] ---- */
 int mplx_potential_weights(mplx_ctx *ctx, double potential_weight, double gradient_weight); /* gradient_weight must be 0 */
 /* updatePotentialMap(pos, range) with setPotentialRadius(radius): every occupied voxel spreads trunc(100 (1 - d)^pow),

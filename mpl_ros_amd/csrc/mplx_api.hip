@@ -102,6 +102,8 @@ struct mplx_ctx {
   bool pend_help = false;
   std::vector<QueryIn> pend_in;
   std::vector<int32_t> pend_order;
+  unsigned long long *table_base = nullptr;  // (diagnostics, MPLX_X_FLAGS & 4)
+  uint32_t launch_count = 0;
   int help_limit = -1;  // workgroups of a launch that may turn into helpers once the query queue is empty (-1: all of them)
 };
 
@@ -810,7 +812,9 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   PA(P.node_pool, (size_t)(nch << NODE_CH_LOG) * rec_bytes(control));
   PA(P.edge_pool, (size_t)(ech << EDGE_CH_LOG) * EDGE_BYTES);
   PA(P.open_pool, (size_t)(och << OPEN_CH_LOG) * OPEN_BYTES);
-  PA(P.table, (size_t)T);
+  static const int xflags_alloc = getenv("MPLX_X_FLAGS") ? atoi(getenv("MPLX_X_FLAGS")) : 0;
+  PA(P.table, (size_t)T * ((xflags_alloc & 4) ? 2 : 1));
+  c->table_base = P.table;
   PA(P.bkt_head, (size_t)slots * 2 * NB * NSUB);
   HIPCHK(c, hipMemsetAsync(P.bkt_head, 0xFF, sizeof(uint32_t) * (size_t)slots * 2 * NB * NSUB, c->stream));  // all heads NIL; queries leave them so
   PA(P.chunk_next, 4);
@@ -1068,6 +1072,9 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
   }
   SearchParams P = c->pools;
   fill_params(c, P);
+  static const int xflags = getenv("MPLX_X_FLAGS") ? atoi(getenv("MPLX_X_FLAGS")) : 0;
+  P.xflags = xflags;
+  if (xflags & 4) P.table = c->table_base + ((c->launch_count++ & 1u) ? (size_t)(P.table_mask + 1) : 0);  // (diagnostic: alternate halves)
   P.cap_rec = c->cap_rec;
   P.nq = nq;
   P.queries = c->d_in;

@@ -23,6 +23,13 @@ constexpr int OWN = 2048;         // LDS (primitive, sample) owner map; larger e
 constexpr uint32_t NIL = 0xFFFFFFFFu;
 constexpr uint64_t TBL_EMPTY = 0xFFFFFFFFFFFFFFFFull;
 constexpr uint32_t CLAIM_BASE = 0xFFFF0000u;  // table id field >= CLAIM_BASE: claimed in this expansion
+// Speculative kernels (mplx_spec.h): a claim carries the batch it was made in -- CLAIM_BASE | (batch & 63) << 9 | thread -- and is RESOLVED
+// before that batch ends: the entry of the state it was made for, or TBL_DEAD_ID when the unit that wanted the state was cut
+// (the slot then stays dead: look-ups pass over it).  A look-up that meets a claim of an EARLIER batch with its query's tag is
+// therefore looking at a store that has not landed yet, and waits for it; it never has to guess what a claim will become.
+constexpr uint32_t TBL_DEAD_ID = 0xFFFFFFFEu;
+constexpr uint32_t CLAIM_BATCH_SHIFT = 9, CLAIM_BATCH_MASK = 0x3Fu;
+constexpr uint32_t CLAIM_WAIT_POLLS = 1u << 18;  // (each a sleep and a trip to memory, ~1 us: a quarter of a second, then MPLX_PLAN_INTERNAL)
 constexpr uint32_t FLAG_CLOSED = 1u, FLAG_OPENED = 2u;
 constexpr int MAX_TRAJ = 1024;
 // predecessor record: action field = control input (low 12 bits) | potential sum of the primitive's samples << 12
@@ -155,6 +162,8 @@ struct SearchParams {
   int32_t help_max;               // helpers per leader (0 or 2..4)
   int32_t help_limit;             // workgroups of the launch that may turn into helpers once the query queue is empty (-1: no limit);
                                   // counted in cache_next[4].  Streamed batches: the rest exit and leave their compute unit to the next batch
+  int32_t xflags;                 // diagnostics (MPLX_X_FLAGS): 1 table probes at agent scope, 2 release / acquire fences around a
+                                  // look-ahead cache record, 4 the launch uses the other half of a doubled state table
   // moving-obstacle environment (astar_poly_kernel): the worlds and the world of each query
   PolyDev poly;
   const int32_t *poly_world;

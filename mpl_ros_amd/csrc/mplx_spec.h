@@ -293,6 +293,27 @@ __device__ __forceinline__ uint32_t dbg_xcc() {
   return x & 15u;
 }
 #endif
+// Check word of a look-ahead cache row (units of 32 lanes: upper half of the row's voxel-read slot).  The record that names a row is
+// written after the row "has landed" (s_waitcnt vmcnt(0) on the helper's side) -- but the acknowledgement of a posted agent-scope
+// store is not a promise that a reader on another XCD sees it before a LATER store to another line: under a write-heavy
+// neighbour (another launch's hipMemset) a leader was seen consuming the record and then the row's previous contents (wrong
+// heuristics: another expansion order, or an OPEN list that runs dry).  The row therefore validates itself end to end: XOR of a
+// term per heuristic the leader will read, the voxel-read count, and a salt of (state key, query, launch epoch) that no other
+// row carries; a leader that reads a row whose check word does not match reads it again until it does.
+__device__ __forceinline__ uint32_t cache_row_term(double h, int lu) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(h);
+  return (((uint32_t)b ^ (uint32_t)(b >> 32)) + (uint32_t)lu) * 0x9E3779B1u;
+}
+__device__ __forceinline__ uint32_t cache_row_salt(uint32_t khash, uint32_t q, uint32_t epoch, uint32_t reads) {
+  return khash ^ (q * 0x85EBCA77u) ^ (epoch * 0xC2B2AE3Du) ^ (reads * 0x27D4EB2Fu) ^ 0xA5A5A5A5u;
+}
+__device__ __forceinline__ uint32_t unit32_xor(uint32_t x) {  // XOR over the 32 lanes of a unit (half a wave), in every lane
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) x ^= (uint32_t)__shfl_xor((int)x, d, 32);
+  return x;
+}
+constexpr uint32_t CACHE_ROW_POLLS = 1u << 18;
+
 // Serve the leader of box `bi` until its query ends: every time it announces a wish list, expand the listed
 // nodes that have no cache entry yet -- get_succ (phases 1-2 of expand_unit) plus the heuristic of every
 // finite successor -- and publish {row, voxel reads, valid mask, blocked mask} in cache_c and the heuristics in
@@ -389,7 +410,13 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
       unit_sync<UL>();
       const uint32_t rp1 = live ? S.hc_row[ku] : 0u;
       if (rp1 && lu < P.n_u) st_f64_agent(&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_h_slot(UL, lu)], h);
-      if (rp1 && lu == UL - 1) st_u64((unsigned long long *)&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)], (unsigned long long)treads);
+      unsigned long long reads_word = (unsigned long long)treads;
+      if constexpr (UL == 32) {  // check word of the row (cache_row_term above)
+        const uint32_t cs = unit32_xor((act && P.eps != 0.0) ? cache_row_term(h, lu) : 0u) ^
+                            cache_row_salt((uint32_t)key_hash64(S.cur_key[ku], nk), q, epoch, treads);
+        reads_word |= (unsigned long long)cs << 32;
+      }
+      if (rp1 && lu == UL - 1) st_u64((unsigned long long *)&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)], reads_word);
       if constexpr (UL > 64) {  // large lattice: every wave of the unit leaves its two words of each mask in the row
         if (rp1 && (tid & 63) == 0) {
           uint32_t *rw = (uint32_t *)(P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL));
@@ -399,6 +426,8 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has landed before the record names it
+      // (large lattices: the row carries the masks as well and has no check word yet -- a full agent-scope release instead)
+      if (UL > 64 || (P.xflags & 2)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       unit_sync<UL>();
       if (rp1 && lu == 0) {
         unsigned long long *cr = (unsigned long long *)&P.cache_c[rec];
@@ -1090,16 +1119,25 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         // the helper's row of a cached candidate -- the heuristics of its successors, the voxel-read count -- is asked
         // for now (agent-scope loads: always a trip to memory) so that it travels during the expansion; used in 2b / 2c
         [[maybe_unused]] double h_row = 0.0;
+        [[maybe_unused]] unsigned long long reads_word = 0ull;  // (units of 32 lanes: voxel reads | check word of the row << 32)
         [[maybe_unused]] uint32_t reads_row = 0u;  // (32 bits asked for: a 64-bit load whose upper half is dead makes the compiler wait for it at once, to reuse the register)
 #if MPLX_X_EARLY_ROW
         if constexpr (HELP) {
           const uint32_t rp1 = live_unit ? S.hc_row[ku] : 0u;
+          if (P.xflags & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           if (rp1) {
             const double *row = P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL);
             bool want = lu < P.n_u && P.eps != 0.0;
             if constexpr (UL <= 64) want = want && (((S.hc_valid[ku] & ~S.hc_blocked[ku]) >> lu) & 1u);
             if (want) h_row = ld_f64_agent(&row[cache_h_slot(UL, lu)]);
-            if (lu == 0) reads_row = ld_u32((const uint32_t *)&row[cache_reads_slot(UL)]);
+            if (lu == 0) {
+              if constexpr (UL == 32) {
+                reads_word = ld_u64((const unsigned long long *)&row[cache_reads_slot(UL)]);
+                reads_row = (uint32_t)reads_word;
+              } else {
+                reads_row = ld_u32((const uint32_t *)&row[cache_reads_slot(UL)]);
+              }
+            }
           }
         }
 #endif
@@ -1116,10 +1154,36 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           if (l.valid && !l.blocked) {
             h64 = lane_hash(l);
             pos0 = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
-            v0 = ld_u64_probe(&P.table[pos0]);
+            v0 = (P.xflags & 1) ? ld_u64(&P.table[pos0]) : ld_u64_probe(&P.table[pos0]);
           }
         });
         const bool act = L.valid && !L.blocked;
+#if MPLX_X_EARLY_ROW
+        if constexpr (HELP && UL == 32) {
+          // the helper's row against its check word (cache_row_term above): what does not match yet is a store on its way
+          const uint32_t rp1 = live_unit ? S.hc_row[ku] : 0u;  // (the same for the 32 lanes of the unit)
+          if (rp1) {
+            const double *row = P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL);
+            const bool want = act && P.eps != 0.0;  // (the lanes whose heuristic was asked for: the record's masks are L.valid / L.blocked now)
+            const uint32_t khash = (uint32_t)key_hash64(S.cur_key[ku], nk);
+            for (uint32_t polls = 0;; polls++) {
+              const uint32_t cs = unit32_xor(want ? cache_row_term(h_row, lu) : 0u);
+              const uint32_t rd = (uint32_t)__shfl((int)(uint32_t)reads_word, 0, 32), stored = (uint32_t)__shfl((int)(uint32_t)(reads_word >> 32), 0, 32);
+              if ((cs ^ cache_row_salt(khash, (uint32_t)q, P.epoch, rd)) == stored) break;
+              if (polls >= CACHE_ROW_POLLS) {  // (never seen: a record whose row did not arrive)
+                if (lu == 0) S.status = 5;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(16);
+              if (want) h_row = ld_f64_agent(&row[cache_h_slot(UL, lu)]);
+              if (lu == 0) {
+                reads_word = ld_u64((const unsigned long long *)&row[cache_reads_slot(UL)]);
+                reads_row = (uint32_t)reads_word;
+              }
+            }
+          }
+        }
+#endif
         {
           uint32_t tot, treads;
           unit_excl_scan<UL, BLOCK>((L.valid ? 1u : 0u) | (act ? 1u << 10 : 0u), S, tid, tot);
@@ -1143,6 +1207,8 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         MPLX_TIC(tc);
         [[maybe_unused]] unsigned long long t2 = __builtin_readcyclecounter();
         int my_slot = 0;
+        bool claimed_new = false;  // this lane claimed a slot of the state table for a state that does not exist yet ...
+        size_t claimed_pos = 0;    // ... this one: it holds the state's entry, or TBL_DEAD_ID, before the batch ends
         // (the table was cleared by the idle waves of the previous batch's bookkeeping -- batch_setup -- unless the
         // expansion borrowed a column for the potential sums)
         constexpr bool CLEAR_HERE = !(MPLX_X_EARLY_SETUP && MPLX_X_EARLY_CLEAR) || POT;
@@ -1207,7 +1273,9 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
             const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
             const size_t mask = (size_t)P.table_mask;
             size_t pos = pos0;
-            const unsigned long long claim = tagq | (unsigned long long)(CLAIM_BASE + (uint32_t)tid);
+            const uint32_t claim_batch = (batch_no & CLAIM_BATCH_MASK) << CLAIM_BATCH_SHIFT;
+            static_assert(BLOCK <= (1 << CLAIM_BATCH_SHIFT), "the thread index of a claim has nine bits");
+            const unsigned long long claim = tagq | (unsigned long long)(CLAIM_BASE + claim_batch + (uint32_t)tid);
             // second round trip (claim the empty slot, or fetch the record the slot names) goes out
             // before the heuristic is computed, so its latency hides behind the f64 work.  (Computing the
             // heuristic only for states found to be new, after the look-up, was measured slower: the slowest
@@ -1239,13 +1307,15 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
 #endif
             bool first = true;
             for (;;) {
-              unsigned long long v = first ? v0 : ld_u64_probe(&P.table[pos]);
+              unsigned long long v = first ? v0 : (P.xflags & 1) ? ld_u64(&P.table[pos]) : ld_u64_probe(&P.table[pos]);
               if (v == TBL_EMPTY) {
                 unsigned long long old = (first && did_cas0) ? cas0 : atomicCAS(&P.table[pos], TBL_EMPTY, claim);
                 first = false;
                 if (old == TBL_EMPTY) {
                   S.bt_id[my_slot] = NIL;  // new state; created when its first sharer commits
                   S.bt_tslot[my_slot] = (uint32_t)pos;
+                  claimed_new = true;
+                  claimed_pos = pos;
                   S.bt_h[my_slot] = hspec;  // of the leader's state = the state the node will be created with
                   S.bt_g[my_slot] = INFINITY;
                   S.bt_flags[my_slot] = 0;
@@ -1259,7 +1329,20 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
               // long held its final entry (the line was fetched between the claiming compare-and-swap and the agent-scope
               // store of the entry, which does not update the L1 copy): taken at face value the probe would move on and
               // create the state a second time.  Look again past the L1 before believing it.
-              if ((uint32_t)v >= CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) v = ld_u64(&P.table[pos]);
+              // And a claim of an EARLIER batch that memory still shows is a store on its way: the lane that made it wrote the
+              // state's entry, or TBL_DEAD_ID, before that batch ended (below, after the commit) -- an agent-scope store that is
+              // posted, not awaited, and that a loaded memory system (another launch's hipMemset, a neighbour's copy kernel) can
+              // hold back for longer than a batch lasts.  Moving on here would create the state a second time (seen: blocking
+              // batches under a background fill load, streamed batches -- profiles/r04s_*); wait for the store instead.
+              if ((uint32_t)v >= CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
+                v = ld_u64(&P.table[pos]);
+                for (uint32_t polls = 0; (uint32_t)v >= CLAIM_BASE && (uint32_t)v < TBL_DEAD_ID && (v & 0xFFFFFFFF00000000ull) == tagq &&
+                                         ((uint32_t)v & (CLAIM_BATCH_MASK << CLAIM_BATCH_SHIFT)) != claim_batch; polls++) {
+                  if (polls >= CLAIM_WAIT_POLLS) { S.status = 5; break; }  // (never seen: a claim nobody resolved)
+                  __builtin_amdgcn_s_sleep(16);
+                  v = ld_u64(&P.table[pos]);
+                }
+              }
               const uint32_t vid = (uint32_t)v;
               if (vid < CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
                 // the record's hot line in 16-byte words, all asked for at once: g | h | flags pred key[0..1] | key[2..] ...
@@ -1477,6 +1560,10 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         }
         __syncthreads();
         MPLX_T2(S, 12, t2);
+        // a slot claimed for a state that no committed unit reached (its units were cut): dead from here on, and said so -- no claim
+        // outlives its batch (see the look-up above)
+        if (claimed_new && S.bt_id[my_slot] == NIL)
+          st_u64(&P.table[claimed_pos], (((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32)) | (unsigned long long)TBL_DEAD_ID);
         if (tid < 64) {  // counters of the committed units, in commit order; lane k holds unit k
           const int l = opaque(tid);
           const bool inb = l < K && l < n_cand && S.cand_live[l < K ? l : 0] != 0;
