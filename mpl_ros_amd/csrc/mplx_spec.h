@@ -1158,32 +1158,6 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           }
         });
         const bool act = L.valid && !L.blocked;
-#if MPLX_X_EARLY_ROW
-        if constexpr (HELP && UL == 32) {
-          // the helper's row against its check word (cache_row_term above): what does not match yet is a store on its way
-          const uint32_t rp1 = live_unit ? S.hc_row[ku] : 0u;  // (the same for the 32 lanes of the unit)
-          if (rp1) {
-            const double *row = P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL);
-            const bool want = act && P.eps != 0.0;  // (the lanes whose heuristic was asked for: the record's masks are L.valid / L.blocked now)
-            const uint32_t khash = (uint32_t)key_hash64(S.cur_key[ku], nk);
-            for (uint32_t polls = 0;; polls++) {
-              const uint32_t cs = unit32_xor(want ? cache_row_term(h_row, lu) : 0u);
-              const uint32_t rd = (uint32_t)__shfl((int)(uint32_t)reads_word, 0, 32), stored = (uint32_t)__shfl((int)(uint32_t)(reads_word >> 32), 0, 32);
-              if ((cs ^ cache_row_salt(khash, (uint32_t)q, P.epoch, rd)) == stored) break;
-              if (polls >= CACHE_ROW_POLLS) {  // (never seen: a record whose row did not arrive)
-                if (lu == 0) S.status = 5;
-                break;
-              }
-              __builtin_amdgcn_s_sleep(16);
-              if (want) h_row = ld_f64_agent(&row[cache_h_slot(UL, lu)]);
-              if (lu == 0) {
-                reads_word = ld_u64((const unsigned long long *)&row[cache_reads_slot(UL)]);
-                reads_row = (uint32_t)reads_word;
-              }
-            }
-          }
-        }
-#endif
         {
           uint32_t tot, treads;
           unit_excl_scan<UL, BLOCK>((L.valid ? 1u : 0u) | (act ? 1u << 10 : 0u), S, tid, tot);
@@ -1193,7 +1167,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
             S.u_fin[ku] = tot >> 10;
             if (HELP && S.hc_row[ku] != 0u)  // voxel reads of the expansion as the helper counted them (slot 31 of its row)
 #if MPLX_X_EARLY_ROW
-              S.u_reads[ku] = reads_row;
+              S.u_reads[ku] = reads_row;  // (units of 32 lanes: written again once the row has passed its check, before the barrier of 2c)
 #else
               S.u_reads[ku] = (uint32_t)ld_u64((const unsigned long long *)&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)]);
 #endif
@@ -1248,6 +1222,35 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           const uint32_t ubit = 0x100u << ku;
           if (atomicOr(&S.bt_dirty[sl], ubit) & ubit) S.unit_seq[ku] = 1;
         }
+#if MPLX_X_EARLY_ROW
+        if constexpr (HELP && UL == 32) {
+          // the helper's row against its check word (cache_row_term above): what does not match yet is a store on its way.
+          // (Placed here, not right after the expansion: the row's agent-scope loads keep travelling during the scans and the
+          //  batch-table insert above.)
+          const uint32_t rp1 = live_unit ? S.hc_row[ku] : 0u;  // (the same for the 32 lanes of the unit)
+          if (rp1) {
+            const double *row = P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL);
+            const bool want = act && P.eps != 0.0;  // (the lanes whose heuristic was asked for: the record's masks are L.valid / L.blocked now)
+            const uint32_t khash = (uint32_t)key_hash64(S.cur_key[ku], nk);
+            for (uint32_t polls = 0;; polls++) {
+              const uint32_t cs = unit32_xor(want ? cache_row_term(h_row, lu) : 0u);
+              const uint32_t rd = (uint32_t)__shfl((int)(uint32_t)reads_word, 0, 32), stored = (uint32_t)__shfl((int)(uint32_t)(reads_word >> 32), 0, 32);
+              if ((cs ^ cache_row_salt(khash, (uint32_t)q, P.epoch, rd)) == stored) break;
+              if (polls >= CACHE_ROW_POLLS) {  // (never seen: a record whose row did not arrive)
+                if (lu == 0) S.status = 5;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(16);
+              if (want) h_row = ld_f64_agent(&row[cache_h_slot(UL, lu)]);
+              if (lu == 0) {
+                reads_word = ld_u64((const unsigned long long *)&row[cache_reads_slot(UL)]);
+                reads_row = (uint32_t)reads_word;
+              }
+            }
+            if (lu == 0) S.u_reads[ku] = reads_row;
+          }
+        }
+#endif
         __syncthreads();
         MPLX_T2(S, 1, t2);
 #ifdef MPLX_LOOKUP_TIMERS

@@ -19,12 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def run(n_batches=8, mode="fill"):
     import torch
     from mpl_ros_amd import mapgen
     from mpl_ros_amd.planner import ACC, VoxelMapPlanner, VoxelMapUtil, Waypoint3D
-    n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    mode = sys.argv[2] if len(sys.argv) > 2 else "fill"
     dev = torch.device("cuda", 0)
     n, res, origin = 512, 0.1, (0.0, 0.0, 0.0)
     grid, _, _, _, _, _ = mapgen.benchmark_map(n)
@@ -93,9 +91,9 @@ def main():
     stop.set()
     if th:
         th.join(timeout=30)
-    print(json.dumps({"probe": "blocking batch with a background fill load", "mode": mode, "kernel": pl.kernelName(), "batches": n_batches, "fill_rounds": fills[0],
-                      "quiet_kernel_ms": quiet_ms, "kernel_ms": ms, "mismatching_queries": len(bad), "detail": bad[:12]}))
+    return ({"probe": "blocking batch with a background fill load", "mode": mode, "kernel": pl.kernelName(), "batches": n_batches, "fill_rounds": fills[0],
+                      "quiet_kernel_ms": quiet_ms, "kernel_ms": ms, "mismatching_queries": len(bad), "detail": bad[:12]})
 
 
 if __name__ == "__main__":
-    main()
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 8, sys.argv[2] if len(sys.argv) > 2 else "fill")))
