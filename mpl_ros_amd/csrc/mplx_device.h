@@ -112,9 +112,16 @@ struct CacheRec {              // per node record of the pool; two self-validati
 // the successor of input i, slot 31 the voxel reads (as bits); the masks live in the cache record.  Larger lattices
 // (units of 128 lanes, <= 128 inputs): 136 doubles -- [0..3] eight 32-bit mask words (valid x 4, blocked x 4), [4] the
 // voxel reads, [8..135] the heuristics; the record's second half then only carries CACHE_READY.
-constexpr int cache_row_doubles(int unit_lanes) { return unit_lanes <= 64 ? 32 : 136; }
-constexpr int cache_h_slot(int unit_lanes, int lu) { return unit_lanes <= 64 ? lu : 8 + lu; }
-constexpr int cache_reads_slot(int unit_lanes) { return unit_lanes <= 64 ? 31 : 4; }
+// MPLX_X_ROW_PAIRS (A/B switch, off in the product; host and kernels must be built alike: tools/build_variant.sh): the small
+// row as 32 pairs {value, check of that value} -- slot 2 i the heuristic of input i, 2 i + 1 its check, 62 / 63 the voxel reads and
+// theirs -- each pair written by ONE 16-byte store and validated by the lane that consumes it (no cross-lane step; a torn pair
+// fails whichever half is old).  DESIGN.md 7.
+#ifndef MPLX_X_ROW_PAIRS
+#define MPLX_X_ROW_PAIRS 0
+#endif
+constexpr int cache_row_doubles(int unit_lanes) { return unit_lanes <= 64 ? (MPLX_X_ROW_PAIRS ? 64 : 32) : 136; }
+constexpr int cache_h_slot(int unit_lanes, int lu) { return unit_lanes <= 64 ? (MPLX_X_ROW_PAIRS ? 2 * lu : lu) : 8 + lu; }
+constexpr int cache_reads_slot(int unit_lanes) { return unit_lanes <= 64 ? (MPLX_X_ROW_PAIRS ? 62 : 31) : 4; }
 
 struct SearchParams {
   // environment

@@ -35,6 +35,9 @@
 #ifndef MPLX_X_EARLY_ROW
 #define MPLX_X_EARLY_ROW 1    // look-ahead cache row (heuristics, voxel-read count) requested as soon as the row is known
 #endif
+#ifndef MPLX_X_EARLY_TOMB
+#define MPLX_X_EARLY_TOMB 0   // (A/B, off) TBL_DEAD_ID of an abandoned claim stored ahead of the parallel commit instead of behind it
+#endif
 #ifndef MPLX_X_EARLY_CLEAR
 #define MPLX_X_EARLY_CLEAR 1  // batch table cleared by the idle waves of the end-of-batch bookkeeping
 #endif
@@ -313,6 +316,12 @@ __device__ __forceinline__ uint32_t unit32_xor(uint32_t x) {  // XOR over the 32
   return x;
 }
 constexpr uint32_t CACHE_ROW_POLLS = 1u << 18;
+// MPLX_X_ROW_PAIRS: check of ONE value of a row (the bits of a heuristic, or the voxel-read count), bound to the state, the query,
+// the launch and the slot
+__device__ __forceinline__ unsigned long long cache_pair_tag(unsigned long long bits, uint32_t khash, uint32_t q, uint32_t epoch, uint32_t slot) {
+  return (bits * 0x9E3779B97F4A7C15ull) ^ (((unsigned long long)khash << 32) | (unsigned long long)q) ^
+         ((unsigned long long)epoch * 0xC2B2AE3D27D4EB4Full) ^ ((unsigned long long)(slot + 1u) << 56) ^ 0x5A5A5A5A5A5A5A5Aull;
+}
 
 // Serve the leader of box `bi` until its query ends: every time it announces a wish list, expand the listed
 // nodes that have no cache entry yet -- get_succ (phases 1-2 of expand_unit) plus the heuristic of every
@@ -409,14 +418,25 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
       }
       unit_sync<UL>();
       const uint32_t rp1 = live ? S.hc_row[ku] : 0u;
+#if MPLX_X_ROW_PAIRS
+      if constexpr (UL == 32) {  // {value, its check}: one 16-byte store per pair
+        const uint32_t kh = (uint32_t)key_hash64(S.cur_key[ku], nk);
+        double *row = P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL);
+        if (rp1 && lu < P.n_u)
+          st_f64x2_agent(&row[cache_h_slot(UL, lu)], h, __longlong_as_double((long long)cache_pair_tag((unsigned long long)__double_as_longlong(h), kh, q, epoch, (uint32_t)lu)));
+        if (rp1 && lu == UL - 1)
+          st_f64x2_agent(&row[cache_reads_slot(UL)], __longlong_as_double((long long)(unsigned long long)treads),
+                         __longlong_as_double((long long)cache_pair_tag((unsigned long long)treads, kh, q, epoch, 63u)));
+      } else
+#endif
       if (rp1 && lu < P.n_u) st_f64_agent(&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_h_slot(UL, lu)], h);
       unsigned long long reads_word = (unsigned long long)treads;
-      if constexpr (UL == 32) {  // check word of the row (cache_row_term above)
+      if constexpr (UL == 32 && !MPLX_X_ROW_PAIRS) {  // check word of the row (cache_row_term above)
         const uint32_t cs = unit32_xor((act && P.eps != 0.0) ? cache_row_term(h, lu) : 0u) ^
                             cache_row_salt((uint32_t)key_hash64(S.cur_key[ku], nk), q, epoch, treads);
         reads_word |= (unsigned long long)cs << 32;
       }
-      if (rp1 && lu == UL - 1) st_u64((unsigned long long *)&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)], reads_word);
+      if (rp1 && lu == UL - 1 && !(UL == 32 && MPLX_X_ROW_PAIRS)) st_u64((unsigned long long *)&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)], reads_word);
       if constexpr (UL > 64) {  // large lattice: every wave of the unit leaves its two words of each mask in the row
         if (rp1 && (tid & 63) == 0) {
           uint32_t *rw = (uint32_t *)(P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL));
@@ -1120,6 +1140,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         // for now (agent-scope loads: always a trip to memory) so that it travels during the expansion; used in 2b / 2c
         [[maybe_unused]] double h_row = 0.0;
         [[maybe_unused]] unsigned long long reads_word = 0ull;  // (units of 32 lanes: voxel reads | check word of the row << 32)
+        [[maybe_unused]] unsigned long long h_tag = 0ull, reads_tag = 0ull;  // (MPLX_X_ROW_PAIRS: the checks of this lane's heuristic and of the reads)
         [[maybe_unused]] uint32_t reads_row = 0u;  // (32 bits asked for: a 64-bit load whose upper half is dead makes the compiler wait for it at once, to reuse the register)
 #if MPLX_X_EARLY_ROW
         if constexpr (HELP) {
@@ -1130,6 +1151,12 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
             bool want = lu < P.n_u && P.eps != 0.0;
             if constexpr (UL <= 64) want = want && (((S.hc_valid[ku] & ~S.hc_blocked[ku]) >> lu) & 1u);
             if (want) h_row = ld_f64_agent(&row[cache_h_slot(UL, lu)]);
+#if MPLX_X_ROW_PAIRS
+            if constexpr (UL == 32) {
+              if (want) h_tag = ld_u64((const unsigned long long *)&row[cache_h_slot(UL, lu) + 1]);
+              if (lu == 0) reads_tag = ld_u64((const unsigned long long *)&row[cache_reads_slot(UL) + 1]);
+            }
+#endif
             if (lu == 0) {
               if constexpr (UL == 32) {
                 reads_word = ld_u64((const unsigned long long *)&row[cache_reads_slot(UL)]);
@@ -1222,7 +1249,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           const uint32_t ubit = 0x100u << ku;
           if (atomicOr(&S.bt_dirty[sl], ubit) & ubit) S.unit_seq[ku] = 1;
         }
-#if MPLX_X_EARLY_ROW
+#if MPLX_X_EARLY_ROW && !MPLX_X_ROW_PAIRS
         if constexpr (HELP && UL == 32) {
           // the helper's row against its check word (cache_row_term above): what does not match yet is a store on its way.
           // (Placed here, not right after the expansion: the row's agent-scope loads keep travelling during the scans and the
@@ -1297,7 +1324,21 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
               // cache record was, read after it)
               if (HELP && S.hc_row[ku] != 0u)
 #if MPLX_X_EARLY_ROW
+              {
+#if MPLX_X_ROW_PAIRS
+                if constexpr (UL == 32) {  // this lane's {heuristic, check}: what does not match yet is a store on its way
+                  const uint32_t kh = (uint32_t)key_hash64(S.cur_key[ku], nk);
+                  const double *row = P.cache_h + (size_t)(S.hc_row[ku] - 1u) * cache_row_doubles(UL);
+                  for (uint32_t polls = 0; cache_pair_tag((unsigned long long)__double_as_longlong(h_row), kh, (uint32_t)q, P.epoch, (uint32_t)lu) != h_tag; polls++) {
+                    if (polls >= CACHE_ROW_POLLS) { S.status = 5; break; }
+                    __builtin_amdgcn_s_sleep(16);
+                    h_row = ld_f64_agent(&row[cache_h_slot(UL, lu)]);
+                    h_tag = ld_u64((const unsigned long long *)&row[cache_h_slot(UL, lu) + 1]);
+                  }
+                }
+#endif
                 hspec = h_row;
+              }
 #else
                 hspec = ld_f64_agent(&P.cache_h[(size_t)(S.hc_row[ku] - 1u) * cache_row_doubles(UL) + cache_h_slot(UL, lu)]);
 #endif
@@ -1376,6 +1417,21 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
             }
           }
         }
+#if MPLX_X_EARLY_ROW && MPLX_X_ROW_PAIRS
+        if constexpr (HELP && UL == 32) {  // the helper's voxel-read count of a cached unit, once its pair checks out
+          if (lu == 0 && live_unit && S.hc_row[ku] != 0u) {
+            const uint32_t kh = (uint32_t)key_hash64(S.cur_key[ku], nk);
+            const double *row = P.cache_h + (size_t)(S.hc_row[ku] - 1u) * cache_row_doubles(UL);
+            for (uint32_t polls = 0; cache_pair_tag(reads_word, kh, (uint32_t)q, P.epoch, 63u) != reads_tag; polls++) {
+              if (polls >= CACHE_ROW_POLLS) { S.status = 5; break; }
+              __builtin_amdgcn_s_sleep(16);
+              reads_word = ld_u64((const unsigned long long *)&row[cache_reads_slot(UL)]);
+              reads_tag = ld_u64((const unsigned long long *)&row[cache_reads_slot(UL) + 1]);
+            }
+            S.u_reads[ku] = (uint32_t)reads_word;
+          }
+        }
+#endif
         MPLX_T2(S, 4, t2);
 #ifdef MPLX_LOOKUP_TIMERS
         if ((tid & 63) == 0) S.cycw[tid >> 6][1] += __builtin_readcyclecounter() - tw;
@@ -1507,9 +1563,20 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           }
           const bool mine = ku < k_stop && S.cand_live[opaque(ku)];
           if (mine && lu == 0) V::flags(Q.node(S.cand_id[ku])) = S.cand_fl[ku] | FLAG_CLOSED;
+#if MPLX_X_EARLY_TOMB
+          if (act && mine) atomicOr(&S.bt_dirty[my_slot], 2u);  // (bit 1, free in the parallel commit: a committed unit reaches this state)
+#endif
           MPLX_T2(S, 8, t2);
           __syncthreads();  // everyone has read status / u_cut before they change
           MPLX_T2(S, 9, t2);
+#if MPLX_X_EARLY_TOMB
+          // a slot claimed for a state no committed unit reaches: its TBL_DEAD_ID goes out with the commit's own stores (behind the
+          // commit's barrier its write-through acknowledgement would be the first thing the next batch waits for)
+          if (claimed_new && !(S.bt_dirty[my_slot] & 2u)) {
+            st_u64(&P.table[claimed_pos], (((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32)) | (unsigned long long)TBL_DEAD_ID);
+            claimed_new = false;
+          }
+#endif
           spec_commit_lanes<UL, K, CONTROL, true, HELP, YAW>(Q, S, tid, q, ku, act && mine, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old, (int)(batch_no & 1u));
           if (tid == 0 && st_after >= 0) S.status = st_after;
           MPLX_T2(S, 10, t2);
