@@ -74,3 +74,22 @@ def test_reference_api_that_needs_no_device_behaves():
         pl.setGradientWeight(0.5)
     with pytest.raises(MplxError):
         pl.updatePotentialMap([0, 0])  # no MapUtil yet
+
+
+def test_streamed_batch_entry_points_refuse_null_handles_without_touching_a_device():
+    """include/mplx.h "streamed batches": every entry point answers MPLX_ERR_ARG (or an empty value) for a null handle."""
+    lib = _capi.load()
+    t = C.c_int64(-1)
+    out = C.c_void_p()
+    assert lib.mplx_stream_create(None, 2, C.byref(out)) == _capi.ERR_ARG and not out.value
+    assert lib.mplx_stream_depth(None) == 0
+    assert lib.mplx_stream_last_error(None) == b""
+    assert lib.mplx_stream_submit(None, 1, None, None, C.byref(t)) == _capi.ERR_ARG and t.value == -1
+    assert lib.mplx_stream_done(None, 0) == _capi.ERR_ARG
+    assert lib.mplx_stream_wait(None, 0, None, None) == _capi.ERR_ARG
+    assert lib.mplx_stream_configure(None, 1, 1, 1, 1, -1, 0, 0, -1) == _capi.ERR_ARG
+    lib.mplx_stream_destroy(None)  # (a no-op)
+    assert lib.mplx_plan_batch_wait(None, None) == _capi.ERR_ARG
+    assert lib.mplx_plan_batch_done(None) == _capi.ERR_ARG
+    assert lib.mplx_set_helper_limit(None, 4) == _capi.ERR_ARG
+    assert lib.mplx_release_pools(None) == _capi.ERR_ARG
