@@ -14,6 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_c4_acc_batch_repeats_under_a_background_fill_load():
+    import gc
+    import torch
+    gc.collect()
+    torch.cuda.empty_cache()  # (the batch's pools take ~ 130 GB, the background buffer 16 GB: nothing of earlier tests should linger)
     spec = importlib.util.spec_from_file_location("r04_jitter_probe", os.path.join(ROOT, "tools", "r04_jitter_probe.py"))
     probe = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(probe)
