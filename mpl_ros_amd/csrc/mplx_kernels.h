@@ -19,6 +19,9 @@
 
 namespace mplx {
 
+#ifndef MPLX_X_CLAIM_WAIT_1N
+#define MPLX_X_CLAIM_WAIT_1N 0
+#endif
 // ------------------------------------------------------------------ small device helpers
 __device__ __forceinline__ unsigned long long ld_u64(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1149,7 +1152,17 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
   }
 #endif
   if (act) {
-    const unsigned long long claim = tagq | (unsigned long long)(CLAIM_BASE + (uint32_t)tid);
+    // MPLX_X_CLAIM_WAIT_1N (A/B switch, off in the product; tools/build_variant.sh claimwait1n): rule R3 of DESIGN.md 3.9 for the
+    // one-node kernels.  Every claim made here becomes an entry within the same expansion (there are no cut units), so a claim of
+    // an EARLIER expansion with this query's tag is an entry store that has not landed yet -- wait for it instead of passing it (and
+    // creating the state a second time).  The claim carries the low bits of the expansion count to tell the two apart.
+#if MPLX_X_CLAIM_WAIT_1N
+    static_assert(BLOCK <= (1 << CLAIM_BATCH_SHIFT), "the thread index of a claim has nine bits");
+    const uint32_t claim_exp = ((uint32_t)S.c_expanded & CLAIM_BATCH_MASK) << CLAIM_BATCH_SHIFT;
+#else
+    const uint32_t claim_exp = 0u;
+#endif
+    const unsigned long long claim = tagq | (unsigned long long)(CLAIM_BASE + claim_exp + (uint32_t)tid);
     bool first = true;
     for (;;) {
       unsigned long long v = first ? v0 : ld_u64(&P.table[pos]);
@@ -1159,6 +1172,14 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
         if (old == TBL_EMPTY) { role = 2; tslot = pos; break; }
         v = old;
       }
+#if MPLX_X_CLAIM_WAIT_1N
+      for (uint32_t polls = 0; (uint32_t)v >= CLAIM_BASE && (uint32_t)v < TBL_DEAD_ID && (v & 0xFFFFFFFF00000000ull) == tagq &&
+                               ((uint32_t)v & (CLAIM_BATCH_MASK << CLAIM_BATCH_SHIFT)) != claim_exp; polls++) {
+        if (polls >= CLAIM_WAIT_POLLS) { S.status = 5; break; }
+        __builtin_amdgcn_s_sleep(16);
+        v = ld_u64(&P.table[pos]);
+      }
+#endif
       const uint32_t vid = (uint32_t)v;
       if (vid < CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
         // one 64 B load answers: same key?  and if so g, h, flags, newest predecessor
