@@ -39,3 +39,7 @@ if [ -f build_tmp/libmplx_fast.so ]; then
 else
   echo "build_tmp/libmplx_fast.so missing: run tools/build_variant.sh fast first"
 fi
+# ---- C. rule R3 for the one-node kernels (tools/build_variant.sh claimwait1n): the parity tests that run them must stay green
+if [ -f build_tmp/libmplx_claimwait1n.so ]; then
+  (MPLX_LIB=$PWD/build_tmp/libmplx_claimwait1n.so timeout 120 python -m pytest tests/test_lpa.py tests/test_gpu_parity.py tests/test_poly_map.py -m gpu -x -q 2>&1 | tail -3) > $OUT/pytest_claimwait1n.txt; cat $OUT/pytest_claimwait1n.txt
+fi
