@@ -25,6 +25,9 @@ extern "C" {
 #define MPLX_ERR_HIP (-1)       /* a HIP runtime call failed (no GPU, OOM, launch failure) */
 #define MPLX_ERR_ARG (-2)       /* invalid argument / call order */
 #define MPLX_ERR_CAPACITY (-3)  /* a device pool is too small for the request */
+#define MPLX_ERR_TIMEOUT (-4)   /* a search launch outlived the context's deadline (mplx_set_deadline) and was aborted: its
+                                   results are void; mplx_last_error() says where every workgroup was.  The context stays
+                                   usable unless the text says it is lost (the launch did not answer the abort word). */
 
 /* plan status (mplx_result.status) */
 #define MPLX_PLAN_OK 0
@@ -35,6 +38,8 @@ extern "C" {
 #define MPLX_PLAN_INTERNAL 5        /* 64-bit key-hash collision inside one speculative batch (never observed) */
 #define MPLX_PLAN_TRAJ_TOO_LONG 6   /* goal reached, mplx_result.cost is valid, but the trajectory has more than 1024
                                        primitives (the device-side recoverTraj buffer): traj_len 0, no primitives */
+#define MPLX_PLAN_ABORTED 7         /* the host aborted the launch (deadline): never handed out -- the call returns
+                                       MPLX_ERR_TIMEOUT -- listed for completeness of the device-side status words */
 
 /* Control kinds = union of use_pos|use_vel|use_acc|use_jrk bits of a Waypoint
  * (mpl_test_node/src/map_planner_node.cpp:155-171 sets the bits; Control::VEL..SNP). */
@@ -252,6 +257,16 @@ int mplx_stream_wait(mplx_stream *s, int64_t ticket, mplx_result *out, mplx_ctx 
 /* At most `limit` workgroups of a launch stay on as helpers once its query queue is empty (-1: all of them, the default
  * of a blocking batch); the others exit, so that the next batch's workgroups get their compute units. */
 int mplx_set_helper_limit(mplx_ctx *ctx, int32_t limit);
+/* Launch guard.  The reference's plan() always returns (mpl_test_node/src/map_planner_node.cpp:186-196); so does every
+ * entry point here that waits for a search launch (mplx_plan, mplx_plan_batch, mplx_plan_batch_wait, mplx_stream_wait,
+ * mplx_poly_plan_batch, mplx_lpa_plan, mplx_lpa_sub_state_space): the wait polls the stream, and a launch older than
+ * `seconds` (default 120, environment MPLX_DEADLINE_S; <= 0: no deadline) is told to stop through a word in host-coherent
+ * memory that every persistent loop of the search kernels reads.  The call then returns MPLX_ERR_TIMEOUT -- results void,
+ * mplx_last_error() lists what each workgroup was doing -- and the context remains usable.  The lanes of an mplx_stream
+ * take the parent's deadline when the stream is created. */
+int mplx_set_deadline(mplx_ctx *ctx, double seconds);
+/* (tests) the context's next search launch spins until the deadline aborts it */
+int mplx_debug_hang_next_launch(mplx_ctx *ctx);
 /* Free the context's device pools (re-created by its next plan): hands the memory to other contexts, e.g. a stream's lanes.
  * The last batch's results and trajectories stay readable; the state-space dumps of a single plan do not. */
 int mplx_release_pools(mplx_ctx *ctx);

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("MPLX_LIB") or os.path.join(_HERE, "csrc", "libmplx.so
 
 VEL, ACC, JRK, SNP = 1, 3, 7, 15
 PLAN_OK, PLAN_NO_PATH, PLAN_START_OCCUPIED, PLAN_MAX_EXPAND, PLAN_POOL_FULL, PLAN_INTERNAL, PLAN_TRAJ_TOO_LONG = 0, 1, 2, 3, 4, 5, 6
-OK, ERR_HIP, ERR_ARG, ERR_CAPACITY = 0, -1, -2, -3
+OK, ERR_HIP, ERR_ARG, ERR_CAPACITY, ERR_TIMEOUT = 0, -1, -2, -3, -4
 
 
 class Waypoint(C.Structure):
@@ -69,6 +69,7 @@ EXPORTS = [
     "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms", "mplx_poly_result_cycles", "mplx_poly_set_helpers", "mplx_poly_last_helpers",
     "mplx_traj_solve", "mplx_traj_sample", "mplx_traj_effort",
     "mplx_plan_batch_submit", "mplx_plan_batch_wait", "mplx_plan_batch_done", "mplx_set_helper_limit", "mplx_release_pools",
+    "mplx_set_deadline", "mplx_debug_hang_next_launch",
     "mplx_stream_create", "mplx_stream_destroy", "mplx_stream_last_error", "mplx_stream_depth", "mplx_stream_configure",
     "mplx_stream_submit", "mplx_stream_done", "mplx_stream_wait",
 ]
@@ -214,6 +215,8 @@ def load():
     L.mplx_plan_batch_done.argtypes = [P]
     L.mplx_set_helper_limit.argtypes = [P, C.c_int32]
     L.mplx_release_pools.argtypes = [P]
+    L.mplx_set_deadline.argtypes = [P, C.c_double]
+    L.mplx_debug_hang_next_launch.argtypes = [P]
     L.mplx_stream_create.argtypes = [P, C.c_int, C.POINTER(P)]
     L.mplx_stream_destroy.argtypes = [P]
     L.mplx_stream_destroy.restype = None

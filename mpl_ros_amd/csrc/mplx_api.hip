@@ -6,7 +6,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <sched.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -105,7 +109,17 @@ struct mplx_ctx {
   unsigned long long *table_base = nullptr;  // (diagnostics, MPLX_X_FLAGS & 4)
   uint32_t launch_count = 0;
   int help_limit = -1;  // workgroups of a launch that may turn into helpers once the query queue is empty (-1: all of them)
+  // launch guard (mplx_device.h GuardBlock): host-coherent block the search kernels poll / leave their watch records in
+  GuardBlock *guard = nullptr;
+  double deadline_s = 120.0;  // a search launch older than this is aborted (mplx_set_deadline; <= 0: wait forever)
+  bool wedged = false;        // a launch did not even answer the abort word: the context's stream is lost
+  bool debug_hang = false;    // (tests) the next search launch spins until the host aborts it
+  uint64_t cfg_epoch = 0;     // bumped by every change of the planner set-up / pool policy (an mplx_stream's lanes follow it)
 };
+#define MPLX_REFUSE_PENDING(c)                                                                                                       \
+  do {                                                                                                                               \
+    if ((c)->pending) return fail((c), MPLX_ERR_ARG, "a submitted batch is still outstanding on this context (mplx_plan_batch_wait first)"); \
+  } while (0)
 
 static int fail(mplx_ctx *c, int code, const char *fmt, ...) {
   char buf[512];
@@ -161,6 +175,15 @@ extern "C" int mplx_ctx_create(int device, mplx_ctx **out) {
     hipDeviceProp_t prop;
     c->n_cus = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
   }
+  // launch guard: one block of host-coherent (fine-grained, mapped) memory -- the kernels reach it over the fabric, the host
+  // reads and writes it as plain memory while a launch is running
+  if (hipHostMalloc((void **)&c->guard, sizeof(GuardBlock), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+    c->guard = nullptr;
+    mplx_ctx_destroy(c);
+    return fail(nullptr, MPLX_ERR_HIP, "hipHostMalloc of the launch-guard block failed");
+  }
+  memset(c->guard, 0, sizeof(GuardBlock));
+  if (const char *e = getenv("MPLX_DEADLINE_S")) c->deadline_s = atof(e);
   *out = c;
   return MPLX_OK;
 }
@@ -183,7 +206,12 @@ static void free_batch(mplx_ctx *c) {
 extern "C" void mplx_ctx_destroy(mplx_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->wedged) {  // a launch that never ended still owns the stream and the pools: freeing them would block for ever -- leak them
+    delete c;
+    return;
+  }
   (void)hipStreamSynchronize(c->stream);
+  if (c->guard) (void)hipHostFree(c->guard);
   free_pools(c);
   free_batch(c);
   if (c->own_map) (void)hipFree(c->map);
@@ -643,6 +671,7 @@ static bool control_ok(int c) { return c == CTRL_VEL || c == CTRL_ACC || c == CT
 
 extern "C" int mplx_planner_config(mplx_ctx *c, const mplx_config *cfg) {
   if (!c || !cfg || !cfg->U) return fail(c, MPLX_ERR_ARG, "null argument");
+  MPLX_REFUSE_PENDING(c);  // (the batch in flight reads dU / dUcost)
   if (!control_ok(cfg->control & ~MPLX_YAW)) return fail(c, MPLX_ERR_ARG, "unsupported control %d", cfg->control);
   if (cfg->n_u <= 0 || cfg->n_u > 256) return fail(c, MPLX_ERR_ARG, "n_u must be in [1,256], got %d", cfg->n_u);
   if (!(cfg->dt > 0)) return fail(c, MPLX_ERR_ARG, "dt must be > 0");
@@ -677,11 +706,13 @@ extern "C" int mplx_planner_config(mplx_ctx *c, const mplx_config *cfg) {
   HIPCHK(c, hipMemcpyAsync(c->dUcost, ucost.data(), sizeof(double) * cfg->n_u, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_cfg = true;
+  c->cfg_epoch++;
   return MPLX_OK;
 }
 
 extern "C" int mplx_set_capacity(mplx_ctx *c, int32_t n_slots, uint64_t max_nodes, uint64_t max_edges, uint64_t max_log) {
   if (!c) return MPLX_ERR_ARG;
+  c->cfg_epoch++;
   if (n_slots > 0) c->n_slots = n_slots;
   if (max_nodes) c->cap_nodes = max_nodes;
   if (max_edges) c->cap_edges = max_edges;
@@ -690,16 +721,20 @@ extern "C" int mplx_set_capacity(mplx_ctx *c, int32_t n_slots, uint64_t max_node
 }
 extern "C" int mplx_set_bucket_width(mplx_ctx *c, double w) {
   if (!c || w < 0) return MPLX_ERR_ARG;
+  c->cfg_epoch++;
   c->bucket_width = w;
   return MPLX_OK;
 }
 extern "C" int mplx_set_speculation(mplx_ctx *c, int32_t mode) {
   if (!c) return MPLX_ERR_ARG;
+  c->cfg_epoch++;
   c->speculation = mode;
   return MPLX_OK;
 }
 extern "C" int mplx_set_helpers(mplx_ctx *c, int32_t per_leader, int32_t reserved, uint64_t cache_rows) {
   if (!c || !(per_leader == -1 || per_leader == 0 || (per_leader >= 2 && per_leader <= 4))) return fail(c, MPLX_ERR_ARG, "helpers per leader: -1 (auto), 0 (off) or 2..4");
+  MPLX_REFUSE_PENDING(c);  // (pools_valid = false below would re-allocate under the batch in flight)
+  c->cfg_epoch++;
   c->helpers = per_leader;
   c->help_reserved = reserved;
   c->help_rows = cache_rows;
@@ -766,6 +801,93 @@ static void fill_params(const mplx_ctx *c, SearchParams &P) {
     det_sincos(P.yaw_max, &sn, &P.yaw_cos);
   }
   P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt * 8.0 : 1.0);
+  P.guard = c->guard;
+}
+
+// ------------------------------------------------------------------ launch guard, host side
+// Every wait for a SEARCH launch goes through guard_wait(): poll the stream; past the context's deadline raise the abort
+// word (the persistent loops of every search kernel read it and end their query with MPLX_PLAN_ABORTED), give the launch
+// a grace period to leave, and return MPLX_ERR_TIMEOUT with the workgroups' watch records in the error text -- never
+// block for ever (the reference's plan() always returns: mpl_test_node/src/map_planner_node.cpp:186-196).
+static const char *guard_phase_name(uint32_t ph) {
+  switch (ph) {
+    case GUARD_BATCH: return "searching";
+    case GUARD_CLAIM_WAIT: return "waiting for a table claim";
+    case GUARD_ROW_WAIT: return "waiting for a look-ahead row";
+    case GUARD_PROBE: return "table probe ran away";
+    case GUARD_HELPER: return "helping";
+    case GUARD_RECOVER: return "recoverTraj";
+    case GUARD_PULL: return "far-bucket list closes on itself";
+    case GUARD_DONE: return "left";
+    case GUARD_TEST_HANG: return "test spin";
+    case GUARD_START: return "query set-up";
+    default: return "?";
+  }
+}
+static std::string guard_dump(const mplx_ctx *c) {
+  std::string out;
+  int shown = 0, live = 0;
+  for (int i = 0; i < GUARD_SLOTS; i++) {
+    const unsigned long long w0 = __atomic_load_n(&c->guard->rec[i].w0, __ATOMIC_RELAXED), w1 = __atomic_load_n(&c->guard->rec[i].w1, __ATOMIC_RELAXED);
+    if (!w0) continue;
+    live++;
+    if (shown >= 12) continue;
+    char b[160];
+    snprintf(b, sizeof(b), "%s[wg %d: %s, query %u, count %llu, info %llu]", shown ? " " : "", i, guard_phase_name((uint32_t)(w0 >> 56)), (unsigned)((w0 >> 40) & 0xFFFFu),
+             w0 & 0xFFFFFFFFFFull, w1);
+    out += b;
+    shown++;
+  }
+  char b[64];
+  snprintf(b, sizeof(b), " (%d workgroup records)", live);
+  return out + b;
+}
+static void guard_arm(mplx_ctx *c) {  // before a search launch: no abort pending, no record of an earlier launch
+  if (!c->guard) return;
+  memset(c->guard, 0, sizeof(GuardBlock));
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+}
+static int guard_wait(mplx_ctx *c, hipStream_t s, const char *what) {
+  if (c->wedged) return fail(c, MPLX_ERR_TIMEOUT, "this context was lost to a launch that never ended (destroy it)");
+  using clk = std::chrono::steady_clock;
+  const auto t0 = clk::now();
+  const double limit = c->deadline_s, grace = 10.0;
+  bool aborted = false;
+  std::string dump;
+  for (;;) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) return fail(c, MPLX_ERR_HIP, "hipStreamQuery failed while waiting for %s: %s", what, hipGetErrorString(e));
+    const double el = std::chrono::duration<double>(clk::now() - t0).count();
+    if (limit > 0 && !aborted && el > limit) {
+      dump = guard_dump(c);
+      __atomic_store_n(&c->guard->abort, 1u, __ATOMIC_SEQ_CST);
+      aborted = true;
+    }
+    if (aborted && el > limit + grace) {
+      c->wedged = true;
+      c->pending = false;
+      return fail(c, MPLX_ERR_TIMEOUT, "%s did not end within %.1f s and did not answer the abort word for another %.0f s; the context is lost. At the deadline: %s; now: %s", what,
+                  limit, grace, dump.c_str(), guard_dump(c).c_str());
+    }
+    if (el < 0.002) sched_yield();
+    else usleep(el < 0.1 ? 50 : 250);
+  }
+  if (aborted) {
+    __atomic_store_n(&c->guard->abort, 0u, __ATOMIC_SEQ_CST);
+    return fail(c, MPLX_ERR_TIMEOUT, "%s did not end within %.1f s and was aborted (results of the launch are void). At the deadline: %s", what, limit, dump.c_str());
+  }
+  return MPLX_OK;
+}
+extern "C" int mplx_set_deadline(mplx_ctx *c, double seconds) {
+  if (!c) return MPLX_ERR_ARG;
+  c->deadline_s = seconds;
+  return MPLX_OK;
+}
+extern "C" int mplx_debug_hang_next_launch(mplx_ctx *c) {  // (tests) the next search launch spins until the deadline aborts it
+  if (!c) return MPLX_ERR_ARG;
+  c->debug_hang = true;
+  return MPLX_OK;
 }
 
 template <typename T>
@@ -1072,8 +1194,11 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
   }
   SearchParams P = c->pools;
   fill_params(c, P);
+  if (c->wedged) return fail(c, MPLX_ERR_TIMEOUT, "this context was lost to a launch that never ended (destroy it)");
   static const int xflags = getenv("MPLX_X_FLAGS") ? atoi(getenv("MPLX_X_FLAGS")) : 0;
-  P.xflags = xflags;
+  P.xflags = xflags | (c->debug_hang ? 8 : 0);
+  c->debug_hang = false;
+  guard_arm(c);
   if (xflags & 4) P.table = c->table_base + ((c->launch_count++ & 1u) ? (size_t)(P.table_mask + 1) : 0);  // (diagnostic: alternate halves)
   P.cap_rec = c->cap_rec;
   P.nq = nq;
@@ -1189,7 +1314,13 @@ static int plan_batch_finish(mplx_ctx *c, mplx_result *out) {
   }
   c->last_out.resize(nq);
   HIPCHK(c, hipMemcpyAsync(c->last_out.data(), c->d_out, sizeof(QueryOut) * nq, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  {
+    const int rw = guard_wait(c, c->stream, "the search launch");
+    if (rw) {
+      c->last_nq = 0;  // nothing of an aborted launch is handed out
+      return rw;
+    }
+  }
   HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
   if (out)
     for (int i = 0; i < nq; i++) fill_result(c->last_out[i], out[i]);
@@ -1258,6 +1389,7 @@ struct mplx_stream {
   std::vector<int64_t> ticket_of;   // ticket outstanding on each lane (-1: free)
   int64_t next_ticket = 0;
   uint64_t map_epoch = 0;           // the parent's map generation the lanes have adopted
+  uint64_t cfg_epoch = 0;           // the parent's set-up generation the lanes have copied
   std::string err;
 };
 static int sfail(mplx_stream *s, int code, const char *msg) {
@@ -1269,6 +1401,24 @@ extern "C" void mplx_stream_destroy(mplx_stream *s) {
   if (!s) return;
   for (mplx_ctx *l : s->lanes) mplx_ctx_destroy(l);
   delete s;
+}
+// a lane takes the parent's planner set-up (control inputs, limits, tolerances, epsilon, cap) and, when the stream is
+// created, its pool policy (mplx_stream_configure then owns that)
+static int stream_lane_setup(mplx_ctx *parent, mplx_ctx *l, bool pools_too) {
+  mplx_config cfg = parent->cfg;
+  cfg.control = parent->cfg.control | (parent->yaw ? MPLX_YAW : 0);
+  cfg.U = parent->U.data();
+  cfg.U_yaw = parent->yaw ? parent->Uyaw.data() : nullptr;
+  int r = mplx_planner_config(l, &cfg);
+  if (r != MPLX_OK) return r;
+  l->bucket_width = parent->bucket_width;
+  l->speculation = parent->speculation;
+  l->deadline_s = parent->deadline_s;
+  if (pools_too) {
+    l->n_slots = parent->n_slots; l->cap_nodes = parent->cap_nodes; l->cap_edges = parent->cap_edges; l->cap_log = parent->cap_log;
+    l->helpers = parent->helpers; l->help_reserved = parent->help_reserved; l->help_rows = parent->help_rows; l->help_limit = parent->help_limit;
+  }
+  return MPLX_OK;
 }
 extern "C" int mplx_stream_create(mplx_ctx *parent, int depth, mplx_stream **out) {
   if (!parent || !out || depth < 1 || depth > 8) return fail(parent, MPLX_ERR_ARG, "bad argument (depth 1..8)");
@@ -1284,18 +1434,7 @@ extern "C" int mplx_stream_create(mplx_ctx *parent, int depth, mplx_stream **out
       s->lanes.push_back(l);
       r = mplx_map_set_device(l, parent->map, parent->dim, parent->origin, parent->res);  // the parent's replica, adopted: no copy
     }
-    if (r == MPLX_OK) {
-      mplx_config cfg = parent->cfg;
-      cfg.control = parent->cfg.control | (parent->yaw ? MPLX_YAW : 0);
-      cfg.U = parent->U.data();
-      cfg.U_yaw = parent->yaw ? parent->Uyaw.data() : nullptr;
-      r = mplx_planner_config(l, &cfg);
-    }
-    if (r == MPLX_OK) {
-      l->n_slots = parent->n_slots; l->cap_nodes = parent->cap_nodes; l->cap_edges = parent->cap_edges; l->cap_log = parent->cap_log;
-      l->bucket_width = parent->bucket_width; l->speculation = parent->speculation;
-      l->helpers = parent->helpers; l->help_reserved = parent->help_reserved; l->help_rows = parent->help_rows; l->help_limit = parent->help_limit;
-    }
+    if (r == MPLX_OK) r = stream_lane_setup(parent, l, true);
     if (r != MPLX_OK) {
       if (l) parent->err = l->err.empty() ? g_create_error : l->err;
       mplx_stream_destroy(s);
@@ -1304,6 +1443,7 @@ extern "C" int mplx_stream_create(mplx_ctx *parent, int depth, mplx_stream **out
   }
   s->ticket_of.assign((size_t)depth, -1);
   s->map_epoch = parent->map_epoch;
+  s->cfg_epoch = parent->cfg_epoch;
   *out = s;
   return MPLX_OK;
 }
@@ -1337,8 +1477,20 @@ extern "C" int mplx_stream_configure(mplx_stream *s, int32_t n_slots, uint64_t t
 extern "C" int mplx_stream_depth(const mplx_stream *s) { return s ? (int)s->lanes.size() : 0; }
 extern "C" int mplx_stream_submit(mplx_stream *s, int nq, const mplx_waypoint *starts, const mplx_waypoint *goals, int64_t *ticket) {
   if (!s || !ticket) return MPLX_ERR_ARG;
+  // A lane plans with the parent's set-up; what a lane cannot carry is refused, never silently dropped: the auxiliary map
+  // (potential field / search region) belongs to the parent context and its POT kernels run without look-ahead helpers
+  if (s->parent->aux) return sfail(s, MPLX_ERR_ARG, "the parent context has an auxiliary map (potential field / search region): streamed batches do not carry it -- use mplx_plan_batch");
   int rm = stream_follow_map(s);
   if (rm) return rm;
+  if (s->parent->cfg_epoch != s->cfg_epoch) {  // the parent was re-configured since the lanes copied its set-up
+    for (mplx_ctx *l : s->lanes)
+      if (l->pending) return sfail(s, MPLX_ERR_ARG, "the parent context was re-configured while batches of the stream are in flight: wait for them first");
+    for (mplx_ctx *l : s->lanes) {
+      int r = stream_lane_setup(s->parent, l, false);
+      if (r) return sfail(s, r, l->err.c_str());
+    }
+    s->cfg_epoch = s->parent->cfg_epoch;
+  }
   for (size_t k = 0; k < s->lanes.size(); k++) {
     if (s->ticket_of[k] >= 0) continue;
     int r = plan_batch_launch(s->lanes[k], nq, starts, goals);
@@ -1409,6 +1561,7 @@ extern "C" int mplx_plan(mplx_ctx *c, const mplx_waypoint *start, const mplx_way
 
 extern "C" int mplx_result_traj(mplx_ctx *c, int q, mplx_primitive *prs, mplx_waypoint *wps, int32_t *actions, int32_t *node_ids) {
   if (!c || q < 0 || q >= c->last_nq) return fail(c, MPLX_ERR_ARG, "no such query");
+  MPLX_REFUSE_PENDING(c);  // (the batch in flight is overwriting the buffers the last batch's results live in)
   HIPCHK(c, hipSetDevice(c->device));
   const int len = c->last_out[q].traj_len;
   if (c->last_out[q].status != MPLX_PLAN_OK || len <= 0) return MPLX_OK;  // (MPLX_PLAN_TRAJ_TOO_LONG: cost only)
@@ -1456,6 +1609,7 @@ extern "C" int mplx_result_traj(mplx_ctx *c, int q, mplx_primitive *prs, mplx_wa
 
 extern "C" int mplx_result_expanded(mplx_ctx *c, int q, uint32_t cap, int32_t *ids, uint32_t *n) {
   if (!c || q < 0 || q >= c->last_nq || !ids || !n) return fail(c, MPLX_ERR_ARG, "bad argument");
+  MPLX_REFUSE_PENDING(c);
   if (!c->batch_rec || !c->d_rec) return fail(c, MPLX_ERR_ARG, "recording disabled (mplx_set_record)");
   HIPCHK(c, hipSetDevice(c->device));
   uint32_t cnt = c->last_out[q].n_recorded;
@@ -1469,6 +1623,7 @@ extern "C" int mplx_result_expanded(mplx_ctx *c, int q, uint32_t cap, int32_t *i
 // StateSpace predecessor lists of the last single plan: for every node in id order, its edges oldest first
 extern "C" int mplx_result_edges(mplx_ctx *c, int32_t *child, int32_t *parent, int32_t *action, uint64_t cap, uint64_t *n_out) {
   if (!c || !c->last_single || !c->pools_valid || !n_out) return fail(c, MPLX_ERR_ARG, "predecessor dump needs a preceding single mplx_plan()");
+  MPLX_REFUSE_PENDING(c);
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n_nodes = c->last_out[0].n_nodes, n_edges = c->last_out[0].n_edges;
   *n_out = n_edges;
@@ -1527,6 +1682,7 @@ extern "C" int mplx_result_edges(mplx_ctx *c, int32_t *child, int32_t *parent, i
 
 extern "C" int mplx_result_nodes(mplx_ctx *c, uint64_t cap, mplx_waypoint *coords, double *g, double *h, int32_t *closed, int32_t *opened) {
   if (!c || !c->last_single || !c->pools_valid) return fail(c, MPLX_ERR_ARG, "state-space dump needs a preceding single mplx_plan()");
+  MPLX_REFUSE_PENDING(c);
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = c->last_out[0].n_nodes;
   if (n == 0) return MPLX_OK;
@@ -1578,6 +1734,7 @@ extern "C" int mplx_result_nodes(mplx_ctx *c, uint64_t cap, mplx_waypoint *coord
 // blocked primitives reach).  Needs the map and the planner set-up of that plan to be still in place.
 extern "C" int mplx_result_blocked(mplx_ctx *c, int32_t *parent, int32_t *action, uint64_t cap, uint64_t *n_out, uint64_t *n_states_all) {
   if (!c || !c->last_single || !c->pools_valid || !n_out) return fail(c, MPLX_ERR_ARG, "blocked-primitive dump needs a preceding single mplx_plan()");
+  MPLX_REFUSE_PENDING(c);
   if (c->last_control != c->cfg.control || c->last_dt != c->cfg.dt || c->last_U != c->U || c->last_yaw != c->yaw || c->last_Uyaw != c->Uyaw)
     return fail(c, MPLX_ERR_ARG, "the planner was re-configured since the plan: blocked primitives cannot be re-derived");
   if (c->last_map_epoch != c->map_epoch)

@@ -123,6 +123,37 @@ constexpr int cache_row_doubles(int unit_lanes) { return unit_lanes <= 64 ? (MPL
 constexpr int cache_h_slot(int unit_lanes, int lu) { return unit_lanes <= 64 ? (MPLX_X_ROW_PAIRS ? 2 * lu : lu) : 8 + lu; }
 constexpr int cache_reads_slot(int unit_lanes) { return unit_lanes <= 64 ? (MPLX_X_ROW_PAIRS ? 62 : 31) : 4; }
 
+// ---- launch guard (round 5): no entry point may wedge its caller (the reference's plan() always returns:
+// mpl_test_node/src/map_planner_node.cpp:186-196).  One block of HOST-coherent memory per context (hipHostMalloc,
+// mapped): the host raises `abort` when a launch has outlived its deadline; every persistent loop of the search kernels
+// reads it (system-scope load over the fabric: once per 64 batches / expansions on a wave that is off the query's serial
+// chain, and inside every wait loop) and ends the query with MPLX_PLAN_ABORTED.  The kernels leave a watch record per
+// workgroup slot in the same block (a posted system-scope store at the same cadence, and from a wait loop that has
+// spun unusually long): what the host prints when a launch had to be aborted -- it reads its own memory, no copy
+// engine, no stream, nothing that could queue behind the launch it is diagnosing.
+constexpr int GUARD_SLOTS = 2048;
+enum GuardPhase : uint32_t {
+  GUARD_BATCH = 1,       // heartbeat of a leader: count = batches (speculative kernels) / expansions (one-node kernels)
+  GUARD_CLAIM_WAIT = 2,  // look-up waiting for a claim of an earlier batch to be resolved (info: table position)
+  GUARD_ROW_WAIT = 3,    // leader waiting for a look-ahead row to pass its check (info: row)
+  GUARD_PROBE = 4,       // table probe that walked implausibly far (info: steps)
+  GUARD_HELPER = 5,      // helper workgroup serving / looking for a leader (info: box)
+  GUARD_RECOVER = 6,     // recoverTraj
+  GUARD_PULL = 7,        // far-bucket walk (info: rounds)
+  GUARD_DONE = 8,        // the workgroup has left the kernel's query loop
+  GUARD_TEST_HANG = 9,   // the test-only spin of MPLX_X_FLAGS & 8
+  GUARD_START = 10,      // query set-up (start node, table insert)
+};
+struct GuardRec {
+  unsigned long long w0;  // phase << 56 | (query & 0xFFFF) << 40 | count (40 bits)
+  unsigned long long w1;  // phase-specific
+};
+struct GuardBlock {
+  uint32_t abort;   // 0: run; else: end every query now
+  uint32_t pad[15];
+  GuardRec rec[GUARD_SLOTS];
+};
+
 struct SearchParams {
   // environment
   int32_t control, n_u, ns, nk;  // ns: state doubles (without t), nk: key ints
@@ -170,7 +201,9 @@ struct SearchParams {
   int32_t help_limit;             // workgroups of the launch that may turn into helpers once the query queue is empty (-1: no limit);
                                   // counted in cache_next[4].  Streamed batches: the rest exit and leave their compute unit to the next batch
   int32_t xflags;                 // diagnostics (MPLX_X_FLAGS): 1 table probes at agent scope, 2 release / acquire fences around a
-                                  // look-ahead cache record, 4 the launch uses the other half of a doubled state table
+                                  // look-ahead cache record, 4 the launch uses the other half of a doubled state table,
+                                  // 8 (tests) workgroup 0 spins until the host aborts the launch
+  GuardBlock *guard;              // launch guard (host-coherent memory; never null in a product launch)
   // moving-obstacle environment (astar_poly_kernel): the worlds and the world of each query
   PolyDev poly;
   const int32_t *poly_world;

@@ -59,6 +59,23 @@ __device__ __forceinline__ void st_f64x2_agent(double *p, double a, double b) {
   const f64x2 v = {a, b};
   asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
+// ---- launch guard (mplx_device.h GuardBlock): the abort word and this workgroup's watch record live in host-coherent
+// memory; system-scope accesses (sc0 sc1) go over the fabric every time.  A load costs a round trip to the host
+// (microseconds): callers keep it off a query's serial chain or inside a loop that is waiting anyway.
+constexpr int PLAN_ABORTED = 7;  // MPLX_PLAN_ABORTED
+__device__ __forceinline__ bool guard_abort(const SearchParams &P) {
+  return P.guard && __hip_atomic_load(&P.guard->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+}
+__device__ __forceinline__ void guard_mark(const SearchParams &P, uint32_t phase, uint32_t q, unsigned long long count, unsigned long long info) {
+  if (!P.guard) return;
+  GuardRec *r = &P.guard->rec[blockIdx.x & (GUARD_SLOTS - 1)];
+  __hip_atomic_store(&r->w1, info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&r->w0, ((unsigned long long)phase << 56) | ((unsigned long long)(q & 0xFFFFu) << 40) | (count & 0xFFFFFFFFFFull), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// every GUARD_POLL_EVERY-th turn of a wait loop looks at the abort word (a wait loop sleeps ~1 us per turn)
+constexpr uint32_t GUARD_POLL_EVERY = 1024;
+
 __device__ __forceinline__ bool entry_less(double f1, double g1, uint32_t i1, double f2, double g2, uint32_t i2) {
   if (f1 != f2) return f1 < f2;
   if (g1 != g2) return g1 < g2;
@@ -824,7 +841,7 @@ __device__ __forceinline__ void demote_fine(const QView<BLOCK, CONTROL, SM> &Q, 
     uint32_t moved = 0;
     for (int sub = tid; sub < NSUB; sub += BLOCK) {
       uint32_t cur = atomicExch(&Q.bkt_head[(size_t)b * NSUB + sub], NIL);
-      while (cur != NIL) {
+      for (uint32_t hops = 0; cur != NIL && hops <= S.n_log; hops++) {
         const uint32_t nxt = Q.open(cur)->next;
         uint32_t old = atomicExch(&Q.bkt_head[(size_t)c1 * NSUB + (cur & (NSUB - 1))], cur);
         Q.open(cur)->next = old;
@@ -1026,8 +1043,20 @@ __device__ __forceinline__ void pull_bucket(const QView<BLOCK, CONTROL, SM> &Q, 
   uint32_t cur = NIL;
   if (tid < WIDE) cur = atomicExch(&Q.bkt_head[(size_t)code * NSUB + base + tid], NIL);
   __syncthreads();
-  for (;;) {
+  // (a sub-list holds log entries of this query, each at most once: more rounds than the log has entries means a list
+  //  that closes on itself -- corrupted memory -- and ends the query with MPLX_PLAN_INTERNAL instead of spinning)
+  const uint32_t max_rounds = S.n_log + 2u;
+  for (uint32_t rounds = 0;; rounds++) {
     if (!block_any<BLOCK>(cur != NIL, S, tid)) break;
+    if (rounds > max_rounds) {  // (uniform)
+      if (tid == 0) {
+        if (S.status < 0) S.status = 5;
+        guard_mark(Q.P, GUARD_PULL, 0u, S.c_expanded, (unsigned long long)rounds);
+      }
+      cur = NIL;
+      __syncthreads();
+      break;
+    }
     while (S.n_near + (uint32_t)WIDE > (uint32_t)SM::NCAP) {
       MPLX_TIC(te);
       evict_half(Q, tid);
@@ -1156,15 +1185,17 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
     // one-node kernels.  Every claim made here becomes an entry within the same expansion (there are no cut units), so a claim of
     // an EARLIER expansion with this query's tag is an entry store that has not landed yet -- wait for it instead of passing it (and
     // creating the state a second time).  The claim carries the low bits of the expansion count to tell the two apart.
-#if MPLX_X_CLAIM_WAIT_1N
     static_assert(BLOCK <= (1 << CLAIM_BATCH_SHIFT), "the thread index of a claim has nine bits");
-    const uint32_t claim_exp = ((uint32_t)S.c_expanded & CLAIM_BATCH_MASK) << CLAIM_BATCH_SHIFT;
-#else
-    const uint32_t claim_exp = 0u;
-#endif
+    const bool claim_wait = MPLX_X_CLAIM_WAIT_1N || (P.xflags & 64);
+    const uint32_t claim_exp = claim_wait ? ((uint32_t)S.c_expanded & CLAIM_BATCH_MASK) << CLAIM_BATCH_SHIFT : 0u;
     const unsigned long long claim = tagq | (unsigned long long)(CLAIM_BASE + claim_exp + (uint32_t)tid);
     bool first = true;
-    for (;;) {
+    for (uint32_t steps = 0;; steps++) {
+      if (steps > (1u << 22)) {  // (a probe never walks this far in a table four times the node capacity: full of foreign entries)
+        S.status = 5;
+        guard_mark(P, GUARD_PROBE, (uint32_t)q, S.c_expanded, (unsigned long long)pos);
+        break;
+      }
       unsigned long long v = first ? v0 : ld_u64(&P.table[pos]);
       first = false;
       if (v == TBL_EMPTY) {
@@ -1172,14 +1203,16 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
         if (old == TBL_EMPTY) { role = 2; tslot = pos; break; }
         v = old;
       }
-#if MPLX_X_CLAIM_WAIT_1N
-      for (uint32_t polls = 0; (uint32_t)v >= CLAIM_BASE && (uint32_t)v < TBL_DEAD_ID && (v & 0xFFFFFFFF00000000ull) == tagq &&
+      for (uint32_t polls = 0; claim_wait && (uint32_t)v >= CLAIM_BASE && (uint32_t)v < TBL_DEAD_ID && (v & 0xFFFFFFFF00000000ull) == tagq &&
                                ((uint32_t)v & (CLAIM_BATCH_MASK << CLAIM_BATCH_SHIFT)) != claim_exp; polls++) {
         if (polls >= CLAIM_WAIT_POLLS) { S.status = 5; break; }
+        if ((polls & (GUARD_POLL_EVERY - 1u)) == GUARD_POLL_EVERY - 1u) {
+          guard_mark(P, GUARD_CLAIM_WAIT, (uint32_t)q, S.c_expanded, (unsigned long long)pos);
+          if (guard_abort(P)) { S.status = PLAN_ABORTED; break; }
+        }
         __builtin_amdgcn_s_sleep(16);
         v = ld_u64(&P.table[pos]);
       }
-#endif
       const uint32_t vid = (uint32_t)v;
       if (vid < CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
         // one 64 B load answers: same key?  and if so g, h, flags, newest predecessor
@@ -1362,8 +1395,15 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
     return g;
   };
   fill_uq<BLOCK, CONTROL>(P, S, tid);
+  if ((P.xflags & 8) && blockIdx.x == 0 && tid == 0) {  // (tests: a launch that does not end by itself -- the host's deadline must)
+    guard_mark(P, GUARD_TEST_HANG, 0u, 0ull, 0ull);
+    while (!guard_abort(P)) __builtin_amdgcn_s_sleep(127);
+  }
   for (;;) {
-    if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
+    if (tid == 0) {
+      S.q_index = atomicAdd(P.next_query, 1);
+      if (guard_abort(P)) S.q_index = P.nq;  // the host has given up on this launch: take no further query
+    }
     __syncthreads();
     const int qi = S.q_index;
     if (qi >= P.nq) break;
@@ -1434,9 +1474,10 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         const unsigned long long h64 = key_hash64(key, NKY);
         const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
         size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
-        for (;;) {  // shared table: the home slot may belong to another query
+        for (unsigned long long steps = 0;; steps++) {  // shared table: the home slot may belong to another query
           unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, tagq | 0ull);
           if (old == TBL_EMPTY) break;
+          if (steps > P.table_mask) { S.status = 5; break; }  // (the table is full: never with the host's sizing)
           pos = (pos + 1) & (size_t)P.table_mask;
         }
         S.n_nodes = 1;
@@ -1535,6 +1576,10 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
             S.status = 0;
           else if (P.max_expand > 0 && S.c_expanded >= (unsigned long long)P.max_expand)
             S.status = 3;
+          else if ((S.c_expanded & 63ull) == 0ull) {  // launch guard: heartbeat + abort word, every 64th expansion
+            guard_mark(P, GUARD_BATCH, (uint32_t)q, S.c_expanded, (unsigned long long)S.n_nodes);
+            if (guard_abort(P)) S.status = PLAN_ABORTED;
+          }
         }
         __syncthreads();
         if (S.status >= 0) break;
@@ -1563,7 +1608,8 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         while (V::pred(Q.node(node)) != NIL) {
           uint32_t best = NIL;
           double min_rhs = INFINITY, min_g = INFINITY;
-          for (uint32_t e = V::pred(Q.node(node)); e != NIL; e = Q.edge(e)->next) {
+          uint32_t hops = 0;
+          for (uint32_t e = V::pred(Q.node(node)); e != NIL && hops <= S.n_edges; e = Q.edge(e)->next, hops++) {
             const EdgeRec er = *Q.edge(e);
             double gp = V::g(Q.node(er.parent));
             const double ec = P.map.aux ? P.ucost[er.action & EDGE_ACTION_MASK] + P.pot_weight * (double)(er.action >> EDGE_POT_SHIFT) : P.ucost[er.action & EDGE_ACTION_MASK];

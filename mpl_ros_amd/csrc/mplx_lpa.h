@@ -115,7 +115,7 @@ __device__ __forceinline__ uint32_t lpa_find(const unsigned long long *table, un
   constexpr int nk = key_len_c(CONTROL);
   const unsigned long long tagq = (h64 >> 48) << 48;
   size_t pos = (size_t)h64 & (size_t)mask;
-  for (;;) {
+  for (unsigned long long steps = 0; steps <= mask; steps++) {  // (bounded: a full table ends the look-up with "absent")
     const unsigned long long v = ld_u64(&table[pos]);
     if (v == TBL_EMPTY) return NIL;
     const uint32_t vid = (uint32_t)v;
@@ -128,6 +128,7 @@ __device__ __forceinline__ uint32_t lpa_find(const unsigned long long *table, un
     }
     pos = (pos + 1) & (size_t)mask;
   }
+  return NIL;
 }
 
 template <int BLOCK>
@@ -485,7 +486,16 @@ __global__ __launch_bounds__(BLOCK) void lpa_plan_kernel(SearchParams P, LpaPara
       __syncthreads();
     }
     // ---- main loop
+    uint32_t guard_it = 0;
     while (S.status < 0) {
+      if ((++guard_it & 63u) == 0u) {  // launch guard (uniform): heartbeat + the host's abort word, every 64th expansion
+        if (tid == 0) {
+          guard_mark(P, GUARD_BATCH, 0u, S.c_expanded, (unsigned long long)S.n_nodes);
+          if (guard_abort(P)) S.status = PLAN_ABORTED;
+        }
+        __syncthreads();
+        if (S.status >= 0) break;
+      }
       while (S.n_near + S.reserve > (uint32_t)NC) {
         evict_half(Q, tid);
         __syncthreads();
@@ -945,7 +955,16 @@ __global__ __launch_bounds__(BLOCK) void lpa_subtree_kernel(SearchParams P, LpaP
   }
   __syncthreads();
   uint32_t n_blocked = 0;
+  uint32_t guard_it = 0;
   while (S.status < 0) {
+    if ((++guard_it & 63u) == 0u) {  // launch guard (uniform): heartbeat + the host's abort word
+      if (tid == 0) {
+        guard_mark(P, GUARD_BATCH, 0u, (unsigned long long)guard_it, (unsigned long long)S.n_nodes);
+        if (guard_abort(P)) S.status = PLAN_ABORTED;
+      }
+      __syncthreads();
+      if (S.status >= 0) break;
+    }
     while (S.n_near + S.reserve > (uint32_t)NC) {
       evict_half(Q, tid);
       __syncthreads();

@@ -406,6 +406,7 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   PCHK(p, hipMemsetAsync(P.chunk_next, 0, 4 * sizeof(uint32_t), st));
   PCHK(p, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * (size_t)n, hipMemcpyHostToDevice, st));
   PCHK(p, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), st));
+  guard_arm(c);
   PCHK(p, hipEventRecord(c->ev0, st));
   if (n_help > 0) {
     // leaders: one 64-lane workgroup per query on the context's stream; helpers: 256-lane workgroups in a launch of
@@ -426,8 +427,16 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   PCHK(p, hipEventRecord(c->ev1, st));
   c->last_out.resize((size_t)n);
   PCHK(p, hipMemcpyAsync(c->last_out.data(), c->d_out, sizeof(QueryOut) * (size_t)n, hipMemcpyDeviceToHost, st));
-  PCHK(p, hipStreamSynchronize(st));
-  if (n_help > 0) PCHK(p, hipStreamSynchronize(p->help_stream));  // (the helpers leave when their leader has published DONE)
+  if (int rw = guard_wait(c, st, "the moving-obstacle search launch")) {
+    c->last_nq = 0;
+    return pfail(p, rw, "%s", c->err.c_str());
+  }
+  if (n_help > 0) {  // (the helpers leave when their leader has published DONE)
+    if (int rw = guard_wait(c, p->help_stream, "the moving-obstacle helper launch")) {
+      c->last_nq = 0;
+      return pfail(p, rw, "%s", c->err.c_str());
+    }
+  }
   PCHK(p, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
   for (int k = 0; k < n; k++) fill_result(c->last_out[(size_t)k], out[k]);
   c->last_nq = n;

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
             if (next < n) { go = 1; break; }
           }
           if (pv & POLY_PUB_DONE) break;
+          if ((spin & 4095) == 4095 && guard_abort(P)) break;  // launch guard: the host has given up on this launch
           __builtin_amdgcn_s_sleep(32);
         }
         hgo = go;
@@ -111,7 +112,10 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
       qi = took ? P.nq : (int)blockIdx.x;
       took = true;
     } else {
-      if (tid == 0) S.q_index = atomicAdd(P.next_query, 1);
+      if (tid == 0) {
+        S.q_index = atomicAdd(P.next_query, 1);
+        if (guard_abort(P)) S.q_index = P.nq;  // the host has given up on this launch: take no further query
+      }
       __syncthreads();
       qi = S.q_index;
     }
@@ -176,9 +180,10 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
         const unsigned long long h64 = key_hash64(key, NK);
         const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
         size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
-        for (;;) {
+        for (unsigned long long steps = 0;; steps++) {
           unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, tagq | 0ull);
           if (old == TBL_EMPTY) break;
+          if (steps > P.table_mask) { S.status = 5; break; }  // (the table is full: never with the host's sizing)
           pos = (pos + 1) & (size_t)P.table_mask;
         }
         S.n_nodes = 1;
@@ -329,6 +334,10 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
             S.status = 0;
           else if (P.max_expand > 0 && S.c_expanded >= (unsigned long long)P.max_expand)
             S.status = 3;
+          else if ((S.c_expanded & 63ull) == 0ull) {  // launch guard: heartbeat + abort word, every 64th expansion
+            guard_mark(P, GUARD_BATCH, (uint32_t)q, S.c_expanded, (unsigned long long)S.n_nodes);
+            if (guard_abort(P)) S.status = PLAN_ABORTED;
+          }
         }
         __syncthreads();
         if (S.status >= 0) break;
@@ -362,7 +371,8 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
         while (V::pred(Q.node(node)) != NIL) {
           uint32_t best = NIL;
           double min_rhs = INFINITY, min_g = INFINITY;
-          for (uint32_t e = V::pred(Q.node(node)); e != NIL; e = Q.edge(e)->next) {
+          uint32_t hops = 0;
+          for (uint32_t e = V::pred(Q.node(node)); e != NIL && hops <= S.n_edges; e = Q.edge(e)->next, hops++) {
             const EdgeRec er = *Q.edge(e);
             double gp = V::g(Q.node(er.parent));
             double rhs = gp + edge_cost(er.parent, er.action);

@@ -38,6 +38,12 @@
 #ifndef MPLX_X_EARLY_TOMB
 #define MPLX_X_EARLY_TOMB 0   // (A/B, off) TBL_DEAD_ID of an abandoned claim stored ahead of the parallel commit instead of behind it
 #endif
+#ifndef MPLX_X_ROW_FENCE
+#define MPLX_X_ROW_FENCE 0    // look-ahead rows (units of 32 lanes) published behind an agent-scope RELEASE fence (buffer_wbl2 sc1 + s_waitcnt) instead of validated by a check word
+#endif
+// run-time twins of the A/B switches (SearchParams::xflags, MPLX_X_FLAGS): 16 row fence, 32 early tombstone, 64 claim wait in the one-node kernels
+#define MPLX_ROW_FENCE(P) (MPLX_X_ROW_FENCE || ((P).xflags & 16))
+#define MPLX_EARLY_TOMB(P) (MPLX_X_EARLY_TOMB || ((P).xflags & 32))
 #ifndef MPLX_X_EARLY_CLEAR
 #define MPLX_X_EARLY_CLEAR 1  // batch table cleared by the idle waves of the end-of-batch bookkeeping
 #endif
@@ -346,6 +352,10 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
         seq = ld_u64(&B->seq);
         if (!box_active(seq, epoch) || ld_u32(&B->q) != q || ld_u32(P.cache_next) >= P.cache_rows) { go = 0; break; }
         if (seq != last_seq) break;
+        if ((spin & 255) == 255) {  // launch guard: the host has given up on this launch
+          guard_mark(P, GUARD_HELPER, q, (unsigned long long)spin, (unsigned long long)S.help_box);
+          if (guard_abort(P)) { S.help_quit = 1; go = 0; break; }
+        }
         // poll gently: every few microseconds (a leader's batch takes ~25)
         for (int z = 0; z < (spin < 8 ? 1 : 4); z++) __builtin_amdgcn_s_sleep(127);
         if (spin > HELP_STALL_POLLS) {  // the leader makes no progress: leave the launch
@@ -447,7 +457,7 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has landed before the record names it
       // (large lattices: the row carries the masks as well and has no check word yet -- a full agent-scope release instead)
-      if (UL > 64 || (P.xflags & 2)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (UL > 64 || (P.xflags & 2) || MPLX_ROW_FENCE(P)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       unit_sync<UL>();
       if (rp1 && lu == 0) {
         unsigned long long *cr = (unsigned long long *)&P.cache_c[rec];
@@ -477,7 +487,7 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
       else if (expired) atomicAdd(P.cache_next + 3, 1u);  // (diagnostics) helpers that found every leader served
       const unsigned long long dw = ld_u64(P.done_word);
       const bool done = (uint32_t)(dw >> 32) == P.epoch && (uint32_t)dw >= (uint32_t)P.nq;
-      S.flag = (expired || done || ld_u32(P.cache_next) >= P.cache_rows) ? 1 : 0;
+      S.flag = (expired || done || ld_u32(P.cache_next) >= P.cache_rows || ((S.help_idle & 15) == 15 && guard_abort(P))) ? 1 : 0;
     }
     __syncthreads();
     if (S.flag) return;
@@ -599,6 +609,10 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
     return g;
   };
   fill_uq<BLOCK, CONTROL>(P, S, tid);
+  if ((P.xflags & 8) && blockIdx.x == 0 && tid == 0) {  // (tests: a launch that does not end by itself -- the host's deadline must)
+    guard_mark(P, GUARD_TEST_HANG, 0u, 0ull, 0ull);
+    while (!guard_abort(P)) __builtin_amdgcn_s_sleep(127);
+  }
   if (tid == 0) {
     unsigned long long pw = 1ull;
     for (int e = 0; e < 17; e++) { S.hpow[e] = pw; pw *= 0x100000001B3ull; }
@@ -606,7 +620,10 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
   for (;;) {
     if (tid == 0) {
       if (HELP && (int)blockIdx.x >= P.help_lead) S.q_index = P.nq;  // a workgroup launched to help only (batch smaller than the machine)
-      else S.q_index = atomicAdd(P.next_query, 1);
+      else {
+        S.q_index = atomicAdd(P.next_query, 1);
+        if (guard_abort(P)) S.q_index = P.nq;  // launch guard: the host has given up on this launch, take no further query
+      }
     }
     __syncthreads();
     const int qi = S.q_index;
@@ -703,9 +720,10 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         const unsigned long long h64 = key_hash64(key, NKY);
         const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
         size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
-        for (;;) {
+        for (unsigned long long steps = 0;; steps++) {
           unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, tagq | 0ull);
           if (old == TBL_EMPTY) break;
+          if (steps > P.table_mask) { S.status = 5; break; }  // (the table is full: never with the host's sizing)
           pos = (pos + 1) & (size_t)P.table_mask;
         }
         S.n_nodes = 1;
@@ -763,6 +781,12 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           if (!ok && S.status < 0) S.status = 4;  // MPLX_PLAN_POOL_FULL
           if constexpr (HELP) {  // (the helper flag: an agent-scope load, every eighth batch)
             if (tid == 192 && (S.cyc[7] & 7ull) <= 1ull) S.helped = ld_u32(&(P.boxes + blockIdx.x)->helpers) != 0u;
+          }
+          // launch guard: heartbeat (posted store) and the host's abort word (a load over the fabric), every 64th batch, on a
+          // wave that only waits for thread 0's counters here
+          if (tid == 192 && (S.cyc[7] & 63ull) <= 1ull) {
+            guard_mark(P, GUARD_BATCH, (uint32_t)q, S.cyc[7], S.c_expanded);
+            if (guard_abort(P) && S.status < 0) S.status = PLAN_ABORTED;
           }
         }
 #if MPLX_X_EARLY_CLEAR
@@ -1255,7 +1279,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           // (Placed here, not right after the expansion: the row's agent-scope loads keep travelling during the scans and the
           //  batch-table insert above.)
           const uint32_t rp1 = live_unit ? S.hc_row[ku] : 0u;  // (the same for the 32 lanes of the unit)
-          if (rp1) {
+          if (rp1 && !MPLX_ROW_FENCE(P)) {
             const double *row = P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL);
             const bool want = act && P.eps != 0.0;  // (the lanes whose heuristic was asked for: the record's masks are L.valid / L.blocked now)
             const uint32_t khash = (uint32_t)key_hash64(S.cur_key[ku], nk);
@@ -1267,6 +1291,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
                 if (lu == 0) S.status = 5;
                 break;
               }
+              if ((polls & (GUARD_POLL_EVERY - 1u)) == GUARD_POLL_EVERY - 1u && lu == 0) guard_mark(P, GUARD_ROW_WAIT, (uint32_t)q, S.cyc[7], (unsigned long long)rp1);
               __builtin_amdgcn_s_sleep(16);
               if (want) h_row = ld_f64_agent(&row[cache_h_slot(UL, lu)]);
               if (lu == 0) {
@@ -1350,7 +1375,12 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
             atomicMax(&S.arr_heur, (unsigned long long)__builtin_readcyclecounter());
 #endif
             bool first = true;
-            for (;;) {
+            for (uint32_t steps = 0;; steps++) {
+              if (steps > (1u << 22)) {  // (a probe never walks this far in a table four times the node capacity)
+                S.status = 5;
+                guard_mark(P, GUARD_PROBE, (uint32_t)q, S.cyc[7], (unsigned long long)pos);
+                break;
+              }
               unsigned long long v = first ? v0 : (P.xflags & 1) ? ld_u64(&P.table[pos]) : ld_u64_probe(&P.table[pos]);
               if (v == TBL_EMPTY) {
                 unsigned long long old = (first && did_cas0) ? cas0 : atomicCAS(&P.table[pos], TBL_EMPTY, claim);
@@ -1383,6 +1413,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
                 for (uint32_t polls = 0; (uint32_t)v >= CLAIM_BASE && (uint32_t)v < TBL_DEAD_ID && (v & 0xFFFFFFFF00000000ull) == tagq &&
                                          ((uint32_t)v & (CLAIM_BATCH_MASK << CLAIM_BATCH_SHIFT)) != claim_batch; polls++) {
                   if (polls >= CLAIM_WAIT_POLLS) { S.status = 5; break; }  // (never seen: a claim nobody resolved)
+                  if ((polls & (GUARD_POLL_EVERY - 1u)) == GUARD_POLL_EVERY - 1u) guard_mark(P, GUARD_CLAIM_WAIT, (uint32_t)q, S.cyc[7], (unsigned long long)pos);
                   __builtin_amdgcn_s_sleep(16);
                   v = ld_u64(&P.table[pos]);
                 }
@@ -1563,20 +1594,18 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           }
           const bool mine = ku < k_stop && S.cand_live[opaque(ku)];
           if (mine && lu == 0) V::flags(Q.node(S.cand_id[ku])) = S.cand_fl[ku] | FLAG_CLOSED;
-#if MPLX_X_EARLY_TOMB
-          if (act && mine) atomicOr(&S.bt_dirty[my_slot], 2u);  // (bit 1, free in the parallel commit: a committed unit reaches this state)
-#endif
+          if (MPLX_EARLY_TOMB(P)) {
+            if (act && mine) atomicOr(&S.bt_dirty[my_slot], 2u);  // (bit 1, free in the parallel commit: a committed unit reaches this state)
+          }
           MPLX_T2(S, 8, t2);
           __syncthreads();  // everyone has read status / u_cut before they change
           MPLX_T2(S, 9, t2);
-#if MPLX_X_EARLY_TOMB
           // a slot claimed for a state no committed unit reaches: its TBL_DEAD_ID goes out with the commit's own stores (behind the
           // commit's barrier its write-through acknowledgement would be the first thing the next batch waits for)
-          if (claimed_new && !(S.bt_dirty[my_slot] & 2u)) {
+          if (MPLX_EARLY_TOMB(P) && claimed_new && !(S.bt_dirty[my_slot] & 2u)) {
             st_u64(&P.table[claimed_pos], (((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32)) | (unsigned long long)TBL_DEAD_ID);
             claimed_new = false;
           }
-#endif
           spec_commit_lanes<UL, K, CONTROL, true, HELP, YAW>(Q, S, tid, q, ku, act && mine, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old, (int)(batch_no & 1u));
           if (tid == 0 && st_after >= 0) S.status = st_after;
           MPLX_T2(S, 10, t2);
@@ -1710,7 +1739,8 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         while (V::pred(Q.node(node)) != NIL) {
           uint32_t best = NIL;
           double min_rhs = INFINITY, min_g = INFINITY;
-          for (uint32_t e = V::pred(Q.node(node)); e != NIL; e = Q.edge(e)->next) {
+          uint32_t hops = 0;
+          for (uint32_t e = V::pred(Q.node(node)); e != NIL && hops <= S.n_edges; e = Q.edge(e)->next, hops++) {
             const EdgeRec er = *Q.edge(e);
             double gp = V::g(Q.node(er.parent));
             const double ec = (POT && P.map.aux) ? P.ucost[er.action & EDGE_ACTION_MASK] + P.pot_weight * (double)(er.action >> EDGE_POT_SHIFT) : P.ucost[er.action & EDGE_ACTION_MASK];

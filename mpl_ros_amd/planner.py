@@ -744,6 +744,17 @@ class VoxelMapPlanner:
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_helper_limit(ctx.h, int(limit)))
 
+    def setDeadline(self, seconds):
+        """Launch guard: a search launch older than `seconds` is aborted and the call raises MplxError (MPLX_ERR_TIMEOUT) with
+        the workgroups' watch records; <= 0: wait for ever.  Default 120 s (environment MPLX_DEADLINE_S)."""
+        ctx = self._ctx()
+        ctx.check(ctx.lib.mplx_set_deadline(ctx.h, float(seconds)))
+
+    def _debugHangNextLaunch(self):
+        """(tests) the next search launch spins until the deadline aborts it."""
+        ctx = self._ctx()
+        ctx.check(ctx.lib.mplx_debug_hang_next_launch(ctx.h))
+
     def releasePools(self):
         """Give the context's device pools back (re-created by the next plan): room for a stream's lanes."""
         ctx = self._ctx()
@@ -1002,6 +1013,11 @@ class PlanStream:
 
     def submit_c(self, S, G, n):
         """submit with pre-marshalled ctypes arrays (a steady stream re-uses them)"""
+        # setters called on the planner since its last plan reach the parent context now; the C side then hands the
+        # set-up to the (idle) lanes -- a streamed batch always plans with what planBatch would plan with
+        if self._pl._dirty and self._pl._control is not None:
+            self._pl._configure(self._pl._control)
+        self._pl._apply_aux()
         t = C.c_int64(-1)
         self._check(self.lib.mplx_stream_submit(self.h, n, S, G, C.byref(t)))
         self._n[t.value] = n

@@ -92,3 +92,31 @@ def test_submit_wait_is_plan_batch_and_a_stream_overlaps_batches_without_changin
     assert [_tuple(r) for r in pl.planBatch(*wps[0])] == ref[0]
     pl.releasePools()
     assert [_tuple(r) for r in pl.planBatch(*wps[0])] == ref[0]
+
+
+@pytest.mark.gpu
+def test_stream_lanes_follow_the_parents_setup_and_refuse_an_auxiliary_map():
+    """a PlanStream must plan with what planBatch would plan with.  Setters called on the planner after stream() reach
+    the lanes with the next submit (epsilon, max_num here); a potential field -- which the lanes cannot carry -- makes the
+    submit fail loudly instead of planning without it."""
+    from mpl_ros_amd._capi import MplxError
+    grid, origin, res = util.small_map(64, seed=5)
+    U = mapgen.control_lattice(1.0, 1, True)
+    mu, pl = util.make_gpu(grid, origin, res, U, n_slots=32, max_nodes=1 << 21, max_edges=1 << 23, max_log=1 << 22, max_expand=30000, **KW)
+    qs = _queries(grid, origin, res, 24, 77)
+    S, G = [util.gpu_wp(s) for s, _ in qs], [util.gpu_wp(g) for _, g in qs]
+    ref = [_tuple(r) for r in pl.planBatch(S, G)]
+    st = pl.stream(2)
+    st.configure(32, 1 << 21, 1 << 23, 1 << 22, -1, 0, 0, -1)
+    assert [_tuple(r) for r in st.wait(st.submit(S, G))] == ref
+    pl.setEpsilon(2.0)
+    pl.setMaxNum(4000)
+    got = [_tuple(r) for r in st.wait(st.submit(S, G))]  # (the submit carries the new set-up to the idle lanes)
+    ref2 = [_tuple(r) for r in pl.planBatch(S, G)]
+    assert got == ref2 and ref2 != ref
+    pl.setPotentialRadius((0.4, 0.4, 0.3)); pl.setPotentialWeight(3.0)
+    pl.updatePotentialMap((2.0, 2.0, 2.0))
+    with pytest.raises(MplxError) as e:
+        st.submit(S, G)
+    assert "auxiliary map" in str(e.value)
+    st.close()
