@@ -69,7 +69,7 @@ EXPORTS = [
     "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms", "mplx_poly_result_cycles", "mplx_poly_set_helpers", "mplx_poly_last_helpers",
     "mplx_traj_solve", "mplx_traj_sample", "mplx_traj_effort",
     "mplx_plan_batch_submit", "mplx_plan_batch_wait", "mplx_plan_batch_done", "mplx_set_helper_limit", "mplx_release_pools",
-    "mplx_set_deadline", "mplx_debug_hang_next_launch",
+    "mplx_set_deadline", "mplx_debug_hang_next_launch", "mplx_debug_query_records",
     "mplx_stream_create", "mplx_stream_destroy", "mplx_stream_last_error", "mplx_stream_depth", "mplx_stream_configure",
     "mplx_stream_submit", "mplx_stream_done", "mplx_stream_wait",
 ]
@@ -217,6 +217,7 @@ def load():
     L.mplx_release_pools.argtypes = [P]
     L.mplx_set_deadline.argtypes = [P, C.c_double]
     L.mplx_debug_hang_next_launch.argtypes = [P]
+    L.mplx_debug_query_records.argtypes = [P, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     L.mplx_stream_create.argtypes = [P, C.c_int, C.POINTER(P)]
     L.mplx_stream_destroy.argtypes = [P]
     L.mplx_stream_destroy.restype = None

@@ -1195,7 +1195,7 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
   SearchParams P = c->pools;
   fill_params(c, P);
   if (c->wedged) return fail(c, MPLX_ERR_TIMEOUT, "this context was lost to a launch that never ended (destroy it)");
-  static const int xflags = getenv("MPLX_X_FLAGS") ? atoi(getenv("MPLX_X_FLAGS")) : 0;
+  const int xflags = getenv("MPLX_X_FLAGS") ? atoi(getenv("MPLX_X_FLAGS")) : 0;  // (diagnostics; read per launch so that a probe can switch between runs)
   P.xflags = xflags | (c->debug_hang ? 8 : 0);
   c->debug_hang = false;
   guard_arm(c);
@@ -1305,6 +1305,15 @@ static int plan_batch_finish(mplx_ctx *c, mplx_result *out) {
   HIPCHK(c, hipSetDevice(c->device));
   const int nq = c->pend_nq;
   c->pending = false;  // (whatever happens below, the batch is not outstanding any more)
+  // Wait for the launch FIRST, with nothing else queued behind it: a device-to-host copy into pageable memory blocks its
+  // caller until the stream has drained, which would put the host to sleep inside the very call the guard must watch.
+  {
+    const int rw = guard_wait(c, c->stream, "the search launch");
+    if (rw) {
+      c->last_nq = 0;  // nothing of an aborted launch is handed out
+      return rw;
+    }
+  }
   if (c->pend_help) {
     HIPCHK(c, hipMemcpyAsync(c->help_ctr_back, c->pools.cache_next, HELP_CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     c->help_stats_pending = true;
@@ -1314,13 +1323,7 @@ static int plan_batch_finish(mplx_ctx *c, mplx_result *out) {
   }
   c->last_out.resize(nq);
   HIPCHK(c, hipMemcpyAsync(c->last_out.data(), c->d_out, sizeof(QueryOut) * nq, hipMemcpyDeviceToHost, c->stream));
-  {
-    const int rw = guard_wait(c, c->stream, "the search launch");
-    if (rw) {
-      c->last_nq = 0;  // nothing of an aborted launch is handed out
-      return rw;
-    }
-  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // (copies only: the launch has ended)
   HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
   if (out)
     for (int i = 0; i < nq; i++) fill_result(c->last_out[i], out[i]);
@@ -1722,6 +1725,32 @@ extern "C" int mplx_result_nodes(mplx_ctx *c, uint64_t cap, mplx_waypoint *coord
       }
     }
   }
+  return MPLX_OK;
+}
+
+// (diagnostics) the raw node records of query q of the last batch -- {g, h, flags, pred, key[], state...} as the kernels
+// keep them (mplx_device.h) -- for offline consistency checks: keys against states, duplicate keys.  *rec_size: bytes per
+// record; bytes: room for *n_records x *rec_size (MPLX_ERR_CAPACITY, with the counts filled in, when cap_bytes is too small).
+extern "C" int mplx_debug_query_records(mplx_ctx *c, int q, uint64_t cap_bytes, void *bytes, uint64_t *n_records, int32_t *rec_size) {
+  if (!c || q < 0 || q >= c->last_nq || !c->pools_valid || !n_records || !rec_size) return fail(c, MPLX_ERR_ARG, "bad argument / no batch / pools released");
+  MPLX_REFUSE_PENDING(c);
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = c->last_out[q].n_nodes;
+  const int rb = rec_bytes(c->pool_control);
+  *n_records = n;
+  *rec_size = rb;
+  if ((uint64_t)n * rb > cap_bytes || !bytes) return fail(c, MPLX_ERR_CAPACITY, "record dump: %zu records of %d bytes", n, rb);
+  std::vector<uint32_t> tbl(MAX_NODE_CH);
+  HIPCHK(c, hipMemcpyAsync(tbl.data(), c->d_node_tables + (size_t)q * MAX_NODE_CH, sizeof(uint32_t) * MAX_NODE_CH, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t per = (size_t)1 << NODE_CH_LOG;
+  for (size_t base = 0; base < n; base += per) {
+    const size_t cnt = n - base < per ? n - base : per;
+    const uint32_t ch = tbl[base >> NODE_CH_LOG];
+    if (ch == NIL) return fail(c, MPLX_ERR_ARG, "inconsistent chunk table");
+    HIPCHK(c, hipMemcpyAsync((char *)bytes + base * rb, c->pools.node_pool + ((size_t)ch << NODE_CH_LOG) * rb, cnt * rb, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return MPLX_OK;
 }
 

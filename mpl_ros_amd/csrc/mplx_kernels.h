@@ -54,10 +54,17 @@ __device__ __forceinline__ double ld_f64_agent(const double *p) { return __longl
 __device__ __forceinline__ void st_f64_agent(double *p, double v) { st_u64((unsigned long long *)p, (unsigned long long)__double_as_longlong(v)); }
 // two f64 through ONE 16-byte agent-scope (sc1, write-through) store: half the write-through transactions of two
 // st_f64_agent (an 8-byte sc1 store is counted -- and carried -- as a partial-line write of its own).  p is 16-byte aligned.
+// The `s_nop 1` INSIDE the string is not padding: a store of more than 8 bytes reads its data registers for two more cycles
+// after it issues, and a vector instruction that overwrites them in that window changes what is stored.  For its own stores the
+// compiler's hazard recogniser inserts the two wait states (gfx940+); it cannot see into an asm string, and the four registers
+// of `v` are dead after the statement -- exactly what it reuses for the next pair.  Until round 5 the string ended with the
+// store: under back-pressure from the memory pipeline (a neighbour's hipMemset, a saturated write queue) a node's state doubles
+// reached memory wrong now and then, the node expanded into successors with other keys ("states created twice": more states,
+// same edges), and a garbage position could ask for billions of samples -- the stall of round 4's driver run.  DESIGN.md 3.9.
 __device__ __forceinline__ void st_f64x2_agent(double *p, double a, double b) {
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   const f64x2 v = {a, b};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 // ---- launch guard (mplx_device.h GuardBlock): the abort word and this workgroup's watch record live in host-coherent
 // memory; system-scope accesses (sc0 sc1) go over the fabric every time.  A load costs a round trip to the host
@@ -1293,9 +1300,11 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
       V::flags(rec) = fl;
     }
   }
+  // (read ahead of the scan's barriers: thread 0 stores the new total at the end of this function, and nothing else separates
+  //  that store from a slower wave's read -- see spec_commit_lanes)
+  const uint32_t base_log = S.n_log;
   uint32_t total_p;
   uint32_t sp = block_excl_scan<BLOCK>(improved ? 1u : 0u, S, tid, total_p);
-  const uint32_t base_log = S.n_log;
   if (improved) open_push(Q, base_log + sp, tg + P.eps * hval, tg, id);
   if (tid == 0) {
     S.n_nodes = base_nodes + n_new;

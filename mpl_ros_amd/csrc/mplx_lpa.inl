@@ -229,13 +229,15 @@ extern "C" int mplx_lpa_plan(mplx_lpa *l, const mplx_waypoint *start, const mplx
   if (!mplx_launch_lpa(0, 0, c->stream, P, A)) return lfail(l, MPLX_ERR_ARG, "LPA* supports lattices of at most 128 control inputs (got %d)", P.n_u);
   LCHK(l, hipGetLastError());
   LCHK(l, hipEventRecord(c->ev1, c->stream));
-  LCHK(l, hipMemcpyAsync(&l->last_out, l->d_out, sizeof(QueryOut), hipMemcpyDeviceToHost, c->stream));
-  LCHK(l, hipMemcpyAsync(&l->st, A.st, sizeof(LpaState), hipMemcpyDeviceToHost, c->stream));
+  // (the guarded wait first: a device-to-host copy into pageable memory would block the host until the stream has drained)
   if (int rw = guard_wait(c, c->stream, "the LPA* search launch")) {  // aborted: the space was left in the middle of an expansion
     l->valid = false;
     l->traj_len = 0;
     return lfail(l, rw, "%s", c->err.c_str());
   }
+  LCHK(l, hipMemcpyAsync(&l->last_out, l->d_out, sizeof(QueryOut), hipMemcpyDeviceToHost, c->stream));
+  LCHK(l, hipMemcpyAsync(&l->st, A.st, sizeof(LpaState), hipMemcpyDeviceToHost, c->stream));
+  LCHK(l, hipStreamSynchronize(c->stream));
   LCHK(l, hipEventElapsedTime(&l->last_ms, c->ev0, c->ev1));
   fill_result(l->last_out, *out);
   if (fresh) {  // whatever the outcome, the old space is gone
@@ -331,11 +333,12 @@ extern "C" int mplx_lpa_sub_state_space(mplx_lpa *l, int32_t time_step) {
   if (!mplx_launch_lpa(2, 0, c->stream, P, A)) return lfail(l, MPLX_ERR_ARG, "lattice too wide for LPA*");
   LCHK(l, hipGetLastError());
   LpaState ns{};
-  LCHK(l, hipMemcpyAsync(&ns, A.st, sizeof(LpaState), hipMemcpyDeviceToHost, c->stream));
   if (int rw = guard_wait(c, c->stream, "the LPA* sub-state-space launch")) {
     l->valid = false;
     return lfail(l, rw, "%s", c->err.c_str());
   }
+  LCHK(l, hipMemcpyAsync(&ns, A.st, sizeof(LpaState), hipMemcpyDeviceToHost, c->stream));
+  LCHK(l, hipStreamSynchronize(c->stream));
   if (!ns.valid) {
     l->valid = false;
     return lfail(l, MPLX_ERR_CAPACITY, "LPA* pools exhausted while rebuilding the sub state space (mplx_lpa_set_capacity)");

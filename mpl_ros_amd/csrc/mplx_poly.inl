@@ -426,7 +426,7 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   PCHK(p, hipGetLastError());
   PCHK(p, hipEventRecord(c->ev1, st));
   c->last_out.resize((size_t)n);
-  PCHK(p, hipMemcpyAsync(c->last_out.data(), c->d_out, sizeof(QueryOut) * (size_t)n, hipMemcpyDeviceToHost, st));
+  // (the guarded waits first: a device-to-host copy into pageable memory would block the host until the stream has drained)
   if (int rw = guard_wait(c, st, "the moving-obstacle search launch")) {
     c->last_nq = 0;
     return pfail(p, rw, "%s", c->err.c_str());
@@ -437,6 +437,8 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
       return pfail(p, rw, "%s", c->err.c_str());
     }
   }
+  PCHK(p, hipMemcpyAsync(c->last_out.data(), c->d_out, sizeof(QueryOut) * (size_t)n, hipMemcpyDeviceToHost, st));
+  PCHK(p, hipStreamSynchronize(st));
   PCHK(p, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
   for (int k = 0; k < n; k++) fill_result(c->last_out[(size_t)k], out[k]);
   c->last_nq = n;

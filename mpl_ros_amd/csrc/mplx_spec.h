@@ -154,6 +154,16 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
     tg = pre.tg;
     improved = tg < old_g;
   }
+  // The pool counters this commit starts from are read HERE, ahead of the scan's barrier: the lane that publishes the new totals
+  // at the end of this function belongs to ONE wave, and nothing but that barrier separates its store from the other waves'
+  // reads.  [Until round 5 the three reads stood behind the scan: a wave that fell behind its publisher -- a unit of 128 lanes is
+  // two waves, the parallel commit is all of them; a memory pipeline under back-pressure is what makes a wave fall behind --
+  // started from the UPDATED counters: its states, predecessor and log records landed past the new totals (holes of unwritten
+  // records behind them, the records themselves overwritten by the next batch).  Found in round 5 on the 1024-query jerk batch
+  // (<128,4,JRK,help>: 20-60 queries differing from run to run, runs of 7-110 all-zero node records in their pools; the
+  // helper-less build of the same source happened to be scheduled the other way round), and the likeliest origin of round 4's
+  // "states created twice under a background fill load" as well.]
+  const uint32_t base_nodes = S.n_nodes, base_edges = S.n_edges, base_log = S.n_log;
   // PAR: every committing unit at once (units proven independent), ids from a workgroup scan in
   // (unit, lane) order = the order the unit-by-unit loop would assign
   uint32_t total;
@@ -178,7 +188,6 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
   } else {
     sc = unit_excl_scan<UL, BLOCK>(packed, S, tid, total);
   }
-  const uint32_t base_nodes = S.n_nodes, base_edges = S.n_edges, base_log = S.n_log;
   uint32_t chain_next = old_pred;
   bool write_pred = true;
   if (PAR && S.any_shared) {  // (uniform) two lanes append an edge to one state: chain them in thread order
@@ -201,8 +210,8 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
       for (int i = 0; i < nk; i++) kk[i] = L.key[i];
       if constexpr (YAW) kk[nk] = L.yaw_key;
       double *st = V::state(rec);
-      if constexpr (HELP) {  // helper workgroups on other compute units read the state: agent-scope (write-through) stores,
-        // 16 bytes at a time (the state starts on a 64-byte boundary of the record)
+      if (HELP && !(P.xflags & 512)) {  // helper workgroups on other compute units read the state: agent-scope (write-through) stores,
+        // 16 bytes at a time (the state starts on a 64-byte boundary of the record)   [MPLX_X_FLAGS & 512, diagnostics: plain stores]
         auto sv = [&](int i) { return i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3]; };
 #pragma unroll
         for (int i = 0; i + 1 < ns; i += 2) st_f64x2_agent(&st[i], sv(i), sv(i + 1));
@@ -608,6 +617,21 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
     if (YAW && g && P.tol_yaw >= 0) g = fabs(yaw - S.hp.goal_yaw) <= P.tol_yaw;
     return g;
   };
+  // A node's state doubles: the HELP builds write them with agent-scope (write-through) stores, for the helper workgroups -- and
+  // such a store does not refresh a copy of the line in this compute unit's own L1 (round 3 found that for the table slots).  A record
+  // whose size is not a multiple of the L1 line (160-byte jerk-state records, 128-byte lines) shares its first line with the tail of
+  // the record before it: reading THAT record's last doubles pulls the line in, and when the neighbour is created afterwards -- at a
+  // batch boundary -- a plain load of its position returns what the pool held before (another query's state of the previous launch,
+  // or garbage: a sample count of billions, i.e. a launch that "hangs").  Round 5 found 34-37 of the 1024 queries of the C4-JRK batch
+  // differing from run to run that way; the 128-byte records of the ACC builds are line-aligned and were never exposed.  The leader
+  // therefore reads state doubles past the L1 whenever they were stored past it.  (MPLX_X_FLAGS & 128: the old plain loads, to show
+  // the difference.)
+  auto ld_state = [&](const double *p) -> double {
+    if constexpr (HELP) {
+      if (!(P.xflags & 128)) return ld_f64_agent(p);
+    }
+    return *p;
+  };
   fill_uq<BLOCK, CONTROL>(P, S, tid);
   if ((P.xflags & 8) && blockIdx.x == 0 && tid == 0) {  // (tests: a launch that does not end by itself -- the host's deadline must)
     guard_mark(P, GUARD_TEST_HANG, 0u, 0ull, 0ull);
@@ -923,7 +947,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           char *prec = Q.node(pf_id);
           pf_g = V::g(prec);
           pf_fl = V::flags(prec);
-          if (lu <= ns + EX) pf_s = V::state(prec)[lu];
+          if (lu <= ns + EX) pf_s = ld_state(&V::state(prec)[lu]);
           if (lu < NKY) pf_k = V::key(prec)[lu];
           if constexpr (HELP) {
             if (S.helped && lu == UL - 1) {
@@ -1113,7 +1137,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
             char *rec = Q.node(cid);
             rg = V::g(rec);
             fl = V::flags(rec);
-            if (lu <= ns + EX) sval = V::state(rec)[lu];
+            if (lu <= ns + EX) sval = ld_state(&V::state(rec)[lu]);
             if (lu < NKY) kval = V::key(rec)[lu];
             if constexpr (HELP) {
               if (S.helped && lu == UL - 1) {
@@ -1151,7 +1175,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         if constexpr (HELP) {
           // did a helper expand this node ahead of time?  The entry must be of THIS state: the helper's hash of the
           // key of the state it expanded against the candidate's own key (guards against anything stale on its side)
-          if (live_unit && S.helped && lu == UL - 1 && (uint32_t)hc_a != 0u && ((uint32_t)hc_b & CACHE_READY) &&
+          if (live_unit && S.helped && !(P.xflags & 256) && lu == UL - 1 && (uint32_t)hc_a != 0u && ((uint32_t)hc_b & CACHE_READY) &&  // [MPLX_X_FLAGS & 256, diagnostics: no hit is taken]
               (uint32_t)(hc_a >> 32) == (uint32_t)key_hash64(S.cur_key[ku], nk)) {
             S.hc_row[ku] = (uint32_t)hc_a;
             S.hc_valid[ku] = (uint32_t)hc_b;
@@ -1279,7 +1303,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           // (Placed here, not right after the expansion: the row's agent-scope loads keep travelling during the scans and the
           //  batch-table insert above.)
           const uint32_t rp1 = live_unit ? S.hc_row[ku] : 0u;  // (the same for the 32 lanes of the unit)
-          if (rp1 && !MPLX_ROW_FENCE(P)) {
+          if (rp1 && !MPLX_ROW_FENCE(P) && !(P.xflags & 1024)) {  // [MPLX_X_FLAGS & 1024, measurement: the row is not checked (round 3's protocol)]
             const double *row = P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL);
             const bool want = act && P.eps != 0.0;  // (the lanes whose heuristic was asked for: the record's masks are L.valid / L.blocked now)
             const uint32_t khash = (uint32_t)key_hash64(S.cur_key[ku], nk);
@@ -1410,7 +1434,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
               // batches under a background fill load, streamed batches -- profiles/r04s_*); wait for the store instead.
               if ((uint32_t)v >= CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
                 v = ld_u64(&P.table[pos]);
-                for (uint32_t polls = 0; (uint32_t)v >= CLAIM_BASE && (uint32_t)v < TBL_DEAD_ID && (v & 0xFFFFFFFF00000000ull) == tagq &&
+                for (uint32_t polls = 0; !(P.xflags & 2048) /* [measurement: no wait, round 3's rule] */ && (uint32_t)v >= CLAIM_BASE && (uint32_t)v < TBL_DEAD_ID && (v & 0xFFFFFFFF00000000ull) == tagq &&
                                          ((uint32_t)v & (CLAIM_BATCH_MASK << CLAIM_BATCH_SHIFT)) != claim_batch; polls++) {
                   if (polls >= CLAIM_WAIT_POLLS) { S.status = 5; break; }  // (never seen: a claim nobody resolved)
                   if ((polls & (GUARD_POLL_EVERY - 1u)) == GUARD_POLL_EVERY - 1u) guard_mark(P, GUARD_CLAIM_WAIT, (uint32_t)q, S.cyc[7], (unsigned long long)pos);
@@ -1602,7 +1626,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           MPLX_T2(S, 9, t2);
           // a slot claimed for a state no committed unit reaches: its TBL_DEAD_ID goes out with the commit's own stores (behind the
           // commit's barrier its write-through acknowledgement would be the first thing the next batch waits for)
-          if (MPLX_EARLY_TOMB(P) && claimed_new && !(S.bt_dirty[my_slot] & 2u)) {
+          if (MPLX_EARLY_TOMB(P) && !(P.xflags & 4096) && claimed_new && !(S.bt_dirty[my_slot] & 2u)) {
             st_u64(&P.table[claimed_pos], (((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32)) | (unsigned long long)TBL_DEAD_ID);
             claimed_new = false;
           }
@@ -1661,7 +1685,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         MPLX_T2(S, 12, t2);
         // a slot claimed for a state that no committed unit reached (its units were cut): dead from here on, and said so -- no claim
         // outlives its batch (see the look-up above)
-        if (claimed_new && S.bt_id[my_slot] == NIL)
+        if (claimed_new && S.bt_id[my_slot] == NIL && !(P.xflags & 4096))  // [MPLX_X_FLAGS & 4096, measurement: abandoned claims stay claims (round 3)]
           st_u64(&P.table[claimed_pos], (((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32)) | (unsigned long long)TBL_DEAD_ID);
         if (tid < 64) {  // counters of the committed units, in commit order; lane k holds unit k
           const int l = opaque(tid);
@@ -1763,8 +1787,8 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           cost = V::g(Q.node(goal_id));
           for (int i = 0; i <= len; i++) {
             const double *st = V::state(Q.node((uint32_t)tn[i]));
-            for (int k = 0; k < 12; k++) ts[i * 13 + k] = k < ns ? st[k] : 0.0;
-            ts[i * 13 + 12] = st[ns + EX];
+            for (int k = 0; k < 12; k++) ts[i * 13 + k] = k < ns ? ld_state(&st[k]) : 0.0;
+            ts[i * 13 + 12] = ld_state(&st[ns + EX]);
             if (YAW && P.traj_yaw) P.traj_yaw[(size_t)q * (MAX_TRAJ + 1) + i] = st[ns];
           }
         } else {

@@ -1,11 +1,17 @@
-"""The blocking C4-ACC batch must reproduce bit for bit while something else writes to the device's memory (round 4).
+"""The blocking C4 batches must reproduce bit for bit while something else writes to the device's memory.
 
-A posted agent-scope store that a loaded memory system holds back used to let a look-up meet its own table claim before the
-entry landed (a state created twice) and a leader read a look-ahead row before its contents (wrong heuristics): invisible on a
-quiet device, 4 differing queries in 10 batches under this load.  No oracle needed: the batch is compared with itself.
+Round 4 found the C4-ACC batch differing in 4 queries of 10 batches under a background fill load (states created twice, OPEN lists
+running dry) and closed most of it with resolved table claims and self-validating look-ahead rows; round 5 found what was underneath --
+the commit read the pool counters behind the scan's barrier, where a wave that had fallen behind (a store queue under back-pressure is
+what makes a wave fall behind) picked up the updated totals -- and the jerk batch showing it on a quiet device.  No oracle needed: a
+batch is compared with itself.  Runs as a subprocess: the probe needs torch on the device for its background load, and torch's
+bundled HIP runtime only initialises in a process where it comes FIRST (tools/fill_load_probe.py).
 (File name: runs last -- a failure here must not hide the parity tests.)"""
-import importlib.util
+import gc
+import json
 import os
+import subprocess
+import sys
 
 import pytest
 
@@ -13,14 +19,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-def test_c4_acc_batch_repeats_under_a_background_fill_load():
-    import gc
-    import torch
-    gc.collect()
-    torch.cuda.empty_cache()  # (the batch's pools take ~ 130 GB, the background buffer 16 GB: nothing of earlier tests should linger)
-    spec = importlib.util.spec_from_file_location("r04_jitter_probe", os.path.join(ROOT, "tools", "r04_jitter_probe.py"))
-    probe = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(probe)
-    out = probe.run(4, "fill")
-    assert out["fill_rounds"] >= 4, out  # (the load really ran next to the batches)
+@pytest.mark.parametrize("lattice,batches", [("acc", 4), ("jrk", 8)])
+def test_c4_batch_repeats_under_a_background_fill_load(lattice, batches):
+    gc.collect()  # (the batch's pools take ~ 130 GB, the background buffer 16 GB: nothing of earlier tests should linger)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fill_load_probe.py"), str(batches), "fill", lattice], capture_output=True, text=True, timeout=420,
+                       cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["fill_rounds"] >= 2, out  # (the load really ran next to the batches)
     assert out["mismatching_queries"] == 0, out

@@ -5,7 +5,11 @@ The streamed leg of bench.py showed a few queries per 20 batches that differ fro
 when two lanes' launches overlap.  Overlap means two things at once: (a) workgroups of a launch start late, on compute units another
 launch has just left, and (b) the other lane's hipMemset kernels and searches run on the same compute units and memory system.  This
 probe keeps (b) and drops (a): ONE context, mplx_plan_batch as usual, while a background thread fills a large buffer over and over on
-a side stream.  usage: r04_jitter_probe.py [batches] [mode]   mode: fill (default) | read | alu | none
+a side stream.  usage: fill_load_probe.py [batches] [mode] [lattice]   mode: fill (default) | read | alu | none; lattice: acc (default:
+the C4-ACC batch, <32,16,ACC,help>) | jrk (the C4-JRK batch, 125 inputs, cap 20 000, <128,4,JRK,help>)
+
+Round 5: the process runs torch FIRST (its bundled HIP runtime must initialise before libmplx's: the other way round torch finds no
+device), which is why tests/test_zz_jitter.py runs this file as a subprocess at the end of a session that has long been planning.
 """
 import json
 import os
@@ -19,10 +23,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(n_batches=8, mode="fill"):
+def run(n_batches=8, mode="fill", lattice="acc"):
     import torch
+    torch.cuda.init()
     from mpl_ros_amd import mapgen
-    from mpl_ros_amd.planner import ACC, VoxelMapPlanner, VoxelMapUtil, Waypoint3D
+    from mpl_ros_amd.planner import ACC, JRK, VoxelMapPlanner, VoxelMapUtil, Waypoint3D
+    jrk = lattice == "jrk"
+    control, cap = (JRK, 20000) if jrk else (ACC, 2_000_000)
     dev = torch.device("cuda", 0)
     n, res, origin = 512, 0.1, (0.0, 0.0, 0.0)
     grid, _, _, _, _, _ = mapgen.benchmark_map(n)
@@ -30,17 +37,19 @@ def run(n_batches=8, mode="fill"):
     mu = VoxelMapUtil(0)
     mu.setMapDevice(map_t.data_ptr(), origin, (n, n, n), res)
     queries = mapgen.c4_queries(grid, origin, res, 1024, rank=0)
-    caps = mapgen.c4_pools(False, 1024, 2_000_000)
+    caps = mapgen.c4_pools(jrk, 1024, cap)
     pl = VoxelMapPlanner(False)
     pl.setMapUtil(mu)
     pl.setVmax(2.0); pl.setAmax(1.0); pl.setDt(1.0)
-    pl.setU(mapgen.control_lattice(1.0, 1, True))
-    pl.setTol(0.5); pl.setMaxNum(2_000_000)
-    pl.setCapacity(1024, caps["nodes"], caps["edges"], caps["log"])
+    if jrk:
+        pl.setJmax(1.0)
+    pl.setU(mapgen.control_lattice(1.0, 2 if jrk else 1, True))
+    pl.setTol(0.5); pl.setMaxNum(cap)
+    pl.setCapacity(768 if jrk else 1024, caps["nodes"], caps["edges"], caps["log"])
     pl.setHelpers(-1, -1)
 
     def wp(p):
-        w = Waypoint3D(ACC)
+        w = Waypoint3D(control)
         w.pos = np.array(p, dtype=np.float64)
         return w
     starts = [wp(q[0]) for q in queries]
@@ -96,4 +105,4 @@ def run(n_batches=8, mode="fill"):
 
 
 if __name__ == "__main__":
-    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 8, sys.argv[2] if len(sys.argv) > 2 else "fill")))
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 8, sys.argv[2] if len(sys.argv) > 2 else "fill", sys.argv[3] if len(sys.argv) > 3 else "acc")))
