@@ -384,9 +384,16 @@ def main():
         # cannot be collected inside this process); only attached when the profile is of this workload
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if args.lattice == "acc" and len(mine) == 1024 and n == 512 and not args.single:
+            # ... and of this BINARY: the committed passes' kernel time (rocprofv3 --kernel-trace) must agree with the kernel time
+            # measured here within 3 %, or the counters are not attached (round 4 shipped counters of the kernel before its last fix)
+            agree = abs(tr["kernel_ms_trace"] - k_ms) <= 0.03 * k_ms
+            if args.lattice == "acc" and len(mine) == 1024 and n == 512 and not args.single and not agree:
+                out["roofline"]["traffic_refused"] = (f"profiles/traffic.json is of a kernel that takes {tr['kernel_ms_trace']:.0f} ms per launch, this run measured "
+                                                      f"{k_ms:.0f} ms: not the same binary / machine state, counters not attached")
+            if args.lattice == "acc" and len(mine) == 1024 and n == 512 and not args.single and agree:
                 out["roofline"]["traffic"] = (tr["FETCH_SIZE_KB"] + tr["WRITE_SIZE_KB"]) * 1024.0
                 out["roofline"]["traffic_source"] = tr["profile"]
+                out["roofline"]["traffic_kernel_ms_trace"] = tr["kernel_ms_trace"]
                 if tr.get("SQ_INSTS_VALU"):
                     # the NEARER ceiling of this kernel is VALU issue, not HBM: a wave64 VALU instruction occupies its SIMD for
                     # 4 cycles, the machine has 1024 SIMDs at 2.4 GHz; insts from the same committed counter passes

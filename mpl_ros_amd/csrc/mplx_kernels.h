@@ -20,7 +20,7 @@
 namespace mplx {
 
 #ifndef MPLX_X_CLAIM_WAIT_1N
-#define MPLX_X_CLAIM_WAIT_1N 0
+#define MPLX_X_CLAIM_WAIT_1N 1
 #endif
 // ------------------------------------------------------------------ small device helpers
 __device__ __forceinline__ unsigned long long ld_u64(const unsigned long long *p) {
