@@ -33,6 +33,17 @@ static double pw(double t, int n) { /* t^n by repeated multiplication, left to r
   return r;
 }
 
+/* ---- audit of open question Q1 (mpl_oracle.h): the recollected upstream form of Primitive1D::p raises t to the powers >= 3 with
+ * std::pow.  With the audit on, every collision sample of is_free(pr) is evaluated BOTH ways and the cells compared: a search whose
+ * count of differing cells is 0 does not depend on the question.  (Global, not per planner: an audit is a single-threaded test run.) */
+static int g_q1_on = 0;
+static uint64_t g_q1_samples = 0, g_q1_pos_bits = 0, g_q1_cells = 0;
+void orc_q1_audit(int on) { g_q1_on = on; g_q1_samples = g_q1_pos_bits = g_q1_cells = 0; }
+void orc_q1_counts(uint64_t out[3]) { out[0] = g_q1_samples; out[1] = g_q1_pos_bits; out[2] = g_q1_cells; }
+static double p1_p_libm_pow(const double *c, double t) { /* [UNVERIFIED Q1] powers >= 3 through libm's pow, the square as t * t */
+  return c[0] / 120 * pow(t, 5) + c[1] / 24 * pow(t, 4) + c[2] / 6 * pow(t, 3) + c[3] / 2 * t * t + c[4] * t + c[5];
+}
+
 /* Primitive1D p/v/a/j  [IN-TREE primitive_geometry_utils.h:12-26 convention] */
 static double p1_p(const double *c, double t) {
   return c[0] / 120 * pw(t, 5) + c[1] / 24 * pw(t, 4) + c[2] / 6 * pw(t, 3) + c[3] / 2 * t * t + c[4] * t + c[5];
@@ -653,6 +664,15 @@ int orc_is_free_primitive(orc_planner *p, const orc_primitive *pr) {
     int32_t pn[3];
     for (int k = 0; k < 3; k++) pt[k] = p1_p(pr->c[k], t);
     orc_float_to_int(p, pt, pn);
+    if (g_q1_on) { /* Q1 audit: the same sample through the recollected upstream form */
+      double pt2[3];
+      int32_t pn2[3];
+      for (int k = 0; k < 3; k++) pt2[k] = p1_p_libm_pow(pr->c[k], t);
+      orc_float_to_int(p, pt2, pn2);
+      g_q1_samples++;
+      if (memcmp(pt, pt2, sizeof(pt)) != 0) g_q1_pos_bits++;
+      if (pn[0] != pn2[0] || pn[1] != pn2[1] || pn[2] != pn2[2]) g_q1_cells++;
+    }
     if (is_outside(p, pn)) return 0;
     p->cnt.n_voxel_reads++;
     if (p->map[get_index(p, pn)] > 0) return 0;

@@ -231,6 +231,14 @@ void orc_grid_fill_cell(orc_grid *, int nx, int ny, int nz);
 void orc_grid_get_map(const orc_grid *, int inflated, int8_t *data);
 uint64_t orc_grid_get_cloud(const orc_grid *, double *pts, uint64_t cap);
 
+/* Audits of the open questions Q1 / Q2 above (tests/test_oracle_kat.py): how much of a given search / mask depends on them.
+ * orc_q1_audit(1) starts counting (single-threaded use), orc_q1_counts: {collision samples evaluated both ways, samples whose
+ * position differs in any bit, samples whose CELL differs}.  orc_q2_mask_audit: {entries of this file's potential mask, entries
+ * of the integer-radius form, offsets whose value differs}. */
+void orc_q1_audit(int on);
+void orc_q1_counts(uint64_t out[3]);
+void orc_q2_mask_audit(double res, const double radius[3], int pw, uint64_t out[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -299,3 +299,65 @@ def test_blocked_successors_are_accounted_like_upstream_hm():
         assert not L.orc_is_free_primitive(P.h, orc.C.byref(pr))
     assert P.num_states_all() > P.num_nodes()
     assert P.num_states_all() <= P.num_nodes() + len(par)
+
+
+def _q1_counts(n, jrk, cap):
+    import ctypes as C
+    from mpl_ros_amd import mapgen
+    from tests import util
+    L = orc.lib()
+    L.orc_q1_audit.argtypes = [C.c_int]
+    L.orc_q1_counts.argtypes = [C.POINTER(C.c_uint64)]
+    grid, origin, res, s, g, _ = mapgen.benchmark_map(n)
+    U = mapgen.control_lattice(1.0, 2 if jrk else 1, True)
+    control = orc.JRK if jrk else orc.ACC
+    kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5, max_expand=cap)
+    if jrk:
+        kw["j_max"] = 1.0
+    P = util.make_oracle(grid, origin, res, control, U, **kw)
+    L.orc_q1_audit(1)
+    try:
+        P.plan(orc.waypoint(s, control=control), orc.waypoint(g, control=control))
+        out = (C.c_uint64 * 3)()
+        L.orc_q1_counts(out)
+    finally:
+        L.orc_q1_audit(0)
+    return P.counters()["n_expansions"], int(out[0]), int(out[1]), int(out[2])
+
+
+def test_open_question_q1_pow_versus_multiplication_changes_no_cell():
+    """mpl_oracle.h Q1 (VERDICT r3 / r4): upstream is recalled to raise t to its powers >= 3 with std::pow, this restatement and the
+    device multiply.  Decidable for the searches themselves: with the audit on, every collision sample is evaluated both ways.
+    ACC primitives have no cubic term -- not one position bit differs (BASELINE C1, C2, C4-ACC do not depend on Q1 at all).
+    JRK primitives: about one sample position in 150 differs in its last bits, and NO sample lands in another cell (29.7 M samples of
+    the 256^3 search at 60 000 expansions, 250 000 expansions of the C3 query on the 512^3 map: DESIGN.md 6); asserted here on a
+    smaller search."""
+    ne, samples, bits, cells = _q1_counts(128, False, 50000)
+    assert ne > 500 and samples > 100000 and bits == 0 and cells == 0
+    ne, samples, bits, cells = _q1_counts(256, True, 15000)
+    assert ne == 15000 and samples > 5_000_000
+    assert bits > 0          # (the question is real: the two forms are not the same function ...)
+    assert cells == 0        # (... and it changes no voxel index of this search)
+
+
+def test_open_question_q2_mask_normalisation_at_the_reference_radii():
+    """mpl_oracle.h Q2: potential mask distance normalised by the metric radius (here) or by the integer cell radius ceil(r / res)
+    (a reviewer's recollection of upstream).  Counted, not argued: at the reference's own setting -- setPotentialRadius(Vec2f(1.5, 1.5))
+    on a 0.1 m map, distance_map_planner_node.cpp:187 -- ceil(r / res) = 15 = r / res and the two forms agree except where
+    100 (1 - d) sits on an integer up to rounding: 4 of 681 mask values differ, by one unit of potential.  With a radius that is not a
+    multiple of the resolution the cell radius itself changes and the masks differ wholesale -- the case the restatement is NOT
+    pinned for."""
+    import ctypes as C
+    L = orc.lib()
+    L.orc_q2_mask_audit.argtypes = [C.c_double, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_uint64)]
+
+    def audit(res, radius, pw=1):
+        out = (C.c_uint64 * 3)()
+        L.orc_q2_mask_audit(res, (C.c_double * 3)(*radius), pw, out)
+        return int(out[0]), int(out[1]), int(out[2])
+    assert audit(0.1, (1.5, 1.5, 0.0)) == (681, 681, 4)
+    assert audit(0.25, (1.0, 1.0, 0.0)) == (45, 45, 0)
+    mine, alt, diff = audit(0.1, (1.0, 1.0, 1.0))
+    assert mine == alt == 4067 and diff == 60          # (3-D, radius a multiple of the resolution: 1.5 % of the values, one unit each)
+    mine, alt, diff = audit(0.1, (0.45, 0.45, 0.0))    # (not a multiple: ceil -> 5 cells instead of 4.5)
+    assert diff > mine // 2
