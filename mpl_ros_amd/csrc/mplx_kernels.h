@@ -19,6 +19,17 @@
 
 namespace mplx {
 
+// Diagnostic / measurement switches of SearchParams::xflags (environment MPLX_X_FLAGS, read per launch): compiled out of the product
+// (every one is a scalar test and a live SGPR on a query's serial chain); -DMPLX_DIAG_FLAGS=1 (tools/build_variant.sh diag) puts them
+// back for tools/r05_jrk_batch.py / tools/r05_ab.py.  Bit 8 -- the test-only spin the launch guard must end -- is always there.
+//   1 table probes at agent scope   2 release / acquire fences around a look-ahead record   4 other half of a doubled table (host)
+//   16 rows behind a release fence instead of the check word   32 TBL_DEAD_ID ahead of the parallel commit   64 claim wait in the
+//   one-node kernels (on by default since round 5)   128 plain loads of sc1-stored state doubles   256 no look-ahead hit is taken
+//   512 plain state stores   1024 rows unchecked   2048 no claim wait   4096 no TBL_DEAD_ID
+#ifndef MPLX_DIAG_FLAGS
+#define MPLX_DIAG_FLAGS 0
+#endif
+#define MPLX_XF(P, bit) (MPLX_DIAG_FLAGS && ((P).xflags & (bit)))
 #ifndef MPLX_X_CLAIM_WAIT_1N
 #define MPLX_X_CLAIM_WAIT_1N 1
 #endif
@@ -1193,7 +1204,7 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
     // an EARLIER expansion with this query's tag is an entry store that has not landed yet -- wait for it instead of passing it (and
     // creating the state a second time).  The claim carries the low bits of the expansion count to tell the two apart.
     static_assert(BLOCK <= (1 << CLAIM_BATCH_SHIFT), "the thread index of a claim has nine bits");
-    const bool claim_wait = MPLX_X_CLAIM_WAIT_1N || (P.xflags & 64);
+    const bool claim_wait = MPLX_X_CLAIM_WAIT_1N || MPLX_XF(P, 64);
     const uint32_t claim_exp = claim_wait ? ((uint32_t)S.c_expanded & CLAIM_BATCH_MASK) << CLAIM_BATCH_SHIFT : 0u;
     const unsigned long long claim = tagq | (unsigned long long)(CLAIM_BASE + claim_exp + (uint32_t)tid);
     bool first = true;

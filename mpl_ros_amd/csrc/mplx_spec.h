@@ -42,8 +42,8 @@
 #define MPLX_X_ROW_FENCE 0    // look-ahead rows (units of 32 lanes) published behind an agent-scope RELEASE fence (buffer_wbl2 sc1 + s_waitcnt) instead of validated by a check word
 #endif
 // run-time twins of the A/B switches (SearchParams::xflags, MPLX_X_FLAGS): 16 row fence, 32 early tombstone, 64 claim wait in the one-node kernels
-#define MPLX_ROW_FENCE(P) (MPLX_X_ROW_FENCE || ((P).xflags & 16))
-#define MPLX_EARLY_TOMB(P) (MPLX_X_EARLY_TOMB || ((P).xflags & 32))
+#define MPLX_ROW_FENCE(P) (MPLX_X_ROW_FENCE || MPLX_XF(P, 16))
+#define MPLX_EARLY_TOMB(P) (MPLX_X_EARLY_TOMB || MPLX_XF(P, 32))
 #ifndef MPLX_X_EARLY_CLEAR
 #define MPLX_X_EARLY_CLEAR 1  // batch table cleared by the idle waves of the end-of-batch bookkeeping
 #endif
@@ -210,7 +210,7 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
       for (int i = 0; i < nk; i++) kk[i] = L.key[i];
       if constexpr (YAW) kk[nk] = L.yaw_key;
       double *st = V::state(rec);
-      if (HELP && !(P.xflags & 512)) {  // helper workgroups on other compute units read the state: agent-scope (write-through) stores,
+      if (HELP && !MPLX_XF(P, 512)) {  // helper workgroups on other compute units read the state: agent-scope (write-through) stores,
         // 16 bytes at a time (the state starts on a 64-byte boundary of the record)   [MPLX_X_FLAGS & 512, diagnostics: plain stores]
         auto sv = [&](int i) { return i < 3 ? L.tn.p[i % 3] : i < 6 ? L.tn.v[i % 3] : i < 9 ? L.tn.a[i % 3] : L.tn.j[i % 3]; };
 #pragma unroll
@@ -466,7 +466,7 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has landed before the record names it
       // (large lattices: the row carries the masks as well and has no check word yet -- a full agent-scope release instead)
-      if (UL > 64 || (P.xflags & 2) || MPLX_ROW_FENCE(P)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (UL > 64 || MPLX_XF(P, 2) || MPLX_ROW_FENCE(P)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       unit_sync<UL>();
       if (rp1 && lu == 0) {
         unsigned long long *cr = (unsigned long long *)&P.cache_c[rec];
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
   // the difference.)
   auto ld_state = [&](const double *p) -> double {
     if constexpr (HELP) {
-      if (!(P.xflags & 128)) return ld_f64_agent(p);
+      if (!MPLX_XF(P, 128)) return ld_f64_agent(p);
     }
     return *p;
   };
@@ -806,10 +806,10 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           if constexpr (HELP) {  // (the helper flag: an agent-scope load, every eighth batch)
             if (tid == 192 && (S.cyc[7] & 7ull) <= 1ull) S.helped = ld_u32(&(P.boxes + blockIdx.x)->helpers) != 0u;
           }
-          // launch guard: heartbeat (posted store) and the host's abort word (a load over the fabric), every 64th batch, on a
-          // wave that only waits for thread 0's counters here
-          if (tid == 192 && (S.cyc[7] & 63ull) <= 1ull) {
-            guard_mark(P, GUARD_BATCH, (uint32_t)q, S.cyc[7], S.c_expanded);
+          // launch guard: heartbeat (posted store) and the host's abort word (a load over the fabric), every 256th batch (~ 4 ms), on
+          // a wave that only waits for thread 0's counters here
+          if (tid == 192 && (batch_no & 255u) == 0u) {  // (batch_no: this thread's own count of the query's batches)
+            guard_mark(P, GUARD_BATCH, (uint32_t)q, (unsigned long long)batch_no, S.c_expanded);
             if (guard_abort(P) && S.status < 0) S.status = PLAN_ABORTED;
           }
         }
@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         if constexpr (HELP) {
           // did a helper expand this node ahead of time?  The entry must be of THIS state: the helper's hash of the
           // key of the state it expanded against the candidate's own key (guards against anything stale on its side)
-          if (live_unit && S.helped && !(P.xflags & 256) && lu == UL - 1 && (uint32_t)hc_a != 0u && ((uint32_t)hc_b & CACHE_READY) &&  // [MPLX_X_FLAGS & 256, diagnostics: no hit is taken]
+          if (live_unit && S.helped && !MPLX_XF(P, 256) && lu == UL - 1 && (uint32_t)hc_a != 0u && ((uint32_t)hc_b & CACHE_READY) &&  // [MPLX_X_FLAGS & 256, diagnostics: no hit is taken]
               (uint32_t)(hc_a >> 32) == (uint32_t)key_hash64(S.cur_key[ku], nk)) {
             S.hc_row[ku] = (uint32_t)hc_a;
             S.hc_valid[ku] = (uint32_t)hc_b;
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
 #if MPLX_X_EARLY_ROW
         if constexpr (HELP) {
           const uint32_t rp1 = live_unit ? S.hc_row[ku] : 0u;
-          if (P.xflags & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          if MPLX_XF(P, 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           if (rp1) {
             const double *row = P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL);
             bool want = lu < P.n_u && P.eps != 0.0;
@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           if (l.valid && !l.blocked) {
             h64 = lane_hash(l);
             pos0 = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
-            v0 = (P.xflags & 1) ? ld_u64(&P.table[pos0]) : ld_u64_probe(&P.table[pos0]);
+            v0 = MPLX_XF(P, 1) ? ld_u64(&P.table[pos0]) : ld_u64_probe(&P.table[pos0]);
           }
         });
         const bool act = L.valid && !L.blocked;
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           // (Placed here, not right after the expansion: the row's agent-scope loads keep travelling during the scans and the
           //  batch-table insert above.)
           const uint32_t rp1 = live_unit ? S.hc_row[ku] : 0u;  // (the same for the 32 lanes of the unit)
-          if (rp1 && !MPLX_ROW_FENCE(P) && !(P.xflags & 1024)) {  // [MPLX_X_FLAGS & 1024, measurement: the row is not checked (round 3's protocol)]
+          if (rp1 && !MPLX_ROW_FENCE(P) && !MPLX_XF(P, 1024)) {  // [MPLX_X_FLAGS & 1024, measurement: the row is not checked (round 3's protocol)]
             const double *row = P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL);
             const bool want = act && P.eps != 0.0;  // (the lanes whose heuristic was asked for: the record's masks are L.valid / L.blocked now)
             const uint32_t khash = (uint32_t)key_hash64(S.cur_key[ku], nk);
@@ -1405,7 +1405,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
                 guard_mark(P, GUARD_PROBE, (uint32_t)q, S.cyc[7], (unsigned long long)pos);
                 break;
               }
-              unsigned long long v = first ? v0 : (P.xflags & 1) ? ld_u64(&P.table[pos]) : ld_u64_probe(&P.table[pos]);
+              unsigned long long v = first ? v0 : MPLX_XF(P, 1) ? ld_u64(&P.table[pos]) : ld_u64_probe(&P.table[pos]);
               if (v == TBL_EMPTY) {
                 unsigned long long old = (first && did_cas0) ? cas0 : atomicCAS(&P.table[pos], TBL_EMPTY, claim);
                 first = false;
@@ -1434,7 +1434,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
               // batches under a background fill load, streamed batches -- profiles/r04s_*); wait for the store instead.
               if ((uint32_t)v >= CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tagq) {
                 v = ld_u64(&P.table[pos]);
-                for (uint32_t polls = 0; !(P.xflags & 2048) /* [measurement: no wait, round 3's rule] */ && (uint32_t)v >= CLAIM_BASE && (uint32_t)v < TBL_DEAD_ID && (v & 0xFFFFFFFF00000000ull) == tagq &&
+                for (uint32_t polls = 0; !MPLX_XF(P, 2048) /* [measurement: no wait, round 3's rule] */ && (uint32_t)v >= CLAIM_BASE && (uint32_t)v < TBL_DEAD_ID && (v & 0xFFFFFFFF00000000ull) == tagq &&
                                          ((uint32_t)v & (CLAIM_BATCH_MASK << CLAIM_BATCH_SHIFT)) != claim_batch; polls++) {
                   if (polls >= CLAIM_WAIT_POLLS) { S.status = 5; break; }  // (never seen: a claim nobody resolved)
                   if ((polls & (GUARD_POLL_EVERY - 1u)) == GUARD_POLL_EVERY - 1u) guard_mark(P, GUARD_CLAIM_WAIT, (uint32_t)q, S.cyc[7], (unsigned long long)pos);
@@ -1626,7 +1626,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
           MPLX_T2(S, 9, t2);
           // a slot claimed for a state no committed unit reaches: its TBL_DEAD_ID goes out with the commit's own stores (behind the
           // commit's barrier its write-through acknowledgement would be the first thing the next batch waits for)
-          if (MPLX_EARLY_TOMB(P) && !(P.xflags & 4096) && claimed_new && !(S.bt_dirty[my_slot] & 2u)) {
+          if (MPLX_EARLY_TOMB(P) && !MPLX_XF(P, 4096) && claimed_new && !(S.bt_dirty[my_slot] & 2u)) {
             st_u64(&P.table[claimed_pos], (((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32)) | (unsigned long long)TBL_DEAD_ID);
             claimed_new = false;
           }
@@ -1685,7 +1685,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         MPLX_T2(S, 12, t2);
         // a slot claimed for a state that no committed unit reached (its units were cut): dead from here on, and said so -- no claim
         // outlives its batch (see the look-up above)
-        if (claimed_new && S.bt_id[my_slot] == NIL && !(P.xflags & 4096))  // [MPLX_X_FLAGS & 4096, measurement: abandoned claims stay claims (round 3)]
+        if (claimed_new && S.bt_id[my_slot] == NIL && !MPLX_XF(P, 4096))  // [MPLX_X_FLAGS & 4096, measurement: abandoned claims stay claims (round 3)]
           st_u64(&P.table[claimed_pos], (((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32)) | (unsigned long long)TBL_DEAD_ID);
         if (tid < 64) {  // counters of the committed units, in commit order; lane k holds unit k
           const int l = opaque(tid);

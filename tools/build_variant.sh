@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds a diagnostic variant of libmplx.so into build_tmp/ (git-ignored; travels with gpurun snapshots).
-# usage: tools/build_variant.sh timers|helpdbg|rowpairs|earlytomb|fast|claimwait1n  -> build_tmp/libmplx_<variant>.so   (use with MPLX_LIB=...)
+# usage: tools/build_variant.sh timers|helpdbg|rowpairs|earlytomb|fast|claimwait1n|diag  -> build_tmp/libmplx_<variant>.so   (use with MPLX_LIB=...)
 #   rowpairs / earlytomb / fast (= both): the two A/B switches of DESIGN.md 7 that should give back the 7 % the round-4 fix of the
 #   table / look-ahead-row race costs; never run on a GPU yet -- compare with the product build under bench.py AND under
 #   tools/r04_jitter_probe.py (the race they must keep closed only shows under a background fill load)
@@ -13,7 +13,8 @@ case $V in
   rowpairs) DEF=-DMPLX_X_ROW_PAIRS=1 ;;
   earlytomb) DEF=-DMPLX_X_EARLY_TOMB=1 ;;
   fast) DEF="-DMPLX_X_ROW_PAIRS=1 -DMPLX_X_EARLY_TOMB=1" ;;
-  claimwait1n) DEF=-DMPLX_X_CLAIM_WAIT_1N=1 ;;   # rule R3 for the one-node kernels (VEL / SNP states, LPA*, lattices > 128): test under tools/r04_jitter_probe.py-style load
+  claimwait1n) DEF=-DMPLX_X_CLAIM_WAIT_1N=1 ;;
+  diag) DEF=-DMPLX_DIAG_FLAGS=1 ;;               # the MPLX_X_FLAGS switches of mplx_kernels.h (tools/r05_jrk_batch.py, tools/r05_ab.py)   # rule R3 for the one-node kernels (VEL / SNP states, LPA*, lattices > 128): test under tools/r04_jitter_probe.py-style load
   *) echo "unknown variant $V"; exit 2 ;;
 esac
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function $DEF"
