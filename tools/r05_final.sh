@@ -5,7 +5,7 @@
 #      and kernel traces of the streamed leg, the C4-JRK batch, the C3 query and the C5 tick      -> profiles/traffic.json
 #   4. C5 / LPA* / C3 / C4-JRK bench lines                   5. all 1024 queries of the C4 batches replayed on the CPU (ACC and JRK)
 set -u
-TAG=${1:-r05z}
+TAG=${1:-r05y}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export MPLX_DEADLINE_S=100 TMPDIR=/tmp
 ROOT=$PWD
@@ -42,7 +42,7 @@ python profiles/summarize_rocprof.py "$OUT/block" > "$OUT/summary_block.txt" 2>&
 python profiles/summarize_rocprof.py "$OUT/bulk" > "$OUT/summary_bulk.txt" 2>&1
 python profiles/summarize_rocprof.py "$OUT/other" > "$OUT/summary_other.txt" 2>&1
 find "$OUT" -name "*.db" -delete
-python tools/make_traffic_json.py "$OUT/summary_block.txt" profiles/r05z_c4acc_blocking.txt "$OUT/summary_bulk.txt" > $OUT/traffic.json 2> $OUT/traffic.err; head -c 600 $OUT/traffic.json; echo
+python tools/make_traffic_json.py "$OUT/summary_block.txt" profiles/${TAG}_c4acc_blocking.txt "$OUT/summary_bulk.txt" > $OUT/traffic.json 2> $OUT/traffic.err; head -c 600 $OUT/traffic.json; echo
 # ---- 4. the other configurations
 timeout 100 python bench.py --config c5 --steps 3 --warmup 1 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; head -c 300 $OUT/bench_c5.json; echo
 timeout 60 python bench.py --config lpa --steps 2 --warmup 1 > $OUT/bench_lpa.json 2> $OUT/bench_lpa.err; head -c 300 $OUT/bench_lpa.json; echo
