@@ -419,6 +419,8 @@ int mplx_poly_last_kernel_ms(const mplx_poly *p, float *ms);
  * outcome is a pure function of the state: results are identical with or without).  per_leader: -1 auto, 0 off, <= 15. */
 int mplx_poly_set_helpers(mplx_poly *p, int32_t per_leader);
 int mplx_poly_last_helpers(const mplx_poly *p); /* helpers per leader of the last launch */
+/* Launch guard of the moving-obstacle search: see mplx_set_deadline (a tick that outlives it returns MPLX_ERR_TIMEOUT). */
+int mplx_poly_set_deadline(mplx_poly *p, double seconds);
 /* shader-clock cycles query q of the last batch spent in [0] pop, [1] get_succ (primitives + collide), [2] look-up + commit */
 int mplx_poly_result_cycles(mplx_poly *p, int32_t q, uint64_t cyc[10]);
 

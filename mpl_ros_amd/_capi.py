@@ -66,7 +66,7 @@ EXPORTS = [
     "mplx_lpa_counts", "mplx_lpa_result_nodes", "mplx_lpa_result_edges", "mplx_lpa_result_expanded", "mplx_lpa_last_kernel_ms",
     "mplx_poly_create", "mplx_poly_destroy", "mplx_poly_last_error", "mplx_poly_config", "mplx_poly_begin", "mplx_poly_set_world",
     "mplx_poly_add_static", "mplx_poly_add_linear", "mplx_poly_add_nonlinear", "mplx_poly_commit", "mplx_poly_get_succ_batch", "mplx_poly_set_capacity", "mplx_poly_plan_batch", "mplx_poly_result_traj",
-    "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms", "mplx_poly_result_cycles", "mplx_poly_set_helpers", "mplx_poly_last_helpers",
+    "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms", "mplx_poly_result_cycles", "mplx_poly_set_helpers", "mplx_poly_last_helpers", "mplx_poly_set_deadline",
     "mplx_traj_solve", "mplx_traj_sample", "mplx_traj_effort",
     "mplx_plan_batch_submit", "mplx_plan_batch_wait", "mplx_plan_batch_done", "mplx_set_helper_limit", "mplx_release_pools",
     "mplx_set_deadline", "mplx_debug_hang_next_launch", "mplx_debug_query_records",
@@ -210,6 +210,7 @@ def load():
     L.mplx_poly_result_cycles.argtypes = [P, C.c_int32, C.POINTER(C.c_uint64)]
     L.mplx_poly_set_helpers.argtypes = [P, C.c_int32]
     L.mplx_poly_last_helpers.argtypes = [P]
+    L.mplx_poly_set_deadline.argtypes = [P, C.c_double]
     L.mplx_plan_batch_submit.argtypes = [P, C.c_int, C.POINTER(Waypoint), C.POINTER(Waypoint)]
     L.mplx_plan_batch_wait.argtypes = [P, C.POINTER(Result)]
     L.mplx_plan_batch_done.argtypes = [P]

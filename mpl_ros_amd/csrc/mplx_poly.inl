@@ -487,3 +487,5 @@ extern "C" int mplx_poly_set_helpers(mplx_poly *p, int32_t per_leader) {
   return MPLX_OK;
 }
 extern "C" int mplx_poly_last_helpers(const mplx_poly *p) { return p ? p->last_n_help : 0; }
+// launch guard of the moving-obstacle search (mplx_set_deadline of the planner's internal context)
+extern "C" int mplx_poly_set_deadline(mplx_poly *p, double seconds) { return p ? mplx_set_deadline(p->ctx, seconds) : MPLX_ERR_ARG; }

@@ -169,6 +169,10 @@ class PolyTeam:
         """Look-ahead helper workgroups per leader (-1 auto, 0 off): results are identical with or without."""
         self.check(self.lib.mplx_poly_set_helpers(self.h, int(per_leader)))
 
+    def set_deadline(self, seconds):
+        """Launch guard: a tick that outlives `seconds` is aborted and plan_batch raises MplxError (MPLX_ERR_TIMEOUT)."""
+        self.check(self.lib.mplx_poly_set_deadline(self.h, float(seconds)))
+
     def last_helpers(self):
         return int(self.lib.mplx_poly_last_helpers(self.h))
 

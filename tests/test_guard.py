@@ -63,3 +63,52 @@ def test_a_batch_that_outlives_its_deadline_is_aborted_and_the_next_one_is_clean
     assert "aborted" in str(e.value), str(e.value)
     pl.setDeadline(60.0)
     assert [word(r) for r in pl.planBatch(S, G)] == ref
+
+
+def test_the_moving_obstacle_tick_and_an_lpastar_plan_honour_their_deadlines():
+    """The other two families of search launches behind the guard: the Team2 tick (16 leaders + look-ahead helper launch on a
+    second stream, ~ 240 ms) and a fresh LPA* plan at 256^3 (one workgroup, ~ 340 ms), each given a deadline far below its run time:
+    MPLX_ERR_TIMEOUT, and the same call repeats exactly afterwards."""
+    from mpl_ros_amd import poly_map as pm
+    from mpl_ros_amd.planner import VoxelMapPlanner
+    # ---- C5 tick under the reference's planner parameters
+    U9 = pm.U9
+    worlds, starts, goals = pm.team2_tick()
+    team = pm.PolyTeam()
+    team.configure(pm.ACC, U9, dt=0.5, v_max=2.0, a_max=1.0, w=10.0)
+    team.set_worlds(worlds)
+    team.set_capacity(16, 1 << 21, 1 << 23, 1 << 22)
+    word = lambda r: (r.status, r.traj_len, r.cost, r.n_expanded, r.n_nodes, r.n_edges, r.expand_hash)
+    ref = [word(r) for r in team.plan_batch(np.arange(16), starts, goals, max_expand=-1, heur_ignore_dynamics=False)]
+    ms = team.last_kernel_ms()
+    assert ms > 20.0, ms
+    team.set_deadline(ms / 1000.0 / 5.0)
+    t0 = time.time()
+    with pytest.raises(MplxError) as e:
+        team.plan_batch(np.arange(16), starts, goals, max_expand=-1, heur_ignore_dynamics=False)
+    assert time.time() - t0 < 10.0 and "aborted" in str(e.value), str(e.value)
+    team.set_deadline(60.0)
+    assert [word(r) for r in team.plan_batch(np.arange(16), starts, goals, max_expand=-1, heur_ignore_dynamics=False)] == ref
+    # ---- LPA*: a fresh plan of the C2 query
+    grid, origin, res, start, goal, _ = mapgen.benchmark_map(256)
+    U = mapgen.control_lattice(1.0, 1, True)
+    mu, a = util.make_gpu(grid, origin, res, U, v_max=2.0, a_max=1.0, tol_pos=0.5)
+    l = VoxelMapPlanner(False)
+    l.setMapUtil(mu)
+    l.setVmax(2.0); l.setAmax(1.0); l.setDt(1.0); l.setU(U); l.setTol(0.5)
+    l.setCapacity(1, 1 << 20, 1 << 22, 1 << 22)
+    l.setLPAstar(True)
+    assert l.plan(util.gpu_wp(start), util.gpu_wp(goal))
+    r0 = l.getResult()
+    first = (r0.status, r0.cost, r0.n_expanded, r0.expand_hash)
+    assert r0.n_expanded > 10000
+    l.reset()
+    l.setDeadline(0.03)
+    t0 = time.time()
+    with pytest.raises(MplxError) as e:
+        l.plan(util.gpu_wp(start), util.gpu_wp(goal))
+    assert time.time() - t0 < 10.0 and "aborted" in str(e.value), str(e.value)
+    l.setDeadline(60.0)
+    assert l.plan(util.gpu_wp(start), util.gpu_wp(goal))
+    r1 = l.getResult()
+    assert (r1.status, r1.cost, r1.n_expanded, r1.expand_hash) == first
