@@ -1066,4 +1066,164 @@ __global__ __launch_bounds__(BLOCK) void lpa_subtree_kernel(SearchParams P, LpaP
   }
 }
 
+// ------------------------------------------------------------------ import of a finished A* (round 5)
+// The FIRST plan of an LPA* planner is an A* from scratch: same pop order ((min(g, rhs) + eps h, min(g, rhs), id) = (f, g, id)
+// while nothing is under-consistent), same states in the same order of creation, same predecessor entries.  The one-workgroup
+// LPA* kernel runs it at ~11 us per expansion; astar_spec_kernel with its helper workgroups at ~1.2.  So a fresh LPA* plan is
+// planned by the speculative kernel on a private lane context and its state space is IMPORTED into the LPA* pools:
+//   states     : record copied; closed (= expanded once) -> g = rhs = g, OPENED | CLOSED | BUILT; open -> rhs = g, g = inf, OPENED
+//   entries    : copied (the potential bits of the action word are zero: LPA* refuses an auxiliary map)
+//   table      : rebuilt with the LPA* hashing (no query bits)
+//   blocked log: the A* keeps no record of successors with cost +inf (D7); re-derived here -- get_succ is pure -- for the
+//                expanded states in EXPANSION order (the A*'s record of expanded ids), lanes ascending: the order lpa_link writes
+//   LpaState, result record, trajectory: from the A*'s own.
+// Everything the replanner does afterwards (updates, repairs, getSubStateSpace) runs on the imported space unchanged;
+// tests/test_lpa.py compares g, rhs, h, flags, every entry and its blocked bit with the CPU LPA* after every step.
+struct LpaImportArgs {
+  const char *node_pool, *edge_pool;        // the A*'s chunked pools
+  const uint32_t *node_table, *edge_table;  // chunk tables of its (only) query
+  const QueryOut *out;                      // its result record
+  const int32_t *rec_ids;                   // expanded node ids in order (out->n_recorded of them)
+  const int32_t *traj_nodes, *traj_actions; // goal -> start
+  const double *traj_states;
+  uint32_t *blk_off;                        // scratch [n_expanded + 1]: blocked successors per expansion, then exclusive offsets
+  unsigned long long *blk_mask;             // scratch [2 x n_expanded]: their lanes
+  int32_t *dst_rec;                         // the LPA* handle's own expansion record (or null)
+  uint32_t dst_cap_rec;
+};
+
+template <int CONTROL>
+__global__ __launch_bounds__(256) void lpa_import_copy_kernel(SearchParams P, LpaParams A, LpaImportArgs I) {
+  constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL), rb = rec_bytes(CONTROL);
+  using V = LView<256, CONTROL>;
+  const QueryOut o = *I.out;
+  const size_t n = (size_t)o.n_nodes, ne = (size_t)o.n_edges;
+  const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gs = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = gt; i < n; i += gs) {
+    const char *src = I.node_pool + (((size_t)I.node_table[i >> NODE_CH_LOG] << NODE_CH_LOG) + (i & (((size_t)1 << NODE_CH_LOG) - 1))) * rb;
+    char *dst = P.node_pool + i * rb;
+    static_assert(rb % 16 == 0, "records are copied in 16-byte words");
+#pragma unroll
+    for (int k = 0; k < rb / 16; k++) ((uint4 *)dst)[k] = ((const uint4 *)src)[k];
+    const double g = V::g(dst);
+    const bool closed = (V::flags(dst) & FLAG_CLOSED) != 0;
+    V::rhs(dst) = g;
+    V::g(dst) = closed ? g : INFINITY;
+    V::flags(dst) = FLAG_OPENED | (closed ? (FLAG_CLOSED | FLAG_BUILT) : 0u);
+    (void)ns;
+    const unsigned long long h64 = key_hash64(V::key(dst), nk);
+    size_t pos = (size_t)h64 & (size_t)P.table_mask;
+    for (unsigned long long steps = 0; steps <= P.table_mask; steps++) {
+      if (atomicCAS(&P.table[pos], TBL_EMPTY, ((h64 >> 48) << 48) | (unsigned long long)i) == TBL_EMPTY) break;
+      pos = (pos + 1) & (size_t)P.table_mask;
+    }
+  }
+  for (size_t j = gt; j < ne; j += gs) {
+    const EdgeRec e = *(const EdgeRec *)(I.edge_pool + (((size_t)I.edge_table[j >> EDGE_CH_LOG] << EDGE_CH_LOG) + (j & (((size_t)1 << EDGE_CH_LOG) - 1))) * EDGE_BYTES);
+    EdgeRec *d = (EdgeRec *)(P.edge_pool + j * EDGE_BYTES);
+    d->parent = e.parent;
+    d->next = e.next;
+    d->action = e.action & EDGE_ACTION_MASK;
+  }
+}
+
+// blocked successors of every expanded state (one workgroup per expansion, grid-stride): lanes as two 64-bit masks + their count
+template <int BLOCK, int CONTROL>
+__global__ __launch_bounds__(BLOCK) void lpa_import_blocked_kernel(SearchParams P, LpaParams A, LpaImportArgs I) {
+  __shared__ Smem<BLOCK> S;
+  __shared__ unsigned long long wmask[BLOCK / 64];
+  constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL), rb = rec_bytes(CONTROL);
+  using V = LView<BLOCK, CONTROL>;
+  const int tid = threadIdx.x;
+  fill_uq<BLOCK, CONTROL>(P, S, tid);
+  const uint32_t n_exp = I.out->n_recorded;
+  for (uint32_t e = blockIdx.x; e < n_exp; e += gridDim.x) {
+    char *rec = P.node_pool + (size_t)(uint32_t)I.rec_ids[e] * rb;  // (the imported copy: kernel order on the stream)
+    __syncthreads();
+    if (tid < 12) S.cur[0][tid] = tid < ns ? V::state(rec)[tid] : 0.0;
+    if (tid == 12) S.cur[0][12] = V::state(rec)[ns];
+    if (tid < nk) S.cur_key[0][tid] = V::key(rec)[tid];
+    __syncthreads();
+    LaneSucc L;
+    expand_unit<BLOCK, BLOCK, CONTROL>(P, S, tid, true, L);
+    const unsigned long long m = __ballot(L.valid && L.blocked);
+    if ((tid & 63) == 0) wmask[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned long long m0 = wmask[0], m1 = BLOCK > 64 ? wmask[BLOCK > 64 ? 1 : 0] : 0ull;
+      I.blk_mask[2 * (size_t)e] = m0;
+      I.blk_mask[2 * (size_t)e + 1] = m1;
+      I.blk_off[e] = (uint32_t)(__popcll(m0) + __popcll(m1));
+    }
+  }
+}
+
+// offsets of the log entries (one workgroup: scan with a carry), the entries, then the scalars: LpaState, result, trajectory
+template <int UNUSED = 0>  // (a template so that the header can be included by two translation units)
+__global__ __launch_bounds__(256) void lpa_import_finish_kernel(SearchParams P, LpaParams A, LpaImportArgs I) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const QueryOut o = *I.out;
+  const uint32_t n_exp = o.n_recorded;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < n_exp; base += 256) {
+    const uint32_t e = base + tid;
+    const uint32_t v = e < n_exp ? I.blk_off[e] : 0u;
+    const uint32_t x = wave_incl_sum<64>(v);
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t pre = carry;
+    for (int w = 0; w < wave; w++) pre += wsum[w];
+    const uint32_t off = pre + x - v;
+    if (e < n_exp && off + v <= A.blocked_cap) {
+      const uint32_t id = (uint32_t)I.rec_ids[e];
+      uint32_t k = off;
+      for (int half = 0; half < 2; half++) {
+        unsigned long long m = I.blk_mask[2 * (size_t)e + half];
+        while (m) {
+          const int b = __ffsll((long long)m) - 1;
+          m &= m - 1ull;
+          A.blocked_log[k++] = make_uint2(id, (uint32_t)(64 * half + b));
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 255) carry = pre + x;
+    __syncthreads();
+  }
+  const uint32_t n_blocked = carry;
+  const bool searched = o.n_nodes > 0;
+  const int len = o.status == 0 ? o.traj_len : 0;
+  // the trajectory buffers of the LPA* handle (goal -> start, like its own recoverTraj leaves them)
+  if (o.status == 0 && searched) {
+    for (int i = tid; i <= len; i += 256) P.traj_nodes[i] = I.traj_nodes[i];
+    for (int i = tid; i < len; i += 256) P.traj_actions[i] = I.traj_actions[i];
+    for (int i = tid; i < (len + 1) * 13; i += 256) P.traj_states[i] = I.traj_states[i];
+  }
+  if (I.dst_rec)
+    for (uint32_t i = tid; i < n_exp && i < I.dst_cap_rec; i += 256) I.dst_rec[i] = I.rec_ids[i];
+  if (tid == 0) {
+    QueryOut r = o;
+    r.slot = 0;
+    for (int i = 0; i < 10; i++) r.cyc[i] = 0;
+    r.n_recorded = n_exp < I.dst_cap_rec ? n_exp : I.dst_cap_rec;
+    LpaState *st = A.st;
+    if (searched) {
+      const bool full = n_blocked > A.blocked_cap || o.n_expanded != (unsigned long long)n_exp;  // (log or expansion record too small)
+      st->n_nodes = (uint32_t)o.n_nodes; st->n_edges = (uint32_t)o.n_edges; st->n_blocked = full ? 0u : n_blocked;
+      st->root_id = 0u;
+      st->goal_id = ((o.status == 0 || o.status == 6) && searched) ? (uint32_t)I.traj_nodes[0] : NIL;
+      st->valid = full ? 0u : 1u;
+      if (full) r.status = 4;  // MPLX_PLAN_POOL_FULL
+      if (o.status == 0 && !full) {
+        st->path_len = (uint32_t)len;
+        for (int i = 0; i <= len; i++) st->path[i] = (uint32_t)I.traj_nodes[len - i];  // start -> goal
+      }
+    }
+    P.out[0] = r;
+  }
+}
+
 }  // namespace mplx

@@ -6,6 +6,7 @@
 namespace mplx { struct LpaParams; }
 bool mplx_launch_lpa(int what, int mode, hipStream_t s, const mplx::SearchParams &P, const mplx::LpaParams &A, int pass = 0, int grid = 1);
 #include "mplx_lpa.h"
+bool mplx_launch_lpa_import(hipStream_t s, const mplx::SearchParams &P, const mplx::LpaParams &A, const mplx::LpaImportArgs &I, int wide);
 
 struct LpaSpace {
   char *node_pool = nullptr, *edge_pool = nullptr;
@@ -45,6 +46,14 @@ struct mplx_lpa {
   std::vector<int32_t> traj_nodes, traj_actions;
   std::vector<double> traj_states;
   float last_ms = 0;
+  // a FRESH plan is an A* from scratch: planned by the speculative kernel on a private lane context (the parent's map replica and
+  // planner set-up, like a lane of an mplx_stream) and imported into the LPA* pools (mplx_lpa.h "import of a finished A*")
+  mplx_ctx *imp = nullptr;
+  uint64_t imp_map_epoch = 0;
+  uint32_t *d_blk_off = nullptr;
+  unsigned long long *d_blk_mask = nullptr;
+  size_t blk_cap = 0;
+  hipEvent_t imp_ev0 = nullptr, imp_ev1 = nullptr;
 };
 
 static int lfail(mplx_lpa *l, int code, const char *fmt, ...) {
@@ -87,6 +96,10 @@ extern "C" void mplx_lpa_destroy(mplx_lpa *l) {
   lpa_free_pools(l);
   (void)hipFree(l->d_in); (void)hipFree(l->d_out); (void)hipFree(l->d_traj_nodes); (void)hipFree(l->d_traj_actions);
   (void)hipFree(l->d_traj_states); (void)hipFree(l->d_rec);
+  (void)hipFree(l->d_blk_off); (void)hipFree(l->d_blk_mask);
+  if (l->imp_ev0) (void)hipEventDestroy(l->imp_ev0);
+  if (l->imp_ev1) (void)hipEventDestroy(l->imp_ev1);
+  if (l->imp) mplx_ctx_destroy(l->imp);
   delete l;
 }
 extern "C" const char *mplx_lpa_last_error(const mplx_lpa *l) { return l ? l->err.c_str() : ""; }
@@ -192,6 +205,59 @@ static bool lpa_same_goal(const mplx_waypoint &a, const mplx_waypoint &b) {
          memcmp(a.acc, b.acc, sizeof(a.acc)) == 0 && memcmp(a.jrk, b.jrk, sizeof(a.jrk)) == 0;
 }
 
+// A fresh LPA* plan = an A* from scratch: planned by the speculative kernel (helper workgroups and all) on the handle's private
+// lane context, then imported into the LPA* pools of space l->cur (P / A: lpa_params of that space).  The lane adopts the
+// parent's map replica and planner set-up like a lane of an mplx_stream; it owns pools of the LPA* handle's capacity.
+static int lpa_plan_by_import(mplx_lpa *l, const mplx_waypoint *start, const mplx_waypoint *goal, const SearchParams &P, const LpaParams &A) {
+  mplx_ctx *c = l->ctx;
+  int r;
+  if (!l->imp) {
+    if ((r = mplx_ctx_create(c->device, &l->imp)) != MPLX_OK) return lfail(l, r, "LPA* import lane: %s", g_create_error.c_str());
+    l->imp_map_epoch = 0;
+    LCHK(l, hipEventCreate(&l->imp_ev0));
+    LCHK(l, hipEventCreate(&l->imp_ev1));
+  }
+  mplx_ctx *lane = l->imp;
+  if (l->imp_map_epoch != c->map_epoch || lane->map != c->map) {  // the parent's map changed (or was replaced): adopt it again
+    if ((r = mplx_map_set_device(lane, c->map, c->dim, c->origin, c->res)) != MPLX_OK) return lfail(l, r, "LPA* import lane: %s", lane->err.c_str());
+    l->imp_map_epoch = c->map_epoch;
+  }
+  if ((r = stream_lane_setup(c, lane, false)) != MPLX_OK) return lfail(l, r, "LPA* import lane: %s", lane->err.c_str());
+  lane->helpers = c->helpers; lane->help_reserved = c->help_reserved; lane->help_rows = c->help_rows; lane->help_limit = -1;
+  mplx_set_capacity(lane, 1, l->cap_nodes, l->cap_edges, l->cap_log);
+  lane->cap_rec = (uint32_t)std::min<uint64_t>(l->cap_nodes, 0xFFFFFFF0ull);  // every expansion closes a state: the record holds the whole order
+  mplx_result res;
+  if ((r = mplx_plan(lane, start, goal, &res)) != MPLX_OK) return lfail(l, r, "%s", lane->err.c_str());
+  const size_t n_exp = lane->last_out[0].n_recorded;
+  if (l->blk_cap < n_exp + 1) {
+    (void)hipFree(l->d_blk_off); (void)hipFree(l->d_blk_mask);
+    l->d_blk_off = nullptr; l->d_blk_mask = nullptr;
+    l->blk_cap = std::max<size_t>(n_exp + 1, (size_t)1 << 16) * 2;
+    LCHK(l, hipMalloc((void **)&l->d_blk_off, sizeof(uint32_t) * l->blk_cap));
+    LCHK(l, hipMalloc((void **)&l->d_blk_mask, sizeof(unsigned long long) * 2 * l->blk_cap));
+  }
+  LpaImportArgs I{};
+  I.node_pool = lane->pools.node_pool; I.edge_pool = lane->pools.edge_pool;
+  I.node_table = lane->d_node_tables; I.edge_table = lane->d_edge_tables;
+  I.out = lane->d_out;
+  I.rec_ids = lane->d_rec;
+  I.traj_nodes = lane->d_traj_nodes; I.traj_actions = lane->d_traj_actions; I.traj_states = lane->d_traj_states;
+  I.blk_off = l->d_blk_off; I.blk_mask = l->d_blk_mask;
+  I.dst_rec = l->cap_rec ? l->d_rec : nullptr; I.dst_cap_rec = l->cap_rec;
+  hipStream_t s = lane->stream;
+  LCHK(l, hipEventRecord(l->imp_ev0, s));
+  LCHK(l, hipMemsetAsync(P.table, 0xFF, (size_t)l->table_slots * sizeof(unsigned long long), s));
+  LCHK(l, hipMemsetAsync(A.st, 0, sizeof(LpaState), s));
+  if (!mplx_launch_lpa_import(s, P, A, I, std::max(1, 4 * c->n_cus))) return lfail(l, MPLX_ERR_ARG, "LPA* supports lattices of at most 128 control inputs (got %d)", P.n_u);
+  LCHK(l, hipGetLastError());
+  LCHK(l, hipEventRecord(l->imp_ev1, s));
+  LCHK(l, hipStreamSynchronize(s));  // (short, bounded kernels: copy, one get_succ per expanded state, a scan)
+  float imp_ms = 0;
+  LCHK(l, hipEventElapsedTime(&imp_ms, l->imp_ev0, l->imp_ev1));
+  l->last_ms = lane->last_ms + imp_ms;
+  return MPLX_OK;
+}
+
 // PlannerBase::plan with setLPAstar(true) (map_replanner_node.cpp:141): repairs and re-uses the state space of the
 // previous plan when the goal, the planner set-up and the start (= the current root) are unchanged; otherwise starts one.
 extern "C" int mplx_lpa_plan(mplx_lpa *l, const mplx_waypoint *start, const mplx_waypoint *goal, mplx_result *out) {
@@ -219,26 +285,38 @@ extern "C" int mplx_lpa_plan(mplx_lpa *l, const mplx_waypoint *start, const mplx
   LpaParams A;
   lpa_params(l, l->cur, P, A);
   A.fresh = fresh ? 1 : 0;
-  if (fresh) {
-    LCHK(l, hipMemsetAsync(P.table, 0xFF, (size_t)l->table_slots * sizeof(unsigned long long), c->stream));
-    LCHK(l, hipMemsetAsync(A.st, 0, sizeof(LpaState), c->stream));
-  }
-  LCHK(l, hipMemcpyAsync(l->d_in, &in, sizeof(QueryIn), hipMemcpyHostToDevice, c->stream));
-  guard_arm(c);
-  LCHK(l, hipEventRecord(c->ev0, c->stream));
-  if (!mplx_launch_lpa(0, 0, c->stream, P, A)) return lfail(l, MPLX_ERR_ARG, "LPA* supports lattices of at most 128 control inputs (got %d)", P.n_u);
-  LCHK(l, hipGetLastError());
-  LCHK(l, hipEventRecord(c->ev1, c->stream));
-  // (the guarded wait first: a device-to-host copy into pageable memory would block the host until the stream has drained)
-  if (int rw = guard_wait(c, c->stream, "the LPA* search launch")) {  // aborted: the space was left in the middle of an expansion
-    l->valid = false;
-    l->traj_len = 0;
-    return lfail(l, rw, "%s", c->err.c_str());
+  static const bool no_import = getenv("MPLX_LPA_NO_IMPORT") != nullptr;  // (diagnostics: the fresh plan on the one-workgroup kernel, as before round 5)
+  const bool by_import = fresh && !no_import && (c->cfg.control == CTRL_ACC || c->cfg.control == CTRL_JRK) && c->cfg.n_u <= 128 &&
+                         (c->speculation < 0 || c->speculation > 1);
+  if (by_import) {
+    if ((r = lpa_plan_by_import(l, start, goal, P, A)) != MPLX_OK) {
+      l->valid = false;
+      l->traj_len = 0;
+      return r;
+    }
+  } else {
+    if (fresh) {
+      LCHK(l, hipMemsetAsync(P.table, 0xFF, (size_t)l->table_slots * sizeof(unsigned long long), c->stream));
+      LCHK(l, hipMemsetAsync(A.st, 0, sizeof(LpaState), c->stream));
+    }
+    LCHK(l, hipMemcpyAsync(l->d_in, &in, sizeof(QueryIn), hipMemcpyHostToDevice, c->stream));
+    guard_arm(c);
+    LCHK(l, hipEventRecord(c->ev0, c->stream));
+    if (!mplx_launch_lpa(0, 0, c->stream, P, A)) return lfail(l, MPLX_ERR_ARG, "LPA* supports lattices of at most 128 control inputs (got %d)", P.n_u);
+    LCHK(l, hipGetLastError());
+    LCHK(l, hipEventRecord(c->ev1, c->stream));
+    // (the guarded wait first: a device-to-host copy into pageable memory would block the host until the stream has drained)
+    if (int rw = guard_wait(c, c->stream, "the LPA* search launch")) {  // aborted: the space was left in the middle of an expansion
+      l->valid = false;
+      l->traj_len = 0;
+      return lfail(l, rw, "%s", c->err.c_str());
+    }
+    LCHK(l, hipStreamSynchronize(c->stream));
+    LCHK(l, hipEventElapsedTime(&l->last_ms, c->ev0, c->ev1));
   }
   LCHK(l, hipMemcpyAsync(&l->last_out, l->d_out, sizeof(QueryOut), hipMemcpyDeviceToHost, c->stream));
   LCHK(l, hipMemcpyAsync(&l->st, A.st, sizeof(LpaState), hipMemcpyDeviceToHost, c->stream));
   LCHK(l, hipStreamSynchronize(c->stream));
-  LCHK(l, hipEventElapsedTime(&l->last_ms, c->ev0, c->ev1));
   fill_result(l->last_out, *out);
   if (fresh) {  // whatever the outcome, the old space is gone
     l->valid = false;

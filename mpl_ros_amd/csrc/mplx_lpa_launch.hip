@@ -29,3 +29,22 @@ bool mplx_launch_lpa(int what, int mode, hipStream_t s, const SearchParams &P, c
   else launch_lpa<128>(what, P.control, s, P, A, mode, pass, grid);
   return true;
 }
+
+// import of a finished A* into the LPA* pools (mplx_lpa.h, round 5): copy + table, blocked successors, finish
+bool mplx_launch_lpa_import(hipStream_t s, const SearchParams &P, const LpaParams &A, const LpaImportArgs &I, int wide) {
+  if (P.n_u > 128) return false;
+#define MPLX_IMP_CASE(C)                                                                                                  \
+  hipLaunchKernelGGL((lpa_import_copy_kernel<C>), dim3(wide), dim3(256), 0, s, P, A, I);                                   \
+  if (P.n_u <= 64) hipLaunchKernelGGL((lpa_import_blocked_kernel<64, C>), dim3(wide), dim3(64), 0, s, P, A, I);            \
+  else hipLaunchKernelGGL((lpa_import_blocked_kernel<128, C>), dim3(wide), dim3(128), 0, s, P, A, I);
+  switch (P.control) {
+    case CTRL_VEL: MPLX_IMP_CASE(CTRL_VEL) break;
+    case CTRL_ACC: MPLX_IMP_CASE(CTRL_ACC) break;
+    case CTRL_JRK: MPLX_IMP_CASE(CTRL_JRK) break;
+    default: MPLX_IMP_CASE(CTRL_SNP) break;
+  }
+#undef MPLX_IMP_CASE
+  hipLaunchKernelGGL((lpa_import_finish_kernel<0>), dim3(1), dim3(256), 0, s, P, A, I);
+  return true;
+}
+
