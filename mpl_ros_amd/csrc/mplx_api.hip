@@ -115,6 +115,11 @@ struct mplx_ctx {
   bool wedged = false;        // a launch did not even answer the abort word: the context's stream is lost
   bool debug_hang = false;    // (tests) the next search launch spins until the host aborts it
   uint64_t cfg_epoch = 0;     // bumped by every change of the planner set-up / pool policy (an mplx_stream's lanes follow it)
+  // expansion filter of the next launches (internal: getSubStateSpace by import, mplx_lpa.inl); null: none
+  const unsigned long long *filter_table = nullptr;
+  unsigned long long filter_mask = 0;
+  const char *filter_pool = nullptr;
+  uint32_t filter_flag = 0;
 };
 #define MPLX_REFUSE_PENDING(c)                                                                                                       \
   do {                                                                                                                               \
@@ -1048,6 +1053,8 @@ bool mplx_launch_spec(int speculation, int grid, hipStream_t s, const mplx::Sear
 bool mplx_launch_spec_help(int grid, hipStream_t s, const mplx::SearchParams &P);
 // yaw-carrying states (mplx_yaw_launch.hip): ACC / JRK lattices of at most 128 inputs; false: none for the configuration
 bool mplx_launch_spec_yaw(int grid, hipStream_t s, const mplx::SearchParams &P);
+// FILTER builds (mplx_filter_launch.hip): SearchParams::filter_* decides which candidates are expanded; false: none for the configuration
+bool mplx_launch_spec_filter(int grid, hipStream_t s, const mplx::SearchParams &P);
 
 static int check_ready(mplx_ctx *c) {
   if (!c) return MPLX_ERR_ARG;
@@ -1211,6 +1218,7 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
   P.node_tables = c->d_node_tables;
   P.edge_tables = c->d_edge_tables;
   P.next_query = c->d_next;
+  if (c->filter_table) filter_set(P, c->filter_table, c->filter_mask, c->filter_pool, c->filter_flag);
   HIPCHK(c, hipMemcpyAsync(c->d_order, order.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(P.table, 0xFF, (size_t)(P.table_mask + 1) * sizeof(unsigned long long), c->stream));
   HIPCHK(c, hipMemsetAsync(P.chunk_next, 0, 4 * sizeof(uint32_t), c->stream));
@@ -1231,7 +1239,7 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
   P.help_lead = slots;
   P.help_max = 0;
   P.help_limit = c->help_limit;
-  const bool help = spec && !tp && !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
+  const bool help = spec && !tp && !c->aux && !c->filter_table && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
                     ((P.n_u <= 31 && (P.control == CTRL_ACC || P.control == CTRL_JRK)) || (P.control == CTRL_JRK && P.n_u > 64 && P.n_u <= 128));
   if (help) {
     // auto: four helpers per leader for the lattices of at most 31 inputs (the capped query of the C4 batch alone: 1.95 s
@@ -1283,6 +1291,10 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
   // yaw-carrying states: the YAW build of the speculative kernel where one exists (ACC / JRK lattices of at most 128 inputs,
   // no auxiliary map), else the one-node kernel below
   bool launched_any = launched;
+  if (c->filter_table) {  // (internal) the filtered search has its own builds and no fallback
+    if (!mplx_launch_spec_filter(grid, c->stream, P)) return fail(c, MPLX_ERR_ARG, "no filtered build of the search kernel for this configuration");
+    launched_any = true;
+  }
   if (!launched_any && c->yaw && (c->speculation < 0 || c->speculation > 1)) launched_any = mplx_launch_spec_yaw(grid, c->stream, P);
   if (!launched_any && !(spec && mplx_launch_spec(c->speculation, grid, c->stream, P))) {
     switch (pick_block(P.n_u)) {

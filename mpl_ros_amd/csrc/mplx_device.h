@@ -209,6 +209,26 @@ struct SearchParams {
   const int32_t *poly_world;
 };
 
+// Expansion filter of the FILTER builds of astar_spec_kernel (getSubStateSpace by import, mplx_lpa.h): a candidate is expanded only
+// if its key is found in `table` (LPA* hashing: no query bits) and the record it names in `pool` carries one of the `flag` bits.
+// The four words travel in the moving-obstacle look-ahead slots of SearchParams, which a voxel-map launch never reads: the layout
+// every other kernel is compiled against stays what it was (tools/device_code_hash.sh: their instruction streams are unchanged).
+struct FilterView {
+  const unsigned long long *table;
+  unsigned long long mask;
+  const char *pool;
+  uint32_t flag;
+};
+__host__ __device__ inline FilterView filter_view(const SearchParams &P) {
+  return FilterView{P.poly.help_mask, (unsigned long long)(uintptr_t)P.poly.help_pub, (const char *)P.poly.help_ring, (uint32_t)P.poly.n_help};
+}
+inline void filter_set(SearchParams &P, const unsigned long long *table, unsigned long long mask, const char *pool, uint32_t flag) {
+  P.poly.help_mask = const_cast<unsigned long long *>(table);
+  P.poly.help_pub = (unsigned long long *)(uintptr_t)mask;
+  P.poly.help_ring = (double *)const_cast<char *>(pool);
+  P.poly.n_help = (int32_t)flag;
+}
+
 // one successor record produced by the expand kernel (mirrors mplx_succ)
 struct SuccOut {
   double pos[3], vel[3], acc[3], jrk[3];

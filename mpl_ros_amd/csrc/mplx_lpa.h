@@ -1090,6 +1090,12 @@ struct LpaImportArgs {
   unsigned long long *blk_mask;             // scratch [2 x n_expanded]: their lanes
   int32_t *dst_rec;                         // the LPA* handle's own expansion record (or null)
   uint32_t dst_cap_rec;
+  // mode 1: the imported search is the Dijkstra of getSubStateSpace (FILTER build: eps = 0, no goal, only states that were BUILT in
+  // the old space expanded; LpaParams::old_* = the space being left).  A state keeps the heuristic it had in the old space; a
+  // state the old space did not hold gets its own (hp: the planner's goal).  No result record, no trajectory: best_child_ and the
+  // goal state are re-found in the new space by key.
+  int32_t mode;
+  HeurParams hp;
 };
 
 template <int CONTROL>
@@ -1110,8 +1116,24 @@ __global__ __launch_bounds__(256) void lpa_import_copy_kernel(SearchParams P, Lp
     V::rhs(dst) = g;
     V::g(dst) = closed ? g : INFINITY;
     V::flags(dst) = FLAG_OPENED | (closed ? (FLAG_CLOSED | FLAG_BUILT) : 0u);
-    (void)ns;
     const unsigned long long h64 = key_hash64(V::key(dst), nk);
+    if (I.mode == 1) {  // (the search ran with eps = 0: no heuristic in the record yet)
+      int32_t key[MAX_KEY];
+#pragma unroll
+      for (int k = 0; k < nk; k++) key[k] = V::key(dst)[k];
+      const uint32_t oid = lpa_find<256, CONTROL>(A.old_table, A.old_table_mask, A.old_node_pool, key, h64);
+      double h = 0.0;
+      if (oid != NIL) {
+        h = *(const double *)(A.old_node_pool + (size_t)oid * rb + 8);
+      } else if (P.eps != 0.0) {
+        State st;
+        const double *sd = V::state(dst);
+#pragma unroll
+        for (int k = 0; k < 12; k++) ((double *)&st)[k] = k < ns ? sd[k] : 0.0;
+        h = get_heur(I.hp, CONTROL, st, key, nk);
+      }
+      V::h(dst) = h;
+    }
     size_t pos = (size_t)h64 & (size_t)P.table_mask;
     for (unsigned long long steps = 0; steps <= P.table_mask; steps++) {
       if (atomicCAS(&P.table[pos], TBL_EMPTY, ((h64 >> 48) << 48) | (unsigned long long)i) == TBL_EMPTY) break;
@@ -1159,7 +1181,7 @@ __global__ __launch_bounds__(BLOCK) void lpa_import_blocked_kernel(SearchParams 
 }
 
 // offsets of the log entries (one workgroup: scan with a carry), the entries, then the scalars: LpaState, result, trajectory
-template <int UNUSED = 0>  // (a template so that the header can be included by two translation units)
+template <int CONTROL>
 __global__ __launch_bounds__(256) void lpa_import_finish_kernel(SearchParams P, LpaParams A, LpaImportArgs I) {
   __shared__ uint32_t wsum[4];
   __shared__ uint32_t carry;
@@ -1194,6 +1216,29 @@ __global__ __launch_bounds__(256) void lpa_import_finish_kernel(SearchParams P, 
     __syncthreads();
   }
   const uint32_t n_blocked = carry;
+  if (I.mode == 1) {  // getSubStateSpace: the scalars of the new space; best_child_ and the goal state re-found by key
+    if (tid == 0) {
+      constexpr int nk = key_len_c(CONTROL), rb = rec_bytes(CONTROL);
+      const LpaState *ost = A.old_st;
+      LpaState *st = A.st;
+      const bool full = o.status == 4 || n_blocked > A.blocked_cap || o.n_expanded != (unsigned long long)n_exp || o.n_nodes == 0;
+      st->n_nodes = (uint32_t)o.n_nodes; st->n_edges = (uint32_t)o.n_edges; st->n_blocked = full ? 0u : n_blocked;
+      st->root_id = 0u;
+      st->valid = full ? 0u : 1u;
+      st->n_changed = full ? ~0ull : o.n_expanded;
+      st->path_len = ost->path_len;
+      auto new_id = [&](uint32_t oid) {
+        if (oid == NIL || oid >= ost->n_nodes) return NIL;
+        const int32_t *kk = (const int32_t *)(A.old_node_pool + (size_t)oid * rb + 24);
+        int32_t key[MAX_KEY];
+        for (int k = 0; k < nk; k++) key[k] = kk[k];
+        return lpa_find<256, CONTROL>(P.table, P.table_mask, P.node_pool, key, key_hash64(key, nk));
+      };
+      for (uint32_t i = 0; i <= ost->path_len; i++) st->path[i] = new_id(ost->path[i]);
+      st->goal_id = new_id(ost->goal_id);
+    }
+    return;
+  }
   const bool searched = o.n_nodes > 0;
   const int len = o.status == 0 ? o.traj_len : 0;
   // the trajectory buffers of the LPA* handle (goal -> start, like its own recoverTraj leaves them)

@@ -208,7 +208,9 @@ static bool lpa_same_goal(const mplx_waypoint &a, const mplx_waypoint &b) {
 // A fresh LPA* plan = an A* from scratch: planned by the speculative kernel (helper workgroups and all) on the handle's private
 // lane context, then imported into the LPA* pools of space l->cur (P / A: lpa_params of that space).  The lane adopts the
 // parent's map replica and planner set-up like a lane of an mplx_stream; it owns pools of the LPA* handle's capacity.
-static int lpa_plan_by_import(mplx_lpa *l, const mplx_waypoint *start, const mplx_waypoint *goal, const SearchParams &P, const LpaParams &A) {
+// the lane of an import: the parent's map replica and planner set-up (dijkstra: eps = 0, no goal, no cap -- getSubStateSpace),
+// pools of the LPA* handle's capacity, an expansion record that holds the whole order
+static int lpa_import_lane(mplx_lpa *l, bool dijkstra) {
   mplx_ctx *c = l->ctx;
   int r;
   if (!l->imp) {
@@ -223,11 +225,25 @@ static int lpa_plan_by_import(mplx_lpa *l, const mplx_waypoint *start, const mpl
     l->imp_map_epoch = c->map_epoch;
   }
   if ((r = stream_lane_setup(c, lane, false)) != MPLX_OK) return lfail(l, r, "LPA* import lane: %s", lane->err.c_str());
+  if (dijkstra) {  // the same lattice and limits; key = g, run until OPEN is empty
+    mplx_config cfg = lane->cfg;
+    cfg.control = lane->cfg.control;
+    cfg.U = lane->U.data();
+    cfg.U_yaw = nullptr;
+    cfg.eps = 0.0;
+    cfg.tol_pos = -1.0; cfg.tol_vel = -1.0; cfg.tol_acc = -1.0;  // (|dp| <= -1 never holds: no goal test ends the search)
+    cfg.t_max = INFINITY;
+    cfg.max_expand = -1;
+    if ((r = mplx_planner_config(lane, &cfg)) != MPLX_OK) return lfail(l, r, "LPA* import lane: %s", lane->err.c_str());
+  }
   lane->helpers = c->helpers; lane->help_reserved = c->help_reserved; lane->help_rows = c->help_rows; lane->help_limit = -1;
   mplx_set_capacity(lane, 1, l->cap_nodes, l->cap_edges, l->cap_log);
   lane->cap_rec = (uint32_t)std::min<uint64_t>(l->cap_nodes, 0xFFFFFFF0ull);  // every expansion closes a state: the record holds the whole order
-  mplx_result res;
-  if ((r = mplx_plan(lane, start, goal, &res)) != MPLX_OK) return lfail(l, r, "%s", lane->err.c_str());
+  return MPLX_OK;
+}
+// the three import kernels on the lane's stream (P / A: lpa_params of the space written), timed into *ms
+static int lpa_import_launch(mplx_lpa *l, const SearchParams &P, const LpaParams &A, int mode, float *ms) {
+  mplx_ctx *c = l->ctx, *lane = l->imp;
   const size_t n_exp = lane->last_out[0].n_recorded;
   if (l->blk_cap < n_exp + 1) {
     (void)hipFree(l->d_blk_off); (void)hipFree(l->d_blk_mask);
@@ -243,7 +259,14 @@ static int lpa_plan_by_import(mplx_lpa *l, const mplx_waypoint *start, const mpl
   I.rec_ids = lane->d_rec;
   I.traj_nodes = lane->d_traj_nodes; I.traj_actions = lane->d_traj_actions; I.traj_states = lane->d_traj_states;
   I.blk_off = l->d_blk_off; I.blk_mask = l->d_blk_mask;
-  I.dst_rec = l->cap_rec ? l->d_rec : nullptr; I.dst_cap_rec = l->cap_rec;
+  I.dst_rec = (mode == 0 && l->cap_rec) ? l->d_rec : nullptr; I.dst_cap_rec = mode == 0 ? l->cap_rec : 0;
+  I.mode = mode;
+  if (mode == 1) {  // the heuristic of a state the old space did not hold: the planner's goal
+    I.hp.w = P.w; I.hp.v_max = P.v_max; I.hp.heur_ignore_dynamics = P.heur_ignore_dynamics;
+    I.hp.goal_control = l->goal.control;
+    wp_to_state(l->goal, I.hp.goal);
+    I.hp.goal_nkey = state_key(l->goal.control, I.hp.goal, I.hp.goal_key);
+  }
   hipStream_t s = lane->stream;
   LCHK(l, hipEventRecord(l->imp_ev0, s));
   LCHK(l, hipMemsetAsync(P.table, 0xFF, (size_t)l->table_slots * sizeof(unsigned long long), s));
@@ -252,10 +275,39 @@ static int lpa_plan_by_import(mplx_lpa *l, const mplx_waypoint *start, const mpl
   LCHK(l, hipGetLastError());
   LCHK(l, hipEventRecord(l->imp_ev1, s));
   LCHK(l, hipStreamSynchronize(s));  // (short, bounded kernels: copy, one get_succ per expanded state, a scan)
+  LCHK(l, hipEventElapsedTime(ms, l->imp_ev0, l->imp_ev1));
+  return MPLX_OK;
+}
+static int lpa_plan_by_import(mplx_lpa *l, const mplx_waypoint *start, const mplx_waypoint *goal, const SearchParams &P, const LpaParams &A) {
+  int r;
+  if ((r = lpa_import_lane(l, false)) != MPLX_OK) return r;
+  mplx_ctx *lane = l->imp;
+  mplx_result res;
+  if ((r = mplx_plan(lane, start, goal, &res)) != MPLX_OK) return lfail(l, r, "%s", lane->err.c_str());
   float imp_ms = 0;
-  LCHK(l, hipEventElapsedTime(&imp_ms, l->imp_ev0, l->imp_ev1));
+  if ((r = lpa_import_launch(l, P, A, 0, &imp_ms)) != MPLX_OK) return r;
   l->last_ms = lane->last_ms + imp_ms;
   return MPLX_OK;
+}
+// getSubStateSpace(k) = a Dijkstra from the k-th state of the last trajectory through the states that had been expanded in the
+// space being left: the FILTER build of the speculative kernel with eps = 0 and no goal, then the same import.  P / A: lpa_params
+// of the NEW space, A.old_* the old one.
+static int lpa_subtree_by_import(mplx_lpa *l, int time_step, const SearchParams &P, const LpaParams &A) {
+  int r;
+  if ((r = lpa_import_lane(l, true)) != MPLX_OK) return r;
+  mplx_ctx *lane = l->imp;
+  mplx_waypoint start{};
+  const double *s = &l->traj_states[(size_t)(l->traj_len - time_step) * 13];
+  for (int k = 0; k < 3; k++) { start.pos[k] = s[k]; start.vel[k] = s[3 + k]; start.acc[k] = s[6 + k]; start.jrk[k] = s[9 + k]; }
+  start.t = s[12];
+  start.control = l->ctx->cfg.control;
+  lane->filter_table = A.old_table; lane->filter_mask = A.old_table_mask; lane->filter_pool = A.old_node_pool; lane->filter_flag = FLAG_BUILT;
+  mplx_result res;
+  r = mplx_plan(lane, &start, &l->goal, &res);
+  lane->filter_table = nullptr;
+  if (r != MPLX_OK) return lfail(l, r, "%s", lane->err.c_str());
+  float imp_ms = 0;
+  return lpa_import_launch(l, P, A, 1, &imp_ms);
 }
 
 // PlannerBase::plan with setLPAstar(true) (map_replanner_node.cpp:141): repairs and re-uses the state space of the
@@ -405,15 +457,24 @@ extern "C" int mplx_lpa_sub_state_space(mplx_lpa *l, int32_t time_step) {
     A.old_st = Aold.st;
     A.time_step = time_step;
   }
-  LCHK(l, hipMemsetAsync(P.table, 0xFF, (size_t)l->table_slots * sizeof(unsigned long long), c->stream));
-  LCHK(l, hipMemsetAsync(A.st, 0, sizeof(LpaState), c->stream));
-  guard_arm(c);
-  if (!mplx_launch_lpa(2, 0, c->stream, P, A)) return lfail(l, MPLX_ERR_ARG, "lattice too wide for LPA*");
-  LCHK(l, hipGetLastError());
+  static const bool no_import = getenv("MPLX_LPA_NO_IMPORT") != nullptr;  // (diagnostics: the one-workgroup Dijkstra, as before round 5)
+  const bool by_import = !no_import && (c->cfg.control == CTRL_ACC || c->cfg.control == CTRL_JRK) && c->cfg.n_u <= 128 && (c->speculation < 0 || c->speculation > 1);
   LpaState ns{};
-  if (int rw = guard_wait(c, c->stream, "the LPA* sub-state-space launch")) {
-    l->valid = false;
-    return lfail(l, rw, "%s", c->err.c_str());
+  if (by_import) {
+    if (int ri = lpa_subtree_by_import(l, time_step, P, A)) {
+      l->valid = false;
+      return ri;
+    }
+  } else {
+    LCHK(l, hipMemsetAsync(P.table, 0xFF, (size_t)l->table_slots * sizeof(unsigned long long), c->stream));
+    LCHK(l, hipMemsetAsync(A.st, 0, sizeof(LpaState), c->stream));
+    guard_arm(c);
+    if (!mplx_launch_lpa(2, 0, c->stream, P, A)) return lfail(l, MPLX_ERR_ARG, "lattice too wide for LPA*");
+    LCHK(l, hipGetLastError());
+    if (int rw = guard_wait(c, c->stream, "the LPA* sub-state-space launch")) {
+      l->valid = false;
+      return lfail(l, rw, "%s", c->err.c_str());
+    }
   }
   LCHK(l, hipMemcpyAsync(&ns, A.st, sizeof(LpaState), hipMemcpyDeviceToHost, c->stream));
   LCHK(l, hipStreamSynchronize(c->stream));

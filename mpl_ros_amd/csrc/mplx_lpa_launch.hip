@@ -36,7 +36,8 @@ bool mplx_launch_lpa_import(hipStream_t s, const SearchParams &P, const LpaParam
 #define MPLX_IMP_CASE(C)                                                                                                  \
   hipLaunchKernelGGL((lpa_import_copy_kernel<C>), dim3(wide), dim3(256), 0, s, P, A, I);                                   \
   if (P.n_u <= 64) hipLaunchKernelGGL((lpa_import_blocked_kernel<64, C>), dim3(wide), dim3(64), 0, s, P, A, I);            \
-  else hipLaunchKernelGGL((lpa_import_blocked_kernel<128, C>), dim3(wide), dim3(128), 0, s, P, A, I);
+  else hipLaunchKernelGGL((lpa_import_blocked_kernel<128, C>), dim3(wide), dim3(128), 0, s, P, A, I);                     \
+  hipLaunchKernelGGL((lpa_import_finish_kernel<C>), dim3(1), dim3(256), 0, s, P, A, I);
   switch (P.control) {
     case CTRL_VEL: MPLX_IMP_CASE(CTRL_VEL) break;
     case CTRL_ACC: MPLX_IMP_CASE(CTRL_ACC) break;
@@ -44,7 +45,6 @@ bool mplx_launch_lpa_import(hipStream_t s, const SearchParams &P, const LpaParam
     default: MPLX_IMP_CASE(CTRL_SNP) break;
   }
 #undef MPLX_IMP_CASE
-  hipLaunchKernelGGL((lpa_import_finish_kernel<0>), dim3(1), dim3(256), 0, s, P, A, I);
   return true;
 }
 

@@ -582,8 +582,11 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
 // key integer and one more state double through candidate fetch, batch table, table look-up and creation; the rules are the
 // one-node kernel's (astar_kernel<..., YAW>: successor yaw and validate_yaw in expand_unit, heuristic of the yaw-less search
 // unless the yaw keys differ from the goal's, optional yaw tolerance in the goal test).  Without helper workgroups.
-template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false, bool POT = false, bool TP = false, bool YAW = false>
+// FILTER (round 5): a candidate is expanded only if SearchParams::filter_* says so -- the Dijkstra of getSubStateSpace walks only the
+// states that had been expanded in the space it leaves; a candidate the filter rejects is dropped like a stale entry.
+template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false, bool POT = false, bool TP = false, bool YAW = false, bool FILTER = false>
 __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchParams P) {
+  static_assert(!(FILTER && (HELP || POT || YAW || TP)), "the filtered search is the plain kernel");
   static_assert(!(HELP && POT), "the look-ahead cache rows carry no potential sums");
   static_assert(!(YAW && (HELP || POT)), "yaw-carrying searches run without helpers and without an auxiliary map");
   constexpr int BLOCK = UL * K;
@@ -1163,6 +1166,35 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         }
         unit_sync<UL>();
         MPLX_T2(S, 20, t3);
+        if constexpr (FILTER) {  // the candidate's key in the filter table: expandable?
+          if (live_unit && lu == 0) {
+            const FilterView F = filter_view(P);
+            const unsigned long long hk = key_hash64(S.cur_key[ku], NKY);
+            const unsigned long long tag = (hk >> 48) << 48;
+            size_t pos = (size_t)hk & (size_t)F.mask;
+            bool ok = false;
+            for (unsigned long long steps = 0; steps <= F.mask; steps++) {
+              const unsigned long long v = ld_u64(&F.table[pos]);
+              if (v == TBL_EMPTY) break;
+              const uint32_t vid = (uint32_t)v;
+              if (vid < CLAIM_BASE && (v & 0xFFFFFFFF00000000ull) == tag) {
+                const char *r = F.pool + (size_t)vid * rec_bytes(CONTROL);
+                const int32_t *kk = (const int32_t *)(r + 24);
+                uint32_t kd = 0;
+#pragma unroll
+                for (int i = 0; i < NKY; i++) kd |= (uint32_t)(kk[i] ^ S.cur_key[ku][i]);
+                if (kd == 0u) {
+                  ok = (*(const uint32_t *)(r + 16) & F.flag) != 0u;
+                  break;
+                }
+              }
+              pos = (pos + 1) & (size_t)F.mask;
+            }
+            if (!ok) S.cand_live[opaque(ku)] = 0;
+          }
+          unit_sync<UL>();
+          live_unit = live_unit && S.cand_live[opaque(ku)] != 0;
+        }
         if (live_unit && lu == 0) {  // goal test of the candidate (applied when, and if, it is committed)
           State sgoal;
           for (int i = 0; i < 12; i++) ((double *)&sgoal)[i] = S.cur[ku][i];

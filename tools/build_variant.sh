@@ -27,7 +27,8 @@ mkdir -p $O
 /opt/rocm/bin/hipcc $F -c -o $O/v_yaw.o $S/mplx_yaw_launch.hip &
 /opt/rocm/bin/hipcc $F -c -o $O/v_lpa.o $S/mplx_lpa_launch.hip &
 /opt/rocm/bin/hipcc $F -c -o $O/v_poly.o $S/mplx_poly_launch.hip &
+/opt/rocm/bin/hipcc $F -c -o $O/v_filter.o $S/mplx_filter_launch.hip &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libmplx_$V.so $O/v_api.o $O/v_spec.o $O/v_help.o $O/v_yaw.o $O/v_lpa.o $O/v_poly.o $S/mplx_host.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libmplx_$V.so $O/v_api.o $O/v_spec.o $O/v_help.o $O/v_yaw.o $O/v_lpa.o $O/v_poly.o $O/v_filter.o $S/mplx_host.o
 rm -f $O/v_*.o
 ls -la $O/libmplx_$V.so
