@@ -5,7 +5,7 @@
 #      and kernel traces of the streamed leg, the C4-JRK batch, the C3 query and the C5 tick      -> profiles/traffic.json
 #   4. C5 / LPA* / C3 / C4-JRK bench lines                   5. all 1024 queries of the C4 batches replayed on the CPU (ACC and JRK)
 set -u
-TAG=${1:-r05y}
+TAG=${1:-r05x}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export MPLX_DEADLINE_S=100 TMPDIR=/tmp
 ROOT=$PWD
