@@ -112,7 +112,8 @@ struct CacheRec {              // per node record of the pool; two self-validati
 // the successor of input i, slot 31 the voxel reads (as bits); the masks live in the cache record.  Larger lattices
 // (units of 128 lanes, <= 128 inputs): 136 doubles -- [0..3] eight 32-bit mask words (valid x 4, blocked x 4), [4] the
 // voxel reads, [8..135] the heuristics; the record's second half then only carries CACHE_READY.
-// MPLX_X_ROW_PAIRS (A/B switch, off in the product; host and kernels must be built alike: tools/build_variant.sh): the small
+// MPLX_X_ROW_PAIRS (A/B switch, off in the product -- measured in round 5: correct, 15 % slower on the blocking C4 step, profiles/r05h_*;
+// host and kernels must be built alike: tools/build_variant.sh rowpairs): the small
 // row as 32 pairs {value, check of that value} -- slot 2 i the heuristic of input i, 2 i + 1 its check, 62 / 63 the voxel reads and
 // theirs -- each pair written by ONE 16-byte store and validated by the lane that consumes it (no cross-lane step; a torn pair
 // fails whichever half is old).  DESIGN.md 7.

@@ -1199,7 +1199,7 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
   }
 #endif
   if (act) {
-    // MPLX_X_CLAIM_WAIT_1N (A/B switch, off in the product; tools/build_variant.sh claimwait1n): rule R3 of DESIGN.md 3.9 for the
+    // MPLX_X_CLAIM_WAIT_1N (on in the product since round 5; the parity and guard suites run with it): rule R3 of DESIGN.md 3.9 for the
     // one-node kernels.  Every claim made here becomes an entry within the same expansion (there are no cut units), so a claim of
     // an EARLIER expansion with this query's tag is an entry store that has not landed yet -- wait for it instead of passing it (and
     // creating the state a second time).  The claim carries the low bits of the expansion count to tell the two apart.

@@ -468,3 +468,80 @@ def test_hip_lpastar_goal_region_case_matches_the_oracle_and_a_fresh_astar():
             assert l.updateBlockedNodes([(cx, cy, 0)]) == L.update_blocked([(cx, cy, 0)])
         costs.append(both())
     assert costs == [67.0, 67.0, 58.0, 56.0, 67.0]
+
+
+@pytest.mark.gpu
+def test_hip_lpastar_imports_a_jerk_lattice_plan_bit_exact_and_survives_degenerate_starts():
+    """Round 5: a fresh LPA* plan is planned by the speculative kernel and imported into the LPA* pools (mplx_lpa.h).  The other tests
+    cover the 27-input ACC lattice; here the 125-input JERK lattice (160-byte records, units of two waves, 128-lane import of the
+    blocked log), capped, against the CPU LPA* -- every state's g / rhs / h / flags, every entry, the blocked log -- then a repair on
+    the imported space after an obstacle lands on the path; and the two plans that never search (start inside the goal region, start
+    occupied) leave no state space behind, like the one-workgroup kernel."""
+    from mpl_ros_amd.planner import VoxelMapPlanner
+    grid, origin, res = util.small_map(64, seed=21, occupancy=0.06)
+    U = mapgen.control_lattice(1.0, 2, True)
+    assert U.shape[0] == 125
+    kw = dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=4000)
+    L = util.make_oracle(grid, origin, res, orc.JRK, U, **kw)
+    L.set_lpastar(True)
+    mu, a = util.make_gpu(grid, origin, res, U, **kw)
+    l = VoxelMapPlanner(False)
+    l.setMapUtil(mu)
+    l.setVmax(2.0); l.setAmax(1.0); l.setJmax(1.0); l.setDt(1.0); l.setU(U); l.setTol(0.5); l.setMaxNum(4000)
+    l.setCapacity(1, 1 << 19, 1 << 22, 1 << 21)
+    l.setLPAstar(True)
+    start, goal = (0.55, 0.55, 0.55), (5.55, 5.55, 5.55)
+    so, go = orc.waypoint(start, control=orc.JRK), orc.waypoint(goal, control=orc.JRK)
+    sg, gg = util.gpu_wp(start, control=orc.JRK), util.gpu_wp(goal, control=orc.JRK)
+    L.reset_counters()
+    st = L.plan(so, go)
+    ok = l.plan(sg, gg)
+    r = l.getResult()
+    assert ok == (st == orc.OK) and r.n_expanded > 500
+
+    def compare(L, l, r, st_o):  # (compare_lpa with JRK waypoints)
+        assert r.status == st_o
+        ids = L.expanded()[0]
+        assert r.n_expanded == L.lpa_iterations() == len(ids) and r.expand_hash == util.expand_hash(ids)
+        ss = l.lpaStateSpace()
+        n = L.num_nodes()
+        assert ss["n_nodes"] == n == r.n_nodes
+        g = np.array([L.node(i)[1] for i in range(n)]); h = np.array([L.node(i)[2] for i in range(n)])
+        closed = np.array([L.node(i)[3] for i in range(n)], dtype=np.int32)
+        rhs = np.array([L.node_rhs(i) for i in range(n)]); opened = np.array([L.node_opened(i) for i in range(n)], dtype=np.int32)
+        assert np.array_equal(ss["g"], g) and np.array_equal(ss["rhs"], rhs) and np.array_equal(ss["h"], h)
+        assert np.array_equal(ss["closed"], closed) and np.array_equal(ss["opened"], opened)
+        co, po, ao = L.edges()
+        assert np.array_equal(ss["child"], co) and np.array_equal(ss["parent"], po) and np.array_equal(ss["action"], ao)
+        assert np.array_equal(ss["blocked"], L.edges_blocked())
+        if st_o == orc.OK:
+            assert r.cost == L.traj_cost
+    compare(L, l, r, st)
+    if st == orc.OK:  # an obstacle on the path, a repair on the imported space
+        tr = L.traj()
+        cells = box_cells(L, tuple(tr["wps"][tr["n"] // 2].pos), 1)
+        g2 = grid.copy()
+        for x, y, z in cells:
+            g2[z, y, x] = 100
+        L.set_map(g2, origin, res)
+        dz, dy, dx = g2.shape
+        mu.setMap(origin, (dx, dy, dz), g2.ravel(), res)
+        assert l.updateBlockedNodes(cells) == L.update_blocked(cells)
+        L.reset_counters()
+        st2 = L.plan(so, go)
+        ok2 = l.plan(sg, gg)
+        assert ok2 == (st2 == orc.OK)
+        compare(L, l, l.getResult(), st2)
+        mu.setMap(origin, (dx, dy, dz), grid.ravel(), res)
+    # plans that never search: no state space is left behind
+    l2 = VoxelMapPlanner(False)
+    l2.setMapUtil(mu)
+    l2.setVmax(2.0); l2.setAmax(1.0); l2.setJmax(1.0); l2.setDt(1.0); l2.setU(U); l2.setTol(0.5)
+    l2.setCapacity(1, 1 << 19, 1 << 22, 1 << 21)
+    l2.setLPAstar(True)
+    assert l2.plan(sg, util.gpu_wp((0.75, 0.55, 0.55), control=orc.JRK))  # the start already satisfies the goal
+    assert l2.getResult().cost == 0.0 and not l2.initialized()
+    occ = np.argwhere(grid > 0)[0]
+    p_occ = ((float(occ[2]) + 0.5) * res + origin[0], (float(occ[1]) + 0.5) * res + origin[1], (float(occ[0]) + 0.5) * res + origin[2])  # (grid is z, y, x)
+    assert not l2.plan(util.gpu_wp(p_occ, control=orc.JRK), gg)
+    assert l2.getResult().status == 2 and not l2.initialized()

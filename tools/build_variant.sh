@@ -1,9 +1,8 @@
 #!/bin/bash
 # Builds a diagnostic variant of libmplx.so into build_tmp/ (git-ignored; travels with gpurun snapshots).
 # usage: tools/build_variant.sh timers|helpdbg|rowpairs|earlytomb|fast|claimwait1n|diag  -> build_tmp/libmplx_<variant>.so   (use with MPLX_LIB=...)
-#   rowpairs / earlytomb / fast (= both): the two A/B switches of DESIGN.md 7 that should give back the 7 % the round-4 fix of the
-#   table / look-ahead-row race costs; never run on a GPU yet -- compare with the product build under bench.py AND under
-#   tools/r04_jitter_probe.py (the race they must keep closed only shows under a background fill load)
+#   rowpairs / earlytomb / fast (= both): the two A/B switches round 4 hoped would give back the cost of its safeguards -- measured in
+#   round 5: rowpairs 15 % slower, earlytomb no gain; kept for re-measurement.  diag: the MPLX_X_FLAGS switches.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 V=${1:-timers}
