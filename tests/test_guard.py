@@ -67,7 +67,7 @@ def test_a_batch_that_outlives_its_deadline_is_aborted_and_the_next_one_is_clean
 
 def test_the_moving_obstacle_tick_and_an_lpastar_plan_honour_their_deadlines():
     """The other two families of search launches behind the guard: the Team2 tick (16 leaders + look-ahead helper launch on a
-    second stream, ~ 240 ms) and a fresh LPA* plan at 256^3 (one workgroup, ~ 340 ms), each given a deadline far below its run time:
+    second stream, ~ 240 ms) and a fresh LPA* plan at 256^3 (speculative kernel + import, ~ 38 ms), each given a deadline far below its run time:
     MPLX_ERR_TIMEOUT, and the same call repeats exactly afterwards."""
     from mpl_ros_amd import poly_map as pm
     from mpl_ros_amd.planner import VoxelMapPlanner
@@ -103,7 +103,7 @@ def test_the_moving_obstacle_tick_and_an_lpastar_plan_honour_their_deadlines():
     first = (r0.status, r0.cost, r0.n_expanded, r0.expand_hash)
     assert r0.n_expanded > 10000
     l.reset()
-    l.setDeadline(0.03)
+    l.setDeadline(0.015)  # (the plan's search launch alone runs ~ 37 ms)
     t0 = time.time()
     with pytest.raises(MplxError) as e:
         l.plan(util.gpu_wp(start), util.gpu_wp(goal))
