@@ -433,6 +433,11 @@ int mplx_result_timing(mplx_ctx *ctx, int q, double *t_begin_s, double *t_end_s,
  * [9] candidates served from the look-ahead cache.  [0]..[6] are zero in the product build of the library (the timers
  * sit on a query's serial chain; built with -DMPLX_PHASE_TIMERS=1 -- tools/build_variant.sh timers -- they are filled) */
 int mplx_result_cycles(mplx_ctx *ctx, int q, uint64_t cyc[10]);
+/* Speculation accounting of query q (the K-way speculative kernels; zeros from the one-node kernels): [0] OPEN entries taken as
+ * candidates, [1] of those found stale and dropped (a pop the reference's loop would skip too), [2] units that ran get_succ,
+ * [3] units whose expansion was thrown away because their batch was cut ahead of them (they return to OPEN and are expanded again).
+ * mplx_result.n_expanded counts committed units only: spec[2] - n_expanded is the work -- and traffic -- speculation wasted. */
+int mplx_result_speculation(mplx_ctx *ctx, int q, uint64_t spec[4]);
 /* duration (ms, HIP events on the context's stream) of the last search / expand kernel launch */
 int mplx_last_kernel_ms(const mplx_ctx *ctx, float *ms);
 /* name of the search kernel mplx_plan / mplx_plan_batch launches for the current configuration */

@@ -55,7 +55,7 @@ EXPORTS = [
     "mplx_map_dilate", "mplx_map_cells", "mplx_map_raytrace", "mplx_map_cloud",
     "mplx_planner_config", "mplx_set_capacity", "mplx_set_bucket_width", "mplx_set_speculation", "mplx_set_helpers", "mplx_helper_stats",
     "mplx_expand_batch", "mplx_heuristic_batch", "mplx_plan", "mplx_plan_batch",
-    "mplx_result_traj", "mplx_set_record", "mplx_result_expanded", "mplx_result_nodes", "mplx_result_edges", "mplx_result_blocked", "mplx_result_timing", "mplx_result_cycles",
+    "mplx_result_traj", "mplx_set_record", "mplx_result_expanded", "mplx_result_nodes", "mplx_result_edges", "mplx_result_blocked", "mplx_result_timing", "mplx_result_cycles", "mplx_result_speculation",
     "mplx_last_kernel_ms", "mplx_version", "mplx_kernel_name", "mplx_plan_epoch",
     "mplx_grid_create", "mplx_grid_destroy", "mplx_grid_last_error", "mplx_grid_allocate", "mplx_grid_info", "mplx_grid_clear",
     "mplx_grid_add_cloud", "mplx_grid_add_cloud_inflate", "mplx_grid_decay", "mplx_grid_clear_column", "mplx_grid_fill_column",
@@ -131,6 +131,7 @@ def load():
     L.mplx_result_blocked.argtypes = [P, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mplx_result_timing.argtypes = [P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), I3]
     L.mplx_result_cycles.argtypes = [P, C.c_int, C.POINTER(C.c_uint64)]
+    L.mplx_result_speculation.argtypes = [P, C.c_int, C.POINTER(C.c_uint64)]
     L.mplx_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float)]
     L.mplx_version.restype = C.c_char_p
     L.mplx_kernel_name.argtypes = [P]

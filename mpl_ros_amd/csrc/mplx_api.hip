@@ -111,7 +111,10 @@ struct mplx_ctx {
   int help_limit = -1;  // workgroups of a launch that may turn into helpers once the query queue is empty (-1: all of them)
   // launch guard (mplx_device.h GuardBlock): host-coherent block the search kernels poll / leave their watch records in
   GuardBlock *guard = nullptr;
-  double deadline_s = 120.0;  // a search launch older than this is aborted (mplx_set_deadline; <= 0: wait forever)
+  // a search launch older than this is aborted (mplx_set_deadline, MPLX_DEADLINE_S).  OPT-IN: the default (<= 0) waits for ever, like the
+  // reference's plan(), whose only bound is max_num (map_planner_node.cpp:186-196); tests and bench.py set one.
+  double deadline_s = 0.0;
+  std::chrono::steady_clock::time_point guard_t0;  // when the guarded launch was armed (guard_arm): the deadline counts from the LAUNCH, not from the wait
   bool wedged = false;        // a launch did not even answer the abort word: the context's stream is lost
   bool debug_hang = false;    // (tests) the next search launch spins until the host aborts it
   uint64_t cfg_epoch = 0;     // bumped by every change of the planner set-up / pool policy (an mplx_stream's lanes follow it)
@@ -755,6 +758,8 @@ extern "C" int mplx_helper_stats(const mplx_ctx *cc, uint32_t stats[4]) {
     c->help_stats[2] = c->help_ctr_back[2];
     c->help_stats[3] = c->help_ctr_back[3];
     c->help_stats_pending = false;
+    if (getenv("MPLX_HELP_XCD_STATS"))  // (diagnostics) helper attachments to a leader of the helper's own XCD / of another one
+      fprintf(stderr, "[help xcd] attachments same-XCD %u, cross-XCD %u\n", c->help_ctr_back[5], c->help_ctr_back[6]);
 #ifdef MPLX_HELP_DEBUG
     {
       fprintf(stderr, "[help debug] stall quits by (helper XCD row, leader XCD column) | attachments:\n");
@@ -768,7 +773,7 @@ extern "C" int mplx_helper_stats(const mplx_ctx *cc, uint32_t stats[4]) {
       if (c->dbg_boxes && hipMemcpy(hb.data(), c->dbg_boxes, sizeof(HelpBox) * hb.size(), hipMemcpyDeviceToHost) == hipSuccess)
         for (size_t i = 0; i < hb.size(); i++)
           if (hb[i].pad1[0] > 1000000ull)
-            fprintf(stderr, "[help debug] slot %zu (XCD %u): longest batch %.1f ms at %.1f ms into query %llu (batch %llu), helped %llu\n", i, (uint32_t)hb[i].pad1[4] - 1u,
+            fprintf(stderr, "[help debug] slot %zu (XCD %u): longest batch %.1f ms at %.1f ms into query %llu (batch %llu), helped %llu\n", i, (uint32_t)hb[i].xcc_plus1 - 1u,
                     hb[i].pad1[0] * 1e-5, (hb[i].pad1[1] >> 1) * 1e-5, hb[i].pad1[2], hb[i].pad1[3], hb[i].pad1[1] & 1ull);
     }
 #endif
@@ -851,13 +856,19 @@ static void guard_arm(mplx_ctx *c) {  // before a search launch: no abort pendin
   if (!c->guard) return;
   memset(c->guard, 0, sizeof(GuardBlock));
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  c->guard_t0 = std::chrono::steady_clock::now();
 }
-static int guard_wait(mplx_ctx *c, hipStream_t s, const char *what) {
+// The clock starts at guard_arm() -- the launch -- so a submitted batch collected later and the two sequential waits of the
+// moving-obstacle path (leaders, then helpers) share ONE deadline.  `keep_abort`: leave the abort word raised on return (the caller
+// still has a second launch of the same search to drain -- mplx_poly_plan_batch's helpers -- and lowers it with guard_disarm()).
+static int guard_wait(mplx_ctx *c, hipStream_t s, const char *what, bool keep_abort = false) {
   if (c->wedged) return fail(c, MPLX_ERR_TIMEOUT, "this context was lost to a launch that never ended (destroy it)");
   using clk = std::chrono::steady_clock;
-  const auto t0 = clk::now();
+  const auto t0 = c->guard_t0;
   const double limit = c->deadline_s, grace = 10.0;
-  bool aborted = false;
+  bool aborted = c->guard && __atomic_load_n(&c->guard->abort, __ATOMIC_RELAXED) != 0u;  // (raised by an earlier wait of the same launch)
+  double t_abort = aborted ? std::chrono::duration<double>(clk::now() - t0).count() : 0.0;
+  const auto tw = clk::now();
   std::string dump;
   for (;;) {
     const hipError_t e = hipStreamQuery(s);
@@ -868,21 +879,26 @@ static int guard_wait(mplx_ctx *c, hipStream_t s, const char *what) {
       dump = guard_dump(c);
       __atomic_store_n(&c->guard->abort, 1u, __ATOMIC_SEQ_CST);
       aborted = true;
+      t_abort = el;
     }
-    if (aborted && el > limit + grace) {
+    if (aborted && el > t_abort + grace) {
       c->wedged = true;
       c->pending = false;
-      return fail(c, MPLX_ERR_TIMEOUT, "%s did not end within %.1f s and did not answer the abort word for another %.0f s; the context is lost. At the deadline: %s; now: %s", what,
+      return fail(c, MPLX_ERR_TIMEOUT, "%s did not end within %.1f s of its launch and did not answer the abort word for another %.0f s; the context is lost. At the deadline: %s; now: %s", what,
                   limit, grace, dump.c_str(), guard_dump(c).c_str());
     }
-    if (el < 0.002) sched_yield();
-    else usleep(el < 0.1 ? 50 : 250);
+    const double waited = std::chrono::duration<double>(clk::now() - tw).count();
+    if (waited < 0.002) sched_yield();
+    else usleep(waited < 0.1 ? 50 : 250);
   }
   if (aborted) {
-    __atomic_store_n(&c->guard->abort, 0u, __ATOMIC_SEQ_CST);
-    return fail(c, MPLX_ERR_TIMEOUT, "%s did not end within %.1f s and was aborted (results of the launch are void). At the deadline: %s", what, limit, dump.c_str());
+    if (!keep_abort) __atomic_store_n(&c->guard->abort, 0u, __ATOMIC_SEQ_CST);
+    return fail(c, MPLX_ERR_TIMEOUT, "%s did not end within %.1f s of its launch and was aborted (results of the launch are void). At the deadline: %s", what, limit, dump.c_str());
   }
   return MPLX_OK;
+}
+static void guard_disarm(mplx_ctx *c) {
+  if (c->guard) __atomic_store_n(&c->guard->abort, 0u, __ATOMIC_SEQ_CST);
 }
 extern "C" int mplx_set_deadline(mplx_ctx *c, double seconds) {
   if (!c) return MPLX_ERR_ARG;
@@ -1859,6 +1875,12 @@ extern "C" int mplx_result_timing(mplx_ctx *c, int q, double *t_begin_s, double 
 extern "C" int mplx_result_cycles(mplx_ctx *c, int q, uint64_t cyc[10]) {
   if (!c || q < 0 || q >= c->last_nq || !cyc) return fail(c, MPLX_ERR_ARG, "no such query");
   for (int i = 0; i < 10; i++) cyc[i] = c->last_out[q].cyc[i];
+  return MPLX_OK;
+}
+
+extern "C" int mplx_result_speculation(mplx_ctx *c, int q, uint64_t spec[4]) {
+  if (!c || q < 0 || q >= c->last_nq || !spec) return fail(c, MPLX_ERR_ARG, "no such query");
+  for (int i = 0; i < 4; i++) spec[i] = c->last_out[q].spec[i];
   return MPLX_OK;
 }
 

@@ -74,6 +74,10 @@ struct QueryOut {
   unsigned long long t_begin, t_end;  // wall_clock64() ticks (100 MHz)
   unsigned long long cyc[10];         // s_memtime cycles: pop, expand, look-up, evict, refill, activate, commit; counts: batches, ordered batches, -
   uint32_t n_recorded, slot;
+  // speculation accounting of the K-way kernels (mplx_result_speculation): OPEN entries taken as candidates, of those found stale and
+  // dropped, units that ran get_succ (live candidates), units whose expansion was thrown away because the batch was cut ahead of
+  // them (they return to OPEN and are expanded again later).  n_expanded counts the committed units only.
+  unsigned long long spec[4];
 };
 
 // ---- helper workgroups (look-ahead expansion of a running query on otherwise idle compute units)
@@ -96,7 +100,8 @@ struct alignas(64) HelpBox {   // one per workgroup slot; every word is written 
   unsigned long long n_expanded;  // progress of the running query (helpers prefer the longest-running leader)
   uint32_t q;                  // query the leader is running
   uint32_t rank;               // position of that query in the launch order (longest predicted first)
-  unsigned long long pad1[5];  // (pad1[0..4]: diagnostics of the -DMPLX_HELP_DEBUG build)
+  unsigned long long pad1[4];  // (pad1[0..3]: diagnostics of the -DMPLX_HELP_DEBUG build)
+  unsigned long long xcc_plus1;  // XCD the leader runs on + 1 (HW_REG_XCC_ID): helpers prefer a leader of their own XCD (shared L2)
   // line 1: written by helpers (atomics), read by the leader every few batches -- kept off the line the leader stores to
   uint32_t helpers;            // bit mask of attached helpers (atomicOr / atomicAnd)
   uint32_t pad2[15];

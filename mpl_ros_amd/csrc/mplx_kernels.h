@@ -270,6 +270,7 @@ struct Smem {
   uint32_t tmp_u;
   double tmp_d0;
   unsigned long long c_expanded, c_closed, c_prims, c_succ, c_succ_finite, c_reads, c_push, c_reopen, c_refill, c_evict, c_hash;
+  unsigned long long c_cand, c_live, c_cut;  // (speculative kernels) candidates taken, live units expanded, expanded units cut and returned to OPEN
   unsigned long long cyc[10];
   double cur_yaw[KUNITS];  // yaw of the node(s) being expanded (yaw-carrying searches)
   __device__ __forceinline__ uint32_t *pot_scratch() { return (uint32_t *)dupset; }
@@ -1670,6 +1671,7 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
       o.expand_hash = S.c_hash;
       o.n_recorded = (uint32_t)(S.c_expanded < P.cap_rec ? S.c_expanded : P.cap_rec);
       o.slot = blockIdx.x;
+      o.spec[0] = o.spec[1] = o.spec[2] = o.spec[3] = 0;  // (one node per iteration: nothing speculative)
       o.t_begin = t_begin;
       o.t_end = wall_clock64();
       for (int i = 0; i < 10; i++) o.cyc[i] = S.cyc[i];

@@ -427,7 +427,15 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   PCHK(p, hipEventRecord(c->ev1, st));
   c->last_out.resize((size_t)n);
   // (the guarded waits first: a device-to-host copy into pageable memory would block the host until the stream has drained)
-  if (int rw = guard_wait(c, st, "the moving-obstacle search launch")) {
+  // (one deadline for both waits -- guard_wait counts from the launch -- and an aborted leader launch does not return before
+  //  the helper launch has been drained too, with the abort word still raised: a helper that has not polled it yet must see it)
+  if (int rw = guard_wait(c, st, "the moving-obstacle search launch", n_help > 0)) {
+    if (n_help > 0 && !c->wedged) {
+      const std::string first = c->err;
+      (void)guard_wait(c, p->help_stream, "the moving-obstacle helper launch");  // (bounded by the same deadline + grace; lowers the abort word)
+      if (!c->wedged) c->err = first;
+      guard_disarm(c);
+    }
     c->last_nq = 0;
     return pfail(p, rw, "%s", c->err.c_str());
   }

@@ -411,6 +411,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
       o.expand_hash = S.c_hash;
       o.n_recorded = (uint32_t)(S.c_expanded < P.cap_rec ? S.c_expanded : P.cap_rec);
       o.slot = blockIdx.x;
+      o.spec[0] = o.spec[1] = o.spec[2] = o.spec[3] = 0;
       o.t_begin = t_begin;
       o.t_end = wall_clock64();
       for (int i = 0; i < 10; i++) o.cyc[i] = S.cyc[i];

@@ -47,6 +47,15 @@
 #ifndef MPLX_X_EARLY_CLEAR
 #define MPLX_X_EARLY_CLEAR 1  // batch table cleared by the idle waves of the end-of-batch bookkeeping
 #endif
+#ifndef MPLX_X_DEFER_LINK
+#define MPLX_X_DEFER_LINK 1   // (round 6) a far-bucket link whose atomicExch is in flight is settled at the head of the next batch only when that
+                              // batch is going to WALK a far list (refill / evict); otherwise by the lane's next commit: the wait for the
+                              // round trip (and, behind it in the in-order vmcnt queue, for the commit's stores) leaves the serial chain
+#endif
+#ifndef MPLX_X_XCD_HELP
+#define MPLX_X_XCD_HELP 1     // (round 6) helpers prefer a leader on their own XCD and then publish rows / records with PLAIN stores: they stay in
+                              // the XCD's L2, where the leader's sc1 loads are served (an sc1 store drops the line: a trip to memory per load)
+#endif
 
 namespace mplx {
 
@@ -102,6 +111,7 @@ struct SmemSpec : Smem<UL * K, K, NCAP_, TP ? MAX_NODE_CH / 4 : MAX_NODE_CH, TP 
   unsigned long long box_seq;   // wish lists published for the running query
   // helper side
   int32_t help_box, help_idx, help_q, help_go, help_quit;
+  int32_t help_near;  // the leader served runs on this workgroup's XCD (MPLX_X_XCD_HELP)
 #ifdef MPLX_HELP_DEBUG
   unsigned long long dbg_t, dbg_gap, dbg_when;
 #endif
@@ -304,13 +314,11 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
 // off the machine is not progress missed.
 constexpr int HELP_IDLE_ROUNDS = 1000;     // x ~54 us
 constexpr int HELP_STALL_POLLS = 100000;   // x >= 3.4 us (13.6 us after the first few)
-#ifdef MPLX_HELP_DEBUG
-__device__ __forceinline__ uint32_t dbg_xcc() {
+__device__ __forceinline__ uint32_t dbg_xcc() {  // XCD this wave runs on (0..7)
   uint32_t x;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
   return x & 15u;
 }
-#endif
 // Check word of a look-ahead cache row (units of 32 lanes: upper half of the row's voxel-read slot).  The record that names a row is
 // written after the row "has landed" (s_waitcnt vmcnt(0) on the helper's side) -- but the acknowledgement of a posted agent-scope
 // store is not a promise that a reader on another XCD sees it before a LATER store to another line: under a write-heavy
@@ -353,6 +361,23 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
   const uint32_t q = (uint32_t)S.help_q;
   const uint32_t epoch = P.epoch;
   unsigned long long last_seq = ((unsigned long long)epoch << 32) | 1ull;
+  // MPLX_X_XCD_HELP: what this helper publishes for a leader on its own XCD goes out as PLAIN stores -- they stay in the XCD's L2,
+  // which is where the leader's sc1 loads are served (an sc1 store is written through and DROPS the line: every load of the row or
+  // of the record is then a trip to memory).  Placement is a matter of speed only: the protocol (row drained before the record,
+  // the row's check word) is the same for both flavours.
+  const bool near = MPLX_X_XCD_HELP && S.help_near != 0;
+  auto pub_f64 = [&](double *p, double v) {
+    if (near) __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else st_f64_agent(p, v);
+  };
+  auto pub_u64 = [&](unsigned long long *p, unsigned long long v) {
+    if (near) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else st_u64(p, v);
+  };
+  auto pub_u32 = [&](uint32_t *p, uint32_t v) {
+    if (near) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else st_u32(p, v);
+  };
   for (;;) {
     if (tid == 0) {
       unsigned long long seq;
@@ -371,7 +396,7 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
           S.help_quit = 1;
           go = 0;
 #ifdef MPLX_HELP_DEBUG
-          atomicAdd(P.cache_next + 128 + (dbg_xcc() & 7u) * 8u + (((uint32_t)B->pad1[4] - 1u) & 7u), 1u);
+          atomicAdd(P.cache_next + 128 + (dbg_xcc() & 7u) * 8u + (((uint32_t)B->xcc_plus1 - 1u) & 7u), 1u);
 #endif
           break;
         }
@@ -448,30 +473,32 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
                          __longlong_as_double((long long)cache_pair_tag((unsigned long long)treads, kh, q, epoch, 63u)));
       } else
 #endif
-      if (rp1 && lu < P.n_u) st_f64_agent(&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_h_slot(UL, lu)], h);
+      if (rp1 && lu < P.n_u) pub_f64(&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_h_slot(UL, lu)], h);
       unsigned long long reads_word = (unsigned long long)treads;
       if constexpr (UL == 32 && !MPLX_X_ROW_PAIRS) {  // check word of the row (cache_row_term above)
         const uint32_t cs = unit32_xor((act && P.eps != 0.0) ? cache_row_term(h, lu) : 0u) ^
                             cache_row_salt((uint32_t)key_hash64(S.cur_key[ku], nk), q, epoch, treads);
         reads_word |= (unsigned long long)cs << 32;
       }
-      if (rp1 && lu == UL - 1 && !(UL == 32 && MPLX_X_ROW_PAIRS)) st_u64((unsigned long long *)&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)], reads_word);
+      if (rp1 && lu == UL - 1 && !(UL == 32 && MPLX_X_ROW_PAIRS)) pub_u64((unsigned long long *)&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)], reads_word);
       if constexpr (UL > 64) {  // large lattice: every wave of the unit leaves its two words of each mask in the row
         if (rp1 && (tid & 63) == 0) {
           uint32_t *rw = (uint32_t *)(P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL));
           const int w2 = 2 * (lu >> 6);
-          st_u32(rw + w2, (uint32_t)bv); st_u32(rw + w2 + 1, (uint32_t)(bv >> 32));
-          st_u32(rw + 4 + w2, (uint32_t)bb); st_u32(rw + 4 + w2 + 1, (uint32_t)(bb >> 32));
+          pub_u32(rw + w2, (uint32_t)bv); pub_u32(rw + w2 + 1, (uint32_t)(bv >> 32));
+          pub_u32(rw + 4 + w2, (uint32_t)bb); pub_u32(rw + 4 + w2 + 1, (uint32_t)(bb >> 32));
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has landed before the record names it
       // (large lattices: the row carries the masks as well and has no check word yet -- a full agent-scope release instead)
-      if (UL > 64 || MPLX_XF(P, 2) || MPLX_ROW_FENCE(P)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      // (a same-XCD row of a large lattice is in the shared L2 once its stores are acknowledged -- the s_waitcnt above; the release
+      //  fence -- a write-back of the whole L2 -- is for readers on other XCDs)
+      if ((UL > 64 && !near) || MPLX_XF(P, 2) || MPLX_ROW_FENCE(P)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       unit_sync<UL>();
       if (rp1 && lu == 0) {
         unsigned long long *cr = (unsigned long long *)&P.cache_c[rec];
-        st_u64(cr + 1, ((unsigned long long)bmask << 32) | (unsigned long long)(vmask | CACHE_READY));
-        st_u64(cr, ((unsigned long long)(uint32_t)key_hash64(S.cur_key[ku], nk) << 32) | (unsigned long long)rp1);
+        pub_u64(cr + 1, ((unsigned long long)bmask << 32) | (unsigned long long)(vmask | CACHE_READY));
+        pub_u64(cr, ((unsigned long long)(uint32_t)key_hash64(S.cur_key[ku], nk) << 32) | (unsigned long long)rp1);
       }
       if (lu == 0) S.hc_row[ku] = 0;
       __syncthreads();
@@ -502,14 +529,22 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
     if (S.flag) return;
     // whom to help: the leader that has been expanding the longest (in steps of 65 536 expansions, ~0.1 s); among
     // those -- at the start of a batch: everybody -- the query predicted longest (earliest in the launch order)
-    unsigned long long best = 0;  // ((steps + 1) << 20) | (2^20 - 1 - min(rank, 2^20 - 1)) < 2^53
+    // MPLX_X_XCD_HELP: a leader on this workgroup's own XCD first (bit 52: the hand-over then stays inside one L2); a helper that has
+    // found nobody for a few rounds takes a leader of another XCD as before
+    unsigned long long best = 0;  // (same XCD << 52) | ((steps + 1) << 20) | (2^20 - 1 - min(rank, 2^20 - 1)) < 2^53
     int bi = -1;
+    const unsigned long long my_xcc = (unsigned long long)(dbg_xcc() + 1u);
+    const bool far_ok = !MPLX_X_XCD_HELP || S.help_idle >= 4;
     for (int b = tid; b < nboxes; b += BLOCK) {
       const HelpBox *B = P.boxes + b;
       if (!box_active(ld_u64(&B->seq), P.epoch)) continue;
       if (__popc(ld_u32(&B->helpers)) >= P.help_max) continue;
+      const bool same = MPLX_X_XCD_HELP && ld_u64(&B->xcc_plus1) == my_xcc;
+      if (!same && !far_ok) continue;
       const uint32_t rk = ld_u32(&B->rank);
-      const unsigned long long key = (((ld_u64(&B->n_expanded) >> 16) + 1ull) << 20) | (unsigned long long)(0xFFFFFu - (rk < 0xFFFFFu ? rk : 0xFFFFFu));
+      unsigned long long steps = (ld_u64(&B->n_expanded) >> 16) + 1ull;
+      if (steps > 0xFFFFFFFFull) steps = 0xFFFFFFFFull;
+      const unsigned long long key = (same ? 1ull << 52 : 0ull) | (steps << 20) | (unsigned long long)(0xFFFFFu - (rk < 0xFFFFFu ? rk : 0xFFFFFu));
       if (key > best) { best = key; bi = b; }
     }
 #pragma unroll
@@ -539,10 +574,12 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
           const uint32_t q = ld_u32(&B->q);
           if (q < (uint32_t)P.nq && box_active(ld_u64(&B->seq), P.epoch)) {
 #ifdef MPLX_HELP_DEBUG
-            atomicAdd(P.cache_next + 192 + (dbg_xcc() & 7u) * 8u + (((uint32_t)B->pad1[4] - 1u) & 7u), 1u);
+            atomicAdd(P.cache_next + 192 + (dbg_xcc() & 7u) * 8u + (((uint32_t)B->xcc_plus1 - 1u) & 7u), 1u);
 #endif
             const QueryIn &in = P.queries[q];
             S.help_q = (int)q;
+            S.help_near = ld_u64(&B->xcc_plus1) == (unsigned long long)(dbg_xcc() + 1u) ? 1 : 0;
+            if (S.help_near) atomicAdd(P.cache_next + 5, 1u); else atomicAdd(P.cache_next + 6, 1u);  // (diagnostics) attachments inside / across XCDs
             S.hp.w = P.w; S.hp.v_max = P.v_max; S.hp.heur_ignore_dynamics = P.heur_ignore_dynamics;
             S.hp.goal_control = in.goal_control;
             S.hp.goal = in.goal;
@@ -677,6 +714,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
       S.c_expanded = S.c_closed = S.c_prims = S.c_succ = S.c_succ_finite = S.c_reads = 0;
       S.c_push = S.c_reopen = S.c_refill = S.c_evict = 0;
       S.c_hash = 0;
+      S.c_cand = S.c_live = S.c_cut = 0;
       S.cur_id = NIL;
       S.helped = 0;
       S.box_seq = 0;
@@ -684,8 +722,8 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         HelpBox *box = P.boxes + blockIdx.x;
         st_u32(&box->q, (uint32_t)q);
         st_u32(&box->rank, (uint32_t)qi);
+        st_u64(&box->xcc_plus1, (unsigned long long)(dbg_xcc() + 1u));
 #ifdef MPLX_HELP_DEBUG
-        box->pad1[4] = dbg_xcc() + 1u;
         S.dbg_t = wall_clock64();
         S.dbg_gap = 0;
         S.dbg_when = 0;
@@ -833,7 +871,14 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
       __syncthreads();
 #endif
       for (;;) {
+#if MPLX_X_DEFER_LINK
+        // settled here only when this batch is going to walk a far list (an eviction can demote buckets, a refill pulls one); otherwise
+        // by the lane's next commit (spec_commit_lanes), or by the first later batch that walks: the atomicExch's return -- and the
+        // commit's stores ahead of it in the in-order vmcnt queue -- is then not waited for on the chain
+        if (pend_idx != NIL && (S.n_near + S.reserve > (uint32_t)SM::NCAP || S.n_near < (uint32_t)K)) {
+#else
         if (pend_idx != NIL) {
+#endif
           Q.open(pend_idx)->next = pend_old;
           pend_idx = NIL;
         }
@@ -1759,6 +1804,11 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
             S.c_succ_finite += fi;
             S.c_reads += rd;
             S.n_near += (uint32_t)__popcll(mb);
+            // speculation accounting: candidates taken / live units (they ran get_succ) / of those, cut and returned to OPEN.  (a batch
+            // that ends the query leaves its uncommitted live units uncounted as cut: nothing expands them again)
+            S.c_cand += (unsigned long long)n_cand;
+            S.c_live += (unsigned long long)__popcll(__ballot(inb));
+            S.c_cut += (unsigned long long)__popcll(mb);
             if (!parallel_commit) S.cyc[8]++;  // batches that needed the unit-by-unit commit
           }
         }
@@ -1837,15 +1887,18 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
       o.expand_hash = S.c_hash;
       o.n_recorded = (uint32_t)(S.c_expanded < P.cap_rec ? S.c_expanded : P.cap_rec);
       o.slot = blockIdx.x;
+      o.spec[0] = S.c_cand; o.spec[1] = S.c_cand - S.c_live; o.spec[2] = S.c_live; o.spec[3] = S.c_cut;
       o.t_begin = t_begin;
       o.t_end = wall_clock64();
       for (int i = 0; i < 10; i++) o.cyc[i] = S.cyc[i];
 #ifdef MPLX_LOOKUP_TIMERS
+      if (P.nq == 1 || q % 61 == 0) {  // (a batch: a sample of its queries -- a thousand workgroups printing at once tear each other's lines)
       printf("cyc2 q%d batches %llu:", q, S.cyc[7]);
       for (int i = 0; i < 24; i++) printf(" %llu", S.cyc2[i] / (S.cyc[7] ? S.cyc[7] : 1ull));
       printf("\n  max-over-lanes: heuristic done %llu, barrier arrival %llu\n", S.sum_heur / S.cyc[7], S.sum_arr / S.cyc[7]);
       printf("  ranking: mean near size %.1f, mean appended %.1f, batches on the all-pairs path %llu, batches with near > 256: %llu, of %llu\n", (double)S.dbg_n / S.cyc[7], (double)S.dbg_na / S.cyc[7], S.dbg_slow, S.dbg_n256, S.cyc[7]);
       for (int j = 0; j < 4; j++) { printf("  per-wave %d:", j); for (int w = 0; w < BLOCK / 64; w++) printf(" %llu", S.cycw[w][j] / (S.cyc[7] ? S.cyc[7] : 1ull)); printf("\n"); }
+      }
 #endif
     }
     for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)

@@ -20,6 +20,11 @@ static void launch_spec(int control, int grid, hipStream_t s, const SearchParams
 // lattices; round 4: JRK states and lattices up to 128 inputs as well)
 bool mplx_launch_spec(int speculation, int grid, hipStream_t s, const SearchParams &P) {
   if (!(P.control == CTRL_ACC || P.control == CTRL_JRK) || P.n_u > 128) return false;  // built for the reference's lattices
+#ifdef MPLX_ONLY_ACC  // (A/B builds of the 27-input ACC kernel only: tools/build_kernel_variant.sh)
+  if (P.control != CTRL_ACC || P.n_u > 31 || P.map.aux) return false;
+  hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024>), dim3(grid), dim3(512), 0, s, P);
+  return true;
+#else
   if (P.map.aux) {  // POT builds: the 16-unit kernel for lattices of at most 32 inputs, four 128-lane units up to 128 inputs
     if (P.n_u <= 32) {
       if (P.control == CTRL_ACC) hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024, false, true>), dim3(grid), dim3(512), 0, s, P);
@@ -49,4 +54,5 @@ bool mplx_launch_spec(int speculation, int grid, hipStream_t s, const SearchPara
   else
     launch_spec<128, 4, 1024, 1024>(P.control, grid, s, P);  // 4 units of two waves each
   return true;
+#endif
 }

@@ -796,6 +796,14 @@ class VoxelMapPlanner:
         ctx.check(ctx.lib.mplx_result_cycles(ctx.h, q, cyc))
         return dict(zip(("pop", "expand", "lookup", "evict", "refill", "activate", "commit", "batches", "dep_batches", "cache_hits"), [int(x) for x in cyc[:10]]))
 
+    def querySpeculation(self, q=0):
+        """Speculation accounting of query q (mplx_result_speculation): candidates taken, stale entries dropped, units expanded,
+        expanded units cut (returned to OPEN and expanded again later)."""
+        ctx = self._ctx()
+        sp = (C.c_uint64 * 4)()
+        ctx.check(ctx.lib.mplx_result_speculation(ctx.h, q, sp))
+        return dict(zip(("candidates", "stale", "units_expanded", "units_cut"), [int(x) for x in sp[:4]]))
+
     # ---- results
     def getTrajCost(self):
         return self.traj_cost_
