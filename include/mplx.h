@@ -190,8 +190,8 @@ int mplx_planner_config(mplx_ctx *ctx, const mplx_config *cfg);
  * queries of one batch -- states, predecessor records, OPEN-log entries (0 = keep current) */
 int mplx_set_capacity(mplx_ctx *ctx, int32_t n_slots, uint64_t total_nodes, uint64_t total_edges, uint64_t total_open_log);
 /* speculative multi-node expansion (results are identical either way): -1 auto (on when
- * n_u <= 128), 0 = sequential kernel (one node per iteration), 2 = on; 8 / 82: measurement variants (eight expansion units;
- * 82: two 256-lane workgroups per compute unit, no helper workgroups -- measured in round 4, no gain) */
+ * n_u <= 128), 0 = sequential kernel (one node per iteration), 2 = on; 8: measurement variant (eight expansion units of one
+ * wave).  [Round 4's 82 -- two 256-lane workgroups per compute unit -- measured no gain and was removed in round 6.] */
 int mplx_set_speculation(mplx_ctx *ctx, int32_t mode);
 /* Helper workgroups: a workgroup with no query (left) to lead expands the front of a running query's OPEN list
  * ahead of time (get_succ and successor heuristics are pure functions of the node, the map and the goal) and
@@ -259,9 +259,11 @@ int mplx_stream_wait(mplx_stream *s, int64_t ticket, mplx_result *out, mplx_ctx 
 int mplx_set_helper_limit(mplx_ctx *ctx, int32_t limit);
 /* Launch guard.  The reference's plan() always returns (mpl_test_node/src/map_planner_node.cpp:186-196); so does every
  * entry point here that waits for a search launch (mplx_plan, mplx_plan_batch, mplx_plan_batch_wait, mplx_stream_wait,
- * mplx_poly_plan_batch, mplx_lpa_plan, mplx_lpa_sub_state_space): the wait polls the stream, and a launch older than
- * `seconds` (default 120, environment MPLX_DEADLINE_S; <= 0: no deadline) is told to stop through a word in host-coherent
- * memory that every persistent loop of the search kernels reads.  The call then returns MPLX_ERR_TIMEOUT -- results void,
+ * mplx_poly_plan_batch, mplx_lpa_plan, mplx_lpa_sub_state_space) WHEN a deadline is set: the wait polls the stream, and a launch
+ * older than `seconds` -- counted from the launch, not from the call that waits for it; one clock for the leader and helper
+ * launches of the moving-obstacle planner -- is told to stop through a word in host-coherent memory that every persistent loop of
+ * the search kernels reads.  Opt-in: the default (<= 0; environment MPLX_DEADLINE_S) sets no deadline -- the reference's plan() has
+ * no wall-clock limit either, only max_num -- and a valid but slow search is never cut short.  The call then returns MPLX_ERR_TIMEOUT -- results void,
  * mplx_last_error() lists what each workgroup was doing -- and the context remains usable.  The lanes of an mplx_stream
  * take the parent's deadline when the stream is created. */
 int mplx_set_deadline(mplx_ctx *ctx, double seconds);

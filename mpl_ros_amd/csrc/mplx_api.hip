@@ -758,8 +758,6 @@ extern "C" int mplx_helper_stats(const mplx_ctx *cc, uint32_t stats[4]) {
     c->help_stats[2] = c->help_ctr_back[2];
     c->help_stats[3] = c->help_ctr_back[3];
     c->help_stats_pending = false;
-    if (getenv("MPLX_HELP_XCD_STATS"))  // (diagnostics) helper attachments to a leader of the helper's own XCD / of another one
-      fprintf(stderr, "[help xcd] attachments same-XCD %u, cross-XCD %u\n", c->help_ctr_back[5], c->help_ctr_back[6]);
 #ifdef MPLX_HELP_DEBUG
     {
       fprintf(stderr, "[help debug] stall quits by (helper XCD row, leader XCD column) | attachments:\n");
@@ -961,7 +959,6 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   PA(P.bkt_head, (size_t)slots * 2 * NB * NSUB);
   HIPCHK(c, hipMemsetAsync(P.bkt_head, 0xFF, sizeof(uint32_t) * (size_t)slots * 2 * NB * NSUB, c->stream));  // all heads NIL; queries leave them so
   PA(P.chunk_next, 4);
-  PA(P.tbl_spill, (size_t)slots * (MAX_NODE_CH + MAX_EDGE_CH + MAX_OPEN_CH));  // chunk-table entries beyond the LDS window (throughput kernel)
   P.boxes = nullptr; P.cache_c = nullptr; P.cache_h = nullptr; P.cache_next = nullptr; P.done_word = nullptr; P.cache_rows = 0;
   if (c->helpers != 0) {  // look-ahead cache of the helper workgroups (used by the speculative kernels, lattices <= 31 inputs)
     // rows of the heuristic cache: a quarter of the state capacity (a node is expanded ahead of time at most once),
@@ -1247,15 +1244,12 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
   // of time.  The launch holds one workgroup per compute unit at most, so all of them are resident together: for a
   // batch smaller than the machine the extra workgroups (blockIdx.x >= help_lead) help from the start; in a large
   // batch the leaders turn into helpers as they run out of queries.
-  // (measurement only: mplx_set_speculation(ctx, 82) = two 256-lane workgroups per compute unit, no helper workgroups -- see
-  //  mplx_spec_launch.hip; measured, no gain, selected by no product configuration)
-  const bool tp = c->speculation == 82 && spec && !c->aux && P.control == CTRL_ACC && P.n_u <= 31;
-  const int n_wg = c->n_cus * (tp ? 2 : 1);  // workgroups of the search kernel the machine holds at once
+  const int n_wg = c->n_cus;  // workgroups of the search kernel the machine holds at once (one per compute unit: 149 KB of LDS)
   int grid = slots;
   P.help_lead = slots;
   P.help_max = 0;
   P.help_limit = c->help_limit;
-  const bool help = spec && !tp && !c->aux && !c->filter_table && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
+  const bool help = spec && !c->aux && !c->filter_table && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 && P.boxes &&
                     ((P.n_u <= 31 && (P.control == CTRL_ACC || P.control == CTRL_JRK)) || (P.control == CTRL_JRK && P.n_u > 64 && P.n_u <= 128));
   if (help) {
     // auto: four helpers per leader for the lattices of at most 31 inputs (the capped query of the C4 batch alone: 1.95 s
@@ -1274,6 +1268,7 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
     const int reserved = c->help_reserved >= 0 ? c->help_reserved : (nq >= 2 * c->n_cus && long_queries ? std::max(1, c->n_cus / 16) * P.help_max : 0);
     if (reserved > 0 && slots + reserved > n_wg) P.help_lead = std::max(1, n_wg - reserved);
     grid = std::max(P.help_lead, std::min(P.help_lead * (P.help_max + 1), n_wg));
+    if (const char *e = getenv("MPLX_HELP_GRID")) grid = std::max(P.help_lead, std::min(atoi(e), n_wg));  // (diagnostics: more would-be helpers than a leader takes)
     HIPCHK(c, hipMemsetAsync(P.boxes, 0, sizeof(HelpBox) * ((size_t)c->pool_slots + 1024), c->stream));
     c->dbg_boxes = P.boxes;
     // (diagnostic, tools/tail_probe.py: MPLX_DEBUG_KEEP_CACHE=1 keeps the look-ahead cache of the previous launch -- the
@@ -1301,7 +1296,7 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
     launched = mplx_launch_spec_help(grid, c->stream, P);
   }
   if (!launched) {
-    grid = tp ? std::min(slots, n_wg) : slots;
+    grid = slots;
     P.help_lead = grid;
   }
   // yaw-carrying states: the YAW build of the speculative kernel where one exists (ACC / JRK lattices of at most 128 inputs,
@@ -1576,11 +1571,9 @@ extern "C" const char *mplx_kernel_name(const mplx_ctx *c) {
     else if (c->speculation == 2) { ul = 128; k = 2; }
     else { ul = 128; k = 4; }
     if (c->aux) { ul = n_u <= 32 ? 32 : 128; k = n_u <= 32 ? 16 : 4; }
-    const bool tp = c->speculation == 82 && !c->aux && control == CTRL_ACC && n_u <= 31;  // (measurement-only variant)
-    if (tp) { ul = 32; k = 8; }
-    const bool help = !tp && !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 &&
+    const bool help = !c->aux && (c->speculation < 0 || c->speculation >= 16) && c->helpers != 0 &&
                       ((ul == 32 && k == 16 && n_u <= 31) || (ul == 128 && k == 4 && control == CTRL_JRK && n_u > 64));
-    snprintf(buf, sizeof(buf), c->aux ? "astar_spec_kernel<%d,%d,%s,pot>" : tp ? "astar_spec_kernel<%d,%d,%s,2-per-CU>" :
+    snprintf(buf, sizeof(buf), c->aux ? "astar_spec_kernel<%d,%d,%s,pot>" :
                                 help ? "astar_spec_kernel<%d,%d,%s,help>" : "astar_spec_kernel<%d,%d,%s>", ul, k, cn);
   }
   return buf;

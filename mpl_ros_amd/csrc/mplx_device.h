@@ -101,7 +101,7 @@ struct alignas(64) HelpBox {   // one per workgroup slot; every word is written 
   uint32_t q;                  // query the leader is running
   uint32_t rank;               // position of that query in the launch order (longest predicted first)
   unsigned long long pad1[4];  // (pad1[0..3]: diagnostics of the -DMPLX_HELP_DEBUG build)
-  unsigned long long xcc_plus1;  // XCD the leader runs on + 1 (HW_REG_XCC_ID): helpers prefer a leader of their own XCD (shared L2)
+  unsigned long long xcc_plus1;  // (-DMPLX_HELP_DEBUG) XCD the leader runs on + 1 (HW_REG_XCC_ID)
   // line 1: written by helpers (atomics), read by the leader every few batches -- kept off the line the leader stores to
   uint32_t helpers;            // bit mask of attached helpers (atomicOr / atomicAnd)
   uint32_t pad2[15];
@@ -179,7 +179,6 @@ struct SearchParams {
   unsigned long long *table;
   unsigned long long table_mask;                   // slots - 1
   uint32_t *bkt_head;                              // per workgroup slot: 2 levels x NB x NSUB
-  uint16_t *tbl_spill;                             // per workgroup slot: chunk-table entries beyond the LDS window (throughput kernel)
   uint32_t cap_rec;
   // queries
   int32_t nq;
@@ -213,26 +212,29 @@ struct SearchParams {
   // moving-obstacle environment (astar_poly_kernel): the worlds and the world of each query
   PolyDev poly;
   const int32_t *poly_world;
+  // expansion filter (FILTER builds of astar_spec_kernel only; null / 0 otherwise): FilterView below
+  const unsigned long long *filter_table;
+  unsigned long long filter_mask;
+  const char *filter_pool;
+  uint32_t filter_flag;
 };
 
 // Expansion filter of the FILTER builds of astar_spec_kernel (getSubStateSpace by import, mplx_lpa.h): a candidate is expanded only
 // if its key is found in `table` (LPA* hashing: no query bits) and the record it names in `pool` carries one of the `flag` bits.
-// The four words travel in the moving-obstacle look-ahead slots of SearchParams, which a voxel-map launch never reads: the layout
-// every other kernel is compiled against stays what it was (tools/device_code_hash.sh: their instruction streams are unchanged).
+// (Round 5 passed the four words in the moving-obstacle look-ahead slots of SearchParams; since round 6 they have fields of their
+//  own at the end of the struct -- ADVICE r5.)
 struct FilterView {
   const unsigned long long *table;
   unsigned long long mask;
   const char *pool;
   uint32_t flag;
 };
-__host__ __device__ inline FilterView filter_view(const SearchParams &P) {
-  return FilterView{P.poly.help_mask, (unsigned long long)(uintptr_t)P.poly.help_pub, (const char *)P.poly.help_ring, (uint32_t)P.poly.n_help};
-}
+__host__ __device__ inline FilterView filter_view(const SearchParams &P) { return FilterView{P.filter_table, P.filter_mask, P.filter_pool, P.filter_flag}; }
 inline void filter_set(SearchParams &P, const unsigned long long *table, unsigned long long mask, const char *pool, uint32_t flag) {
-  P.poly.help_mask = const_cast<unsigned long long *>(table);
-  P.poly.help_pub = (unsigned long long *)(uintptr_t)mask;
-  P.poly.help_ring = (double *)const_cast<char *>(pool);
-  P.poly.n_help = (int32_t)flag;
+  P.filter_table = table;
+  P.filter_mask = mask;
+  P.filter_pool = pool;
+  P.filter_flag = flag;
 }
 
 // one successor record produced by the expand kernel (mirrors mplx_succ)

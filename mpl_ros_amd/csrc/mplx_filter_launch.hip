@@ -10,9 +10,9 @@ using namespace mplx;
 template <int UL, int K, int BTN, int NCAP>
 static void launch_filter(int control, int grid, hipStream_t s, const SearchParams &P) {
   if (control == CTRL_ACC)
-    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_ACC, BTN, NCAP, false, false, false, false, true>), dim3(grid), dim3(UL * K), 0, s, P);
+    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_ACC, BTN, NCAP, false, false, false, true>), dim3(grid), dim3(UL * K), 0, s, P);
   else
-    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_JRK, BTN, NCAP, false, false, false, false, true>), dim3(grid), dim3(UL * K), 0, s, P);
+    hipLaunchKernelGGL((astar_spec_kernel<UL, K, CTRL_JRK, BTN, NCAP, false, false, false, true>), dim3(grid), dim3(UL * K), 0, s, P);
 }
 
 bool mplx_launch_spec_filter(int grid, hipStream_t s, const SearchParams &P) {

@@ -214,19 +214,16 @@ struct EdgeRec {  // predecessor record (EDGE_BYTES)
 };
 static_assert(sizeof(OpenRec) == OPEN_BYTES && sizeof(EdgeRec) == EDGE_BYTES, "record sizes");
 
-// NWIN / EWIN / OWIN: entries of the query's three chunk tables that live in LDS (the resident window).  The default holds a
-// whole table (33 M states, 134 M predecessor records, 33 M log entries per query: 8 KB); the throughput instantiation of the
-// speculative kernel keeps a quarter and spills the rest to HBM (QView::spill), so that two workgroups fit a compute unit.
-template <int BLOCK, int KUNITS = 1, int NCAP_ = NC, int NWIN = MAX_NODE_CH, int EWIN = MAX_EDGE_CH, int OWIN = MAX_OPEN_CH>
+// The query's three chunk tables live in LDS whole (33 M states, 134 M predecessor records, 33 M log entries per query: 8 KB).
+template <int BLOCK, int KUNITS = 1, int NCAP_ = NC>
 struct Smem {
   static constexpr int NCAP = NCAP_;  // near-set capacity
-  static constexpr int NODE_WIN = NWIN, EDGE_WIN = EWIN, OPEN_WIN = OWIN;
   // OPEN near set
   double near_f[NCAP_], near_g[NCAP_];
   uint32_t near_id[NCAP_], near_idx[NCAP_];
   uint32_t cnt[2][NB];  // entries per bucket: [0] fine level (inside coarse bucket cur1), [1] coarse level
   // chunk tables of the running query
-  uint16_t node_tbl[NWIN], edge_tbl[EWIN], open_tbl[OWIN];  // pool chunk ids (the host keeps pools below 65536 chunks)
+  uint16_t node_tbl[MAX_NODE_CH], edge_tbl[MAX_EDGE_CH], open_tbl[MAX_OPEN_CH];  // pool chunk ids (the host keeps pools below 65536 chunks)
   // expansion scratch
   // pre-divided non-zero polynomial coefficients (pack_q_c) of a sample's primitive, split into the
   // part that only depends on the control input (per query) and the part that only depends on the
@@ -567,7 +564,7 @@ __device__ __forceinline__ void expand_unit(const SearchParams &P, SM &S, int ti
   const uint32_t *__restrict__ bricks = P.map.bricks;
   const int dx = P.map.dim[0], dy = P.map.dim[1], dz = P.map.dim[2];
   const int nb0 = P.map.nb[0], nb1 = P.map.nb[1];
-  constexpr int UNR = 4;
+  constexpr int UNR = 4;  // (round 6: 6 / 8 in flight measured 3 % / 10 % slower -- spilled registers)
   if (!S.slow[ku]) {
     // Staged over the UNR pairs of a lane (all LDS reads of a stage are independent, one wait per
     // stage), branch-free: dead slots recompute the last live pair, outside cells read voxel 0, and
@@ -763,23 +760,10 @@ struct QView {
   const SearchParams &P;
   SM &S;
   uint32_t *bkt_head;
-  // HBM home of the chunk-table entries beyond the LDS window (kernels whose SM keeps whole tables never touch it):
-  // this workgroup slot's [MAX_NODE_CH | MAX_EDGE_CH | MAX_OPEN_CH] 16-bit entries.  Written by the thread that takes a
-  // chunk, read by the workgroup after the barrier that follows (one compute unit, one L1: plain accesses).
-  uint16_t *spill = nullptr;
   // pool chunk of the query's c-th node / predecessor / OPEN-log chunk
-  __device__ __forceinline__ uint32_t node_chunk(uint32_t c) const {
-    if constexpr (SM::NODE_WIN < MAX_NODE_CH) { if (c >= (uint32_t)SM::NODE_WIN) return spill[c]; }
-    return S.node_tbl[c];
-  }
-  __device__ __forceinline__ uint32_t edge_chunk(uint32_t c) const {
-    if constexpr (SM::EDGE_WIN < MAX_EDGE_CH) { if (c >= (uint32_t)SM::EDGE_WIN) return spill[MAX_NODE_CH + c]; }
-    return S.edge_tbl[c];
-  }
-  __device__ __forceinline__ uint32_t open_chunk(uint32_t c) const {
-    if constexpr (SM::OPEN_WIN < MAX_OPEN_CH) { if (c >= (uint32_t)SM::OPEN_WIN) return spill[MAX_NODE_CH + MAX_EDGE_CH + c]; }
-    return S.open_tbl[c];
-  }
+  __device__ __forceinline__ uint32_t node_chunk(uint32_t c) const { return S.node_tbl[c]; }
+  __device__ __forceinline__ uint32_t edge_chunk(uint32_t c) const { return S.edge_tbl[c]; }
+  __device__ __forceinline__ uint32_t open_chunk(uint32_t c) const { return S.open_tbl[c]; }
   __device__ __forceinline__ char *node(uint32_t i) const {
     return P.node_pool + (((size_t)node_chunk(i >> NODE_CH_LOG) << NODE_CH_LOG) + (i & ((1u << NODE_CH_LOG) - 1))) * rec_bytes(CONTROL);
   }
@@ -794,20 +778,20 @@ struct QView {
     return (OpenRec *)(P.open_pool + (((size_t)open_chunk(i >> OPEN_CH_LOG) << OPEN_CH_LOG) + (i & ((1u << OPEN_CH_LOG) - 1))) * OPEN_BYTES);
   }
   // (one thread) make sure the query owns chunks for `need` items of a pool; false when the pool -- or the query's table -- is exhausted
-  __device__ __forceinline__ bool take_chunks(uint16_t *tbl, int win, uint16_t *home, uint32_t &owned, uint32_t need, int ch_log, int max_ch, uint32_t *next, uint32_t pool_chunks) const {
+  __device__ __forceinline__ bool take_chunks(uint16_t *tbl, uint32_t &owned, uint32_t need, int ch_log, int max_ch, uint32_t *next, uint32_t pool_chunks) const {
     const uint32_t want = (need + (1u << ch_log) - 1) >> ch_log;
     while (owned < want) {
       if (owned >= (uint32_t)max_ch) return false;
       const uint32_t c = atomicAdd(next, 1u);
       if (c >= pool_chunks) return false;
-      if (owned < (uint32_t)win) tbl[owned] = (uint16_t)c; else home[owned] = (uint16_t)c;
+      tbl[owned] = (uint16_t)c;
       owned++;
     }
     return true;
   }
-  __device__ __forceinline__ bool ensure_nodes(uint32_t need) const { return take_chunks(S.node_tbl, SM::NODE_WIN, spill, S.node_chunks, need, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks); }
-  __device__ __forceinline__ bool ensure_edges(uint32_t need) const { return take_chunks(S.edge_tbl, SM::EDGE_WIN, spill + MAX_NODE_CH, S.edge_chunks, need, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks); }
-  __device__ __forceinline__ bool ensure_open(uint32_t need) const { return take_chunks(S.open_tbl, SM::OPEN_WIN, spill + MAX_NODE_CH + MAX_EDGE_CH, S.open_chunks, need, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks); }
+  __device__ __forceinline__ bool ensure_nodes(uint32_t need) const { return take_chunks(S.node_tbl, S.node_chunks, need, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks); }
+  __device__ __forceinline__ bool ensure_edges(uint32_t need) const { return take_chunks(S.edge_tbl, S.edge_chunks, need, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks); }
+  __device__ __forceinline__ bool ensure_open(uint32_t need) const { return take_chunks(S.open_tbl, S.open_chunks, need, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks); }
   // record field accessors
   static __device__ __forceinline__ double &g(char *r) { return *(double *)r; }
   static __device__ __forceinline__ double &h(char *r) { return *(double *)(r + 8); }

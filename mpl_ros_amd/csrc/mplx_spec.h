@@ -47,16 +47,12 @@
 #ifndef MPLX_X_EARLY_CLEAR
 #define MPLX_X_EARLY_CLEAR 1  // batch table cleared by the idle waves of the end-of-batch bookkeeping
 #endif
-#ifndef MPLX_X_DEFER_LINK
-#define MPLX_X_DEFER_LINK 1   // (round 6) a far-bucket link whose atomicExch is in flight is settled at the head of the next batch only when that
-                              // batch is going to WALK a far list (refill / evict); otherwise by the lane's next commit: the wait for the
-                              // round trip (and, behind it in the in-order vmcnt queue, for the commit's stores) leaves the serial chain
-#endif
-#ifndef MPLX_X_XCD_HELP
-#define MPLX_X_XCD_HELP 1     // (round 6) helpers prefer a leader on their own XCD and then publish rows / records with PLAIN stores: they stay in
-                              // the XCD's L2, where the leader's sc1 loads are served (an sc1 store drops the line: a trip to memory per load)
-#endif
-
+// Measured in round 6 and NOT kept (profiles/r06_ab_negative_results.json; every variant returned identical results):
+//   * settling a pending far-bucket link only when the next batch walks a far list: tail 2032 vs 2028 ms, bulk 136.1 vs 134.6 ms;
+//   * helpers that prefer a leader of their own XCD and publish rows / records with plain stores (kept in the shared L2 instead of
+//     written through): one long query with four same-XCD helpers 2057-2084 vs 2030 ms, the blocking C4 step 2516 vs 2301 ms (helpers
+//     wait for a same-XCD leader while others go unserved) -- the hand-over's trips to memory are not what bounds a batch;
+//   * 6 / 8 voxel loads in flight per lane in the sampling loop instead of 4: bulk 139.0 / 148.4 vs 134.6 ms (17 / 33 spilled VGPRs).
 namespace mplx {
 
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain
@@ -68,10 +64,9 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// TP (throughput instantiation): a quarter of the chunk tables resident in LDS, the rest in HBM (QView::spill)
 // YAW: yaw-carrying states -- one more key integer (round(yaw / 0.1)) behind the control kind's own
-template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool TP = false, bool YAW = false>
-struct SmemSpec : Smem<UL * K, K, NCAP_, TP ? MAX_NODE_CH / 4 : MAX_NODE_CH, TP ? MAX_EDGE_CH / 4 : MAX_EDGE_CH, TP ? MAX_OPEN_CH / 4 : MAX_OPEN_CH> {
+template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool YAW = false>
+struct SmemSpec : Smem<UL * K, K, NCAP_> {
   static constexpr int BLOCK = UL * K, BT = BTN, NK = key_len_c(CONTROL) + (YAW ? 1 : 0);
   static_assert(NK <= MAX_KEY, "yaw-carrying SNP states (13 key integers) stay on the one-node kernel");
   // candidates in pop order
@@ -111,7 +106,6 @@ struct SmemSpec : Smem<UL * K, K, NCAP_, TP ? MAX_NODE_CH / 4 : MAX_NODE_CH, TP 
   unsigned long long box_seq;   // wish lists published for the running query
   // helper side
   int32_t help_box, help_idx, help_q, help_go, help_quit;
-  int32_t help_near;  // the leader served runs on this workgroup's XCD (MPLX_X_XCD_HELP)
 #ifdef MPLX_HELP_DEBUG
   unsigned long long dbg_t, dbg_gap, dbg_when;
 #endif
@@ -314,11 +308,13 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
 // off the machine is not progress missed.
 constexpr int HELP_IDLE_ROUNDS = 1000;     // x ~54 us
 constexpr int HELP_STALL_POLLS = 100000;   // x >= 3.4 us (13.6 us after the first few)
+#ifdef MPLX_HELP_DEBUG
 __device__ __forceinline__ uint32_t dbg_xcc() {  // XCD this wave runs on (0..7)
   uint32_t x;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
   return x & 15u;
 }
+#endif
 // Check word of a look-ahead cache row (units of 32 lanes: upper half of the row's voxel-read slot).  The record that names a row is
 // written after the row "has landed" (s_waitcnt vmcnt(0) on the helper's side) -- but the acknowledgement of a posted agent-scope
 // store is not a promise that a reader on another XCD sees it before a LATER store to another line: under a write-heavy
@@ -361,23 +357,6 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
   const uint32_t q = (uint32_t)S.help_q;
   const uint32_t epoch = P.epoch;
   unsigned long long last_seq = ((unsigned long long)epoch << 32) | 1ull;
-  // MPLX_X_XCD_HELP: what this helper publishes for a leader on its own XCD goes out as PLAIN stores -- they stay in the XCD's L2,
-  // which is where the leader's sc1 loads are served (an sc1 store is written through and DROPS the line: every load of the row or
-  // of the record is then a trip to memory).  Placement is a matter of speed only: the protocol (row drained before the record,
-  // the row's check word) is the same for both flavours.
-  const bool near = MPLX_X_XCD_HELP && S.help_near != 0;
-  auto pub_f64 = [&](double *p, double v) {
-    if (near) __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else st_f64_agent(p, v);
-  };
-  auto pub_u64 = [&](unsigned long long *p, unsigned long long v) {
-    if (near) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else st_u64(p, v);
-  };
-  auto pub_u32 = [&](uint32_t *p, uint32_t v) {
-    if (near) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else st_u32(p, v);
-  };
   for (;;) {
     if (tid == 0) {
       unsigned long long seq;
@@ -473,32 +452,30 @@ __device__ __forceinline__ void helper_serve(const SearchParams &P, SM &S, int t
                          __longlong_as_double((long long)cache_pair_tag((unsigned long long)treads, kh, q, epoch, 63u)));
       } else
 #endif
-      if (rp1 && lu < P.n_u) pub_f64(&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_h_slot(UL, lu)], h);
+      if (rp1 && lu < P.n_u) st_f64_agent(&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_h_slot(UL, lu)], h);
       unsigned long long reads_word = (unsigned long long)treads;
       if constexpr (UL == 32 && !MPLX_X_ROW_PAIRS) {  // check word of the row (cache_row_term above)
         const uint32_t cs = unit32_xor((act && P.eps != 0.0) ? cache_row_term(h, lu) : 0u) ^
                             cache_row_salt((uint32_t)key_hash64(S.cur_key[ku], nk), q, epoch, treads);
         reads_word |= (unsigned long long)cs << 32;
       }
-      if (rp1 && lu == UL - 1 && !(UL == 32 && MPLX_X_ROW_PAIRS)) pub_u64((unsigned long long *)&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)], reads_word);
+      if (rp1 && lu == UL - 1 && !(UL == 32 && MPLX_X_ROW_PAIRS)) st_u64((unsigned long long *)&P.cache_h[(size_t)(rp1 - 1u) * cache_row_doubles(UL) + cache_reads_slot(UL)], reads_word);
       if constexpr (UL > 64) {  // large lattice: every wave of the unit leaves its two words of each mask in the row
         if (rp1 && (tid & 63) == 0) {
           uint32_t *rw = (uint32_t *)(P.cache_h + (size_t)(rp1 - 1u) * cache_row_doubles(UL));
           const int w2 = 2 * (lu >> 6);
-          pub_u32(rw + w2, (uint32_t)bv); pub_u32(rw + w2 + 1, (uint32_t)(bv >> 32));
-          pub_u32(rw + 4 + w2, (uint32_t)bb); pub_u32(rw + 4 + w2 + 1, (uint32_t)(bb >> 32));
+          st_u32(rw + w2, (uint32_t)bv); st_u32(rw + w2 + 1, (uint32_t)(bv >> 32));
+          st_u32(rw + 4 + w2, (uint32_t)bb); st_u32(rw + 4 + w2 + 1, (uint32_t)(bb >> 32));
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row has landed before the record names it
       // (large lattices: the row carries the masks as well and has no check word yet -- a full agent-scope release instead)
-      // (a same-XCD row of a large lattice is in the shared L2 once its stores are acknowledged -- the s_waitcnt above; the release
-      //  fence -- a write-back of the whole L2 -- is for readers on other XCDs)
-      if ((UL > 64 && !near) || MPLX_XF(P, 2) || MPLX_ROW_FENCE(P)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (UL > 64 || MPLX_XF(P, 2) || MPLX_ROW_FENCE(P)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       unit_sync<UL>();
       if (rp1 && lu == 0) {
         unsigned long long *cr = (unsigned long long *)&P.cache_c[rec];
-        pub_u64(cr + 1, ((unsigned long long)bmask << 32) | (unsigned long long)(vmask | CACHE_READY));
-        pub_u64(cr, ((unsigned long long)(uint32_t)key_hash64(S.cur_key[ku], nk) << 32) | (unsigned long long)rp1);
+        st_u64(cr + 1, ((unsigned long long)bmask << 32) | (unsigned long long)(vmask | CACHE_READY));
+        st_u64(cr, ((unsigned long long)(uint32_t)key_hash64(S.cur_key[ku], nk) << 32) | (unsigned long long)rp1);
       }
       if (lu == 0) S.hc_row[ku] = 0;
       __syncthreads();
@@ -529,22 +506,14 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
     if (S.flag) return;
     // whom to help: the leader that has been expanding the longest (in steps of 65 536 expansions, ~0.1 s); among
     // those -- at the start of a batch: everybody -- the query predicted longest (earliest in the launch order)
-    // MPLX_X_XCD_HELP: a leader on this workgroup's own XCD first (bit 52: the hand-over then stays inside one L2); a helper that has
-    // found nobody for a few rounds takes a leader of another XCD as before
-    unsigned long long best = 0;  // (same XCD << 52) | ((steps + 1) << 20) | (2^20 - 1 - min(rank, 2^20 - 1)) < 2^53
+    unsigned long long best = 0;  // ((steps + 1) << 20) | (2^20 - 1 - min(rank, 2^20 - 1)) < 2^53
     int bi = -1;
-    const unsigned long long my_xcc = (unsigned long long)(dbg_xcc() + 1u);
-    const bool far_ok = !MPLX_X_XCD_HELP || S.help_idle >= 4;
     for (int b = tid; b < nboxes; b += BLOCK) {
       const HelpBox *B = P.boxes + b;
       if (!box_active(ld_u64(&B->seq), P.epoch)) continue;
       if (__popc(ld_u32(&B->helpers)) >= P.help_max) continue;
-      const bool same = MPLX_X_XCD_HELP && ld_u64(&B->xcc_plus1) == my_xcc;
-      if (!same && !far_ok) continue;
       const uint32_t rk = ld_u32(&B->rank);
-      unsigned long long steps = (ld_u64(&B->n_expanded) >> 16) + 1ull;
-      if (steps > 0xFFFFFFFFull) steps = 0xFFFFFFFFull;
-      const unsigned long long key = (same ? 1ull << 52 : 0ull) | (steps << 20) | (unsigned long long)(0xFFFFFu - (rk < 0xFFFFFu ? rk : 0xFFFFFu));
+      const unsigned long long key = (((ld_u64(&B->n_expanded) >> 16) + 1ull) << 20) | (unsigned long long)(0xFFFFFu - (rk < 0xFFFFFu ? rk : 0xFFFFFu));
       if (key > best) { best = key; bi = b; }
     }
 #pragma unroll
@@ -578,8 +547,6 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
 #endif
             const QueryIn &in = P.queries[q];
             S.help_q = (int)q;
-            S.help_near = ld_u64(&B->xcc_plus1) == (unsigned long long)(dbg_xcc() + 1u) ? 1 : 0;
-            if (S.help_near) atomicAdd(P.cache_next + 5, 1u); else atomicAdd(P.cache_next + 6, 1u);  // (diagnostics) attachments inside / across XCDs
             S.hp.w = P.w; S.hp.v_max = P.v_max; S.hp.heur_ignore_dynamics = P.heur_ignore_dynamics;
             S.hp.goal_control = in.goal_control;
             S.hp.goal = in.goal;
@@ -610,25 +577,19 @@ __device__ __forceinline__ void helper_loop(const SearchParams &P, SM &S, int ti
 // POT: the auxiliary map (potential field / search region, MapDev::aux) is read next to the occupancy and the edge cost is
 // ucost + pot_weight * (sum of the potential over the primitive's samples): per lane, carried in the predecessor record
 // like in the one-node kernel.  Without helper workgroups (their cache rows carry no potential sums).
-// TP: the throughput instantiation -- two workgroups per compute unit (<= 80 KB of LDS each: the chunk tables' resident window
-// is a quarter, the rest spills to HBM), for batches of many queries where a compute unit's two workgroups -- two
-// independent queries -- hide each other's barriers and memory round trips.
-// (second launch bound = waves per SIMD the register allocation must leave room for: a 256-lane workgroup alone would be given
-// the whole 512-entry register file -- arch VGPRs plus AGPRs as spill space -- and a second workgroup could not join it)
 // YAW (round 4): yaw-carrying states (use_yaw lattices, map_planner_node.cpp:119-139,165) on the speculative kernel: one more
 // key integer and one more state double through candidate fetch, batch table, table look-up and creation; the rules are the
 // one-node kernel's (astar_kernel<..., YAW>: successor yaw and validate_yaw in expand_unit, heuristic of the yaw-less search
 // unless the yaw keys differ from the goal's, optional yaw tolerance in the goal test).  Without helper workgroups.
 // FILTER (round 5): a candidate is expanded only if SearchParams::filter_* says so -- the Dijkstra of getSubStateSpace walks only the
 // states that had been expanded in the space it leaves; a candidate the filter rejects is dropped like a stale entry.
-template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false, bool POT = false, bool TP = false, bool YAW = false, bool FILTER = false>
-__global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchParams P) {
-  static_assert(!(FILTER && (HELP || POT || YAW || TP)), "the filtered search is the plain kernel");
+template <int UL, int K, int CONTROL, int BTN, int NCAP_, bool HELP = false, bool POT = false, bool YAW = false, bool FILTER = false>
+__global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
+  static_assert(!(FILTER && (HELP || POT || YAW)), "the filtered search is the plain kernel");
   static_assert(!(HELP && POT), "the look-ahead cache rows carry no potential sums");
   static_assert(!(YAW && (HELP || POT)), "yaw-carrying searches run without helpers and without an auxiliary map");
   constexpr int BLOCK = UL * K;
-  using SM = SmemSpec<UL, K, CONTROL, BTN, NCAP_, TP, YAW>;
-  static_assert(!TP || sizeof(SM) <= 80 * 1024, "two workgroups of the throughput instantiation must fit the 160 KB of a compute unit");
+  using SM = SmemSpec<UL, K, CONTROL, BTN, NCAP_, YAW>;
   constexpr int BT = SM::BT;
   __shared__ SM S;
   using V = QView<BLOCK, CONTROL, SM>;
@@ -636,7 +597,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
   // HELP: workgroups with no query left to lead turn into helpers (helper_loop above); a leader publishes the front
   // of its OPEN list and picks up the look-ahead cache entries they leave.  Compiled out of the plain variant (the
   // kernel sits at the register limit).
-  const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB, TP ? P.tbl_spill + (size_t)blockIdx.x * (MAX_NODE_CH + MAX_EDGE_CH + MAX_OPEN_CH) : nullptr};
+  const V Q{P, S, P.bkt_head + (size_t)blockIdx.x * 2 * NB * NSUB};
   constexpr int nk = key_len_c(CONTROL), ns = key_len_c(CONTROL);
   constexpr int NKY = nk + (YAW ? 1 : 0), EX = YAW ? 1 : 0;  // key integers / extra state doubles (the yaw) of a record
   // key of a lane's successor incl. the yaw key, its 64-bit hash
@@ -722,8 +683,8 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
         HelpBox *box = P.boxes + blockIdx.x;
         st_u32(&box->q, (uint32_t)q);
         st_u32(&box->rank, (uint32_t)qi);
-        st_u64(&box->xcc_plus1, (unsigned long long)(dbg_xcc() + 1u));
 #ifdef MPLX_HELP_DEBUG
+        box->xcc_plus1 = dbg_xcc() + 1u;
         S.dbg_t = wall_clock64();
         S.dbg_gap = 0;
         S.dbg_when = 0;
@@ -871,14 +832,7 @@ __global__ __launch_bounds__(UL *K, TP ? 2 : 1) void astar_spec_kernel(SearchPar
       __syncthreads();
 #endif
       for (;;) {
-#if MPLX_X_DEFER_LINK
-        // settled here only when this batch is going to walk a far list (an eviction can demote buckets, a refill pulls one); otherwise
-        // by the lane's next commit (spec_commit_lanes), or by the first later batch that walks: the atomicExch's return -- and the
-        // commit's stores ahead of it in the in-order vmcnt queue -- is then not waited for on the chain
-        if (pend_idx != NIL && (S.n_near + S.reserve > (uint32_t)SM::NCAP || S.n_near < (uint32_t)K)) {
-#else
         if (pend_idx != NIL) {
-#endif
           Q.open(pend_idx)->next = pend_old;
           pend_idx = NIL;
         }

@@ -35,14 +35,6 @@ bool mplx_launch_spec(int speculation, int grid, hipStream_t s, const SearchPara
     }
     return true;
   }
-  // `speculation == 82` (measurement only, round 4): two 256-lane workgroups of eight expansion units per compute unit instead of one
-  // 512-lane workgroup of sixteen, WITHOUT helper workgroups (bench.py --two-per-cu).  Measured on the C4-ACC batch capped at
-  // 20 000 expansions per query: 130.6 ms against 128.1 ms -- no gain (the bulk phase is bound by the compute
-  // unit's issue slots, not by one query's latency) -- so no product configuration selects it.
-  if (speculation == 82 && P.n_u <= 31 && P.control == CTRL_ACC) {
-    hipLaunchKernelGGL((astar_spec_kernel<32, 8, CTRL_ACC, 512, 512, false, false, true>), dim3(grid), dim3(256), 0, s, P);
-    return true;
-  }
   if (P.n_u <= 32 && speculation == 8)
     launch_spec<64, 8, 512, 512>(P.control, grid, s, P);     // 8 units of one wave each
   else if (P.n_u <= 32)

@@ -13,22 +13,22 @@ bool mplx_launch_spec_yaw(int grid, hipStream_t s, const SearchParams &P) {
   if (!(P.control == CTRL_ACC || P.control == CTRL_JRK) || P.n_u > 128 || P.map.aux) return false;
   if (P.n_u <= 32) {  // 27 inputs: the 2-D yaw lattice of map_planner_node.cpp (3 x 3 x 3 yaw rates)
     if (P.control == CTRL_ACC)
-      hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024, false, false, false, true>), dim3(grid), dim3(512), 0, s, P);
+      hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_ACC, 1024, 1024, false, false, true>), dim3(grid), dim3(512), 0, s, P);
     else
-      hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_JRK, 1024, 1024, false, false, false, true>), dim3(grid), dim3(512), 0, s, P);
+      hipLaunchKernelGGL((astar_spec_kernel<32, 16, CTRL_JRK, 1024, 1024, false, false, true>), dim3(grid), dim3(512), 0, s, P);
     return true;
   }
   if (P.n_u <= 64) {
     if (P.control == CTRL_ACC)
-      hipLaunchKernelGGL((astar_spec_kernel<64, 4, CTRL_ACC, 512, 512, false, false, false, true>), dim3(grid), dim3(256), 0, s, P);
+      hipLaunchKernelGGL((astar_spec_kernel<64, 4, CTRL_ACC, 512, 512, false, false, true>), dim3(grid), dim3(256), 0, s, P);
     else
-      hipLaunchKernelGGL((astar_spec_kernel<64, 4, CTRL_JRK, 512, 512, false, false, false, true>), dim3(grid), dim3(256), 0, s, P);
+      hipLaunchKernelGGL((astar_spec_kernel<64, 4, CTRL_JRK, 512, 512, false, false, true>), dim3(grid), dim3(256), 0, s, P);
     return true;
   }
   // 81 inputs: the 3-D yaw lattice (3 x 3 x 3 x 3 yaw rates)
   if (P.control == CTRL_ACC)
-    hipLaunchKernelGGL((astar_spec_kernel<128, 4, CTRL_ACC, 1024, 1024, false, false, false, true>), dim3(grid), dim3(512), 0, s, P);
+    hipLaunchKernelGGL((astar_spec_kernel<128, 4, CTRL_ACC, 1024, 1024, false, false, true>), dim3(grid), dim3(512), 0, s, P);
   else
-    hipLaunchKernelGGL((astar_spec_kernel<128, 4, CTRL_JRK, 1024, 1024, false, false, false, true>), dim3(grid), dim3(512), 0, s, P);
+    hipLaunchKernelGGL((astar_spec_kernel<128, 4, CTRL_JRK, 1024, 1024, false, false, true>), dim3(grid), dim3(512), 0, s, P);
   return true;
 }

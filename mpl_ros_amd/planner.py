@@ -746,7 +746,7 @@ class VoxelMapPlanner:
 
     def setDeadline(self, seconds):
         """Launch guard: a search launch older than `seconds` is aborted and the call raises MplxError (MPLX_ERR_TIMEOUT) with
-        the workgroups' watch records; <= 0: wait for ever.  Default 120 s (environment MPLX_DEADLINE_S)."""
+        the workgroups' watch records; <= 0: wait for ever.  Default: none (opt-in; environment MPLX_DEADLINE_S); the clock starts at the launch."""
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_deadline(ctx.h, float(seconds)))
 

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The library's launch deadline is opt-in (a plan() of the reference has no wall-clock limit); the suite gives every search launch two
+# minutes so that a kernel bug ends a test with MPLX_ERR_TIMEOUT instead of wedging the run (tests/test_guard.py sets its own).
+os.environ.setdefault("MPLX_DEADLINE_S", "120")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver)")
 

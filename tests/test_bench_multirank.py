@@ -63,3 +63,4 @@ def test_one_rank_over_rccl_takes_the_multi_rank_path():
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["queries_total"] == 64 and len(d["per_rank"]) == 1
     assert d["strong"]["queries_total"] == 64 and d["strong"]["expansions_per_step"] == d["expansions_per_step"]  # one rank: the two phases hold the same stream
     assert "RCCL" in d["config"]["parallelism"] and d["map_setup_s"]["rccl_broadcast"] >= 0
+

@@ -345,3 +345,36 @@ def test_reference_robot_team_plans_through_the_backend_unchanged():
         assert got["n"] == len(robot.segs) and np.array_equal(segs, robot.segs)
         n_replanned += 1
     assert n_replanned == 16 and A.plans >= 16 + 24
+
+
+def _build_multi_gpu_driver(tmp_path):
+    exe = str(tmp_path / "multi_gpu_driver")
+    libdir = os.path.join(ROOT, "mpl_ros_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "multi_gpu_driver.cpp"), os.path.join(libdir, "libmplx.so"), "-Wl,-rpath," + libdir,
+                           "-L/opt/rocm/lib", "-lamdhip64", "-lrccl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_rccl_host_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """The C++ twin of dist.py (tests/cpp/multi_gpu_driver.cpp: ncclCommInitAll -> ncclBroadcast of the map -> mplx_map_set_device ->
+    sharded mplx_plan_batch) compiles against <rccl/rccl.h> and include/mplx.h and refuses to run without a device."""
+    import torch
+    exe = _build_multi_gpu_driver(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    out = subprocess.run([exe, "64", "8"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 3 and "no HIP device" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_broadcast_then_sharded_plans_equal_one_gpu(tmp_path):
+    """A C++ host doing the multi-GPU path itself: RCCL broadcast of the voxel map into every visible GPU's HBM,
+    one context per GPU on its replica, the query stream dealt longest-first in a snake, rows merged -- and every row equal to what
+    GPU 0 plans alone.  Runs with however many GPUs the box has (1 on the builder's box: the communicator, the broadcast call and
+    mplx_map_set_device are still the real ones)."""
+    exe = _build_multi_gpu_driver(tmp_path)
+    out = subprocess.run([exe, "128", "96"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["rows_differing_from_one_gpu"] == 0 and r["plans_ok"] > 48 and sum(r["per_gpu_queries"]) == 96

@@ -102,8 +102,11 @@ def test_the_moving_obstacle_tick_and_an_lpastar_plan_honour_their_deadlines():
     r0 = l.getResult()
     first = (r0.status, r0.cost, r0.n_expanded, r0.expand_hash)
     assert r0.n_expanded > 10000
+    ms = l.lastKernelMs()  # (the plan's search launch: ~ 37 ms on the round-5 kernel)
+    if ms < 8.0:
+        pytest.skip(f"the LPA* plan's launch takes {ms:.1f} ms: too short to be given a quarter of its time")
     l.reset()
-    l.setDeadline(0.015)  # (the plan's search launch alone runs ~ 37 ms)
+    l.setDeadline(ms / 1000.0 / 4.0)  # (derived from the measured launch, not a constant of one machine)
     t0 = time.time()
     with pytest.raises(MplxError) as e:
         l.plan(util.gpu_wp(start), util.gpu_wp(goal))

@@ -29,6 +29,11 @@ l2) cd /tmp
     cd $ROOT
     python profiles/summarize_rocprof.py $OUT > $OUT/summary_l2.txt 2>&1; tail -30 $OUT/summary_l2.txt
     find $OUT -name "*.db" -delete ;;
+xcd1) # one long query: helpers of the leader's own XCD (33 workgroups launched: blocks 8, 16, 24, 32 share XCD 0 with the leader)
+    for v in base x; do for g in 5 33; do
+      MPLX_HELP_GRID=$g MPLX_HELP_XCD_STATS=1 MPLX_LIB=$ROOT/build_tmp/libmplx_$v.so timeout 200 python tools/ab.py 2 tail > $OUT/xcd1_${v}_$g.json 2> $OUT/xcd1_${v}_$g.err
+      python -c "import json;d=json.load(open('$OUT/xcd1_${v}_$g.json'));print('$v grid $g', d['tail']['kernel_ms'], d['tail']['digests'])"; grep "help xcd" $OUT/xcd1_${v}_$g.err | tail -1
+    done; done ;;
 ab:*) # ab:<variant>[,<variant>...]:<reps>:<modes separated by +>   e.g. ab:base,e1:3:block+bulk+tail
     IFS=: read _ vars reps modes <<< "$s"
     for v in ${vars//,/ }; do
