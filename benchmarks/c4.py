@@ -130,6 +130,10 @@ def run(args):
     pl.setMaxNum(max_expand)
     pl.setCapacity(min(slots, n_local), caps["nodes"], caps["edges"], caps["log"])
     pl.setHelpers(args.helpers, args.help_reserved)
+    # pool recycling (round 6): finished queries hand their chunks back, the pools hold the concurrently running queries
+    recycle = not args.single and os.environ.get("MPLX_BENCH_NO_RECYCLE") != "1"
+    if recycle:
+        pl.setPoolRecycling(True)
 
     def wp(p):
         w = Waypoint3D(control)

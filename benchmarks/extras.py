@@ -11,7 +11,7 @@ from .common import _log
 
 
 def _compact(d, extra=()):
-    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "higher_is_better", "expansions_per_step", "plan_status_counts", "parity_sample") + tuple(extra)
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "higher_is_better", "expansions_per_step", "plan_status_counts", "parity_sample", "vs_cpu_single_thread") + tuple(extra)
     out = {k: d[k] for k in keep if k in d}
     out["workload"] = d["config"]["workload"]
     r = d.get("roofline", {})

@@ -189,6 +189,13 @@ int mplx_planner_config(mplx_ctx *ctx, const mplx_config *cfg);
 /* device pools: number of queries in flight (workgroups) and the TOTAL capacities shared by all
  * queries of one batch -- states, predecessor records, OPEN-log entries (0 = keep current) */
 int mplx_set_capacity(mplx_ctx *ctx, int32_t n_slots, uint64_t total_nodes, uint64_t total_edges, uint64_t total_open_log);
+/* Pool recycling for BATCHES on the speculative kernels (mplx_plan_batch*, mplx_stream_*; off by default): a query that has finished
+ * -- its result and trajectory are written -- hands its chunks of the three pools back, and the queries that start later take them
+ * again, so the capacities of mplx_set_capacity need to cover what the batch's CONCURRENTLY running queries hold (one per compute
+ * unit), not the sum over all of them.  The per-query results, trajectories and counters are what they are without it (same search,
+ * bit for bit); what is given up are the state spaces of the batch's queries after the call (mplx_debug_query_records refuses).
+ * A single mplx_plan never recycles.  A query that finds the pools empty ends with MPLX_PLAN_POOL_FULL as before. */
+int mplx_set_pool_recycling(mplx_ctx *ctx, int32_t on);
 /* speculative multi-node expansion (results are identical either way): -1 auto (on when
  * n_u <= 128), 0 = sequential kernel (one node per iteration), 2 = on; 8: measurement variant (eight expansion units of one
  * wave).  [Round 4's 82 -- two 256-lane workgroups per compute unit -- measured no gain and was removed in round 6.] */
@@ -335,6 +342,11 @@ int mplx_lpa_update_cleared(mplx_lpa *l, int n_cells, const int32_t *cells, uint
 /* PlannerBase::getSubStateSpace(time_step) (map_replanner_node.cpp:245): re-root the state space at the time_step-th
  * state of the last trajectory (the caller then plans from getTraj().getWaypoints()[time_step]); also compacts the pools */
 int mplx_lpa_sub_state_space(mplx_lpa *l, int32_t time_step);
+/* How getSubStateSpace re-roots (results of every later plan are the same either way; the state spaces differ in which states they
+ * keep).  0: Dijkstra from the new root through the states that had been expanded in the space being left (round 4/5).  1: an A*
+ * from the new root to the planner's goal, kept as the new space -- the cheaper of the two as soon as the old space is large (C2
+ * size: 23 ms against 113 ms).  2 (default): 1 when the space being left holds more than 16384 states, else 0. */
+int mplx_lpa_set_reroot(mplx_lpa *l, int32_t mode);
 /* results: the stored trajectory of the last successful plan; the state space (rhs next to g; built = expanded at least once;
  * blocked = the entry's primitive is not free in the current map) */
 int mplx_lpa_traj_len(const mplx_lpa *l);

@@ -62,14 +62,14 @@ EXPORTS = [
     "mplx_grid_fill_cell", "mplx_grid_get_map", "mplx_grid_get_cloud", "mplx_grid_to_map",
     "mplx_potential_weights", "mplx_potential_update", "mplx_search_region_set", "mplx_potential_clear", "mplx_aux_get", "mplx_aux_cloud", "mplx_aux_token",
     "mplx_lpa_create", "mplx_lpa_destroy", "mplx_lpa_last_error", "mplx_lpa_set_capacity", "mplx_lpa_set_record", "mplx_lpa_plan", "mplx_lpa_initialized",
-    "mplx_lpa_reset", "mplx_lpa_update_blocked", "mplx_lpa_update_cleared", "mplx_lpa_sub_state_space", "mplx_lpa_traj_len", "mplx_lpa_result_traj",
+    "mplx_lpa_reset", "mplx_lpa_update_blocked", "mplx_lpa_update_cleared", "mplx_lpa_sub_state_space", "mplx_lpa_set_reroot", "mplx_lpa_traj_len", "mplx_lpa_result_traj",
     "mplx_lpa_counts", "mplx_lpa_result_nodes", "mplx_lpa_result_edges", "mplx_lpa_result_expanded", "mplx_lpa_last_kernel_ms",
     "mplx_poly_create", "mplx_poly_destroy", "mplx_poly_last_error", "mplx_poly_config", "mplx_poly_begin", "mplx_poly_set_world",
     "mplx_poly_add_static", "mplx_poly_add_linear", "mplx_poly_add_nonlinear", "mplx_poly_commit", "mplx_poly_get_succ_batch", "mplx_poly_set_capacity", "mplx_poly_plan_batch", "mplx_poly_result_traj",
     "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms", "mplx_poly_result_cycles", "mplx_poly_set_helpers", "mplx_poly_last_helpers", "mplx_poly_set_deadline",
     "mplx_traj_solve", "mplx_traj_sample", "mplx_traj_effort",
     "mplx_plan_batch_submit", "mplx_plan_batch_wait", "mplx_plan_batch_done", "mplx_set_helper_limit", "mplx_release_pools",
-    "mplx_set_deadline", "mplx_debug_hang_next_launch", "mplx_debug_query_records",
+    "mplx_set_deadline", "mplx_set_pool_recycling", "mplx_debug_hang_next_launch", "mplx_debug_query_records",
     "mplx_stream_create", "mplx_stream_destroy", "mplx_stream_last_error", "mplx_stream_depth", "mplx_stream_configure",
     "mplx_stream_submit", "mplx_stream_done", "mplx_stream_wait",
 ]
@@ -163,6 +163,7 @@ def load():
     L.mplx_lpa_update_blocked.argtypes = [P, C.c_int, C.c_void_p, U64]
     L.mplx_lpa_update_cleared.argtypes = [P, C.c_int, C.c_void_p, U64]
     L.mplx_lpa_sub_state_space.argtypes = [P, C.c_int32]
+    L.mplx_lpa_set_reroot.argtypes = [P, C.c_int32]
     L.mplx_lpa_traj_len.argtypes = [P]
     L.mplx_lpa_result_traj.argtypes = [P, C.POINTER(Primitive), C.POINTER(Waypoint), I3, I3]
     L.mplx_lpa_counts.argtypes = [P, U64, U64, U64]
@@ -218,6 +219,7 @@ def load():
     L.mplx_set_helper_limit.argtypes = [P, C.c_int32]
     L.mplx_release_pools.argtypes = [P]
     L.mplx_set_deadline.argtypes = [P, C.c_double]
+    L.mplx_set_pool_recycling.argtypes = [P, C.c_int32]
     L.mplx_debug_hang_next_launch.argtypes = [P]
     L.mplx_debug_query_records.argtypes = [P, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     L.mplx_stream_create.argtypes = [P, C.c_int, C.POINTER(P)]

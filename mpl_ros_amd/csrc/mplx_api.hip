@@ -106,7 +106,16 @@ struct mplx_ctx {
   bool pend_help = false;
   std::vector<QueryIn> pend_in;
   std::vector<int32_t> pend_order;
-  unsigned long long *table_base = nullptr;  // (diagnostics, MPLX_X_FLAGS & 4)
+  // pool recycling (mplx_set_pool_recycling): the chunk bitmaps on the device, their initial (all free) image, and whether the last
+  // batch ran with them (its queries' state spaces are gone then: the state-space getters refuse)
+  bool recycle = false;
+  uint32_t *d_chunk_bits = nullptr;
+  std::vector<uint32_t> chunk_bits_init;
+  uint32_t chunk_word0[3] = {0, 0, 0}, chunk_words[3] = {0, 0, 0};
+  bool last_recycled = false;
+  bool pool_recycle = false;  // what the pools were allocated for (the table is sized for more states than the pool holds at once)
+  unsigned long long *table_base = nullptr;  // the shared state table as allocated
+  uint32_t tbl_epoch = TBL_EPOCHS;           // epoch of the table's slots of the last launch (table_prepare); TBL_EPOCHS: clear before use
   uint32_t launch_count = 0;
   int help_limit = -1;  // workgroups of a launch that may turn into helpers once the query queue is empty (-1: all of them)
   // launch guard (mplx_device.h GuardBlock): host-coherent block the search kernels poll / leave their watch records in
@@ -727,6 +736,13 @@ extern "C" int mplx_set_capacity(mplx_ctx *c, int32_t n_slots, uint64_t max_node
   if (max_log) c->cap_log = max_log;
   return MPLX_OK;
 }
+extern "C" int mplx_set_pool_recycling(mplx_ctx *c, int32_t on) {
+  if (!c) return MPLX_ERR_ARG;
+  MPLX_REFUSE_PENDING(c);
+  c->cfg_epoch++;
+  c->recycle = on != 0;
+  return MPLX_OK;
+}
 extern "C" int mplx_set_bucket_width(mplx_ctx *c, double w) {
   if (!c || w < 0) return MPLX_ERR_ARG;
   c->cfg_epoch++;
@@ -909,6 +925,20 @@ extern "C" int mplx_debug_hang_next_launch(mplx_ctx *c) {  // (tests) the next s
   return MPLX_OK;
 }
 
+// The shared state table before a batch launch: its slots carry the launch epoch (mplx_device.h tbl_empty / tbl_tagq), so the next
+// batch just moves on to the next epoch -- what the previous ones left is "empty" to it -- and the table is cleared only when the
+// epochs wrap (every 255th launch) or the table is new.  [Until round 5: a hipMemset of the whole table, 17-23 GB at C4 size, per batch.]
+static int table_prepare(mplx_ctx *c, SearchParams &P, hipStream_t s) {
+  static const bool always_clear = getenv("MPLX_TABLE_CLEAR") != nullptr;  // (diagnostics: the old behaviour)
+  c->tbl_epoch++;
+  if (c->tbl_epoch >= TBL_EPOCHS || always_clear) {
+    HIPCHK(c, hipMemsetAsync(P.table, 0xFF, (size_t)(P.table_mask + 1) * sizeof(unsigned long long), s));
+    c->tbl_epoch = 0;
+  }
+  P.tbl_epoch = c->tbl_epoch;
+  return MPLX_OK;
+}
+
 template <typename T>
 static int pool_alloc(mplx_ctx *c, T **p, size_t count) {
   void *v = nullptr;
@@ -932,7 +962,7 @@ static uint64_t next_pow2(uint64_t v) {
 static int ensure_pools(mplx_ctx *c, int slots) {
   const int control = c->cfg.control;
   if (c->pools_valid && c->pool_slots >= slots && c->pool_control == control && c->pool_nodes == c->cap_nodes &&
-      c->pool_edges == c->cap_edges && c->pool_log == c->cap_log && (c->helpers != 0) == (c->pools.boxes != nullptr) &&
+      c->pool_edges == c->cap_edges && c->pool_log == c->cap_log && (c->helpers != 0) == (c->pools.boxes != nullptr) && c->pool_recycle == c->recycle &&
       (c->helpers == 0 || c->pool_help_lanes == (c->cfg.n_u <= 31 ? 32 : 128)))
     return MPLX_OK;
   free_pools(c);
@@ -947,18 +977,38 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   // chunk ids are 16 bits in the kernels' LDS chunk tables: 2.1 G nodes / 4.3 G edges / 2.1 G log records
   if (nch > 0xFFFFull || ech > 0xFFFFull || och > 0xFFFFull) return fail(c, MPLX_ERR_ARG, "capacity too large (more than 65535 chunks in a pool)");
   if ((nch << NODE_CH_LOG) > (1ull << 30)) return fail(c, MPLX_ERR_ARG, "capacity too large (more than 2^30 states: the state table is indexed with 32 bits)");
-  const uint64_t T = next_pow2(4ull * (nch << NODE_CH_LOG));  // load factor <= 0.25: the slowest lane of a batch sets the pace, and its probe chain is a chain of HBM round trips
+  // load factor <= 0.25: the slowest lane of a batch sets the pace, and its probe chain is a chain of HBM round trips.  With recycling the
+  // pool holds what the CONCURRENT queries need while the table keeps an entry for every state the batch ever creates: twice the slots
+  // (2^32 at most: a claimed slot's index travels in 32 bits)
+  const uint64_t T = std::min<uint64_t>(next_pow2((c->recycle ? 8ull : 4ull) * (nch << NODE_CH_LOG)), 1ull << 32);
   int r;
 #define PA(ptr, cnt) if ((r = pool_alloc(c, &(ptr), (cnt))) != MPLX_OK) { free_pools(c); return r; }
   PA(P.node_pool, (size_t)(nch << NODE_CH_LOG) * rec_bytes(control));
   PA(P.edge_pool, (size_t)(ech << EDGE_CH_LOG) * EDGE_BYTES);
   PA(P.open_pool, (size_t)(och << OPEN_CH_LOG) * OPEN_BYTES);
-  static const int xflags_alloc = getenv("MPLX_X_FLAGS") ? atoi(getenv("MPLX_X_FLAGS")) : 0;
-  PA(P.table, (size_t)T * ((xflags_alloc & 4) ? 2 : 1));
+  PA(P.table, (size_t)T);
   c->table_base = P.table;
+  c->tbl_epoch = TBL_EPOCHS;  // (a fresh allocation: the first launch clears it and starts the epochs at 0 -- table_prepare)
   PA(P.bkt_head, (size_t)slots * 2 * NB * NSUB);
   HIPCHK(c, hipMemsetAsync(P.bkt_head, 0xFF, sizeof(uint32_t) * (size_t)slots * 2 * NB * NSUB, c->stream));  // all heads NIL; queries leave them so
   PA(P.chunk_next, 4);
+  c->pool_recycle = c->recycle;
+  c->d_chunk_bits = nullptr;
+  if (c->recycle) {  // one bit per chunk, set = free: the image every launch starts from
+    const uint64_t n[3] = {nch, ech, och};
+    uint32_t w0 = 0;
+    c->chunk_bits_init.clear();
+    for (int k = 0; k < 3; k++) {
+      c->chunk_word0[k] = w0;
+      c->chunk_words[k] = (uint32_t)((n[k] + 31) / 32);
+      for (uint32_t w = 0; w < c->chunk_words[k]; w++) {
+        const uint64_t left = n[k] - 32ull * w;
+        c->chunk_bits_init.push_back(left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u));
+      }
+      w0 += c->chunk_words[k];
+    }
+    PA(c->d_chunk_bits, (size_t)w0);
+  }
   P.boxes = nullptr; P.cache_c = nullptr; P.cache_h = nullptr; P.cache_next = nullptr; P.done_word = nullptr; P.cache_rows = 0;
   if (c->helpers != 0) {  // look-ahead cache of the helper workgroups (used by the speculative kernels, lattices <= 31 inputs)
     // rows of the heuristic cache: a quarter of the state capacity (a node is expanded ahead of time at most once),
@@ -1219,7 +1269,6 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
   P.xflags = xflags | (c->debug_hang ? 8 : 0);
   c->debug_hang = false;
   guard_arm(c);
-  if (xflags & 4) P.table = c->table_base + ((c->launch_count++ & 1u) ? (size_t)(P.table_mask + 1) : 0);  // (diagnostic: alternate halves)
   P.cap_rec = c->cap_rec;
   P.nq = nq;
   P.queries = c->d_in;
@@ -1233,13 +1282,23 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
   P.next_query = c->d_next;
   if (c->filter_table) filter_set(P, c->filter_table, c->filter_mask, c->filter_pool, c->filter_flag);
   HIPCHK(c, hipMemcpyAsync(c->d_order, order.data(), sizeof(int32_t) * nq, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(P.table, 0xFF, (size_t)(P.table_mask + 1) * sizeof(unsigned long long), c->stream));
+  if (int rt = table_prepare(c, P, c->stream)) return rt;
   HIPCHK(c, hipMemsetAsync(P.chunk_next, 0, 4 * sizeof(uint32_t), c->stream));
+  P.chunk_bits = nullptr;
   HIPCHK(c, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * nq, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), c->stream));
   // (yaw-carrying states run on the one-node kernels; a potential field / search region on the POT build of the
   //  speculative kernel for ACC lattices of at most 32 inputs -- mplx_launch_spec decides -- without helper workgroups)
   const bool spec = (c->speculation < 0 || c->speculation > 1) && !c->yaw;
+  // pool recycling: the speculative kernels only (the one-node kernels bump-allocate), batches only (a single query has nobody to hand
+  // its chunks to -- and its state space stays readable)
+  const bool recycle = c->recycle && nq > 1 && spec && !c->filter_table && (P.control == CTRL_ACC || P.control == CTRL_JRK) && P.n_u <= 128 && c->d_chunk_bits;
+  if (recycle) {
+    HIPCHK(c, hipMemcpyAsync(c->d_chunk_bits, c->chunk_bits_init.data(), sizeof(uint32_t) * c->chunk_bits_init.size(), hipMemcpyHostToDevice, c->stream));
+    P.chunk_bits = c->d_chunk_bits;
+    for (int k = 0; k < 3; k++) { P.chunk_word0[k] = c->chunk_word0[k]; P.chunk_words[k] = c->chunk_words[k]; }
+  }
+  c->last_recycled = recycle;
   // Helper workgroups: a workgroup with no query (left) to lead expands the front of a running leader's OPEN list ahead
   // of time.  The launch holds one workgroup per compute unit at most, so all of them are resident together: for a
   // batch smaller than the machine the extra workgroups (blockIdx.x >= help_lead) help from the start; in a large
@@ -1440,6 +1499,7 @@ static int stream_lane_setup(mplx_ctx *parent, mplx_ctx *l, bool pools_too) {
   l->bucket_width = parent->bucket_width;
   l->speculation = parent->speculation;
   l->deadline_s = parent->deadline_s;
+  l->recycle = parent->recycle;
   if (pools_too) {
     l->n_slots = parent->n_slots; l->cap_nodes = parent->cap_nodes; l->cap_edges = parent->cap_edges; l->cap_log = parent->cap_log;
     l->helpers = parent->helpers; l->help_reserved = parent->help_reserved; l->help_rows = parent->help_rows; l->help_limit = parent->help_limit;
@@ -1754,6 +1814,7 @@ extern "C" int mplx_result_nodes(mplx_ctx *c, uint64_t cap, mplx_waypoint *coord
 // record; bytes: room for *n_records x *rec_size (MPLX_ERR_CAPACITY, with the counts filled in, when cap_bytes is too small).
 extern "C" int mplx_debug_query_records(mplx_ctx *c, int q, uint64_t cap_bytes, void *bytes, uint64_t *n_records, int32_t *rec_size) {
   if (!c || q < 0 || q >= c->last_nq || !c->pools_valid || !n_records || !rec_size) return fail(c, MPLX_ERR_ARG, "bad argument / no batch / pools released");
+  if (c->last_recycled) return fail(c, MPLX_ERR_ARG, "the last batch ran with pool recycling (mplx_set_pool_recycling): the state spaces of its queries were handed back to the pools");
   MPLX_REFUSE_PENDING(c);
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = c->last_out[q].n_nodes;

@@ -22,6 +22,13 @@ constexpr int NC = 512;           // near OPEN capacity (LDS)
 constexpr int OWN = 2048;         // LDS (primitive, sample) owner map; larger expansions fall back to a search
 constexpr uint32_t NIL = 0xFFFFFFFFu;
 constexpr uint64_t TBL_EMPTY = 0xFFFFFFFFFFFFFFFFull;
+// Slots of the batch searches' SHARED state table (astar_spec_kernel, astar_kernel, astar_poly_kernel) carry the launch epoch of the
+// table (SearchParams::tbl_epoch, 0..254) in their top byte: [63:56] epoch | [55:48] tag = top byte of the key hash | [47:32] query |
+// [31:0] id / claim.  A slot whose epoch is not the launch's is EMPTY -- a cleared slot (0xFF..) as well as anything an earlier batch
+// left -- so the table is not cleared between batches (17-23 GB of hipMemset per C4 batch until round 5); the host clears it when
+// the epoch wraps.  A claim compare-and-swaps against the stale value it saw.  (LPA*'s private tables keep the 16-bit tag and are
+// cleared per fresh plan: mplx_lpa.h.)
+constexpr uint32_t TBL_EPOCHS = 255;
 constexpr uint32_t CLAIM_BASE = 0xFFFF0000u;  // table id field >= CLAIM_BASE: claimed in this expansion
 // Speculative kernels (mplx_spec.h): a claim carries the batch it was made in -- CLAIM_BASE | (batch & 63) << 9 | thread -- and is RESOLVED
 // before that batch ends: the entry of the state it was made for, or TBL_DEAD_ID when the unit that wanted the state was cut
@@ -176,8 +183,14 @@ struct SearchParams {
   char *node_pool, *edge_pool, *open_pool;
   uint32_t node_chunks, edge_chunks, open_chunks;  // pool sizes in chunks
   uint32_t *chunk_next;                            // [3] bump counters: node, edge, open
+  // pool recycling (mplx_set_pool_recycling; round 6): a finished query hands its chunks back, so a batch's pools hold what its
+  // CONCURRENT queries need, not the sum over all of them.  One bit per chunk (set: free), the three pools' words one after the
+  // other; null: bump allocation from chunk_next, nothing is returned (state spaces stay readable after the batch).
+  uint32_t *chunk_bits;
+  uint32_t chunk_word0[3], chunk_words[3];         // first word / number of words of the node, edge, open pool
   unsigned long long *table;
   unsigned long long table_mask;                   // slots - 1
+  uint32_t tbl_epoch;                              // launch epoch of the shared table's slots (tbl_empty / tbl_tagq)
   uint32_t *bkt_head;                              // per workgroup slot: 2 levels x NB x NSUB
   uint32_t cap_rec;
   // queries
@@ -218,6 +231,11 @@ struct SearchParams {
   const char *filter_pool;
   uint32_t filter_flag;
 };
+
+__host__ __device__ inline bool tbl_empty(unsigned long long v, uint32_t epoch) { return (uint32_t)(v >> 56) != epoch; }
+__host__ __device__ inline unsigned long long tbl_tagq(unsigned long long h64, uint32_t q, uint32_t epoch) {
+  return ((unsigned long long)epoch << 56) | ((h64 >> 56) << 48) | ((unsigned long long)(q & 0xFFFFu) << 32);
+}
 
 // Expansion filter of the FILTER builds of astar_spec_kernel (getSubStateSpace by import, mplx_lpa.h): a candidate is expanded only
 // if its key is found in `table` (LPA* hashing: no query bits) and the record it names in `pool` carries one of the `flag` bits.

@@ -777,21 +777,41 @@ struct QView {
   __device__ __forceinline__ OpenRec *open(uint32_t i) const {
     return (OpenRec *)(P.open_pool + (((size_t)open_chunk(i >> OPEN_CH_LOG) << OPEN_CH_LOG) + (i & ((1u << OPEN_CH_LOG) - 1))) * OPEN_BYTES);
   }
+  // (one thread) a free chunk of pool `pool` from the recycling bitmap (set bit: free), NIL when there is none.  The scan starts at a
+  // word that differs from workgroup to workgroup; a chunk is taken with atomicAnd -- whoever sees the bit in the returned word owns it.
+  // Rare (once per 32 768 states): no attempt at speed.
+  __device__ __forceinline__ uint32_t chunk_take(int pool) const {
+    uint32_t *bits = P.chunk_bits + P.chunk_word0[pool];
+    const uint32_t nw = P.chunk_words[pool];
+    const uint32_t w0 = (blockIdx.x * 2654435761u) % nw;
+    for (uint32_t k = 0; k < nw; k++) {
+      const uint32_t w = (w0 + k) % nw;
+      uint32_t v = __hip_atomic_load(&bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (v) {
+        const uint32_t b = (uint32_t)__ffs((int)v) - 1u;
+        const uint32_t old = atomicAnd(&bits[w], ~(1u << b));
+        if (old & (1u << b)) return w * 32u + b;
+        v = old & ~(1u << b);
+      }
+    }
+    return NIL;
+  }
+  __device__ __forceinline__ void chunk_give(int pool, uint32_t c) const { atomicOr(&P.chunk_bits[P.chunk_word0[pool] + (c >> 5)], 1u << (c & 31u)); }
   // (one thread) make sure the query owns chunks for `need` items of a pool; false when the pool -- or the query's table -- is exhausted
-  __device__ __forceinline__ bool take_chunks(uint16_t *tbl, uint32_t &owned, uint32_t need, int ch_log, int max_ch, uint32_t *next, uint32_t pool_chunks) const {
+  __device__ __forceinline__ bool take_chunks(uint16_t *tbl, uint32_t &owned, uint32_t need, int ch_log, int max_ch, int pool, uint32_t pool_chunks) const {
     const uint32_t want = (need + (1u << ch_log) - 1) >> ch_log;
     while (owned < want) {
       if (owned >= (uint32_t)max_ch) return false;
-      const uint32_t c = atomicAdd(next, 1u);
+      const uint32_t c = P.chunk_bits ? chunk_take(pool) : atomicAdd(P.chunk_next + pool, 1u);
       if (c >= pool_chunks) return false;
       tbl[owned] = (uint16_t)c;
       owned++;
     }
     return true;
   }
-  __device__ __forceinline__ bool ensure_nodes(uint32_t need) const { return take_chunks(S.node_tbl, S.node_chunks, need, NODE_CH_LOG, MAX_NODE_CH, P.chunk_next + 0, P.node_chunks); }
-  __device__ __forceinline__ bool ensure_edges(uint32_t need) const { return take_chunks(S.edge_tbl, S.edge_chunks, need, EDGE_CH_LOG, MAX_EDGE_CH, P.chunk_next + 1, P.edge_chunks); }
-  __device__ __forceinline__ bool ensure_open(uint32_t need) const { return take_chunks(S.open_tbl, S.open_chunks, need, OPEN_CH_LOG, MAX_OPEN_CH, P.chunk_next + 2, P.open_chunks); }
+  __device__ __forceinline__ bool ensure_nodes(uint32_t need) const { return take_chunks(S.node_tbl, S.node_chunks, need, NODE_CH_LOG, MAX_NODE_CH, 0, P.node_chunks); }
+  __device__ __forceinline__ bool ensure_edges(uint32_t need) const { return take_chunks(S.edge_tbl, S.edge_chunks, need, EDGE_CH_LOG, MAX_EDGE_CH, 1, P.edge_chunks); }
+  __device__ __forceinline__ bool ensure_open(uint32_t need) const { return take_chunks(S.open_tbl, S.open_chunks, need, OPEN_CH_LOG, MAX_OPEN_CH, 2, P.open_chunks); }
   // record field accessors
   static __device__ __forceinline__ double &g(char *r) { return *(double *)r; }
   static __device__ __forceinline__ double &h(char *r) { return *(double *)(r + 8); }
@@ -1165,7 +1185,7 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
   int role = 0;  // 1 found, 2 creator
   uint32_t id = NIL;
   size_t tslot = 0;
-  const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
+  const unsigned long long tagq = tbl_tagq(h64, (uint32_t)q, P.tbl_epoch);
   double old_g = INFINITY, hval = 0.0;
   uint32_t fl = 0, old_pred = NIL;
   char *rec = nullptr;
@@ -1201,9 +1221,9 @@ __device__ __forceinline__ void commit_parallel(const QView<BLOCK, CONTROL, SM> 
       }
       unsigned long long v = first ? v0 : ld_u64(&P.table[pos]);
       first = false;
-      if (v == TBL_EMPTY) {
-        unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, claim);
-        if (old == TBL_EMPTY) { role = 2; tslot = pos; break; }
+      if (tbl_empty(v, P.tbl_epoch)) {  // (cleared, or left by a batch of another epoch: claimed against the value seen)
+        unsigned long long old = atomicCAS(&P.table[pos], v, claim);
+        if (old == v) { role = 2; tslot = pos; break; }
         v = old;
       }
       for (uint32_t polls = 0; claim_wait && (uint32_t)v >= CLAIM_BASE && (uint32_t)v < TBL_DEAD_ID && (v & 0xFFFFFFFF00000000ull) == tagq &&
@@ -1477,11 +1497,11 @@ __global__ __launch_bounds__(BLOCK) void astar_kernel(SearchParams P) {
         V::flags(rec) = FLAG_OPENED;
         V::pred(rec) = NIL;
         const unsigned long long h64 = key_hash64(key, NKY);
-        const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
+        const unsigned long long tagq = tbl_tagq(h64, (uint32_t)q, P.tbl_epoch);
         size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
         for (unsigned long long steps = 0;; steps++) {  // shared table: the home slot may belong to another query
-          unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, tagq | 0ull);
-          if (old == TBL_EMPTY) break;
+          const unsigned long long seen = ld_u64(&P.table[pos]);  // (a slot of another epoch is empty: claimed against the value seen)
+          if (tbl_empty(seen, P.tbl_epoch) && atomicCAS(&P.table[pos], seen, tagq | 0ull) == seen) break;
           if (steps > P.table_mask) { S.status = 5; break; }  // (the table is full: never with the host's sizing)
           pos = (pos + 1) & (size_t)P.table_mask;
         }

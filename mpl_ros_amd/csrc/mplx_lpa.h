@@ -1095,6 +1095,8 @@ struct LpaImportArgs {
   // the old space expanded; LpaParams::old_* = the space being left).  A state keeps the heuristic it had in the old space; a
   // state the old space did not hold gets its own (hp: the planner's goal).  No result record, no trajectory: best_child_ and the
   // goal state are re-found in the new space by key.
+  // mode 2 (round 6, L5b): the imported search is a fresh A* from the k-th state of the last trajectory -- getSubStateSpace by planning
+  // afresh; imported like mode 0, except that the handle's stored trajectory / result stay and best_child_ is re-found by key.
   int32_t mode;
   HeurParams hp;
 };
@@ -1242,6 +1244,33 @@ __global__ __launch_bounds__(256) void lpa_import_finish_kernel(SearchParams P, 
   }
   const bool searched = o.n_nodes > 0;
   const int len = o.status == 0 ? o.traj_len : 0;
+  if (I.mode == 2) {  // getSubStateSpace by planning afresh (L5b): the imported A* IS the new space; the handle's stored trajectory and
+    // result record are the last plan's and stay; best_child_ is re-found by key, the goal state is the fresh plan's
+    if (tid == 0) {
+      constexpr int nk = key_len_c(CONTROL), rb = rec_bytes(CONTROL);
+      const LpaState *ost = A.old_st;
+      LpaState *st = A.st;
+      const bool full = !searched || o.status == 4 || n_blocked > A.blocked_cap || o.n_expanded != (unsigned long long)n_exp;
+      st->n_nodes = (uint32_t)o.n_nodes; st->n_edges = (uint32_t)o.n_edges; st->n_blocked = full ? 0u : n_blocked;
+      st->root_id = 0u;
+      st->goal_id = ((o.status == 0 || o.status == 6) && searched) ? (uint32_t)I.traj_nodes[0] : NIL;
+      st->valid = full ? 0u : 1u;
+      st->n_changed = full ? ~0ull : o.n_expanded;
+      st->path_len = ost->path_len;
+      for (uint32_t i = 0; i <= ost->path_len; i++) {
+        const uint32_t oid = ost->path[i];
+        uint32_t nid = NIL;
+        if (searched && oid != NIL && oid < ost->n_nodes) {
+          const int32_t *kk = (const int32_t *)(A.old_node_pool + (size_t)oid * rb + 24);
+          int32_t key[MAX_KEY];
+          for (int k = 0; k < nk; k++) key[k] = kk[k];
+          nid = lpa_find<256, CONTROL>(P.table, P.table_mask, P.node_pool, key, key_hash64(key, nk));
+        }
+        st->path[i] = nid;
+      }
+    }
+    return;
+  }
   // the trajectory buffers of the LPA* handle (goal -> start, like its own recoverTraj leaves them)
   if (o.status == 0 && searched) {
     for (int i = tid; i <= len; i += 256) P.traj_nodes[i] = I.traj_nodes[i];

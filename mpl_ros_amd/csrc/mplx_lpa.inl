@@ -40,6 +40,11 @@ struct mplx_lpa {
   mplx_waypoint goal{};
   int32_t root_key[MAX_KEY] = {};
   QueryOut last_out{};
+  int reroot_mode = 2;  // getSubStateSpace: 0 Dijkstra through the expanded states, 1 plan afresh from the new root, 2 auto (mplx_lpa_set_reroot)
+  // what the import lane was last configured for (lpa_import_lane): the parent's cfg_epoch, 1 plan / 2 Dijkstra, the handle's capacities
+  uint64_t imp_cfg_epoch = ~0ull;
+  int imp_mode = 0;
+  uint64_t imp_cap_nodes = 0, imp_cap_edges = 0, imp_cap_log = 0;
   LpaState st{};                 // host copy of the current space's scalars
   // the last trajectory (getTraj() returns the Trajectory stored at plan time, also after getSubStateSpace)
   int traj_len = 0;
@@ -224,11 +229,20 @@ static int lpa_import_lane(mplx_lpa *l, bool dijkstra) {
     if ((r = mplx_map_set_device(lane, c->map, c->dim, c->origin, c->res)) != MPLX_OK) return lfail(l, r, "LPA* import lane: %s", lane->err.c_str());
     l->imp_map_epoch = c->map_epoch;
   }
+  //  the lane is re-configured -- device buffers of the lattice freed and allocated, a stream synchronisation -- only when the
+  // parent's set-up changed since, or when the lane last ran in the other mode (plan / Dijkstra): not on every replanning call
+  const int want_mode = dijkstra ? 2 : 1;
+  if (l->imp_cfg_epoch == c->cfg_epoch && l->imp_mode == want_mode && l->imp_cap_nodes == l->cap_nodes && l->imp_cap_edges == l->cap_edges && l->imp_cap_log == l->cap_log) {
+    lane->deadline_s = c->deadline_s;
+    lane->helpers = c->helpers; lane->help_reserved = c->help_reserved; lane->help_rows = c->help_rows; lane->help_limit = -1;
+    return MPLX_OK;
+  }
   if ((r = stream_lane_setup(c, lane, false)) != MPLX_OK) return lfail(l, r, "LPA* import lane: %s", lane->err.c_str());
   if (dijkstra) {  // the same lattice and limits; key = g, run until OPEN is empty
     mplx_config cfg = lane->cfg;
     cfg.control = lane->cfg.control;
-    cfg.U = lane->U.data();
+    const std::vector<double> u_copy = lane->U;  // (mplx_planner_config assigns lane->U from cfg.U: never from the vector's own storage)
+    cfg.U = u_copy.data();
     cfg.U_yaw = nullptr;
     cfg.eps = 0.0;
     cfg.tol_pos = -1.0; cfg.tol_vel = -1.0; cfg.tol_acc = -1.0;  // (|dp| <= -1 never holds: no goal test ends the search)
@@ -239,6 +253,9 @@ static int lpa_import_lane(mplx_lpa *l, bool dijkstra) {
   lane->helpers = c->helpers; lane->help_reserved = c->help_reserved; lane->help_rows = c->help_rows; lane->help_limit = -1;
   mplx_set_capacity(lane, 1, l->cap_nodes, l->cap_edges, l->cap_log);
   lane->cap_rec = (uint32_t)std::min<uint64_t>(l->cap_nodes, 0xFFFFFFF0ull);  // every expansion closes a state: the record holds the whole order
+  l->imp_cfg_epoch = c->cfg_epoch;
+  l->imp_mode = want_mode;
+  l->imp_cap_nodes = l->cap_nodes; l->imp_cap_edges = l->cap_edges; l->imp_cap_log = l->cap_log;
   return MPLX_OK;
 }
 // the three import kernels on the lane's stream (P / A: lpa_params of the space written), timed into *ms
@@ -308,6 +325,23 @@ static int lpa_subtree_by_import(mplx_lpa *l, int time_step, const SearchParams 
   if (r != MPLX_OK) return lfail(l, r, "%s", lane->err.c_str());
   float imp_ms = 0;
   return lpa_import_launch(l, P, A, 1, &imp_ms);
+}
+
+// getSubStateSpace(k) by planning afresh (L5b of oracle/mpl_oracle_lpa.inc): an A* from the k-th state of the last trajectory to the
+// planner's goal on the import lane, imported into the NEW space (P / A: lpa_params of it, A.old_*: the space being left).
+static int lpa_subtree_by_fresh_plan(mplx_lpa *l, int time_step, const SearchParams &P, const LpaParams &A) {
+  int r;
+  if ((r = lpa_import_lane(l, false)) != MPLX_OK) return r;
+  mplx_ctx *lane = l->imp;
+  mplx_waypoint start{};
+  const double *s = &l->traj_states[(size_t)(l->traj_len - time_step) * 13];
+  for (int k = 0; k < 3; k++) { start.pos[k] = s[k]; start.vel[k] = s[3 + k]; start.acc[k] = s[6 + k]; start.jrk[k] = s[9 + k]; }
+  start.t = s[12];
+  start.control = l->ctx->cfg.control;
+  mplx_result res;
+  if ((r = mplx_plan(lane, &start, &l->goal, &res)) != MPLX_OK) return lfail(l, r, "%s", lane->err.c_str());
+  float imp_ms = 0;
+  return lpa_import_launch(l, P, A, 2, &imp_ms);
 }
 
 // PlannerBase::plan with setLPAstar(true) (map_replanner_node.cpp:141): repairs and re-uses the state space of the
@@ -435,6 +469,12 @@ static int lpa_update(mplx_lpa *l, int mode, int n_cells, const int32_t *cells, 
 extern "C" int mplx_lpa_update_blocked(mplx_lpa *l, int n_cells, const int32_t *cells, uint64_t *n_changed) { return lpa_update(l, 0, n_cells, cells, n_changed); }
 extern "C" int mplx_lpa_update_cleared(mplx_lpa *l, int n_cells, const int32_t *cells, uint64_t *n_changed) { return lpa_update(l, 1, n_cells, cells, n_changed); }
 
+constexpr uint32_t LPA_REROOT_AUTO = 16384;  // (= ORC_LPA_REROOT_AUTO of the oracle: both sides must take the same branch)
+extern "C" int mplx_lpa_set_reroot(mplx_lpa *l, int32_t mode) {
+  if (!l || mode < 0 || mode > 2) return lfail(l, MPLX_ERR_ARG, "mode 0 (Dijkstra through the expanded states), 1 (plan afresh from the new root) or 2 (auto)");
+  l->reroot_mode = mode;
+  return MPLX_OK;
+}
 // PlannerBase::getSubStateSpace(time_step) (map_replanner_node.cpp:245)
 extern "C" int mplx_lpa_sub_state_space(mplx_lpa *l, int32_t time_step) {
   if (!l) return MPLX_ERR_ARG;
@@ -460,7 +500,23 @@ extern "C" int mplx_lpa_sub_state_space(mplx_lpa *l, int32_t time_step) {
   static const bool no_import = getenv("MPLX_LPA_NO_IMPORT") != nullptr;  // (diagnostics: the one-workgroup Dijkstra, as before round 5)
   const bool by_import = !no_import && (c->cfg.control == CTRL_ACC || c->cfg.control == CTRL_JRK) && c->cfg.n_u <= 128 && (c->speculation < 0 || c->speculation > 1);
   LpaState ns{};
-  if (by_import) {
+  // how (mplx_lpa_set_reroot; L5 / L5b of oracle/mpl_oracle_lpa.inc): the Dijkstra through the expanded states of the space being
+  // left, or -- cheaper as soon as that space is large: the new search has a heuristic and a goal -- an A* from the new root
+  const bool fresh_plan = by_import && (l->reroot_mode == 1 || (l->reroot_mode == 2 && l->st.n_nodes > LPA_REROOT_AUTO));
+  if (fresh_plan) {
+    if (int ri = lpa_subtree_by_fresh_plan(l, time_step, P, A)) {
+      l->valid = false;
+      return ri;
+    }
+    LCHK(l, hipMemcpyAsync(&ns, A.st, sizeof(LpaState), hipMemcpyDeviceToHost, c->stream));
+    LCHK(l, hipStreamSynchronize(c->stream));
+    if (!ns.valid) {  // (the new root already satisfies the goal, or the pools ran out: no space is kept -- the next plan() starts one)
+      const bool no_search = l->imp->last_out[0].n_nodes == 0;
+      l->valid = false;
+      if (no_search) return MPLX_OK;
+      return lfail(l, MPLX_ERR_CAPACITY, "LPA* pools exhausted while rebuilding the sub state space (mplx_lpa_set_capacity)");
+    }
+  } else if (by_import) {
     if (int ri = lpa_subtree_by_import(l, time_step, P, A)) {
       l->valid = false;
       return ri;

@@ -402,7 +402,7 @@ extern "C" int mplx_poly_plan_batch(mplx_poly *p, int32_t n, const int32_t *worl
   hipStream_t st = c->stream;
   PCHK(p, hipMemcpyAsync(p->d_world_of, world_of, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
   PCHK(p, hipMemcpyAsync(c->d_order, order.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, st));
-  PCHK(p, hipMemsetAsync(P.table, 0xFF, (size_t)(P.table_mask + 1) * sizeof(unsigned long long), st));
+  if (int rt = table_prepare(c, P, st)) return pfail(p, rt, "%s", c->err.c_str());
   PCHK(p, hipMemsetAsync(P.chunk_next, 0, 4 * sizeof(uint32_t), st));
   PCHK(p, hipMemcpyAsync(c->d_in, in.data(), sizeof(QueryIn) * (size_t)n, hipMemcpyHostToDevice, st));
   PCHK(p, hipMemsetAsync(c->d_next, 0, sizeof(int32_t), st));

@@ -178,11 +178,11 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
         V::flags(rec) = FLAG_OPENED;
         V::pred(rec) = NIL;
         const unsigned long long h64 = key_hash64(key, NK);
-        const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
+        const unsigned long long tagq = tbl_tagq(h64, (uint32_t)q, P.tbl_epoch);
         size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
         for (unsigned long long steps = 0;; steps++) {
-          unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, tagq | 0ull);
-          if (old == TBL_EMPTY) break;
+          const unsigned long long seen = ld_u64(&P.table[pos]);  // (a slot of another epoch is empty: claimed against the value seen)
+          if (tbl_empty(seen, P.tbl_epoch) && atomicCAS(&P.table[pos], seen, tagq | 0ull) == seen) break;
           if (steps > P.table_mask) { S.status = 5; break; }  // (the table is full: never with the host's sizing)
           pos = (pos + 1) & (size_t)P.table_mask;
         }
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) void astar_poly_kernel(SearchParams P) {
         // isFree(start.pos, t) and isFree(pr, t) of all primitives against all obstacles
         auto hook = [&]() {  // the table slot has arrived: start fetching the record it names (the commit reads it)
                                   const uint32_t vid = (uint32_t)v0;
-                                  if (v0 != TBL_EMPTY && vid < CLAIM_BASE && (v0 >> 32) == ((h64 >> 48) << 16 | (unsigned long long)(uint32_t)q))
+                                  if (vid < CLAIM_BASE && (v0 >> 32) == (tbl_tagq(h64, (uint32_t)q, P.tbl_epoch) >> 32))
                                     __builtin_prefetch(Q.node(vid), 0, 3);
                                 };
         const bool looked = n_help > 0 && (pmask & POLY_MASK_READY) != 0ull;  // (uniform)

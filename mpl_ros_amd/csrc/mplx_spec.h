@@ -234,7 +234,7 @@ __device__ __forceinline__ void spec_commit_lanes(const V &Q, SM &S, int tid, in
       S.bt_id[my_slot] = id;
       S.bt_h[my_slot] = hspec;
       const unsigned long long h64 = S.bt_hash[my_slot];
-      st_u64(&P.table[S.bt_tslot[my_slot]], (((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32)) | id);
+      st_u64(&P.table[S.bt_tslot[my_slot]], tbl_tagq(h64, (uint32_t)q, P.tbl_epoch) | id);
     }
     const uint32_t eidx = base_edges + ((sc >> 10) & 0x3FFu);
     EdgeRec *e = Q.edge(eidx);
@@ -744,11 +744,11 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         V::flags(rec) = FLAG_OPENED;
         V::pred(rec) = NIL;
         const unsigned long long h64 = key_hash64(key, NKY);
-        const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
+        const unsigned long long tagq = tbl_tagq(h64, (uint32_t)q, P.tbl_epoch);
         size_t pos = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
         for (unsigned long long steps = 0;; steps++) {
-          unsigned long long old = atomicCAS(&P.table[pos], TBL_EMPTY, tagq | 0ull);
-          if (old == TBL_EMPTY) break;
+          const unsigned long long seen = ld_u64(&P.table[pos]);  // (a slot of another epoch is empty: claimed against the value seen)
+          if (tbl_empty(seen, P.tbl_epoch) && atomicCAS(&P.table[pos], seen, tagq | 0ull) == seen) break;
           if (steps > P.table_mask) { S.status = 5; break; }  // (the table is full: never with the host's sizing)
           pos = (pos + 1) & (size_t)P.table_mask;
         }
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             atomicOr(&S.dep_cause, 1);
 #endif
           } else {
-            const unsigned long long tagq = ((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32);
+            const unsigned long long tagq = tbl_tagq(h64, (uint32_t)q, P.tbl_epoch);
             const size_t mask = (size_t)P.table_mask;
             size_t pos = pos0;
             const uint32_t claim_batch = (batch_no & CLAIM_BATCH_MASK) << CLAIM_BATCH_SHIFT;
@@ -1392,8 +1392,8 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             // lane of the workgroup sets the pace either way, and the overlap is lost.)
             unsigned long long cas0 = 0;
             bool did_cas0 = false;
-            if (v0 == TBL_EMPTY) {
-              cas0 = atomicCAS(&P.table[pos], TBL_EMPTY, claim);
+            if (tbl_empty(v0, P.tbl_epoch)) {  // (cleared, or left by a batch of another epoch: claimed against the value seen)
+              cas0 = atomicCAS(&P.table[pos], v0, claim);
               did_cas0 = true;
             } else if ((uint32_t)v0 < CLAIM_BASE && (v0 & 0xFFFFFFFF00000000ull) == tagq) {
               __builtin_prefetch(Q.node((uint32_t)v0), 0, 3);
@@ -1437,10 +1437,10 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
                 break;
               }
               unsigned long long v = first ? v0 : MPLX_XF(P, 1) ? ld_u64(&P.table[pos]) : ld_u64_probe(&P.table[pos]);
-              if (v == TBL_EMPTY) {
-                unsigned long long old = (first && did_cas0) ? cas0 : atomicCAS(&P.table[pos], TBL_EMPTY, claim);
+              if (tbl_empty(v, P.tbl_epoch)) {
+                unsigned long long old = (first && did_cas0) ? cas0 : atomicCAS(&P.table[pos], v, claim);
                 first = false;
-                if (old == TBL_EMPTY) {
+                if (old == v) {
                   S.bt_id[my_slot] = NIL;  // new state; created when its first sharer commits
                   S.bt_tslot[my_slot] = (uint32_t)pos;
                   claimed_new = true;
@@ -1658,7 +1658,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           // a slot claimed for a state no committed unit reaches: its TBL_DEAD_ID goes out with the commit's own stores (behind the
           // commit's barrier its write-through acknowledgement would be the first thing the next batch waits for)
           if (MPLX_EARLY_TOMB(P) && !MPLX_XF(P, 4096) && claimed_new && !(S.bt_dirty[my_slot] & 2u)) {
-            st_u64(&P.table[claimed_pos], (((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32)) | (unsigned long long)TBL_DEAD_ID);
+            st_u64(&P.table[claimed_pos], tbl_tagq(h64, (uint32_t)q, P.tbl_epoch) | (unsigned long long)TBL_DEAD_ID);
             claimed_new = false;
           }
           spec_commit_lanes<UL, K, CONTROL, true, HELP, YAW>(Q, S, tid, q, ku, act && mine, my_slot, k_stop, L, hspec, pre, pend_idx, pend_old, (int)(batch_no & 1u));
@@ -1717,14 +1717,14 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         // a slot claimed for a state that no committed unit reached (its units were cut): dead from here on, and said so -- no claim
         // outlives its batch (see the look-up above)
         if (claimed_new && S.bt_id[my_slot] == NIL && !MPLX_XF(P, 4096))  // [MPLX_X_FLAGS & 4096, measurement: abandoned claims stay claims (round 3)]
-          st_u64(&P.table[claimed_pos], (((h64 >> 48) << 48) | ((unsigned long long)(uint32_t)q << 32)) | (unsigned long long)TBL_DEAD_ID);
+          st_u64(&P.table[claimed_pos], tbl_tagq(h64, (uint32_t)q, P.tbl_epoch) | (unsigned long long)TBL_DEAD_ID);
         if (tid < 64) {  // counters of the committed units, in commit order; lane k holds unit k
           const int l = opaque(tid);
           const bool inb = l < K && l < n_cand && S.cand_live[l < K ? l : 0] != 0;
           const bool done = inb && l < k_stop;
           const bool back = inb && l >= k_stop && S.status < 0;  // behind a cut: returns to OPEN untouched
           const uint32_t cur = l < K ? S.cand_id[l] : 0u;
-          const unsigned long long m = __ballot(done), mb = __ballot(back);
+          const unsigned long long m = __ballot(done), mb = __ballot(back), live_m = __ballot(inb);
           const unsigned long long below = (1ull << l) - 1ull;
           const unsigned long long ne0 = S.c_expanded;
           // (lanes >= K hold 0: the sums over the first row of 16 lanes are the totals)
@@ -1761,7 +1761,7 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
             // speculation accounting: candidates taken / live units (they ran get_succ) / of those, cut and returned to OPEN.  (a batch
             // that ends the query leaves its uncommitted live units uncounted as cut: nothing expands them again)
             S.c_cand += (unsigned long long)n_cand;
-            S.c_live += (unsigned long long)__popcll(__ballot(inb));
+            S.c_live += (unsigned long long)__popcll(live_m);
             S.c_cut += (unsigned long long)__popcll(mb);
             if (!parallel_commit) S.cyc[8]++;  // batches that needed the unit-by-unit commit
           }
@@ -1855,10 +1855,49 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
       }
 #endif
     }
+    // ---- pool recycling (SearchParams::chunk_bits): the finished query hands its chunks back to the pools
+    bool recycled = false;
+    if (P.chunk_bits) {
+      recycled = true;
+      if constexpr (HELP) {
+        // Not while a helper may still be reading this query's records (it detaches when it sees the box inactive: the store ahead of
+        // recoverTraj; in flight it has at most one wish list, ~100 us).  A helper that kept serving after the chunks had changed hands
+        // could publish a row computed against THIS query's goal for a record that belongs to the next owner by then.  Bounded
+        // (R4): a helper that does not leave keeps the chunks out of circulation for the rest of the launch, nothing else.
+        if (P.boxes) {
+          if (tid == 0) {
+            int ok = 1;
+            const HelpBox *box = P.boxes + blockIdx.x;
+            for (uint32_t polls = 0; ld_u32(&box->helpers) != 0u; polls++) {
+              if (polls > 40000u || ((polls & 1023u) == 1023u && guard_abort(P))) { ok = 0; break; }
+              __builtin_amdgcn_s_sleep(32);
+            }
+            S.flag = ok;
+          }
+          __syncthreads();
+          recycled = S.flag != 0;
+          __syncthreads();
+          if (recycled && searched) {  // the look-ahead records of its states: zero again for the next owner (written through: helpers on other XCDs read them)
+            for (uint32_t ch = 0; ch < S.node_chunks; ch++) {
+              double *base = (double *)(P.cache_c + ((size_t)Q.node_chunk(ch) << NODE_CH_LOG));
+              static_assert(sizeof(CacheRec) == 16, "one 16-byte store per record");
+              for (uint32_t i = tid; i < (1u << NODE_CH_LOG); i += BLOCK) st_f64x2_agent(base + 2 * (size_t)i, 0.0, 0.0);
+            }
+          }
+        }
+      }
+      __syncthreads();  // (drains the stores above: the chunks are handed over clean)
+      if (recycled) {
+        for (uint32_t i = tid; i < S.node_chunks; i += BLOCK) Q.chunk_give(0, Q.node_chunk(i));
+        for (uint32_t i = tid; i < S.edge_chunks; i += BLOCK) Q.chunk_give(1, Q.edge_chunk(i));
+        for (uint32_t i = tid; i < S.open_chunks; i += BLOCK) Q.chunk_give(2, Q.open_chunk(i));
+      }
+    }
+    // chunk tables of the query for the host's state-space getters (a recycling launch keeps no state space: the host refuses them)
     for (uint32_t i = tid; i < (uint32_t)MAX_NODE_CH; i += BLOCK)
-      P.node_tables[(size_t)q * MAX_NODE_CH + i] = i < S.node_chunks ? Q.node_chunk(i) : NIL;
+      P.node_tables[(size_t)q * MAX_NODE_CH + i] = (i < S.node_chunks && !P.chunk_bits) ? Q.node_chunk(i) : NIL;
     for (uint32_t i = tid; i < (uint32_t)MAX_EDGE_CH; i += BLOCK)
-      P.edge_tables[(size_t)q * MAX_EDGE_CH + i] = i < S.edge_chunks ? Q.edge_chunk(i) : NIL;
+      P.edge_tables[(size_t)q * MAX_EDGE_CH + i] = (i < S.edge_chunks && !P.chunk_bits) ? Q.edge_chunk(i) : NIL;
     if constexpr (HELP) {
       if (tid == 0) atomicAdd(P.done_word, 1ull);
     }

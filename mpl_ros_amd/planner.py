@@ -432,7 +432,16 @@ class VoxelMapPlanner:
             self._lpa = _Lpa(ctx)
             if self._cap is not None:
                 self._lpa.check(ctx.lib.mplx_lpa_set_capacity(self._lpa.h, self._cap[1], self._cap[2], self._cap[3]))
+            if getattr(self, "_reroot", None) is not None:
+                self._lpa.check(ctx.lib.mplx_lpa_set_reroot(self._lpa.h, self._reroot))
         return self._lpa
+
+    def setSubStateSpaceMode(self, mode):
+        """How getSubStateSpace re-roots (mplx_lpa_set_reroot): 0 Dijkstra through the expanded states of the space being left,
+        1 an A* from the new root kept as the new space, 2 (default) auto -- 1 for spaces of more than 16384 states."""
+        self._reroot = int(mode)
+        if self._lpa is not None:
+            self._lpa.check(self._lpa.lib.mplx_lpa_set_reroot(self._lpa.h, self._reroot))
 
     def initialized(self):
         """PlannerBase::initialized() (map_replanner_node.cpp:195,232,244): an LPA* state space exists."""
@@ -743,6 +752,12 @@ class VoxelMapPlanner:
         """At most `limit` workgroups of a launch stay on as helpers once its query queue is empty (-1: all)."""
         ctx = self._ctx()
         ctx.check(ctx.lib.mplx_set_helper_limit(ctx.h, int(limit)))
+
+    def setPoolRecycling(self, on=True):
+        """Batches on the speculative kernels: finished queries hand their pool chunks back (mplx_set_pool_recycling), so setCapacity
+        has to cover the concurrently running queries only.  Same results; the batch's state spaces are not kept."""
+        ctx = self._ctx()
+        ctx.check(ctx.lib.mplx_set_pool_recycling(ctx.h, 1 if on else 0))
 
     def setDeadline(self, seconds):
         """Launch guard: a search launch older than `seconds` is aborted and the call raises MplxError (MPLX_ERR_TIMEOUT) with

@@ -467,6 +467,7 @@ struct orc_planner {
   double pot_weight, grad_weight;
   /* LPA* (mpl_oracle_lpa.inc) */
   int use_lpa, lpa_valid;
+  int lpa_reroot; /* getSubStateSpace: 0 Dijkstra through the expanded states (L5), 1 plan afresh (L5b), 2 auto (default) */
   orc_lentry *lq;
   int n_lq, cap_lq;
   int root_id, goal_id;
@@ -487,6 +488,7 @@ orc_planner *orc_create(void) {
   p->cfg.t_max = INFINITY;
   p->cfg.max_expand = -1;
   p->traj_cost = INFINITY;
+  p->lpa_reroot = 2;
   return p;
 }
 static void free_search(orc_planner *p) {

@@ -210,6 +210,7 @@ int orc_lpa_initialized(const orc_planner *);               /* PlannerBase::init
 int orc_lpa_update_blocked(orc_planner *, int n_cells, const int32_t *cells); /* MapPlanner::updateBlockedNodes; entries changed */
 int orc_lpa_update_cleared(orc_planner *, int n_cells, const int32_t *cells); /* MapPlanner::updateClearedNodes */
 void orc_lpa_sub_state_space(orc_planner *, int time_step); /* PlannerBase::getSubStateSpace */
+void orc_lpa_set_reroot(orc_planner *, int mode);              /* how: 0 Dijkstra through the expanded states (L5), 1 plan afresh from the k-th state (L5b), 2 auto (default) */
 int orc_lpa_iterations(const orc_planner *);                /* states popped by the last plan() */
 double orc_get_node_rhs(const orc_planner *, int id);
 int orc_get_node_opened(const orc_planner *, int id);

@@ -135,6 +135,7 @@ def lib():
         L.orc_lpa_update_blocked.argtypes = [P, C.c_int, C.c_void_p]
         L.orc_lpa_update_cleared.argtypes = [P, C.c_int, C.c_void_p]
         L.orc_lpa_sub_state_space.argtypes = [P, C.c_int]
+        L.orc_lpa_set_reroot.argtypes = [P, C.c_int]
         L.orc_get_node_rhs.argtypes = [P, C.c_int]
         L.orc_get_node_rhs.restype = C.c_double
         L.orc_get_node_opened.argtypes = [P, C.c_int]
@@ -391,6 +392,10 @@ class Planner:
     def update_cleared(self, cells):
         c = np.ascontiguousarray(cells, dtype=np.int32).reshape(-1, 3)
         return int(self.L.orc_lpa_update_cleared(self.h, c.shape[0], c.ctypes.data))
+
+    def set_reroot(self, mode):
+        """getSubStateSpace: 0 Dijkstra through the expanded states (L5), 1 plan afresh from the k-th path state (L5b), 2 auto"""
+        self.L.orc_lpa_set_reroot(self.h, int(mode))
 
     def sub_state_space(self, time_step):
         self.L.orc_lpa_sub_state_space(self.h, int(time_step))

@@ -329,9 +329,37 @@ def test_oracle_lpastar_equals_fresh_astar_on_a_3d_map():
     assert L.lpa_iterations() < n0
 
 
+def test_oracle_subspace_by_fresh_plan_keeps_cost_and_the_stored_trajectory():
+    """L5b (round 6): getSubStateSpace realised as a fresh plan from the k-th path state.  Same path cost as the Dijkstra
+    realisation (L5) and as a fresh A* from the new start; the stored trajectory survives; the next plan() from the new root
+    finds a consistent space (no expansion)."""
+    grid, origin, res, start, sv, goal = scenario_3d("skir")
+    U = mapgen.control_lattice(1.0, 1, True)
+    res_by_mode = {}
+    for mode in (0, 1):
+        L = util.make_oracle(grid, origin, res, orc.ACC, U, **KW3)
+        L.set_lpastar(True)
+        L.set_reroot(mode)
+        so, go = orc.waypoint(start, vel=sv), orc.waypoint(goal)
+        assert L.plan(so, go) == orc.OK
+        tr = L.traj()
+        L.sub_state_space(1)
+        tr2 = L.traj()
+        assert np.array_equal(tr["actions"], tr2["actions"]) and tr2["node_ids"][1] == 0  # the new root is state 0 of the new space
+        w1 = tr["wps"][1]
+        s1 = orc.waypoint(tuple(w1.pos), vel=tuple(w1.vel))
+        L.reset_counters()
+        assert L.plan(s1, go) == orc.OK
+        res_by_mode[mode] = (L.traj_cost, L.lpa_iterations(), L.num_nodes())
+    A = util.make_oracle(grid, origin, res, orc.ACC, U, **KW3)
+    assert A.plan(s1, go) == orc.OK
+    assert res_by_mode[0][0] == res_by_mode[1][0] == A.traj_cost
+    assert res_by_mode[1][1] == 0 and res_by_mode[1][2] <= res_by_mode[0][2]  # consistent already; the fresh space is the smaller one
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["skir", "c2_256"])
-def test_hip_lpastar_on_3d_maps_bit_exact_and_equal_to_fresh_astar(name):
+@pytest.mark.parametrize("name,reroot", [("skir", 0), ("skir", 1), ("c2_256", 0), ("c2_256", 2)])
+def test_hip_lpastar_on_3d_maps_bit_exact_and_equal_to_fresh_astar(name, reroot):
     """LPA* replayed on the skir 3-D map and on the 256^3 random-box map of BASELINE C2 (27-input lattice): the HIP LPA*
     against the oracle's bit for bit (expansion order, every state's g / rhs / flags, every predecessor entry with its
     blocked flag, trajectory), and after every repair cost == a fresh device A* on the edited map.  Prints the kernel time
@@ -350,6 +378,8 @@ def test_hip_lpastar_on_3d_maps_bit_exact_and_equal_to_fresh_astar(name):
     l.setVmax(2.0); l.setAmax(1.0); l.setDt(1.0); l.setU(U); l.setTol(0.5)
     l.setCapacity(1, 1 << 18, 1 << 20, 1 << 21) if big else l.setCapacity(1, 1 << 16, 1 << 18, 1 << 18)
     l.setLPAstar(True)
+    l.setSubStateSpaceMode(reroot)  # (0 Dijkstra, 1 fresh plan, 2 auto: the fresh plan at C2 size)
+    L.set_reroot(reroot)
     go, gg = orc.waypoint(goal), util.gpu_wp(goal)
     times = []
 
@@ -398,6 +428,8 @@ def test_hip_lpastar_on_3d_maps_bit_exact_and_equal_to_fresh_astar(name):
     w1 = tg.getWaypoints()[1]
     rl3, ra3 = replan("one primitive ahead", orc.waypoint(tuple(w1.pos), vel=tuple(w1.vel)), util.gpu_wp(tuple(w1.pos), vel=tuple(w1.vel)))
     assert rl3.n_expanded < ra3.n_expanded and rl3.cost < cost0
+    if reroot == 1 or (reroot == 2 and big):
+        assert rl3.n_expanded == 0  # re-rooted by a fresh plan: the space is consistent for the new start
     print(f"LPA* on {name}: (step, LPA* expansions, LPA* kernel ms, fresh A* expansions, fresh A* kernel ms)", times)
 
 

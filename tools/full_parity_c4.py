@@ -5,7 +5,7 @@ hash, cost (bit-exact f64), path actions.  ~4 minutes of host time.  usage (GPU 
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
+from benchmarks import common as bench
 from mpl_ros_amd import mapgen
 from mpl_ros_amd.planner import ACC, JRK, VoxelMapPlanner, VoxelMapUtil, Waypoint3D
 from oracle import orc

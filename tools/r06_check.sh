@@ -6,7 +6,7 @@ TESTS=${*:-"tests/test_guard.py tests/test_cpp_shim.py tests/test_lpa.py tests/t
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 (timeout 900 python -u -m pytest $TESTS -m gpu -x -q --durations=8 2>&1 | tail -25) > $OUT/pytest.txt 2>&1; tail -4 $OUT/pytest.txt
-/usr/bin/time -v timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; grep "Elapsed" $OUT/bench_default.err
+T0=$(date +%s); timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench wall $(( $(date +%s) - T0 )) s"
 grep "bench +" $OUT/bench_default.err | tail -30 | cut -c1-200
 python - <<PY
 import json
