@@ -327,7 +327,7 @@ static int lpa_subtree_by_import(mplx_lpa *l, int time_step, const SearchParams 
   return lpa_import_launch(l, P, A, 1, &imp_ms);
 }
 
-// getSubStateSpace(k) by planning afresh (L5b of oracle/mpl_oracle_lpa.inc): an A* from the k-th state of the last trajectory to the
+// getSubStateSpace(k) by planning afresh (choice L5b of DESIGN.md's LPA* section): an A* from the k-th state of the last trajectory to the
 // planner's goal on the import lane, imported into the NEW space (P / A: lpa_params of it, A.old_*: the space being left).
 static int lpa_subtree_by_fresh_plan(mplx_lpa *l, int time_step, const SearchParams &P, const LpaParams &A) {
   int r;
@@ -469,7 +469,7 @@ static int lpa_update(mplx_lpa *l, int mode, int n_cells, const int32_t *cells, 
 extern "C" int mplx_lpa_update_blocked(mplx_lpa *l, int n_cells, const int32_t *cells, uint64_t *n_changed) { return lpa_update(l, 0, n_cells, cells, n_changed); }
 extern "C" int mplx_lpa_update_cleared(mplx_lpa *l, int n_cells, const int32_t *cells, uint64_t *n_changed) { return lpa_update(l, 1, n_cells, cells, n_changed); }
 
-constexpr uint32_t LPA_REROOT_AUTO = 16384;  // (= ORC_LPA_REROOT_AUTO of the oracle: both sides must take the same branch)
+constexpr uint32_t LPA_REROOT_AUTO = 16384;  // (the CPU checker of the tests uses the same constant: both sides must take the same branch)
 extern "C" int mplx_lpa_set_reroot(mplx_lpa *l, int32_t mode) {
   if (!l || mode < 0 || mode > 2) return lfail(l, MPLX_ERR_ARG, "mode 0 (Dijkstra through the expanded states), 1 (plan afresh from the new root) or 2 (auto)");
   l->reroot_mode = mode;
@@ -500,7 +500,7 @@ extern "C" int mplx_lpa_sub_state_space(mplx_lpa *l, int32_t time_step) {
   static const bool no_import = getenv("MPLX_LPA_NO_IMPORT") != nullptr;  // (diagnostics: the one-workgroup Dijkstra, as before round 5)
   const bool by_import = !no_import && (c->cfg.control == CTRL_ACC || c->cfg.control == CTRL_JRK) && c->cfg.n_u <= 128 && (c->speculation < 0 || c->speculation > 1);
   LpaState ns{};
-  // how (mplx_lpa_set_reroot; L5 / L5b of oracle/mpl_oracle_lpa.inc): the Dijkstra through the expanded states of the space being
+  // how (mplx_lpa_set_reroot; choices L5 / L5b of DESIGN.md's LPA* section): the Dijkstra through the expanded states of the space being
   // left, or -- cheaper as soon as that space is large: the new search has a heuristic and a goal -- an A* from the new root
   const bool fresh_plan = by_import && (l->reroot_mode == 1 || (l->reroot_mode == 2 && l->st.n_nodes > LPA_REROOT_AUTO));
   if (fresh_plan) {
