@@ -115,9 +115,14 @@ def run(args):
     else:
         max_expand = args.max_expand if args.max_expand > 0 else (2_000_000 if args.single else 20000)
         slots = args.slots or 768
-    caps = mapgen.c4_pools(jrk, n_local, max_expand, per_q=args.max_nodes)
+    # pool recycling (round 6): finished queries hand their chunks back, so the pools hold what the CONCURRENTLY running queries need.
+    # Measured on the C4-ACC batch (profiles/r06e_*): 358.8 M states created in all, at most 185.5 M held at any one time (final
+    # sizes of the queries running together) -- 250 000 per query of the batch instead of 450 000 (256 M states: 1.38 x that peak)
+    recycle = not args.single and os.environ.get("MPLX_BENCH_NO_RECYCLE") != "1"
+    per_q = args.max_nodes or (250_000 if (recycle and not jrk and n_local >= 1024) else 0)
+    caps = mapgen.c4_pools(jrk, n_local, max_expand, per_q=per_q)
     if not jrk and n_local < 1024:  # a small share of a heavy-tailed stream: leave room for its longest queries
-        caps = mapgen.c4_pools(jrk, max(n_local, 256), max_expand, per_q=args.max_nodes)
+        caps = mapgen.c4_pools(jrk, max(n_local, 256), max_expand, per_q=per_q)
     pl = VoxelMapPlanner(False)
     pl.setMapUtil(mu)
     pl.setVmax(2.0)
@@ -130,8 +135,6 @@ def run(args):
     pl.setMaxNum(max_expand)
     pl.setCapacity(min(slots, n_local), caps["nodes"], caps["edges"], caps["log"])
     pl.setHelpers(args.helpers, args.help_reserved)
-    # pool recycling (round 6): finished queries hand their chunks back, the pools hold the concurrently running queries
-    recycle = not args.single and os.environ.get("MPLX_BENCH_NO_RECYCLE") != "1"
     if recycle:
         pl.setPoolRecycling(True)
 
@@ -281,6 +284,7 @@ def run(args):
                 "map_dim": [n, n, n],
                 "n_primitives": int(U.shape[0]),
                 "slots_per_gpu": min(slots, n_local),
+                "pools": {"recycling": bool(recycle), "states": int(caps["nodes"]), "predecessor_records": int(caps["edges"]), "open_log": int(caps["log"])},
                 "helpers": {"per_leader": args.helpers, "reserved": args.help_reserved, **(pl.helperStats() if mine else {})},
                 "parallelism": f"queries sharded, {world} map replica(s), RCCL broadcast",
             },
@@ -309,7 +313,7 @@ def run(args):
                          "kernel": pl.kernelName(), "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
                          "bytes_per_expansion": alg / max(n_exp, 1), "launch": "rank 0's share of the stream"},
         }
-        # HBM traffic of the same launch from the committed rocprofv3 PMC passes (tools/profile_c4.sh; counters
+        # HBM traffic of the same launch from the committed rocprofv3 PMC passes (tools/r06_final.sh; counters
         # cannot be collected inside this process); only attached when the profile is of this workload
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
@@ -384,7 +388,7 @@ def run(args):
             except Exception as e:  # (e.g. the lanes' pools do not fit next to something else on the device: the blocking line stands on its own)
                 out["stream"] = {"error": f"{type(e).__name__}: {e}"}
                 _log(f"streamed leg failed: {out['stream']['error']}")
-            try:  # HBM traffic per streamed launch from the committed counter passes of the same leg (tools/profile_r04.sh)
+            try:  # HBM traffic per streamed launch from the committed counter passes of the same leg (tools/r06_final.sh)
                 trs = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("stream")
                 if trs and args.lattice == "acc" and len(mine) == 1024 and n == 512 and args.stream_split == 1:
                     out["stream"]["roofline"]["traffic_per_batch"] = (trs["FETCH_SIZE_KB"] + trs["WRITE_SIZE_KB"]) * 1024.0
@@ -400,7 +404,7 @@ def run(args):
         tq = mapgen.c4_queries(grid, origin, res, args.queries * world, rank=0)
         tparts = mdist.partition(tq, world, args.shard)
         tmine = tparts[rank]
-        tcaps = mapgen.c4_pools(jrk, max(len(tmine), 1), max_expand, per_q=args.max_nodes)
+        tcaps = mapgen.c4_pools(jrk, max(len(tmine), 1), max_expand, per_q=args.max_nodes or (250_000 if (recycle and not jrk and len(tmine) >= 1024) else 0))
         pl.setCapacity(min(slots, max(len(tmine), 1)), tcaps["nodes"], tcaps["edges"], tcaps["log"])
         tstarts = [wp(tq[i][0]) for i in tmine]
         tgoals = [wp(tq[i][1]) for i in tmine]
@@ -479,7 +483,8 @@ def stream_leg(args, pl, starts, goals, ref_results, n_batches, control, jrk, ma
     order = sorted(range(nq), key=lambda i: -float(np.sum((starts[i].pos - goals[i].pos) ** 2)))
     parts = [order[k::split] for k in range(split)]
     n_part = max(len(p) for p in parts)
-    caps = mapgen.c4_pools(jrk, max(n_part, 256), max_expand, per_q=args.max_nodes or ((420_000 if split == 1 else 450_000) if not jrk else 0))
+    recycle = os.environ.get("MPLX_BENCH_NO_RECYCLE") != "1"  # (the lanes take the planner's recycling policy: 250 000 states per query of the batch, see run())
+    caps = mapgen.c4_pools(jrk, max(n_part, 256), max_expand, per_q=args.max_nodes or (((250_000 if recycle else 420_000) if split == 1 else 450_000) if not jrk else 0))
     st = pl.stream(depth)
     # a lane = one workgroup per compute unit, all of them leading (no reserved helper share unless asked); when a batch's queue
     # is empty at most --stream-helper-limit of its workgroups stay on to help its longest queries, the others exit

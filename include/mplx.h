@@ -278,7 +278,7 @@ int mplx_set_deadline(mplx_ctx *ctx, double seconds);
 int mplx_debug_hang_next_launch(mplx_ctx *ctx);
 /* (diagnostics) raw node records {g f64, h f64, flags u32, pred u32, key i32[nk], pad to 64 B, state f64[ns], t} of query q of
  * the last batch, in node-id order; *rec_size bytes each (128 VEL/ACC, 160 JRK, 192 SNP).  MPLX_ERR_CAPACITY with the counts
- * filled in when cap_bytes is too small.  Used by tools/r05_jrk_batch.py to check every state against its key. */
+ * filled in when cap_bytes is too small.  (How round 5's race was found: every state checked against its key.) */
 int mplx_debug_query_records(mplx_ctx *ctx, int q, uint64_t cap_bytes, void *bytes, uint64_t *n_records, int32_t *rec_size);
 /* Free the context's device pools (re-created by its next plan): hands the memory to other contexts, e.g. a stream's lanes.
  * The last batch's results and trajectories stay readable; the state-space dumps of a single plan do not. */

@@ -980,7 +980,8 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   // load factor <= 0.25: the slowest lane of a batch sets the pace, and its probe chain is a chain of HBM round trips.  With recycling the
   // pool holds what the CONCURRENT queries need while the table keeps an entry for every state the batch ever creates: twice the slots
   // (2^32 at most: a claimed slot's index travels in 32 bits)
-  const uint64_t T = std::min<uint64_t>(next_pow2((c->recycle ? 8ull : 4ull) * (nch << NODE_CH_LOG)), 1ull << 32);
+  static const uint64_t fac_env = getenv("MPLX_TABLE_FACTOR") ? (uint64_t)atoi(getenv("MPLX_TABLE_FACTOR")) : 0;  // (measurement: slots per pool state)
+  const uint64_t T = std::min<uint64_t>(next_pow2((fac_env ? fac_env : (c->recycle ? 8ull : 4ull)) * (nch << NODE_CH_LOG)), 1ull << 32);
   int r;
 #define PA(ptr, cnt) if ((r = pool_alloc(c, &(ptr), (cnt))) != MPLX_OK) { free_pools(c); return r; }
   PA(P.node_pool, (size_t)(nch << NODE_CH_LOG) * rec_bytes(control));
@@ -1330,7 +1331,7 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
     if (const char *e = getenv("MPLX_HELP_GRID")) grid = std::max(P.help_lead, std::min(atoi(e), n_wg));  // (diagnostics: more would-be helpers than a leader takes)
     HIPCHK(c, hipMemsetAsync(P.boxes, 0, sizeof(HelpBox) * ((size_t)c->pool_slots + 1024), c->stream));
     c->dbg_boxes = P.boxes;
-    // (diagnostic, tools/tail_probe.py: MPLX_DEBUG_KEEP_CACHE=1 keeps the look-ahead cache of the previous launch -- the
+    // (diagnostic, tools/ab.py tail: MPLX_DEBUG_KEEP_CACHE=1 keeps the look-ahead cache of the previous launch -- the
     // same query planned again then finds an entry for every node, the fresh ones included: the time without any miss)
     static const bool keep_cache = getenv("MPLX_DEBUG_KEEP_CACHE") != nullptr;
     const bool kept = keep_cache && c->help_cache_filled;

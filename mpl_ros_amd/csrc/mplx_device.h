@@ -219,7 +219,7 @@ struct SearchParams {
   int32_t help_limit;             // workgroups of the launch that may turn into helpers once the query queue is empty (-1: no limit);
                                   // counted in cache_next[4].  Streamed batches: the rest exit and leave their compute unit to the next batch
   int32_t xflags;                 // diagnostics (MPLX_X_FLAGS): 1 table probes at agent scope, 2 release / acquire fences around a
-                                  // look-ahead cache record, 4 the launch uses the other half of a doubled state table,
+                                  // look-ahead cache record,
                                   // 8 (tests) workgroup 0 spins until the host aborts the launch
   GuardBlock *guard;              // launch guard (host-coherent memory; never null in a product launch)
   // moving-obstacle environment (astar_poly_kernel): the worlds and the world of each query

@@ -21,8 +21,8 @@ namespace mplx {
 
 // Diagnostic / measurement switches of SearchParams::xflags (environment MPLX_X_FLAGS, read per launch): compiled out of the product
 // (every one is a scalar test and a live SGPR on a query's serial chain); -DMPLX_DIAG_FLAGS=1 (tools/build_variant.sh diag) puts them
-// back for tools/r05_jrk_batch.py / tools/r05_ab.py.  Bit 8 -- the test-only spin the launch guard must end -- is always there.
-//   1 table probes at agent scope   2 release / acquire fences around a look-ahead record   4 other half of a doubled table (host)
+// back (round 5's tools/r05_jrk_batch.py / r05_ab.py, in the history).  Bit 8 -- the test-only spin the launch guard must end -- is always there.
+//   1 table probes at agent scope   2 release / acquire fences around a look-ahead record   (4: round 5's doubled table, removed)
 //   16 rows behind a release fence instead of the check word   32 TBL_DEAD_ID ahead of the parallel commit   64 claim wait in the
 //   one-node kernels (on by default since round 5)   128 plain loads of sc1-stored state doubles   256 no look-ahead hit is taken
 //   512 plain state stores   1024 rows unchecked   2048 no claim wait   4096 no TBL_DEAD_ID

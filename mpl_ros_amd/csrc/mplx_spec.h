@@ -1886,7 +1886,17 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
           }
         }
       }
-      __syncthreads();  // (drains the stores above: the chunks are handed over clean)
+      __syncthreads();  // (every wave's stores of this query -- and the zeroes above -- are acknowledged)
+      // The chunks may go to a workgroup on ANOTHER XCD, and the XCDs' write-back L2s are not coherent with each other: what this
+      // query left dirty in this XCD's L2 (its plain stores: records, predecessor entries, log entries) must reach memory NOW -- written
+      // back later, by an eviction, it would land on top of the next owner's data (seen in the first version of this code: a recovered
+      // trajectory that followed predecessor records of the chunk's previous life).  One agent-scope release (buffer_wbl2 sc1) per
+      // finished query; the explicit wait is the guide's: the compiler may drop its own behind the write-back.
+      if (recycled && tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
       if (recycled) {
         for (uint32_t i = tid; i < S.node_chunks; i += BLOCK) Q.chunk_give(0, Q.node_chunk(i));
         for (uint32_t i = tid; i < S.edge_chunks; i += BLOCK) Q.chunk_give(1, Q.edge_chunk(i));

@@ -35,7 +35,8 @@ def test_recycled_batch_equals_the_unrecycled_batch_in_much_smaller_pools(helper
     U = mapgen.control_lattice(1.0, 1, True)
     S = [util.gpu_wp(s) for s, g in queries]
     G = [util.gpu_wp(g) for s, g in queries]
-    mu, pl = util.make_gpu(grid, origin, res, U, n_slots=16, max_nodes=1 << 24, max_edges=1 << 26, max_log=1 << 25, max_expand=150000, **KW)
+    SLOTS = 4  # (workgroups that lead at a time: what the recycled pools have to hold)
+    mu, pl = util.make_gpu(grid, origin, res, U, n_slots=SLOTS, max_nodes=1 << 24, max_edges=1 << 26, max_log=1 << 25, max_expand=150000, **KW)
     pl.setHelpers(helpers, -1)
     ref = pl.planBatch(S, G)
     ref_traj = [pl.getTraj(k).actions.copy() for k in range(len(S))]
@@ -43,11 +44,11 @@ def test_recycled_batch_equals_the_unrecycled_batch_in_much_smaller_pools(helper
     biggest = max(r.n_nodes for r in ref)
     assert sum(r.status == 0 for r in ref) > 48 and total_nodes > 16 * 32768
     del pl
-    # 16 workgroups in flight: pools for 16 of the biggest query (rounded up to chunks), a fraction of the batch's total
-    cap_n = 16 * (biggest + 2 * 32768)
-    cap_e = max(16 * 8 * (biggest + 65536), 1 << 22)
-    assert cap_n < 0.6 * total_nodes, (cap_n, total_nodes)
-    mu2, pr = util.make_gpu(grid, origin, res, U, n_slots=16, max_nodes=cap_n, max_edges=cap_e, max_log=cap_e // 2, max_expand=150000, **KW)
+    # pools for SLOTS of the biggest query (rounded up to chunks): a fraction of the batch's total
+    cap_n = SLOTS * (biggest + 2 * 32768)
+    cap_e = SLOTS * (max(r.n_edges for r in ref) + 2 * 65536)
+    assert cap_n < 0.6 * total_nodes and cap_e < 0.6 * total_edges, (cap_n, total_nodes, cap_e, total_edges)
+    mu2, pr = util.make_gpu(grid, origin, res, U, n_slots=SLOTS, max_nodes=cap_n, max_edges=cap_e, max_log=cap_e, max_expand=150000, **KW)
     pr.setHelpers(helpers, -1)
     pr.setPoolRecycling(True)
     for rep in range(3):  # (repeats: chunks that come back in another order, helpers that lag behind)
@@ -103,14 +104,16 @@ def test_streamed_batches_recycle_like_blocking_ones():
     U = mapgen.control_lattice(1.0, 1, True)
     S = [util.gpu_wp(s) for s, g in queries]
     G = [util.gpu_wp(g) for s, g in queries]
-    mu, pl = util.make_gpu(grid, origin, res, U, n_slots=16, max_nodes=1 << 23, max_edges=1 << 25, max_log=1 << 24, max_expand=100000, **KW)
-    ref = [word(r) for r in pl.planBatch(S, G)]
+    mu, pl = util.make_gpu(grid, origin, res, U, n_slots=4, max_nodes=1 << 23, max_edges=1 << 25, max_log=1 << 24, max_expand=100000, **KW)
+    ref_r = pl.planBatch(S, G)
+    ref = [word(r) for r in ref_r]
     total = sum(w[4] for w in ref)
     biggest = max(w[4] for w in ref)
     pl.setPoolRecycling(True)
     st = pl.stream(2)
-    cap_n = 16 * (biggest + 2 * 32768)
-    st.configure(16, cap_n, max(16 * 8 * (biggest + 65536), 1 << 22), max(16 * 4 * (biggest + 65536), 1 << 21), -1, 0, 0, 4)
+    cap_n = 4 * (biggest + 2 * 32768)
+    cap_e = 4 * (max(r.n_edges for r in ref_r) + 2 * 65536)
+    st.configure(4, cap_n, cap_e, cap_e, -1, 0, 0, 4)
     tickets = [st.submit(S, G) for _ in range(2)]
     for rep in range(4):
         t = tickets.pop(0)
@@ -118,4 +121,3 @@ def test_streamed_batches_recycle_like_blocking_ones():
         tickets.append(st.submit(S, G))
     for t in tickets:
         assert [word(r) for r in st.wait(t)] == ref
-    assert cap_n < total or total < 16 * 32768

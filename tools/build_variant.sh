@@ -13,7 +13,7 @@ case $V in
   earlytomb) DEF=-DMPLX_X_EARLY_TOMB=1 ;;
   fast) DEF="-DMPLX_X_ROW_PAIRS=1 -DMPLX_X_EARLY_TOMB=1" ;;
   claimwait1n) DEF=-DMPLX_X_CLAIM_WAIT_1N=1 ;;
-  diag) DEF=-DMPLX_DIAG_FLAGS=1 ;;               # the MPLX_X_FLAGS switches of mplx_kernels.h (tools/r05_jrk_batch.py, tools/r05_ab.py)   # rule R3 for the one-node kernels (VEL / SNP states, LPA*, lattices > 128): test under tools/r04_jitter_probe.py-style load
+  diag) DEF=-DMPLX_DIAG_FLAGS=1 ;;               # the MPLX_X_FLAGS switches of mplx_kernels.h (round 5's r05_jrk_batch.py, r05_ab.py)   # rule R3 for the one-node kernels (VEL / SNP states, LPA*, lattices > 128): test under tools/r04_jitter_probe.py-style load
   *) echo "unknown variant $V"; exit 2 ;;
 esac
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function $DEF"
