@@ -977,11 +977,14 @@ static int ensure_pools(mplx_ctx *c, int slots) {
   // chunk ids are 16 bits in the kernels' LDS chunk tables: 2.1 G nodes / 4.3 G edges / 2.1 G log records
   if (nch > 0xFFFFull || ech > 0xFFFFull || och > 0xFFFFull) return fail(c, MPLX_ERR_ARG, "capacity too large (more than 65535 chunks in a pool)");
   if ((nch << NODE_CH_LOG) > (1ull << 30)) return fail(c, MPLX_ERR_ARG, "capacity too large (more than 2^30 states: the state table is indexed with 32 bits)");
-  // load factor <= 0.25: the slowest lane of a batch sets the pace, and its probe chain is a chain of HBM round trips.  With recycling the
-  // pool holds what the CONCURRENT queries need while the table keeps an entry for every state the batch ever creates: twice the slots
-  // (2^32 at most: a claimed slot's index travels in 32 bits)
+  // Slots per pool state: 16 (load factor <= 0.06; 2^32 slots at most: a claimed slot's index travels in 32 bits).  The slowest of a
+  // batch's ~190 look-up lanes sets the pace, and every extra probe is a dependent trip to memory: measured on one box (round 6,
+  // profiles/r06j_ab_table_probe.json) the blocking C4-ACC step takes 3596 / 2498 / 2296 / 2192 ms with 2 / 4 / 8 / 16 slots per
+  // state (recycled pools of 256 M states: the table also keeps an entry for every state of the batch's finished queries), the
+  // capped query alone 2011 vs 1974 ms with 4 vs 16.  Rounds 1-5 used 4.  The table is cleared once per 255 launches, not per batch
+  // (table_prepare), so its size costs memory only: 32 GB at C4 size.
   static const uint64_t fac_env = getenv("MPLX_TABLE_FACTOR") ? (uint64_t)atoi(getenv("MPLX_TABLE_FACTOR")) : 0;  // (measurement: slots per pool state)
-  const uint64_t T = std::min<uint64_t>(next_pow2((fac_env ? fac_env : (c->recycle ? 8ull : 4ull)) * (nch << NODE_CH_LOG)), 1ull << 32);
+  const uint64_t T = std::min<uint64_t>(next_pow2((fac_env ? fac_env : 16ull) * (nch << NODE_CH_LOG)), 1ull << 32);
   int r;
 #define PA(ptr, cnt) if ((r = pool_alloc(c, &(ptr), (cnt))) != MPLX_OK) { free_pools(c); return r; }
   PA(P.node_pool, (size_t)(nch << NODE_CH_LOG) * rec_bytes(control));

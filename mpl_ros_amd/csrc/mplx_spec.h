@@ -52,7 +52,16 @@
 //   * helpers that prefer a leader of their own XCD and publish rows / records with plain stores (kept in the shared L2 instead of
 //     written through): one long query with four same-XCD helpers 2057-2084 vs 2030 ms, the blocking C4 step 2516 vs 2301 ms (helpers
 //     wait for a same-XCD leader while others go unserved) -- the hand-over's trips to memory are not what bounds a batch;
-//   * 6 / 8 voxel loads in flight per lane in the sampling loop instead of 4: bulk 139.0 / 148.4 vs 134.6 ms (17 / 33 spilled VGPRs).
+//   * 6 / 8 voxel loads in flight per lane in the sampling loop instead of 4: bulk 139.0 / 148.4 vs 134.6 ms (17 / 33 spilled VGPRs);
+//   * examining 2 K OPEN entries per batch (each unit's two lane halves fetch one record, staged through LDS) and expanding the first K
+//     LIVE ones, so that stale entries -- 13 % of the candidates -- do not cost a unit its slot: identical results, tail 2273 vs 2027 ms,
+//     bulk 139.6 vs 135.2 ms (profiles/r06h_ab_refill_negative.json): one more barrier, 27 spilled VGPRs, and a fresh push inside the
+//     first 2 K entries shifts every later one away from the record its half unit had prefetched -- an exposed refetch in most batches.
+#ifndef MPLX_X_PROBE2
+#define MPLX_X_PROBE2 1       // (round 6) the look-up's first load brings the home slot AND its neighbour (almost always the same 64-byte line): a
+                              // key whose home slot is taken by another state no longer costs the slowest lane of the batch a second dependent trip
+#endif
+
 namespace mplx {
 
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain
@@ -1255,12 +1264,16 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
         // first probe of the state-space table: issued as soon as the successor's key exists, i.e. before
         // its voxels are sampled (a blocked successor wastes one load), consumed after the batch table is built
         unsigned long long h64 = 0, v0 = TBL_EMPTY;
+        [[maybe_unused]] unsigned long long v1 = TBL_EMPTY;  // (MPLX_X_PROBE2) the slot behind the home slot, loaded with it
         size_t pos0 = 0;
         expand_unit<UL, BLOCK, CONTROL, HELP, POT, YAW>(P, S, tid, live_unit, L, [&](const LaneSucc &l) {
           if (l.valid && !l.blocked) {
             h64 = lane_hash(l);
             pos0 = (size_t)(h64 ^ ((unsigned long long)(uint32_t)q * 0x9E3779B97F4A7C15ull)) & (size_t)P.table_mask;
             v0 = MPLX_XF(P, 1) ? ld_u64(&P.table[pos0]) : ld_u64_probe(&P.table[pos0]);
+#if MPLX_X_PROBE2
+            v1 = ld_u64_probe(&P.table[(pos0 + 1) & (size_t)P.table_mask]);
+#endif
           }
         });
         const bool act = L.valid && !L.blocked;
@@ -1436,7 +1449,13 @@ __global__ __launch_bounds__(UL *K) void astar_spec_kernel(SearchParams P) {
                 guard_mark(P, GUARD_PROBE, (uint32_t)q, S.cyc[7], (unsigned long long)pos);
                 break;
               }
+#if MPLX_X_PROBE2
+              // (a view of the second slot as old as the first one's: rule R3 covers it the same way -- a stale EMPTY is caught by the
+              //  compare-and-swap, an own-tag claim is read again past the L1, anything foreign moves the probe on)
+              unsigned long long v = first ? v0 : (steps == 1u && !MPLX_XF(P, 1)) ? v1 : MPLX_XF(P, 1) ? ld_u64(&P.table[pos]) : ld_u64_probe(&P.table[pos]);
+#else
               unsigned long long v = first ? v0 : MPLX_XF(P, 1) ? ld_u64(&P.table[pos]) : ld_u64_probe(&P.table[pos]);
+#endif
               if (tbl_empty(v, P.tbl_epoch)) {
                 unsigned long long old = (first && did_cas0) ? cas0 : atomicCAS(&P.table[pos], v, claim);
                 first = false;
