@@ -25,7 +25,6 @@ figure), and the sample doubles as a full-size parity check of the timed GPU res
 """
 
 import argparse
-import copy
 import json
 import os
 import sys
@@ -85,6 +84,7 @@ def parse_args(argv=None):
                          "the lanes are sized for a part, so --stream-depth can grow with it (2 parts x 4 lanes fit where 1 x 2 do)")
     ap.add_argument("--stream-reserved", type=int, default=0, help="streamed leg: workgroups of every lane's launch that never lead (help from the start)")
     ap.add_argument("--dump-queries", default="", help="write per-query expansions / device timing of the last step to this JSON file")
+    ap.add_argument("--warmup-cap", type=int, default=0, help="warm-up steps run with this expansion cap (a long single query is warmed up on a prefix of its search)")
     ap.add_argument("--extras", type=int, default=-1,
                     help="the other BASELINE configurations as extra keys of the C4 line (c2, c3, c5, lpa: each with its own roofline, single-thread "
                          "CPU baseline and parity check); -1 auto = on for the default 1-GPU C4-ACC line, 0 off, 1 on")

@@ -1,13 +1,15 @@
 """The other BASELINE configurations as extra keys of the driver's C4 line: c2 (config 2: one ACC query on the
 256^3 map), c3 (config 3: one JRK query on the 512^3 map, cap 2 000 000), c5 (config 5: the 16-robot tick), lpa (the replanning
-cycle at C2 size).  Each is the leg `bench.py --single ...` / `--config c5` / `--config lpa` runs, with few steps, reduced to its
+cycle at C2 size).  Each is the leg `bench.py --single ...` / `--config c5` / `--config lpa` runs -- in a process of its own -- with few steps, reduced to its
 headline numbers: value, kernel time, its own roofline, a single-thread CPU baseline and a parity check of the timed results.
 A leg that fails is reported as {"error": ...}; it never takes the C4 line down."""
-import copy
+import json
+import os
+import subprocess
+import sys
 import time
 
-from . import c4, c5, lpa
-from .common import _log
+from .common import ROOT, _log
 
 
 def _compact(d, extra=()):
@@ -24,42 +26,31 @@ def _compact(d, extra=()):
     return out
 
 
-def _single(args, n, lattice, steps, warmup, cpu_seconds, warmup_cap=0):
-    a = copy.copy(args)
-    a.single, a.map, a.lattice, a.steps, a.warmup, a.stream, a.cpu_seconds, a.max_expand, a.queries = True, n, lattice, steps, warmup, 0, cpu_seconds, 0, 1
-    a.warmup_cap = warmup_cap
-    a.dump_queries = ""
-    return _compact(c4.run(a), ("speculation",))
+def _child(argv, timeout_s):
+    """One leg as a process of its own (`python bench.py ...`): a leg that dies -- a device fault ends its process -- costs the line
+    one key, not the line; its ONE JSON line is parsed from stdout."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + [str(a) for a in argv]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"exit code {r.returncode}: {(r.stderr or r.stdout)[-400:]}")
+    return json.loads(lines[-1])
 
 
 def run(args):
     out = {}
     legs = (
-        ("c2", lambda: _single(args, 256, "acc", 5, 1, 3.0)),
-        ("c3", lambda: _single(args, 512, "jrk", 1, 1, 5.0, warmup_cap=20000)),
-        ("c5", lambda: _c5(args)),
-        ("lpa", lambda: _lpa(args)),
+        ("c2", ["--single", "--map", 256, "--lattice", "acc", "--steps", 5, "--warmup", 1, "--cpu-seconds", 3, "--stream", 0, "--extras", 0], ("speculation",), 90),
+        ("c3", ["--single", "--map", 512, "--lattice", "jrk", "--steps", 1, "--warmup", 1, "--warmup-cap", 20000, "--cpu-seconds", 5, "--stream", 0, "--extras", 0], ("speculation",), 120),
+        ("c5", ["--config", "c5", "--steps", 3, "--warmup", 1, "--cpu-seconds", 1], ("tick_ms", "lookahead"), 90),
+        ("lpa", ["--config", "lpa", "--map", 256, "--steps", 2, "--warmup", 1, "--cpu-seconds", 1], ("cycle", "lpa_vs_fresh_after_obstacle"), 90),
     )
-    for name, fn in legs:
+    for name, argv, extra, timeout_s in legs:
         t0 = time.perf_counter()
         _log(f"extra configuration {name}")
         try:
-            out[name] = fn()
+            out[name] = _compact(_child(argv, timeout_s), extra)
         except Exception as e:  # noqa: BLE001  (the C4 line stands on its own)
             out[name] = {"error": f"{type(e).__name__}: {e}"}
         out[name]["leg_seconds"] = round(time.perf_counter() - t0, 1)
     return out
-
-
-def _c5(args):
-    a = copy.copy(args)
-    a.steps, a.warmup, a.cpu_seconds, a.max_expand, a.c5_capped, a.helpers = 3, 1, 1.0, 0, False, -1
-    d = c5.run(a)
-    return _compact(d, ("tick_ms", "lookahead"))
-
-
-def _lpa(args):
-    a = copy.copy(args)
-    a.steps, a.warmup, a.map, a.cpu_seconds = 2, 1, 256, 1.0
-    d = lpa.run(a)
-    return _compact(d, ("cycle", "lpa_vs_fresh_after_obstacle", "reroot"))

@@ -60,6 +60,11 @@ def main():
             mu, pl = util.make_gpu(g2, o2, r2, U, max_nodes=1 << 22, max_edges=1 << 24, max_log=1 << 23, **kw)
             run = lambda: (pl.plan(util.gpu_wp(s2), util.gpu_wp(t2)), [pl.getResult()])[1]
         pl.setDeadline(100.0)
+        if os.environ.get("AB_BUCKET_WIDTH"):  # (width of a coarse OPEN bucket in units of f; default 8 w dt)
+            pl.setBucketWidth(float(os.environ["AB_BUCKET_WIDTH"]))
+        if os.environ.get("AB_HELPERS") and mode != "bulk":  # "per_leader,reserved"
+            a, b = os.environ["AB_HELPERS"].split(",")
+            pl.setHelpers(int(a), int(b))
         ms, digs, n_exp = [], set(), 0
         for it in range(reps + 1):
             R = run()
