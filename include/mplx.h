@@ -432,6 +432,41 @@ int mplx_poly_last_kernel_ms(const mplx_poly *p, float *ms);
  * compute units run the collision tests of the states a search has just created, before the search pops them (the
  * outcome is a pure function of the state: results are identical with or without).  per_leader: -1 auto, 0 off, <= 15. */
 int mplx_poly_set_helpers(mplx_poly *p, int32_t per_leader);
+/* ---- LPA* on the moving-obstacle planner (round 6): PlannerBase::plan with setLPAstar(true), PolyMapPlanner::updateNodes
+ *      (mpl_external_planner/.../poly_map_planner/poly_map_planner.h:61-93) and getSubStateSpace, as
+ *      mpl_test_node/src/poly_map_replanner_node.cpp:123-186,231 drives them.  One handle = one planner's device-resident state space
+ *      (states with g / rhs, predecessor entries with a blocked bit -- EVERY successor get_succ emits has one, the blocked ones too,
+ *      as the reference's node records do); worlds, lattice and limits are those of the mplx_poly handle it was created on
+ *      (re-commit the world after the obstacles / the start time changed, then call update_nodes).  Time-keyed ACC / JRK states. ---- */
+typedef struct mplx_plpa mplx_plpa;
+int mplx_plpa_create(mplx_poly *p, mplx_plpa **out);
+void mplx_plpa_destroy(mplx_plpa *l);
+const char *mplx_plpa_last_error(const mplx_plpa *l);
+int mplx_plpa_set_capacity(mplx_plpa *l, uint64_t max_nodes, uint64_t max_edges, uint64_t max_open_log);
+int mplx_plpa_initialized(const mplx_plpa *l);   /* PlannerBase::initialized() */
+int mplx_plpa_reset(mplx_plpa *l);               /* drop the state space */
+/* plan(start, goal) in world `world`; start / goal: pos2 vel2 acc2 jrk2 t.  Repairs and re-uses the previous plan's state space when the
+ * goal and the start (= the current root) are unchanged; otherwise starts one. */
+int mplx_plpa_plan(mplx_plpa *l, int32_t world, const double *start, const double *goal, double eps, double tol_pos, double tol_vel, int32_t max_expand,
+                   int32_t heur_ignore_dynamics, mplx_result *out);
+/* updateNodes(): every predecessor entry re-tested against the world as committed now (forward_action + isFree(pr, pred.t)); entries
+ * whose outcome changed flip (increaseCost / decreaseCost) and the look-ahead values of their states are recomputed.  Counts: entries
+ * that became blocked / free; mplx_plpa_changed lists them by entry number (getBlockedPrimitives / getClearedPrimitives: the entry's
+ * parent state and action are in mplx_plpa_result_entries / _nodes). */
+int mplx_plpa_update_nodes(mplx_plpa *l, int32_t world, uint64_t *n_blocked, uint64_t *n_cleared);
+int mplx_plpa_changed(mplx_plpa *l, uint64_t cap, int32_t *entry, int32_t *now_blocked, uint64_t *n);
+/* getSubStateSpace(time_step): re-root at the time_step-th state of the last trajectory, by planning afresh from it (the next plan()
+ * from that state finds a consistent space) */
+int mplx_plpa_sub_state_space(mplx_plpa *l, int32_t world, int32_t time_step);
+int mplx_plpa_traj_len(const mplx_plpa *l);
+int mplx_plpa_result_traj(mplx_plpa *l, int32_t *actions, int32_t *node_ids, double *states);
+int mplx_plpa_last_kernel_ms(const mplx_plpa *l, float *ms);
+int mplx_plpa_counts(const mplx_plpa *l, uint64_t *n_nodes, uint64_t *n_entries);
+int mplx_plpa_result_expanded(mplx_plpa *l, uint32_t cap, int32_t *ids, uint32_t *n);
+/* state-space dumps (parity tests): per state pos2 vel2 acc2 jrk2 t, g, rhs, h, closed / opened / built flags; per entry, in creation
+ * order: child, parent, action, blocked */
+int mplx_plpa_result_nodes(mplx_plpa *l, uint64_t cap, double *states, double *g, double *rhs, double *h, int32_t *closed, int32_t *opened, int32_t *built);
+int mplx_plpa_result_entries(mplx_plpa *l, uint64_t cap, int32_t *child, int32_t *parent, int32_t *action, int32_t *blocked);
 int mplx_poly_last_helpers(const mplx_poly *p); /* helpers per leader of the last launch */
 /* Launch guard of the moving-obstacle search: see mplx_set_deadline (a tick that outlives it returns MPLX_ERR_TIMEOUT). */
 int mplx_poly_set_deadline(mplx_poly *p, double seconds);

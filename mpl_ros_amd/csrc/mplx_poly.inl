@@ -6,6 +6,7 @@
 bool mplx_launch_poly_get_succ(bool general, int grid, hipStream_t s, const mplx::PolyDev &D, int K, const int32_t *world_of, const double *states, mplx::PolySuccOut *out, int32_t *flags);
 bool mplx_launch_poly_search(int control, bool general, int block, int grid, hipStream_t s, const mplx::SearchParams &P);
 
+#include "mplx_poly_lpa_host.h"
 struct mplx_poly {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -247,6 +248,22 @@ static mplx::PolyDev poly_dev(const mplx_poly *p) {
   return D;
 }
 static_assert(sizeof(mplx::PolySuccOut) == sizeof(mplx_poly_succ), "PolySuccOut must mirror mplx_poly_succ");
+
+// (internal: mplx_poly_lpa_host.h) the view the LPA* translation unit works with
+extern "C" int mplx_poly_internal_view(mplx_poly *p, mplx_poly_view *out) {
+  if (!p || !out) return MPLX_ERR_ARG;
+  if (!p->have_cfg) return pfail(p, MPLX_ERR_ARG, "mplx_poly_config first");
+  if (!p->committed) return pfail(p, MPLX_ERR_ARG, "mplx_poly_commit first");
+  out->dev = poly_dev(p);
+  out->general = poly_general(p) ? 1 : 0;
+  out->n_worlds = (int32_t)p->worlds.size();
+  out->device = p->device;
+  out->stream = p->ctx->stream;
+  out->guard = p->ctx->guard;
+  out->deadline_s = p->ctx->deadline_s;
+  out->tbl_unused = 0.0;
+  return MPLX_OK;
+}
 
 extern "C" int mplx_poly_get_succ_batch(mplx_poly *p, int32_t K, const int32_t *world_of, const double *states, mplx_poly_succ *out) {
   if (!p || K <= 0 || !world_of || !states || !out) return pfail(p, MPLX_ERR_ARG, "bad argument");

@@ -211,6 +211,10 @@ class PolyTeam:
         self.check(self.lib.mplx_poly_result_cycles(self.h, int(q), cyc))
         return dict(pop=int(cyc[0]), get_succ=int(cyc[1]), commit=int(cyc[2]), primitives=int(cyc[3]), start_test=int(cyc[4]), prepare=int(cyc[5]), items_lane0=int(cyc[6]), items_wait=int(cyc[7]), lookahead_hits=int(cyc[8]))
 
+    def lpa(self):
+        """A PolyLpa on this team's worlds: the LPA* planner of poly_map_replanner_node.cpp (setLPAstar(true), updateNodes, getSubStateSpace)."""
+        return PolyLpa(self)
+
     def last_kernel_ms(self):
         ms = C.c_float()
         self.check(self.lib.mplx_poly_last_kernel_ms(self.h, C.byref(ms)))
@@ -320,3 +324,91 @@ class RobotTeam:
         res = plan_many(worlds, starts, goals)
         ok = all(self._adopt(self.robots[i], time, rr, U) for i, rr in zip(due, res))
         return ok, due
+
+
+class PolyLpa:
+    """PolyMapPlanner2D with setLPAstar(true) (poly_map_replanner_node.cpp:341-352): a device-resident LPA* state space over the
+    moving-obstacle environment of ONE world of a PolyTeam (mplx_plpa_*).  The flow of replanCallback / plan() there:
+    team.set_worlds(...) (setLinearObstacles, setStartTime) -> update_nodes() -> plan(start, goal) -> sub_state_space(1)."""
+
+    def __init__(self, team, world=0):
+        self.team, self.lib, self.world = team, team.lib, int(world)
+        h = C.c_void_p()
+        code = self.lib.mplx_plpa_create(team.h, C.byref(h))
+        if code != _capi.OK:
+            raise MplxError(f"mplx_plpa_create failed ({code})")
+        self.h = h
+        self.result = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.mplx_plpa_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def check(self, code):
+        if code != _capi.OK:
+            raise MplxError(f"mplx error {code}: {self.lib.mplx_plpa_last_error(self.h).decode()}")
+
+    def set_capacity(self, nodes, edges, open_log):
+        self.check(self.lib.mplx_plpa_set_capacity(self.h, int(nodes), int(edges), int(open_log)))
+
+    def initialized(self):
+        return bool(self.lib.mplx_plpa_initialized(self.h))
+
+    def reset(self):
+        self.check(self.lib.mplx_plpa_reset(self.h))
+
+    def plan(self, start, goal, eps=1.0, tol_pos=0.5, tol_vel=-1.0, max_expand=-1, heur_ignore_dynamics=True):
+        s = np.ascontiguousarray(start, dtype=np.float64); g = np.ascontiguousarray(goal, dtype=np.float64)
+        R = _capi.Result()
+        self.check(self.lib.mplx_plpa_plan(self.h, self.world, s.ctypes.data, g.ctypes.data, float(eps), float(tol_pos), float(tol_vel), int(max_expand),
+                                           int(bool(heur_ignore_dynamics)), C.byref(R)))
+        self.result = R
+        return R.status == _capi.PLAN_OK
+
+    def update_nodes(self):
+        """PolyMapPlanner::updateNodes -> (entries that became blocked, entries that became free, [(entry, now blocked)] by entry number)"""
+        nb, nc, n = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.check(self.lib.mplx_plpa_update_nodes(self.h, self.world, C.byref(nb), C.byref(nc)))
+        self.check(self.lib.mplx_plpa_changed(self.h, 0, None, None, C.byref(n)))
+        e = np.zeros(max(n.value, 1), dtype=np.int32); b = np.zeros(max(n.value, 1), dtype=np.int32)
+        self.check(self.lib.mplx_plpa_changed(self.h, n.value, e.ctypes.data, b.ctypes.data, C.byref(n)))
+        return int(nb.value), int(nc.value), list(zip(e[:n.value].tolist(), b[:n.value].tolist()))
+
+    def sub_state_space(self, time_step):
+        self.check(self.lib.mplx_plpa_sub_state_space(self.h, self.world, int(time_step)))
+
+    def traj(self):
+        n = int(self.lib.mplx_plpa_traj_len(self.h))
+        act = np.zeros(max(n, 1), dtype=np.int32); ids = np.zeros(n + 1, dtype=np.int32); st = np.zeros((n + 1, 9))
+        if n:
+            self.check(self.lib.mplx_plpa_result_traj(self.h, act.ctypes.data, ids.ctypes.data, st.ctypes.data))
+        return act[:n], ids[:n + 1] if n else ids[:0], st[:n + 1] if n else st[:0]
+
+    def expanded_ids(self):
+        cap = int(self.result.n_expanded) if self.result is not None else 0
+        ids = np.zeros(max(cap, 1), dtype=np.int32)
+        n = C.c_uint32()
+        self.check(self.lib.mplx_plpa_result_expanded(self.h, cap, ids.ctypes.data, C.byref(n)))
+        return ids[:n.value]
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self.check(self.lib.mplx_plpa_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def state_space(self):
+        nn, ne = C.c_uint64(), C.c_uint64()
+        self.check(self.lib.mplx_plpa_counts(self.h, C.byref(nn), C.byref(ne)))
+        n, m = int(nn.value), int(ne.value)
+        states = np.zeros((max(n, 1), 9)); g = np.zeros(max(n, 1)); rhs = np.zeros(max(n, 1)); h = np.zeros(max(n, 1))
+        closed = np.zeros(max(n, 1), dtype=np.int32); opened = closed.copy(); built = closed.copy()
+        self.check(self.lib.mplx_plpa_result_nodes(self.h, max(n, 1), states.ctypes.data, g.ctypes.data, rhs.ctypes.data, h.ctypes.data, closed.ctypes.data,
+                                                   opened.ctypes.data, built.ctypes.data))
+        child = np.zeros(max(m, 1), dtype=np.int32); parent = child.copy(); action = child.copy(); blocked = child.copy()
+        self.check(self.lib.mplx_plpa_result_entries(self.h, max(m, 1), child.ctypes.data, parent.ctypes.data, action.ctypes.data, blocked.ctypes.data))
+        return dict(n_nodes=n, states=states[:n], g=g[:n], rhs=rhs[:n], h=h[:n], closed=closed[:n], opened=opened[:n], built=built[:n],
+                    child=child[:m], parent=parent[:m], action=action[:m], blocked=blocked[:m], initialized=self.initialized())

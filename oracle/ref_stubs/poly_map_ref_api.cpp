@@ -242,4 +242,274 @@ void refpoly_get_traj(int *node_ids, int *actions) {
   for (size_t i = 0; i < n; i++) actions[i] = g_traj_act[n - 1 - i];
 }
 void refpoly_get_node(int id, double *state, double *g, double *hh) { wp_to(g_nodes[id].coord, state); *g = g_nodes[id].g; *hh = g_nodes[id].h; }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// LPA* over the reference environment (round 6): PlannerBase::plan with setLPAstar(true), PolyMapPlanner::updateNodes
+// (poly_map_planner.h:61-93) and getSubStateSpace, as poly_map_replanner_node.cpp:123-186,231 drives them.  The search and the state
+// space (graph_search.h LPAstar, state_space.h) are un-vendored [UNVERIFIED]; this is the restatement of oracle/mpl_oracle_lpa.inc
+// (choices L1, L4, L6, L7) on the COMPILED reference environment, with two differences that follow the in-tree code:
+//   * every successor get_succ emits is a state with a predecessor entry -- also the ones whose primitive is blocked (cost +inf), as
+//     poly_map_planner.h:70-86 walks them (pred_coord / pred_action_id / pred_action_cost, "if (!isinf(cost))" / "if (isinf(cost))"):
+//     there is no blocked log here (deviation D7 of the voxel oracle does not apply);
+//   * updateNodes is the in-tree loop: every entry of every state re-tested with forward_action + isFree(pr, pred.t); what became
+//     blocked / free is collected (getBlockedPrimitives / getClearedPrimitives), increaseCost / decreaseCost = the entry's cost turns
+//     +inf / back to calculate_intrinsic_cost(pr), and the rhs of every state whose entries changed is recomputed.
+//   * getSubStateSpace(k): by planning afresh from the k-th state of the last trajectory (L5b) -- the only realisation here.
+// Entries are numbered in creation order (expansion order, then the order get_succ emits): the number both sides report.
+struct LNode {
+  Waypoint2D coord;
+  double g, rhs, h;
+  int closed, opened, built;
+  std::vector<int> pred, pact, pentry, pblk;
+  std::vector<double> pcost;  // calculate_intrinsic_cost(pr), whether blocked or not
+};
+struct LEntry { double k, kg; int id; };
+struct LSpace {
+  std::vector<LNode> nodes;
+  std::map<std::vector<int>, int> table;
+  int root = -1, goal_id = -1, n_entries = 0, iterations = 0, valid = 0;
+  double goal[9] = {0}, cost = std::numeric_limits<double>::infinity();
+  std::vector<int> expanded, traj_nodes, traj_act;
+  std::vector<int> changed_entry, changed_blocked;
+  std::vector<int> echild, eparent, eaction;  // entry -> (child, parent, action)
+};
+static LSpace LS;
+static const double L_INF = std::numeric_limits<double>::infinity();
+
+static double l_rhs_of(const LNode &nd) {
+  double rhs = L_INF;
+  for (size_t e = 0; e < nd.pred.size(); e++) {
+    if (nd.pblk[e]) continue;
+    const double v = LS.nodes[nd.pred[e]].g + nd.pcost[e];
+    if (v < rhs) rhs = v;
+  }
+  return rhs;
+}
+int refpoly_lpa_initialized() { return LS.valid; }
+void refpoly_lpa_reset() { LS = LSpace(); }
+
+int refpoly_lpa_plan(void *h, const double *start, const double *goal, int control, double eps, double tol_pos, int max_expand, int heur_mode) {
+  Ref *r = (Ref *)h;
+  LS.cost = L_INF;
+  LS.expanded.clear(); LS.traj_nodes.clear(); LS.traj_act.clear();
+  LS.iterations = 0;
+  Waypoint2D s = wp_of(start, control), g = wp_of(goal, control);
+  s.enable_t = true;
+  if (!r->env->is_free(s.pos)) return 2;
+  const double v_max = r->env->v_max_, w = r->env->w_;
+  auto heur = [&](const Waypoint2D &x) {
+    if (eps == 0) return 0.0;
+    if (heur_mode == 0) {
+      OrcWaypoint o = OrcWaypoint();
+      for (int i = 0; i < 2; i++) { o.pos[i] = x.pos(i); o.vel[i] = x.vel(i); o.acc[i] = x.acc(i); o.jrk[i] = x.jrk(i); }
+      o.t = x.t;
+      o.control = control;
+      o.enable_t = 1;
+      return g_heur_fn(g_heur_planner, &o);
+    }
+    const double d = std::max(std::fabs(x.pos(0) - g.pos(0)), std::fabs(x.pos(1) - g.pos(1)));
+    return v_max > 0 ? w * d / v_max : w * d;
+  };
+  if (heur_mode == 0 && !g_heur_fn) return -1;
+  auto is_goal = [&](const Waypoint2D &x) { return std::max(std::fabs(x.pos(0) - g.pos(0)), std::fabs(x.pos(1) - g.pos(1))) <= tol_pos; };
+  bool same_goal = true;
+  for (int i = 0; i < 8; i++) same_goal = same_goal && LS.goal[i] == goal[i];
+  if (LS.valid && !same_goal) LS.valid = 0;  // L6
+  for (int i = 0; i < 9; i++) LS.goal[i] = goal[i];
+  if (is_goal(s)) { LS.cost = 0; return 0; }
+  if (LS.valid) {  // L6: the start must be the current root
+    auto f = LS.table.find(s.key());
+    if (f == LS.table.end() || f->second != LS.root) LS.valid = 0;
+  }
+  if (!LS.valid) {
+    LS.nodes.clear(); LS.table.clear(); LS.echild.clear(); LS.eparent.clear(); LS.eaction.clear();
+    LS.n_entries = 0;
+    LS.nodes.push_back(LNode{s, L_INF, 0.0, heur(s), 0, 1, 0, {}, {}, {}, {}, {}});
+    LS.table[s.key()] = 0;
+    LS.root = 0;
+    LS.goal_id = -1;
+    LS.valid = 1;
+  }
+  auto key_of = [&](const LNode &nd) { return std::min(nd.g, nd.rhs) + eps * nd.h; };
+  auto ecmp = [](const LEntry &a, const LEntry &b) { if (a.k != b.k) return a.k > b.k; if (a.kg != b.kg) return a.kg > b.kg; return a.id > b.id; };
+  std::priority_queue<LEntry, std::vector<LEntry>, decltype(ecmp)> open(ecmp);
+  auto push = [&](int id) { const LNode &nd = LS.nodes[id]; open.push(LEntry{key_of(nd), std::min(nd.g, nd.rhs), id}); };
+  auto entry_valid = [&](const LEntry &e) {
+    const LNode &nd = LS.nodes[e.id];
+    if (nd.g == nd.rhs) return false;
+    return e.k == key_of(nd) && e.kg == std::min(nd.g, nd.rhs);
+  };
+  auto update_node = [&](int id, bool g_changed) {  // oracle/mpl_oracle_lpa.inc lpa_update_node
+    LNode &nd = LS.nodes[id];
+    const double old_rhs = nd.rhs;
+    if (id != LS.root) nd.rhs = l_rhs_of(nd);
+    if (nd.g != nd.rhs) {
+      const bool had_entry = !g_changed && nd.opened && !nd.closed && nd.rhs == old_rhs;
+      nd.opened = 1;
+      nd.closed = 0;
+      if (!had_entry) push(id);
+    } else if (nd.opened && !nd.closed) {
+      nd.closed = 1;
+    }
+  };
+  for (size_t i = 0; i < LS.nodes.size(); i++)  // L1: OPEN = the inconsistent states, rebuilt
+    if (LS.nodes[i].g != LS.nodes[i].rhs) push((int)i);
+  int gid = -1;  // L7
+  for (size_t i = 0; i < LS.nodes.size(); i++) {
+    const LNode &nd = LS.nodes[i];
+    if (nd.g != nd.rhs || std::isinf(nd.g) || !is_goal(nd.coord)) continue;
+    if (gid < 0) { gid = (int)i; continue; }
+    const LNode &b = LS.nodes[gid];
+    const double k = key_of(nd), kb = key_of(b);
+    if (k < kb || (k == kb && nd.g < b.g)) gid = (int)i;
+  }
+  if (gid < 0 && LS.goal_id >= 0 && LS.goal_id < (int)LS.nodes.size() && is_goal(LS.nodes[LS.goal_id].coord)) gid = LS.goal_id;
+  vec_E<Waypoint2D> succ;
+  std::vector<decimal_t> cost;
+  std::vector<int> act;
+  int status = 0;
+  for (;;) {
+    while (!open.empty() && !entry_valid(open.top())) open.pop();
+    const bool gcons = gid < 0 || LS.nodes[gid].g == LS.nodes[gid].rhs;
+    const double kgoal = gid < 0 ? L_INF : key_of(LS.nodes[gid]);
+    if (open.empty()) {
+      if (!(gid >= 0 && gcons && !std::isinf(LS.nodes[gid].g))) status = 1;
+      break;
+    }
+    if (!(open.top().k < kgoal || !gcons)) break;
+    LS.iterations++;
+    const int u = open.top().id;
+    open.pop();
+    LS.nodes[u].opened = 1;
+    LS.nodes[u].closed = 1;
+    LS.expanded.push_back(u);
+    if (LS.nodes[u].g > LS.nodes[u].rhs) {
+      LS.nodes[u].g = LS.nodes[u].rhs;
+    } else {
+      LS.nodes[u].g = L_INF;
+      update_node(u, true);
+    }
+    const Waypoint2D cw = LS.nodes[u].coord;
+    const bool first = !LS.nodes[u].built;
+    r->env->get_succ(cw, succ, cost, act);
+    std::vector<int> kids;
+    for (size_t k = 0; k < succ.size(); k++) {
+      Waypoint2D tn = succ[k];
+      tn.control = cw.control;
+      auto f = LS.table.find(tn.key());
+      int id = f == LS.table.end() ? -1 : f->second;
+      if (first) {
+        if (id < 0) {
+          id = (int)LS.nodes.size();
+          LS.nodes.push_back(LNode{tn, L_INF, L_INF, heur(tn), 0, 0, 0, {}, {}, {}, {}, {}});
+          LS.table[tn.key()] = id;
+        }
+        Primitive2D pr;
+        r->env->forward_action(cw, act[k], pr);
+        LNode &c = LS.nodes[id];
+        c.pred.push_back(u); c.pact.push_back(act[k]); c.pentry.push_back(LS.n_entries); c.pblk.push_back(std::isinf(cost[k]) ? 1 : 0);
+        c.pcost.push_back(r->env->calculate_intrinsic_cost(pr));
+        LS.echild.push_back(id); LS.eparent.push_back(u); LS.eaction.push_back(act[k]);
+        LS.n_entries++;
+      } else if (id < 0) {
+        continue;
+      }
+      if (std::isinf(cost[k])) continue;  // (a blocked entry cannot lower the successor's rhs)
+      if (std::find(kids.begin(), kids.end(), id) == kids.end()) kids.push_back(id);
+    }
+    LS.nodes[u].built = 1;
+    for (int id : kids) update_node(id, false);
+    if (is_goal(LS.nodes[u].coord) && !std::isinf(LS.nodes[u].g)) gid = u;
+    if (max_expand > 0 && LS.iterations >= max_expand) { status = 3; break; }
+  }
+  LS.goal_id = gid;
+  if (status != 0) return status;
+  // recoverTraj (oracle/mpl_oracle.c recover_traj): minimise g(pred) + cost over the non-blocked entries, ties -> larger g(pred), then the oldest
+  int node = gid;
+  LS.traj_nodes.push_back(node);
+  while (!LS.nodes[node].pred.empty()) {
+    int best = -1;
+    double min_rhs = L_INF, min_g = L_INF;
+    const LNode &nd = LS.nodes[node];
+    for (size_t e = 0; e < nd.pred.size(); e++) {
+      const double gp = LS.nodes[nd.pred[e]].g, c = nd.pblk[e] ? L_INF : nd.pcost[e];
+      if (min_rhs > gp + c) { min_rhs = gp + c; min_g = gp; best = (int)e; }
+      else if (!std::isinf(c) && min_rhs == gp + c && min_g < gp) { min_g = gp; best = (int)e; }
+    }
+    if (best < 0) return 1;
+    LS.traj_act.push_back(nd.pact[best]);
+    node = nd.pred[best];
+    LS.traj_nodes.push_back(node);
+    if (node == LS.root) break;
+    if (LS.traj_nodes.size() > LS.nodes.size() + 1) return 1;
+  }
+  if (node != LS.root) return 1;
+  LS.cost = LS.nodes[gid].g;
+  return 0;
+}
+
+// PolyMapPlanner::updateNodes (poly_map_planner.h:61-93) after the obstacles / the start time of the environment were changed
+int refpoly_lpa_update_nodes(void *h, int *n_blocked, int *n_cleared) {
+  Ref *r = (Ref *)h;
+  LS.changed_entry.clear(); LS.changed_blocked.clear();
+  int nb = 0, nc = 0;
+  if (!LS.valid) { *n_blocked = 0; *n_cleared = 0; return 0; }
+  std::vector<int> dirty(LS.nodes.size(), 0);
+  for (size_t i = 0; i < LS.nodes.size(); i++) {
+    LNode &nd = LS.nodes[i];
+    for (size_t e = 0; e < nd.pred.size(); e++) {
+      Primitive2D pr;
+      const Waypoint2D &pc = LS.nodes[nd.pred[e]].coord;
+      r->env->forward_action(pc, nd.pact[e], pr);
+      const bool free_ = r->map_util->isFree(pr, pc.t);
+      if (!free_ && !nd.pblk[e]) { nd.pblk[e] = 1; dirty[i] = 1; nb++; LS.changed_entry.push_back(nd.pentry[e]); LS.changed_blocked.push_back(1); }
+      else if (free_ && nd.pblk[e]) { nd.pblk[e] = 0; dirty[i] = 1; nc++; LS.changed_entry.push_back(nd.pentry[e]); LS.changed_blocked.push_back(0); }
+    }
+  }
+  for (size_t i = 0; i < LS.nodes.size(); i++)  // increaseCost / decreaseCost: the look-ahead value of every state whose entries changed
+    if (dirty[i] && (int)i != LS.root) LS.nodes[i].rhs = l_rhs_of(LS.nodes[i]);
+  *n_blocked = nb; *n_cleared = nc;
+  return 0;
+}
+// getSubStateSpace(k) (poly_map_replanner_node.cpp:231) by planning afresh from the k-th state of the last trajectory (L5b)
+int refpoly_lpa_sub_state_space(void *h, int k, int control, double eps, double tol_pos, int max_expand, int heur_mode) {
+  if (!LS.valid || LS.traj_act.empty() || k < 0 || k > (int)LS.traj_act.size()) return 0;
+  const int n = (int)LS.traj_act.size();
+  double s[9], goal[9];
+  wp_to(LS.nodes[LS.traj_nodes[n - k]].coord, s);  // (traj_nodes is goal -> start)
+  for (int i = 0; i < 9; i++) goal[i] = LS.goal[i];
+  LS.valid = 0;
+  refpoly_lpa_plan(h, s, goal, control, eps, tol_pos, max_expand, heur_mode);
+  LS.expanded.clear(); LS.traj_nodes.clear(); LS.traj_act.clear();  // (not a plan: no expansion record, no trajectory of its own)
+  LS.cost = L_INF;
+  return 0;
+}
+int refpoly_lpa_num_nodes() { return (int)LS.nodes.size(); }
+int refpoly_lpa_num_entries() { return LS.n_entries; }
+int refpoly_lpa_iterations() { return LS.iterations; }
+double refpoly_lpa_cost() { return LS.cost; }
+int refpoly_lpa_traj_len() { return (int)LS.traj_act.size(); }
+void refpoly_lpa_get_expanded(int *ids) { for (size_t i = 0; i < LS.expanded.size(); i++) ids[i] = LS.expanded[i]; }
+void refpoly_lpa_get_traj(int *node_ids, int *actions) {
+  const size_t n = LS.traj_act.size();
+  for (size_t i = 0; i <= n && !LS.traj_nodes.empty(); i++) node_ids[i] = LS.traj_nodes[n - i];
+  for (size_t i = 0; i < n; i++) actions[i] = LS.traj_act[n - 1 - i];
+}
+// per state: pos2 vel2 acc2 jrk2 t | g rhs h | closed opened built
+void refpoly_lpa_get_node(int id, double *state, double *vals, int *flags) {
+  const LNode &nd = LS.nodes[id];
+  wp_to(nd.coord, state);
+  vals[0] = nd.g; vals[1] = nd.rhs; vals[2] = nd.h;
+  flags[0] = nd.closed; flags[1] = nd.opened; flags[2] = nd.built;
+}
+// per entry, in creation order: child, parent, action, blocked
+void refpoly_lpa_get_entries(int *child, int *parent, int *action, int *blocked) {
+  for (int e = 0; e < LS.n_entries; e++) { child[e] = LS.echild[e]; parent[e] = LS.eparent[e]; action[e] = LS.eaction[e]; blocked[e] = 0; }
+  for (const LNode &nd : LS.nodes)
+    for (size_t e = 0; e < nd.pred.size(); e++) blocked[nd.pentry[e]] = nd.pblk[e];
+}
+int refpoly_lpa_num_changed() { return (int)LS.changed_entry.size(); }
+void refpoly_lpa_get_changed(int *entry, int *now_blocked) {
+  for (size_t i = 0; i < LS.changed_entry.size(); i++) { entry[i] = LS.changed_entry[i]; now_blocked[i] = LS.changed_blocked[i]; }
+}
 }

@@ -40,6 +40,15 @@ def lib():
         L.refpoly_get_expanded.argtypes = [C.c_void_p]
         L.refpoly_get_traj.argtypes = [C.c_void_p, C.c_void_p]
         L.refpoly_get_node.argtypes = [C.c_int, C.c_void_p, C.POINTER(D), C.POINTER(D)]
+        L.refpoly_lpa_plan.argtypes = [P, C.c_void_p, C.c_void_p, C.c_int, D, D, C.c_int, C.c_int]
+        L.refpoly_lpa_update_nodes.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.refpoly_lpa_sub_state_space.argtypes = [P, C.c_int, C.c_int, D, D, C.c_int, C.c_int]
+        L.refpoly_lpa_cost.restype = D
+        L.refpoly_lpa_get_expanded.argtypes = [C.c_void_p]
+        L.refpoly_lpa_get_traj.argtypes = [C.c_void_p, C.c_void_p]
+        L.refpoly_lpa_get_node.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.refpoly_lpa_get_entries.argtypes = [C.c_void_p] * 4
+        L.refpoly_lpa_get_changed.argtypes = [C.c_void_p] * 2
         _lib = L
     return _lib
 
@@ -63,6 +72,60 @@ class RefWorld:
         self.env_kw = dict(dt=float(dt), v_max=float(v_max), a_max=float(a_max), j_max=float(j_max), w=float(w))
         self.goal_control = None  # control kind of the goal waypoint (None: that of the search states, as robot.hpp builds it)
         L.refpoly_set_env(self.h, len(self.U), self.U.ctypes.data, float(dt), float(v_max), float(a_max), float(j_max), float(w))
+
+    def reload(self, world):
+        """The obstacles moved / the planner's start time changed (poly_map_replanner_node.cpp:123-131: setLinearObstacles, setStartTime)"""
+        L = self.L
+        L.refpoly_clear_obstacles(self.h)
+        L.refpoly_set_start_time(self.h, world.start_t)
+        for o in world.static:
+            L.refpoly_add_static(self.h, len(o.poly), o.poly.ctypes.data, float(o.p[0]), float(o.p[1]))
+        for o in world.linear:
+            L.refpoly_add_linear(self.h, len(o.poly), o.poly.ctypes.data, float(o.p[0]), float(o.p[1]), float(o.v[0]), float(o.v[1]), o.cov_v)
+        for o in world.nonlinear:
+            L.refpoly_add_nonlinear(self.h, len(o.poly), o.poly.ctypes.data, len(o.segs), o.segs.ctypes.data, self.control, o.start_t,
+                                    int(o.disappear_front), int(o.disappear_back))
+
+    # ---- LPA* over the compiled reference environment (oracle/ref_stubs/poly_map_ref_api.cpp, one state space per process)
+    def lpa_reset(self):
+        self.L.refpoly_lpa_reset()
+
+    def lpa_plan(self, start, goal, eps=1.0, tol_pos=0.5, max_expand=-1):
+        """PlannerBase::plan with setLPAstar(true) (distance heuristic: setHeurIgnoreDynamics(true))"""
+        s = np.ascontiguousarray(start, dtype=np.float64); g = np.ascontiguousarray(goal, dtype=np.float64)
+        self._lpa_kw = (float(eps), float(tol_pos), int(max_expand))
+        st = self.L.refpoly_lpa_plan(self.h, s.ctypes.data, g.ctypes.data, self.control, float(eps), float(tol_pos), int(max_expand), 1)
+        ne, nl = self.L.refpoly_lpa_iterations(), self.L.refpoly_lpa_traj_len()
+        ids = np.zeros(max(ne, 1), dtype=np.int32)
+        self.L.refpoly_lpa_get_expanded(ids.ctypes.data)
+        tn = np.zeros(nl + 1, dtype=np.int32); ta = np.zeros(max(nl, 1), dtype=np.int32)
+        if st == 0 and nl:
+            self.L.refpoly_lpa_get_traj(tn.ctypes.data, ta.ctypes.data)
+        return dict(status=st, expanded=ids[:ne], cost=self.L.refpoly_lpa_cost(), actions=ta[:nl], node_ids=tn[:nl + 1] if nl else tn[:0])
+
+    def lpa_update_nodes(self):
+        """PolyMapPlanner::updateNodes -> (entries that became blocked, entries that became free, [(entry, now blocked)] by entry)"""
+        nb, nc = C.c_int(), C.c_int()
+        self.L.refpoly_lpa_update_nodes(self.h, C.byref(nb), C.byref(nc))
+        n = self.L.refpoly_lpa_num_changed()
+        e = np.zeros(max(n, 1), dtype=np.int32); b = np.zeros(max(n, 1), dtype=np.int32)
+        self.L.refpoly_lpa_get_changed(e.ctypes.data, b.ctypes.data)
+        order = np.argsort(e[:n], kind="stable")
+        return nb.value, nc.value, list(zip(e[:n][order].tolist(), b[:n][order].tolist()))
+
+    def lpa_sub_state_space(self, k):
+        eps, tol_pos, max_expand = self._lpa_kw
+        self.L.refpoly_lpa_sub_state_space(self.h, int(k), self.control, eps, tol_pos, max_expand, 1)
+
+    def lpa_state_space(self):
+        n, ne = self.L.refpoly_lpa_num_nodes(), self.L.refpoly_lpa_num_entries()
+        states = np.zeros((n, 9)); vals = np.zeros((n, 3)); flags = np.zeros((n, 3), dtype=np.int32)
+        for i in range(n):
+            self.L.refpoly_lpa_get_node(i, states[i].ctypes.data, vals[i].ctypes.data, flags[i].ctypes.data)
+        child = np.zeros(max(ne, 1), dtype=np.int32); parent = child.copy(); action = child.copy(); blocked = child.copy()
+        self.L.refpoly_lpa_get_entries(child.ctypes.data, parent.ctypes.data, action.ctypes.data, blocked.ctypes.data)
+        return dict(n_nodes=n, states=states, g=vals[:, 0], rhs=vals[:, 1], h=vals[:, 2], closed=flags[:, 0], opened=flags[:, 1], built=flags[:, 2],
+                    child=child[:ne], parent=parent[:ne], action=action[:ne], blocked=blocked[:ne], initialized=bool(self.L.refpoly_lpa_initialized()))
 
     def __del__(self):
         try:

@@ -287,16 +287,29 @@ REF_NODE = "/root/reference/mpl_test_node/src"
 MULTI_ROBOT_BIN = os.path.join(ROOT, "tests", "cpp", "_bin", "multi_robot_driver")
 
 
+def _build_ref_node_driver(binary, source):
+    os.makedirs(os.path.dirname(binary), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mpl_shim"),
+                           "-I" + REF_POLY, "-I" + os.path.join(ROOT, "tests", "cpp", "stubs"), "-I" + REF_NODE, "-o", binary,
+                           os.path.join(ROOT, "tests", "cpp", source), os.path.join(LIBDIR, "libmplx.so"),
+                           "-Wl,-rpath,$ORIGIN/../../../mpl_ros_amd/csrc"])
+
+
 def build_multi_robot_driver():
     """Compiles tests/cpp/multi_robot_driver.cpp -- which #includes the reference's robot_team.hpp / robot.hpp from where they
     lie, unchanged -- with include/mpl_shim AHEAD of the reference's include path (so PolyMapPlanner is the shim's
     device-backed one; env_poly_map.h, poly_map_util.h, simple_obstacle.h remain the reference's).  Needs the reference
     tree: done in this container (__graft_entry__.build()); the GPU box runs the prebuilt binary (it travels like the .so files)."""
-    os.makedirs(os.path.dirname(MULTI_ROBOT_BIN), exist_ok=True)
-    subprocess.check_call(["g++", "-O2", "-std=c++14", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "mpl_shim"),
-                           "-I" + REF_POLY, "-I" + os.path.join(ROOT, "tests", "cpp", "stubs"), "-I" + REF_NODE, "-o", MULTI_ROBOT_BIN,
-                           os.path.join(ROOT, "tests", "cpp", "multi_robot_driver.cpp"), os.path.join(LIBDIR, "libmplx.so"),
-                           "-Wl,-rpath,$ORIGIN/../../../mpl_ros_amd/csrc"])
+    _build_ref_node_driver(MULTI_ROBOT_BIN, "multi_robot_driver.cpp")
+
+
+POLY_REPLANNER_BIN = os.path.join(ROOT, "tests", "cpp", "_bin", "poly_map_replanner_driver")
+
+
+def build_poly_replanner_driver():
+    """tests/cpp/poly_map_replanner_driver.cpp: the flow of the reference's poly_map_replanner_node.cpp (A* and LPA* planners side by
+    side among moving obstacles, updateNodes per replan) over the shim; #includes the reference's obstacle_config.hpp from where it lies."""
+    _build_ref_node_driver(POLY_REPLANNER_BIN, "poly_map_replanner_driver.cpp")
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_NODE), reason="reference tree not present (GPU box)")
@@ -345,6 +358,48 @@ def test_reference_robot_team_plans_through_the_backend_unchanged():
         assert got["n"] == len(robot.segs) and np.array_equal(segs, robot.segs)
         n_replanned += 1
     assert n_replanned == 16 and A.plans >= 16 + 24
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_NODE), reason="reference tree not present (GPU box)")
+def test_poly_replanner_driver_compiles_against_the_device_backed_planner_and_fails_loudly_without_gpu():
+    import ctypes
+    from mpl_ros_amd import _capi
+    build_poly_replanner_driver()
+    h = ctypes.c_void_p()
+    if _capi.load().mplx_ctx_create(0, ctypes.byref(h)) == _capi.OK:
+        _capi.load().mplx_ctx_destroy(h)
+    else:
+        out = subprocess.run([POLY_REPLANNER_BIN, "2"], capture_output=True, text=True, timeout=120)
+        assert '"astar_ok": 0' in out.stdout and '"lpastar_ok": 0' in out.stdout  # (no device: both planners refuse, nothing is planned on the CPU)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(POLY_REPLANNER_BIN) or os.path.isdir(REF_NODE)), reason="poly_map_replanner_driver not prebuilt and no reference tree to build it from")
+def test_reference_poly_replanner_flow_lpastar_equals_astar_every_replan():
+    """mpl_test_node/src/poly_map_replanner_node.cpp's flow (launch/poly_map_replanner_node/test.launch: 40 m x 40 m,
+    Simple2DConfig0's ten moving obstacles, start (2,2), goal (38,38), v_max 2, a_max 1, u 1, dt 1, setTol(0.5, 0.1)) through the shim:
+    per replan message the LPA* planner (updateNodes + plan + getSubStateSpace(1)) and the A* planner (plans afresh) must return the same
+    cost -- the A* side is what tests/test_poly_map.py pins to the search through the compiled reference environment, and the LPA* side
+    is pinned state by state in tests/test_poly_lpa.py; here it is the reference's own node flow end to end."""
+    if not os.path.exists(POLY_REPLANNER_BIN):
+        build_poly_replanner_driver()
+    ok_replans, rows = 0, []
+    for pair in [(), (2, 38, 38, 2), (38, 2, 2, 38), (2, 20, 38, 20), (20, 2, 20, 38)]:  # (): test.launch's (2,2) -> (38,38)
+        out = subprocess.run([POLY_REPLANNER_BIN, "16"] + [str(x) for x in pair], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        last = out.stdout.strip().splitlines()[-1]
+        r = json.loads(last[last.index("{"):])
+        R = r["replans"]
+        # every replan: the same outcome and the same cost from both planners; a failure ends the run for both ("terminated")
+        assert r["done"] >= 1 and r["costs_agree"] == r["done"], (pair, R)
+        good = [x for x in R if x["astar_ok"] and x["lpastar_ok"]]
+        assert all(x["astar_cost"] == x["lpastar_cost"] for x in good) and len(good) >= len(R) - 1
+        assert R[0]["astar_expanded"] == R[0]["lpastar_expanded"]  # (the first LPA* plan is an A*)
+        ok_replans += len(good)
+        rows.append((pair, [(x["astar_expanded"], x["lpastar_expanded"], x["blocked_primitives"], x["cleared_primitives"]) for x in R]))
+    assert ok_replans >= 20
+    assert sum(b + c for _, row in rows for (_, _, b, c) in row[1:]) > 0
+    print("poly_map_replanner flow (A* expansions, LPA* expansions, blocked, cleared) per replan:", rows)
 
 
 def _build_multi_gpu_driver(tmp_path):

@@ -68,9 +68,9 @@ other)
   timeout 60 python bench.py --config lpa --steps 2 --warmup 1 > $OUT/bench_lpa.json 2> $OUT/bench_lpa.err; head -c 300 $OUT/bench_lpa.json; echo
   timeout 120 python bench.py --single --lattice jrk --steps 1 --warmup 1 --cpu-seconds 5 > $OUT/bench_c3.json 2> $OUT/bench_c3.err; head -c 300 $OUT/bench_c3.json; echo
   timeout 120 python bench.py --lattice jrk --steps 5 --warmup 2 --cpu-seconds 8 --stream 0 > $OUT/bench_c4jrk.json 2> $OUT/bench_c4jrk.err; head -c 300 $OUT/bench_c4jrk.json; echo
-  # the C4-JRK batch at the survey's cap (2 000 000 per query): fits one lane since the pools are recycled
-  # (48 workgroups lead at a time -- what 288 GB hold of 2 M-expansion jerk searches: ~17 M states each; --max-nodes = pool states / 1024)
-  MPLX_DEADLINE_S=1500 timeout 1500 python bench.py --lattice jrk --max-expand 2000000 --slots 48 --max-nodes 800000 --steps 1 --warmup 0 --cpu-seconds 20 --stream 0 > $OUT/bench_c4jrk_2m.json 2> $OUT/bench_c4jrk_2m.err; head -c 400 $OUT/bench_c4jrk_2m.json; echo; tail -3 $OUT/bench_c4jrk_2m.err ;;
+  # the C4-JRK batch at the survey's cap (2 000 000 per query): recycled pools of 48 leading workgroups, launches of 96 queries
+  # (the epoch-tagged table holds what a launch creates), a CPU replay of every 64-th query at the full cap
+  MPLX_DEADLINE_S=600 timeout 1200 python tools/c4jrk_full_cap.py $OUT/bench_c4jrk_2m.json > $OUT/bench_c4jrk_2m.out 2> $OUT/bench_c4jrk_2m.err; head -c 600 $OUT/bench_c4jrk_2m.out; echo; tail -3 $OUT/bench_c4jrk_2m.err ;;
 phase)
   for m in tail bulk; do
     MPLX_LIB=$ROOT/build_tmp/libmplx_timers.so timeout 200 python tools/phase_table.py run $m > $OUT/phase_$m.raw 2> $OUT/phase_$m.err
