@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 # MPLX_ERR_TIMEOUT and the workgroups' watch records instead of the driver's kill)
 os.environ.setdefault("MPLX_DEADLINE_S", "120")
 
-from benchmarks import c4, c5, extras, lpa  # noqa: E402
+from benchmarks import c4, c5, extras, lpa, plpa  # noqa: E402
 from benchmarks.common import _log  # noqa: E402
 
 
@@ -64,11 +64,12 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the N-thread CPU leg (0 = all cores, at most 64)")
     ap.add_argument("--helpers", type=int, default=-1, help="helper workgroups per leading workgroup: -1 auto (4; 2 for the 125-input lattice), 0 off, 2..4")
     ap.add_argument("--help-reserved", type=int, default=-1, help="workgroups that only ever help (-1 auto)")
-    ap.add_argument("--config", choices=["c4", "c5", "lpa"], default="c4",
+    ap.add_argument("--config", choices=["c4", "c5", "lpa", "plpa"], default="c4",
                     help="c4 (default): the query batch on the voxel map; c5: BASELINE config 5 -- one decentralised replanning tick of 16 robots "
                          "(Team2) through the moving-obstacle planner, batched in one launch; lpa: the replanning cycle of map_replanner_node.cpp "
                          "(plan, obstacle on the path -> updateBlockedNodes, removed -> updateClearedNodes, getSubStateSpace(1)) on the --map^3 map, "
-                         "LPA* repair time next to a fresh device A*")
+                         "LPA* repair time next to a fresh device A*; plpa: LPA* on the moving-obstacle planner, the flow of poly_map_replanner_node.cpp "
+                         "(updateNodes, plan, getSubStateSpace(1) per replan) next to the batched A* planning afresh")
     ap.add_argument("--c5-capped", action="store_true",
                     help="--config c5: round 3's variant (distance heuristic, max_expand 20000) instead of the reference's planner parameters")
     ap.add_argument("--no-throughput", action="store_true",
@@ -98,6 +99,9 @@ def main():
         return
     if args.config == "lpa":
         print(json.dumps(lpa.run(args)), flush=True)
+        return
+    if args.config == "plpa":
+        print(json.dumps(plpa.run(args)), flush=True)
         return
     default_line = (args.gpus == 1 and not args.single and args.lattice == "acc" and args.map == 512 and args.max_expand == 0 and
                     args.queries == 1024 and args.cpu_seconds > 0 and os.environ.get("MPLX_BENCH_FORCE_DIST") != "1")

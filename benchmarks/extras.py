@@ -1,6 +1,6 @@
 """The other BASELINE configurations as extra keys of the driver's C4 line: c2 (config 2: one ACC query on the
 256^3 map), c3 (config 3: one JRK query on the 512^3 map, cap 2 000 000), c5 (config 5: the 16-robot tick), lpa (the replanning
-cycle at C2 size).  Each is the leg `bench.py --single ...` / `--config c5` / `--config lpa` runs -- in a process of its own -- with few steps, reduced to its
+cycle at C2 size), plpa (LPA* on the moving-obstacle planner: the replanner node's flow).  Each is the leg `bench.py --single ...` / `--config c5` / `--config lpa` runs -- in a process of its own -- with few steps, reduced to its
 headline numbers: value, kernel time, its own roofline, a single-thread CPU baseline and a parity check of the timed results.
 A leg that fails is reported as {"error": ...}; it never takes the C4 line down."""
 import json
@@ -44,6 +44,7 @@ def run(args):
         ("c3", ["--single", "--map", 512, "--lattice", "jrk", "--steps", 1, "--warmup", 1, "--warmup-cap", 20000, "--cpu-seconds", 5, "--stream", 0, "--extras", 0], ("speculation",), 120),
         ("c5", ["--config", "c5", "--steps", 3, "--warmup", 1, "--cpu-seconds", 1], ("tick_ms", "lookahead"), 90),
         ("lpa", ["--config", "lpa", "--map", 256, "--steps", 2, "--warmup", 1, "--cpu-seconds", 1], ("cycle", "lpa_vs_fresh_after_obstacle"), 90),
+        ("plpa", ["--config", "plpa", "--steps", 3, "--warmup", 1, "--cpu-seconds", 1], ("replans", "fresh_plan_wall_ms_mean", "repair_vs_fresh", "all_costs_equal_fresh"), 60),
     )
     for name, argv, extra, timeout_s in legs:
         t0 = time.perf_counter()

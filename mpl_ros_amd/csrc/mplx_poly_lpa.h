@@ -112,6 +112,11 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
   __shared__ int32_t su_key[POLY_MAX_U][MAX_KEY + 1];
   __shared__ int32_t su_valid[POLY_MAX_U], su_blocked[POLY_MAX_U];
   __shared__ double su_cost[POLY_MAX_U];
+  __shared__ uint32_t su_id[POLY_MAX_U];             // the successor's state if the table holds it (looked up by its own lane)
+  __shared__ unsigned long long su_epos[POLY_MAX_U]; // else the empty slot its probe ended at
+  __shared__ uint32_t s_kids[POLY_MAX_U];            // states whose look-ahead value this expansion may have changed, in order
+  __shared__ double s_kid_rhs[POLY_MAX_U], su_h[POLY_MAX_U];
+  __shared__ int32_t s_nkids, s_created;
   using V = LView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
   const QView<BLOCK, CONTROL> Q{P, S, P.bkt_head};
@@ -298,21 +303,30 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         state_key_c<CONTROL>(tn, key);
         key[ns] = (int32_t)round((cur_t + P.dt) / 0.1);
         for (int i = 0; i < NK; i++) su_key[tid][i] = key[i];
+        // the table look-up of this successor, all lanes at once (the table does not change until the link below)
+        size_t epos = 0;
+        su_id[tid] = valid ? plpa_find<CONTROL, NK>(P, key, key_hash64(key, NK), &epos) : NIL;
+        su_epos[tid] = (unsigned long long)epos;
+        su_h[tid] = (valid && su_id[tid] == NIL && P.eps != 0.0) ? get_heur(S.hp, CONTROL, tn, key, NK) : 0.0;  // (of a state that may have to be created)
       }
       __syncthreads();
       if (S.status >= 0) break;
       // ---- link (first expansion) and updateNode of the successors, by one lane, in the order get_succ emits them
       if (tid == 0) {
         const bool first = s_first != 0;
-        uint32_t kids[POLY_MAX_U];
+        uint32_t *kids = s_kids;
         int nk_ = 0;
         uint32_t n_valid = 0, n_fin = 0;
+        s_created = 0;
         for (int i = 0; i < P.n_u && S.status < 0; i++) {
           if (!su_valid[i]) continue;
           n_valid++;
           const unsigned long long h64 = key_hash64(su_key[i], NK);
-          size_t epos = 0;
-          uint32_t id = plpa_find<CONTROL, NK>(P, su_key[i], h64, &epos);
+          size_t epos = (size_t)su_epos[i];
+          uint32_t id = su_id[i];
+          // (a state created a moment ago by an earlier input of this expansion: the lane's look-up could not see it, and the empty
+          //  slot it found may be taken by now)
+          if (id == NIL && s_created) id = plpa_find<CONTROL, NK>(P, su_key[i], h64, &epos);
           if (first) {
             if (id == NIL) {
               if (epos == (size_t)~0ull || (unsigned long long)S.n_nodes + 1ull > ((unsigned long long)P.node_chunks << NODE_CH_LOG)) { S.status = 4; break; }
@@ -327,12 +341,13 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
               const double *src = (const double *)&tn;
               for (int k = 0; k < ns; k++) st[k] = src[k];
               st[ns] = cur_t + P.dt;
-              V::h(rec) = P.eps == 0.0 ? 0.0 : get_heur(S.hp, CONTROL, tn, su_key[i], NK);
+              V::h(rec) = su_h[i];
               V::g(rec) = INFINITY;
               V::rhs(rec) = INFINITY;
               V::flags(rec) = 0;
               V::pred(rec) = NIL;
               st_u64(&P.table[epos], ((h64 >> 48) << 48) | (unsigned long long)id);
+              s_created = 1;
             }
             if ((unsigned long long)S.n_edges + 1ull > ((unsigned long long)P.edge_chunks << EDGE_CH_LOG)) { S.status = 4; break; }
             const uint32_t eidx = S.n_edges++;
@@ -354,12 +369,24 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         S.c_prims += (unsigned long long)P.n_u;
         S.c_succ += n_valid;
         S.c_succ_finite += n_fin;
+        s_nkids = S.status < 0 ? nk_ : 0;
+      }
+      __syncthreads();
+      // the look-ahead value of every child, one lane each (entries and g values are final for this expansion)
+      if (tid < s_nkids) {
+        const uint32_t id = s_kids[tid];
+        char *rec = Q.node(id);
+        s_kid_rhs[tid] = id != root ? plpa_rhs_of<CONTROL, V>(Q, P, rec) : V::rhs(rec);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const int nk_ = s_nkids;
+        const uint32_t *kids = s_kids;
         for (int j = 0; j < nk_ && S.status < 0; j++) {  // updateNode(child)
           const uint32_t id = kids[j];
           char *rec = Q.node(id);
           const double g = V::g(rec), old_r = V::rhs(rec);
-          double nr = old_r;
-          if (id != root) nr = plpa_rhs_of<CONTROL, V>(Q, P, rec);
+          const double nr = s_kid_rhs[j];
           uint32_t fl = V::flags(rec);
           V::rhs(rec) = nr;
           if (!f64_same(g, nr)) {

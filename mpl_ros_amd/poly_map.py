@@ -113,6 +113,39 @@ def team2_tick(dt=0.5, t_now=1.0, traj_time=4.0):
     return worlds, starts, goals
 
 
+REPLANNER_OBS = [((6, 12), (0, -0.6)), ((10, 6), (0, 0.5)), ((13, 14), (-0.3, -0.7)), ((16, 9), (0, 0.4)), ((8, 9.5), (0.4, 0.0))]
+
+
+def replanner_world(t, turn=False, scale=1):
+    """Synthetic world of the replanner flow (poly_map_replanner_node.cpp: setLinearObstacles(obstacles as they are at t) +
+    setStartTime(t) per replan), seen at time t: a (20 scale) m square map with 2 m boxes moving at constant velocity
+    (PolyhedronLinearObstacle2D, cov_v 0.2) -- five of them at scale 1; at scale 2 the same five at twice the coordinates plus
+    five more, shifted.  turn: from t = 2 on the last box of a set moves the other way and the second one stops -- primitives
+    the planner had found free get blocked, blocked ones get free.  Start / goal: replanner_endpoints(scale)."""
+    W = PolyWorld((0.0, 0.0), (20.0 * scale, 20.0 * scale), start_t=t)
+    rec = rectangle(1.0)
+    sets = [(float(scale), (0.0, 0.0))] + ([(float(scale), (7.0, -5.0))] if scale > 1 else [])
+    for sc, off in sets:
+        for k, (p, v) in enumerate(REPLANNER_OBS):
+            p, v = np.array(p, float) * sc + np.array(off), np.array(v, float)
+            pos = p + v * t
+            if turn and t >= 2.0:
+                if k == 4:
+                    pos = p + v * 2.0 - v * (t - 2.0)
+                    v = -v
+                if k == 1:
+                    pos = p + v * 2.0
+                    v = 0 * v
+            W.linear.append(LinearObstacle(rec, pos, v, cov_v=0.2))
+    return W
+
+
+def replanner_endpoints(scale=1):
+    start = np.zeros(9); start[0], start[1] = 0.5, 10.0 * scale
+    goal = np.zeros(9); goal[0], goal[1] = 20.0 * scale - 1.0, 10.0 * scale
+    return start, goal
+
+
 class PolyTeam:
     """The worlds of several planners on the device + the shared planner set-up (setVmax/setAmax/setDt/setU/setW)."""
 

@@ -15,33 +15,7 @@ from mpl_ros_amd import poly_map as pm
 from oracle import refpoly
 
 KW = dict(dt=1.0, v_max=2.0, a_max=1.0, w=10.0)
-OBS = [((6, 12), (0, -0.6)), ((10, 6), (0, 0.5)), ((13, 14), (-0.3, -0.7)), ((16, 9), (0, 0.4)), ((8, 9.5), (0.4, 0.0))]
-
-
-def world(t, turn=False):
-    """A 20 m x 20 m map with five 2 m boxes moving at constant velocity (PolyhedronLinearObstacle2D, cov_v 0.2), seen at time t:
-    setLinearObstacles(obs at t) + setStartTime(t).  turn: from t = 2 on the last box moves the other way and the second one stops --
-    primitives the planner had found free get blocked, blocked ones get free."""
-    W = pm.PolyWorld((0.0, 0.0), (20.0, 20.0), start_t=t)
-    rec = pm.rectangle(1.0)
-    for k, (p, v) in enumerate(OBS):
-        p, v = np.array(p, float), np.array(v, float)
-        pos = p + v * t
-        if turn and t >= 2.0:
-            if k == 4:
-                pos = p + v * 2.0 - v * (t - 2.0)
-                v = -v
-            if k == 1:
-                pos = p + v * 2.0
-                v = 0 * v
-        W.linear.append(pm.LinearObstacle(rec, pos, v, cov_v=0.2))
-    return W
-
-
-def endpoints():
-    start = np.zeros(9); start[0], start[1] = 0.5, 10.0
-    goal = np.zeros(9); goal[0], goal[1] = 19.0, 10.0
-    return start, goal
+world, endpoints = pm.replanner_world, pm.replanner_endpoints  # (the synthetic replanner world: five moving boxes on a 20 m map)
 
 
 pytestmark = pytest.mark.skipif(not refpoly.available(), reason="oracle/_ref/libpolymap_ref.so not built (make -C oracle ref)")

@@ -2,15 +2,15 @@
 max_num 2 000 000) on ONE GPU: 1024 queries, each up to 2 M expansions and ~16 M states (C3: 16.0 M states, 51 M predecessor
 records, 18 M OPEN-log entries).
 
-What makes it fit (round 6): the pools are recycled (mplx_set_pool_recycling), so they hold the 48 queries that run at a time
-(48 x 16 M = 768 M states, 131 GB) and not the batch's sum (16 G states).  What recycling does NOT shrink is the shared state table:
+What makes it fit (round 6): the pools are recycled (mplx_set_pool_recycling), so they hold the 36 queries that run at a time
+(36 x 25 M = 900 M states, 144 GB) and not the batch's sum (17.6 G states).  What recycling does NOT shrink is the shared state table:
 its slots are epoch-tagged per LAUNCH, so the entries of a launch's finished queries stay in it until the launch ends -- the table
-(2^32 slots at most, 32 GB) has to hold the states a launch CREATES.  The batch therefore goes down in launches of 96 queries (two
-rounds of the 48 leading workgroups, <= 1.5 G entries, load <= 0.36); the next launch's epoch makes the slots empty again without a
+(2^32 slots at most, 32 GB) has to hold the states a launch CREATES.  The batch therefore goes down in launches of 72 queries (two
+rounds of the 36 leading workgroups, <= 1.5 G entries, load <= 0.35); the next launch's epoch makes the slots empty again without a
 clear.  Every query's result is what it is in any other batching (queries are independent).
 
 Parity sample: every 64-th query replayed on the CPU checker at the full cap, 16 worker processes (a 2 M-expansion jerk search
-holds ~4 GB on the host).  Prints one JSON line.   usage (GPU box): python tools/c4jrk_full_cap.py [out.json] [queries per launch = 96]"""
+holds ~4 GB on the host).  Prints one JSON line.   usage (GPU box): python tools/c4jrk_full_cap.py [out.json] [queries per launch = 2 x leading workgroups]"""
 import json
 import os
 import sys
@@ -25,8 +25,8 @@ from mpl_ros_amd.planner import JRK, VoxelMapPlanner, VoxelMapUtil, Waypoint3D
 from oracle import orc
 
 NQ = int(os.environ.get("C4JRK_QUERIES", "1024"))
-PER_LAUNCH = int(sys.argv[2]) if len(sys.argv) > 2 else 96
-SLOTS, CAP = 48, 2_000_000
+SLOTS, CAP = int(os.environ.get("C4JRK_SLOTS", "36")), 2_000_000
+PER_LAUNCH = int(sys.argv[2]) if len(sys.argv) > 2 else 2 * SLOTS
 n, res, origin = 512, 0.1, (0.0, 0.0, 0.0)
 grid, _, _, _, _, _ = mapgen.benchmark_map(n)
 queries = mapgen.c4_queries(grid, origin, res, 1024, rank=0)[:NQ]
@@ -35,7 +35,8 @@ mu = VoxelMapUtil(0)
 mu.setMap(origin, (n, n, n), grid.ravel(), res)
 pl = VoxelMapPlanner(False)
 pl.setMapUtil(mu); pl.setVmax(2.0); pl.setAmax(1.0); pl.setJmax(1.0); pl.setDt(1.0); pl.setU(U); pl.setTol(0.5); pl.setMaxNum(CAP)
-POOL = dict(nodes=SLOTS * 17_000_000, edges=SLOTS * 56_000_000, log=SLOTS * 24_000_000)
+POOL = dict(nodes=SLOTS * 25_000_000, edges=SLOTS * 80_000_000, log=SLOTS * 34_000_000)  # (per query: C3 makes 16.0 M / 51 M / 18 M; the batch's capped queries ~20.5 M states;
+# measured: 48 x 17 M left 146 queries reporting POOL_FULL, 40 x 22 M 15)
 pl.setCapacity(SLOTS, POOL["nodes"], POOL["edges"], POOL["log"])
 pl.setPoolRecycling(True)
 pl.setDeadline(float(os.environ.get("MPLX_DEADLINE_S", "300")))
@@ -88,9 +89,12 @@ try:
     cpu_s = time.time() - t1
 finally:
     os.remove(map_path)
-bad = []
+bad, not_comparable = [], []
 for k, (ne, nn, cost, h, actions) in st["per_query"].items():
     r = R[k]
+    if r.status == 4:  # the device reported this query's pools full (never silently truncated): nothing to compare
+        not_comparable.append(k)
+        continue
     ok = ne == r.n_expanded and nn == r.n_nodes and h == r.expand_hash and (cost == r.cost or (np.isinf(r.cost) and not np.isfinite(cost)))
     if ok and actions is not None:
         ok = np.array_equal(traj[k], actions)
@@ -104,7 +108,8 @@ out = {"metric": "node_expansions_per_s", "value": n_exp / gpu_s, "unit": "expan
        "plan_status_counts": {"ok": status[0], "no_path": status[1], "start_occupied": status[2], "max_expand": status[3], "pool_full": status[4],
                               "internal": status[5], "traj_too_long": status[6]},
        "launch_table": launches,
-       "parity_sample": {"queries": sorted(st["per_query"].keys()), "mismatches": len(bad), "first_bad": bad[:5],
+       "parity_sample": {"queries": sorted(st["per_query"].keys()), "mismatches": len(bad), "first_bad": bad[:5], "reported_pool_full_on_device": not_comparable,
+                         "device_status": {int(k): int(R[k].status) for k in sorted(st["per_query"].keys())},
                          "checked": "n_expanded, n_nodes, expand_hash (order-dependent), cost (bit-exact f64), path actions -- CPU checker at the full cap",
                          "cpu_wall_s": round(cpu_s, 1), "cpu_expansions_per_s_per_core": st["n_exp"] / max(st["busy"], 1e-9) if st.get("busy") else None,
                          "same_words_from_single_plans_without_recycling": single}}

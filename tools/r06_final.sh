@@ -28,7 +28,7 @@ try:
     d=json.load(open("$OUT/bench_default.json")); s=d.get("stream") or {}
     print("default: blocking", round(d["value"]/1e6,2), "M/s", round(d["ms_per_step"],1), "ms frac", round(d["roofline"]["frac"],5), "| stream", round(s.get("value",0)/1e6,2), "M/s", s.get("steady_state_ms_per_batch"), s.get("parity",{}).get("mismatches_vs_blocking_step"), "| parity", d.get("parity_sample"), "| cpu", d.get("cpu_baseline",{}).get("value"))
     print("speculation", d.get("speculation"))
-    for k in ("c2","c3","c5","lpa"):
+    for k in ("c2","c3","c5","lpa","plpa"):
         e=d.get(k,{})
         print(k, {x: e.get(x) for x in ("value","ms_per_step","leg_seconds","error","vs_cpu_single_thread")}, "parity", (e.get("parity_sample") or {}).get("mismatches"), "frac", e.get("roofline",{}).get("frac"))
 except Exception as e:
@@ -66,6 +66,7 @@ prof)
 other)
   timeout 100 python bench.py --config c5 --steps 3 --warmup 1 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; head -c 300 $OUT/bench_c5.json; echo
   timeout 60 python bench.py --config lpa --steps 2 --warmup 1 > $OUT/bench_lpa.json 2> $OUT/bench_lpa.err; head -c 300 $OUT/bench_lpa.json; echo
+  timeout 60 python bench.py --config plpa --steps 3 --warmup 1 > $OUT/bench_plpa.json 2> $OUT/bench_plpa.err; head -c 300 $OUT/bench_plpa.json; echo
   timeout 120 python bench.py --single --lattice jrk --steps 1 --warmup 1 --cpu-seconds 5 > $OUT/bench_c3.json 2> $OUT/bench_c3.err; head -c 300 $OUT/bench_c3.json; echo
   timeout 120 python bench.py --lattice jrk --steps 5 --warmup 2 --cpu-seconds 8 --stream 0 > $OUT/bench_c4jrk.json 2> $OUT/bench_c4jrk.err; head -c 300 $OUT/bench_c4jrk.json; echo
   # the C4-JRK batch at the survey's cap (2 000 000 per query): recycled pools of 48 leading workgroups, launches of 96 queries
