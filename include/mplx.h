@@ -194,7 +194,10 @@ int mplx_set_capacity(mplx_ctx *ctx, int32_t n_slots, uint64_t total_nodes, uint
  * again, so the capacities of mplx_set_capacity need to cover what the batch's CONCURRENTLY running queries hold (one per compute
  * unit), not the sum over all of them.  The per-query results, trajectories and counters are what they are without it (same search,
  * bit for bit); what is given up are the state spaces of the batch's queries after the call (mplx_debug_query_records refuses).
- * A single mplx_plan never recycles.  A query that finds the pools empty ends with MPLX_PLAN_POOL_FULL as before. */
+ * A single mplx_plan never recycles.  A query that finds the pools empty ends with MPLX_PLAN_POOL_FULL as before.
+ * What recycling does not shrink is the shared state table: its slots are tagged with the launch's epoch, so a finished query's entries
+ * stay until the launch ends -- the table (16 slots per pool state, 2^32 at most) has to hold the states one LAUNCH creates; a batch
+ * that creates more is submitted as several calls (tools/c4jrk_full_cap.py). */
 int mplx_set_pool_recycling(mplx_ctx *ctx, int32_t on);
 /* speculative multi-node expansion (results are identical either way): -1 auto (on when
  * n_u <= 128), 0 = sequential kernel (one node per iteration), 2 = on; 8: measurement variant (eight expansion units of one

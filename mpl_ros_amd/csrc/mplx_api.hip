@@ -824,7 +824,9 @@ static void fill_params(const mplx_ctx *c, SearchParams &P) {
     double sn;
     det_sincos(P.yaw_max, &sn, &P.yaw_cos);
   }
-  P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt * 8.0 : 1.0);
+  // width of a coarse OPEN bucket in units of f: BUCKET_FACTOR edge costs of w dt (measurement: MPLX_BUCKET_FACTOR)
+  static const double bucket_factor = [] { const char *e = getenv("MPLX_BUCKET_FACTOR"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 8.0; }();
+  P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt * bucket_factor : 1.0);
   P.guard = c->guard;
 }
 

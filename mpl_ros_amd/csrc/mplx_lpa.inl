@@ -180,6 +180,11 @@ static void lpa_params(const mplx_lpa *l, int space, SearchParams &P, LpaParams 
   const mplx_ctx *c = l->ctx;
   P = SearchParams{};
   fill_params(c, P);
+  // The one-workgroup kernels pop ONE state per iteration: with the batch kernels' bucket width (8 edge costs; a fine bucket is 1 / 1024
+  // of it) almost every pop is a refill from the far lists.  64 edge costs measured best at C2 size (profiles/r06p_*: repair 8.25 ->
+  // 6.74 ms; 512: 7.04, 4096: 10.6).  The pop order does not depend on it.  (measurement: MPLX_LPA_BUCKET_FACTOR)
+  static const double bucket_factor = [] { const char *e = getenv("MPLX_LPA_BUCKET_FACTOR"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 64.0; }();
+  if (c->bucket_width <= 0 && P.w * P.dt > 0) P.bucket_width = P.w * P.dt * bucket_factor;
   const LpaSpace &s = l->sp[space];
   P.node_pool = s.node_pool; P.edge_pool = s.edge_pool; P.open_pool = l->open_pool;
   P.node_chunks = (uint32_t)std::max<uint64_t>(1, (l->cap_nodes + (1u << NODE_CH_LOG) - 1) >> NODE_CH_LOG);

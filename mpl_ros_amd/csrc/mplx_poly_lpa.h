@@ -31,6 +31,7 @@ struct PlpaArgs {
   uint32_t *changed;    // (update) edge index | now blocked << 31, appended in no particular order
   uint32_t changed_cap;
   uint32_t *counters;   // (update) [0] entries that became blocked, [1] became free, [2] appended to `changed`, [3] unsupported degree met
+  double *edge_cost;    // per predecessor entry: calculate_intrinsic_cost of its primitive, written when the entry is (the parent state never changes)
 };
 
 // isFree(pr, t) of PolyMapUtil (poly_map_util.h:92-109) for the primitive `cs` that starts at time t_rel (relative to the world's start
@@ -58,18 +59,18 @@ __device__ __forceinline__ void plpa_edge_prim(const SearchParams &P, char *prec
   const double u[2] = {P.poly.U[2 * action], P.poly.U[2 * action + 1]};
   poly_prim_build(CONTROL, pos, vel, u, cs, acc);
 }
-// rhs of a state from its non-blocked predecessor entries (an exact minimum: order-independent)
+// rhs of a state from its non-blocked predecessor entries (an exact minimum: order-independent).  The entry's cost is the value
+// get_succ computed when the entry was made -- J(control) + 0.001 J(VEL) + w dt of the primitive from the parent state, which is fixed.
 template <int CONTROL, class V, class QV>
-__device__ __forceinline__ double plpa_rhs_of(const QV &Q, const SearchParams &P, char *rec) {
+__device__ __forceinline__ double plpa_rhs_of(const QV &Q, const double *edge_cost, char *rec) {
   double rhs = INFINITY;
-  for (uint32_t e = V::pred(rec); e != NIL; e = Q.edge(e)->next) {
+  for (uint32_t e = V::pred(rec); e != NIL;) {
     const EdgeRec er = *Q.edge(e);
-    if (er.action & EDGE_BLOCKED) continue;
-    char *prec = Q.node(er.parent);
-    double cs[2][6];
-    plpa_edge_prim<CONTROL, V>(P, prec, er.action, cs);
-    const double v = V::g(prec) + poly_intrinsic_cost(CONTROL, cs, P.dt, P.w, P.dt);
-    if (v < rhs) rhs = v;
+    if (!(er.action & EDGE_BLOCKED)) {
+      const double v = V::g(Q.node(er.parent)) + edge_cost[e];
+      if (v < rhs) rhs = v;
+    }
+    e = er.next;
   }
   return rhs;
 }
@@ -116,6 +117,8 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
   __shared__ unsigned long long su_epos[POLY_MAX_U]; // else the empty slot its probe ended at
   __shared__ uint32_t s_kids[POLY_MAX_U];            // states whose look-ahead value this expansion may have changed, in order
   __shared__ double s_kid_rhs[POLY_MAX_U], su_h[POLY_MAX_U];
+  __shared__ double s_kid_g[POLY_MAX_U], s_kid_oldr[POLY_MAX_U];
+  __shared__ uint32_t s_kid_fl[POLY_MAX_U], su_pred[POLY_MAX_U], s_fid[POLY_MAX_U], s_feidx[POLY_MAX_U];
   __shared__ int32_t s_nkids, s_created;
   using V = LView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
           V::g(rec) = INFINITY;
           S.cur_g = INFINITY;
           double nr = r;
-          if (u != root) nr = plpa_rhs_of<CONTROL, V>(Q, P, rec);
+          if (u != root) nr = plpa_rhs_of<CONTROL, V>(Q, A.edge_cost, rec);
           V::rhs(rec) = nr;
           if (nr < INFINITY) {  // inconsistent again: back into OPEN (its key changed: always a new entry)
             fl &= ~FLAG_CLOSED;
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         size_t epos = 0;
         su_id[tid] = valid ? plpa_find<CONTROL, NK>(P, key, key_hash64(key, NK), &epos) : NIL;
         su_epos[tid] = (unsigned long long)epos;
+        su_pred[tid] = su_id[tid] != NIL ? V::pred(Q.node(su_id[tid])) : NIL;  // (head of its predecessor list as it is before this expansion)
         su_h[tid] = (valid && su_id[tid] == NIL && P.eps != 0.0) ? get_heur(S.hp, CONTROL, tn, key, NK) : 0.0;  // (of a state that may have to be created)
       }
       __syncthreads();
@@ -353,9 +357,15 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
             const uint32_t eidx = S.n_edges++;
             EdgeRec *e = Q.edge(eidx);
             char *rec = Q.node(id);
+            // the list's head: the entry an earlier input of this expansion gave the same state, else what the lane read (NIL for a new state)
+            uint32_t head = id == su_id[i] ? su_pred[i] : NIL;
+            for (int j = 0; j < i; j++)
+              if (su_valid[j] && s_fid[j] == id) head = s_feidx[j];
+            s_fid[i] = id; s_feidx[i] = eidx;
             e->parent = u;
-            e->next = V::pred(rec);
+            e->next = head;
             e->action = (uint32_t)i | (su_blocked[i] ? EDGE_BLOCKED : 0u);
+            A.edge_cost[eidx] = su_cost[i];
             V::pred(rec) = eidx;
           } else if (id == NIL) {
             continue;
@@ -376,7 +386,8 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
       if (tid < s_nkids) {
         const uint32_t id = s_kids[tid];
         char *rec = Q.node(id);
-        s_kid_rhs[tid] = id != root ? plpa_rhs_of<CONTROL, V>(Q, P, rec) : V::rhs(rec);
+        s_kid_rhs[tid] = id != root ? plpa_rhs_of<CONTROL, V>(Q, A.edge_cost, rec) : V::rhs(rec);
+        s_kid_g[tid] = V::g(rec); s_kid_oldr[tid] = V::rhs(rec); s_kid_fl[tid] = V::flags(rec);
       }
       __syncthreads();
       if (tid == 0) {
@@ -385,9 +396,9 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         for (int j = 0; j < nk_ && S.status < 0; j++) {  // updateNode(child)
           const uint32_t id = kids[j];
           char *rec = Q.node(id);
-          const double g = V::g(rec), old_r = V::rhs(rec);
+          const double g = s_kid_g[j], old_r = s_kid_oldr[j];
           const double nr = s_kid_rhs[j];
-          uint32_t fl = V::flags(rec);
+          uint32_t fl = s_kid_fl[j];
           V::rhs(rec) = nr;
           if (!f64_same(g, nr)) {
             const bool had_entry = (fl & FLAG_OPENED) && !(fl & FLAG_CLOSED) && f64_same(nr, old_r);
@@ -445,10 +456,7 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         for (uint32_t e = V::pred(Q.node(node)); e != NIL; e = Q.edge(e)->next) {
           const EdgeRec er = *Q.edge(e);
           if (er.action & EDGE_BLOCKED) continue;
-          char *prec = Q.node(er.parent);
-          double cs[2][6];
-          plpa_edge_prim<CONTROL, V>(P, prec, er.action, cs);
-          const double gp = V::g(prec), rhs = gp + poly_intrinsic_cost(CONTROL, cs, P.dt, P.w, P.dt);
+          const double gp = V::g(Q.node(er.parent)), rhs = gp + A.edge_cost[e];
           if (rhs < min_rhs || (rhs == min_rhs && gp >= min_g)) { min_rhs = rhs; min_g = gp; best = e; }
         }
         if (best == NIL || !(min_rhs < INFINITY)) { ok = false; break; }
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(64) void plpa_update_kernel(SearchParams P, PlpaArg
         if (k < A.changed_cap) A.changed[k] = e | (blocked_now ? 0x80000000u : 0u);
       }
     }
-    if (changed && i != root) V::rhs(rec) = plpa_rhs_of<CONTROL, V>(Q, P, rec);
+    if (changed && i != root) V::rhs(rec) = plpa_rhs_of<CONTROL, V>(Q, A.edge_cost, rec);
   }
 }
 

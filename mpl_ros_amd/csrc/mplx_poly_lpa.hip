@@ -41,6 +41,7 @@ struct mplx_plpa {
   int32_t *d_traj_nodes = nullptr, *d_traj_actions = nullptr, *d_rec = nullptr;
   double *d_traj_states = nullptr;
   uint32_t *d_changed = nullptr, *d_counters = nullptr;
+  double *d_edge_cost = nullptr;
   uint32_t cap_rec = 0;
   // host copies
   LpaState st{};
@@ -80,7 +81,8 @@ static uint64_t np2(uint64_t v) {
 static void plpa_free(mplx_plpa *l) {
   (void)hipFree(l->node_pool); (void)hipFree(l->edge_pool); (void)hipFree(l->open_pool); (void)hipFree(l->table); (void)hipFree(l->bkt_head);
   (void)hipFree(l->d_st); (void)hipFree(l->d_in); (void)hipFree(l->d_out); (void)hipFree(l->d_traj_nodes); (void)hipFree(l->d_traj_actions);
-  (void)hipFree(l->d_traj_states); (void)hipFree(l->d_changed); (void)hipFree(l->d_counters); (void)hipFree(l->d_rec);
+  (void)hipFree(l->d_traj_states); (void)hipFree(l->d_changed); (void)hipFree(l->d_counters); (void)hipFree(l->d_rec); (void)hipFree(l->d_edge_cost);
+  l->d_edge_cost = nullptr;
   l->node_pool = l->edge_pool = l->open_pool = nullptr;
   l->table = nullptr; l->bkt_head = nullptr; l->d_st = nullptr; l->d_in = nullptr; l->d_out = nullptr;
   l->d_traj_nodes = l->d_traj_actions = l->d_rec = nullptr; l->d_traj_states = nullptr; l->d_changed = l->d_counters = nullptr;
@@ -109,6 +111,7 @@ static int plpa_ensure(mplx_plpa *l, int control) {
   LH(l, hipMalloc((void **)&l->d_traj_states, sizeof(double) * (MAX_TRAJ + 1) * 13));
   LH(l, hipMalloc((void **)&l->d_changed, sizeof(uint32_t) * (size_t)(ech << EDGE_CH_LOG)));
   LH(l, hipMalloc((void **)&l->d_counters, sizeof(uint32_t) * 4));
+  LH(l, hipMalloc((void **)&l->d_edge_cost, sizeof(double) * (size_t)(ech << EDGE_CH_LOG)));
   l->cap_rec = (uint32_t)std::min<uint64_t>(l->cap_nodes, 1u << 24);
   LH(l, hipMalloc((void **)&l->d_rec, sizeof(int32_t) * (size_t)l->cap_rec));
   l->pool_control = control;
@@ -122,7 +125,9 @@ static void plpa_params(const mplx_plpa *l, const mplx_poly_view &v, SearchParam
   P.dt = v.dev.dt; P.v_max = v.dev.v_max; P.a_max = v.dev.a_max; P.j_max = v.dev.j_max; P.w = v.dev.w;
   P.eps = l->eps; P.tol_pos = l->tol_pos; P.tol_vel = l->tol_vel; P.tol_acc = -1.0; P.t_max = INFINITY;
   P.max_expand = l->max_expand; P.heur_ignore_dynamics = l->heur_ignore_dynamics;
-  P.bucket_width = P.w * P.dt > 0 ? P.w * P.dt * 8.0 : 1.0;
+  // (coarse OPEN bucket; a fine one is 1 / 1024 of it.  Measurement: MPLX_PLPA_BUCKET_FACTOR)
+  static const double bucket_factor = [] { const char *e = getenv("MPLX_PLPA_BUCKET_FACTOR"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 8.0; }();
+  P.bucket_width = P.w * P.dt > 0 ? P.w * P.dt * bucket_factor : 1.0;
   P.node_pool = l->node_pool; P.edge_pool = l->edge_pool; P.open_pool = l->open_pool;
   P.node_chunks = (uint32_t)std::max<uint64_t>(1, (l->cap_nodes + (1u << NODE_CH_LOG) - 1) >> NODE_CH_LOG);
   P.edge_chunks = (uint32_t)std::max<uint64_t>(1, (l->cap_edges + (1u << EDGE_CH_LOG) - 1) >> EDGE_CH_LOG);
@@ -242,7 +247,7 @@ static int plpa_plan_impl(mplx_plpa *l, int32_t world, const double *start, cons
   SearchParams P;
   plpa_params(l, v, P);
   PlpaArgs A{};
-  A.st = l->d_st; A.fresh = fresh ? 1 : 0; A.world = world;
+  A.st = l->d_st; A.fresh = fresh ? 1 : 0; A.world = world; A.edge_cost = l->d_edge_cost;
   hipStream_t s = v.stream;
   LH(l, hipMemcpyAsync(l->d_in, &in, sizeof(QueryIn), hipMemcpyHostToDevice, s));
   if (fresh) {
@@ -319,7 +324,7 @@ extern "C" int mplx_plpa_update_nodes(mplx_plpa *l, int32_t world, uint64_t *n_b
   SearchParams P;
   plpa_params(l, v, P);
   PlpaArgs A{};
-  A.st = l->d_st; A.world = world; A.changed = l->d_changed; A.counters = l->d_counters;
+  A.st = l->d_st; A.world = world; A.changed = l->d_changed; A.counters = l->d_counters; A.edge_cost = l->d_edge_cost;
   A.changed_cap = (uint32_t)std::min<uint64_t>((uint64_t)P.edge_chunks << EDGE_CH_LOG, 0xFFFFFFF0ull);
   hipStream_t s = v.stream;
   LH(l, hipMemsetAsync(l->d_counters, 0, sizeof(uint32_t) * 4, s));

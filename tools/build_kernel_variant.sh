@@ -21,6 +21,6 @@ for u in api spec help yaw lpa poly filter; do
   fi
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libmplx_$N.so $OBJS $S/mplx_host.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $O/libmplx_$N.so $OBJS $S/mplx_poly_lpa.o $S/mplx_host.o
 rm -f $O/kv_${N}_*.o
 ls -la $O/libmplx_$N.so
