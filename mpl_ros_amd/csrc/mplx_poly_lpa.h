@@ -120,6 +120,11 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
   __shared__ double s_kid_g[POLY_MAX_U], s_kid_oldr[POLY_MAX_U];
   __shared__ uint32_t s_kid_fl[POLY_MAX_U], su_pred[POLY_MAX_U], s_fid[POLY_MAX_U], s_feidx[POLY_MAX_U];
   __shared__ int32_t s_nkids, s_created;
+  // isFree(pr, t) of the nine primitives against all obstacles, spread over the lanes below the pair level (poly_collide_all)
+  __shared__ double pcs[POLY_MAX_U][2][6];
+  __shared__ int32_t phit[POLY_MAX_U], pstart_hit, punsupported, php_max;
+  __shared__ PolyPrep pprep[POLY_MAX_OBS];
+  __shared__ uint32_t phit_idx[POLY_MAX_U * POLY_MAX_OBS], puns_idx[POLY_MAX_U * POLY_MAX_OBS];
   using V = LView<BLOCK, CONTROL>;
   const int tid = threadIdx.x;
   const QView<BLOCK, CONTROL> Q{P, S, P.bkt_head};
@@ -291,14 +296,10 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         for (int k = 0; k < 3; k++) { tn.a[k] = 0.0; tn.j[k] = 0.0; }
         if constexpr (CONTROL == CTRL_JRK) { tn.a[0] = pp_a_auto(c[0], T); tn.a[1] = pp_a_auto(c[1], T); }
         const bool valid = poly_inside(W.bbox, 4, tn.p[0], tn.p[1]) && poly_validate(CONTROL, c, T, P.v_max, P.a_max, P.j_max);
-        int blocked = 0;
-        if (valid) {
-          const int fr = plpa_prim_free<GEN>(D, W, c, T, t_rel);
-          if (fr < 0) S.status = 5;  // (a hyperplane equation of a degree this build does not solve)
-          blocked = fr == 1 ? 0 : 1;
-        }
+        for (int a = 0; a < 2; a++)
+          for (int b = 0; b < 6; b++) pcs[tid][a][b] = c[a][b];
+        phit[tid] = 0;
         su_valid[tid] = valid ? 1 : 0;
-        su_blocked[tid] = blocked;
         su_cost[tid] = poly_intrinsic_cost(CONTROL, c, T, P.w, P.dt);
         su_state[tid][0] = tn.p[0]; su_state[tid][1] = tn.p[1]; su_state[tid][2] = tn.v[0]; su_state[tid][3] = tn.v[1];
         su_state[tid][4] = tn.a[0]; su_state[tid][5] = tn.a[1];
@@ -313,6 +314,14 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         su_pred[tid] = su_id[tid] != NIL ? V::pred(Q.node(su_id[tid])) : NIL;  // (head of its predecessor list as it is before this expansion)
         su_h[tid] = (valid && su_id[tid] == NIL && P.eps != 0.0) ? get_heur(S.hp, CONTROL, tn, key, NK) : 0.0;  // (of a state that may have to be created)
       }
+      if (tid == 0) { pstart_hit = 0; punsupported = 0; }
+      __syncthreads();
+      // PolyMapUtil::isFree(pr, t) of every valid primitive: the start point against every obstacle, then collide() per obstacle -- the same
+      // routine the batched A* of this environment runs (pinned against the compiled reference there), all 64 lanes
+      poly_collide_all<BLOCK, PolyNoHook, GEN>(D, W, pcs, su_valid, P.n_u, T, t_rel, pprep, phit_idx, puns_idx, &php_max, phit, &punsupported, &pstart_hit, tid, 0, PolyNoHook());
+      __syncthreads();
+      if (tid < P.n_u) su_blocked[tid] = (su_valid[tid] && (pstart_hit || phit[tid])) ? 1 : 0;
+      if (tid == 0 && punsupported) S.status = 5;  // (a hyperplane equation of a degree this build does not solve)
       __syncthreads();
       if (S.status >= 0) break;
       // ---- link (first expansion) and updateNode of the successors, by one lane, in the order get_succ emits them

@@ -14,17 +14,18 @@ import pytest
 from mpl_ros_amd import poly_map as pm
 from oracle import refpoly
 
-KW = dict(dt=1.0, v_max=2.0, a_max=1.0, w=10.0)
+KW = {pm.ACC: dict(dt=1.0, v_max=2.0, a_max=1.0, w=10.0), pm.JRK: dict(dt=1.0, v_max=2.0, a_max=1.0, j_max=1.0, w=10.0)}
+CASES = [(pm.ACC, False), (pm.ACC, True), (pm.JRK, True)]  # (control, obstacles that change course)
 world, endpoints = pm.replanner_world, pm.replanner_endpoints  # (the synthetic replanner world: five moving boxes on a 20 m map)
 
 
 pytestmark = pytest.mark.skipif(not refpoly.available(), reason="oracle/_ref/libpolymap_ref.so not built (make -C oracle ref)")
 
 
-@pytest.mark.parametrize("turn", [False, True])
-def test_oracle_poly_lpastar_equals_fresh_astar_on_the_replanner_flow(turn):
-    R = refpoly.RefWorld(world(0.0, turn), pm.ACC, pm.U9, **KW)
-    A = refpoly.RefWorld(world(0.0, turn), pm.ACC, pm.U9, **KW)
+@pytest.mark.parametrize("control,turn", CASES)
+def test_oracle_poly_lpastar_equals_fresh_astar_on_the_replanner_flow(control, turn):
+    R = refpoly.RefWorld(world(0.0, turn), control, pm.U9, **KW[control])
+    A = refpoly.RefWorld(world(0.0, turn), control, pm.U9, **KW[control])
     R.lpa_reset()
     start, goal = endpoints()
     t, saw_blocked, saw_cleared, repairs = 0.0, 0, 0, []
@@ -52,16 +53,17 @@ def test_oracle_poly_lpastar_equals_fresh_astar_on_the_replanner_flow(turn):
 
 
 KEYS = ("states", "g", "rhs", "h", "closed", "opened", "built", "child", "parent", "action", "blocked")
-COLS = [0, 1, 2, 3, 8]  # pos2 vel2 t: what an ACC state is keyed on (the reference's Waypoint also carries the control input it arrived with as `acc`)
+# what a state is keyed on -- ACC: pos2 vel2 t (the reference's Waypoint also carries the control input it arrived with as `acc`); JRK: + acc2
+COLS = {pm.ACC: [0, 1, 2, 3, 8], pm.JRK: [0, 1, 2, 3, 4, 5, 8]}
 
 
-def same_spaces(sd, so, where=""):
+def same_spaces(sd, so, control, where=""):
     for k in KEYS:
-        a, b = (sd[k][:, COLS], so[k][:, COLS]) if k == "states" else (sd[k], so[k])
+        a, b = (sd[k][:, COLS[control]], so[k][:, COLS[control]]) if k == "states" else (sd[k], so[k])
         assert np.array_equal(a, b), (where, k)
 
 
-def compare(Lo, l, ro, ok):
+def compare(Lo, l, ro, ok, control):
     """device PolyLpa `l` against the oracle's state space after the same call sequence: bit-exact"""
     r = l.result
     assert r.status == ro["status"] and ok == (ro["status"] == 0)
@@ -71,7 +73,7 @@ def compare(Lo, l, ro, ok):
     if not so["initialized"]:
         return
     assert sd["n_nodes"] == so["n_nodes"] == r.n_nodes
-    same_spaces(sd, so)
+    same_spaces(sd, so, control)
     if ro["status"] == 0:
         assert r.cost == ro["cost"]
         act, ids, st = l.traj()
@@ -79,12 +81,12 @@ def compare(Lo, l, ro, ok):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("turn", [False, True])
-def test_hip_poly_lpastar_replays_the_replanner_flow_bit_exact(turn):
-    Lo = refpoly.RefWorld(world(0.0, turn), pm.ACC, pm.U9, **KW)
+@pytest.mark.parametrize("control,turn", CASES)
+def test_hip_poly_lpastar_replays_the_replanner_flow_bit_exact(control, turn):
+    Lo = refpoly.RefWorld(world(0.0, turn), control, pm.U9, **KW[control])
     Lo.lpa_reset()
     team = pm.PolyTeam()
-    team.configure(pm.ACC, pm.U9, **KW)
+    team.configure(control, pm.U9, **KW[control])
     team.set_worlds([world(0.0, turn)])
     team.set_capacity(1, 1 << 18, 1 << 21, 1 << 20)
     l = team.lpa()
@@ -99,7 +101,7 @@ def test_hip_poly_lpastar_replays_the_replanner_flow_bit_exact(turn):
         changes += uo[0] + uo[1]
         ro = Lo.lpa_plan(start, goal)
         ok = l.plan(start, goal)
-        compare(Lo, l, ro, ok)
+        compare(Lo, l, ro, ok, control)
         # cost == a fresh device A* on the same world (the batched tick planner)
         ra = team.plan_batch([0], [start], [goal], max_expand=-1)[0]
         assert ra.status == l.result.status and ra.cost == l.result.cost
@@ -110,10 +112,10 @@ def test_hip_poly_lpastar_replays_the_replanner_flow_bit_exact(turn):
         Lo.lpa_sub_state_space(1)
         l.sub_state_space(1)
         so, sd = Lo.lpa_state_space(), l.state_space()
-        same_spaces(sd, so, "after getSubStateSpace")
+        same_spaces(sd, so, control, "after getSubStateSpace")
         start = st[1].copy()
         t += 1.0
         start[8] = t
     assert changes > 0 and repairs[0][0] == repairs[0][1]
     assert sum(x[0] for x in repairs[1:]) < sum(x[1] for x in repairs[1:])
-    print("poly LPA* (turn=%s): (LPA* expansions, fresh A* expansions, LPA* kernel ms, fresh kernel ms) per tick" % turn, repairs)
+    print("poly LPA* (control=%s turn=%s): (LPA* expansions, fresh A* expansions, LPA* kernel ms, fresh kernel ms) per tick" % (control, turn), repairs)

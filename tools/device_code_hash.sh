@@ -4,7 +4,7 @@
 B=/opt/rocm/lib/llvm/bin
 D=${1:-$(dirname "$0")/../mpl_ros_amd/csrc}
 T=$(mktemp -d)
-for o in mplx_help_launch mplx_spec_launch mplx_yaw_launch mplx_lpa_launch mplx_poly_launch mplx_api; do
+for o in mplx_help_launch mplx_spec_launch mplx_filter_launch mplx_yaw_launch mplx_lpa_launch mplx_poly_launch mplx_poly_lpa mplx_api; do
   [ -f $D/$o.o ] || continue
   $B/llvm-objcopy -O binary --only-section=.hip_fatbin $D/$o.o $T/$o.fatbin
   $B/clang-offload-bundler --unbundle --type=o --input=$T/$o.fatbin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$T/$o.co 2>/dev/null
