@@ -59,6 +59,13 @@ def run(n_batches=8, mode="fill", lattice="acc"):
     again = [key(r) for r in pl.planBatch(starts, goals)]
     quiet_ms = pl.lastKernelMs()
     assert again == want, "the quiet blocking batch does not repeat"
+    recycle = os.environ.get("FILL_NO_RECYCLE") != "1"
+    if recycle:  # (round 6) the batches under load run like bench.py's: recycled pools of about half the size, compared with the un-recycled quiet batch
+        small = mapgen.c4_pools(jrk, 1024, cap, per_q=(0 if jrk else 250_000))
+        if jrk:
+            small = {k: v // 2 for k, v in small.items()}
+        pl.setPoolRecycling(True)
+        pl.setCapacity(768 if jrk else 1024, small["nodes"], small["edges"], small["log"])
     stop = threading.Event()
     fills = [0]
 
@@ -101,7 +108,7 @@ def run(n_batches=8, mode="fill", lattice="acc"):
     if th:
         th.join(timeout=30)
     return ({"probe": "blocking batch with a background fill load", "mode": mode, "kernel": pl.kernelName(), "batches": n_batches, "fill_rounds": fills[0],
-                      "quiet_kernel_ms": quiet_ms, "kernel_ms": ms, "mismatching_queries": len(bad), "detail": bad[:12]})
+                      "quiet_kernel_ms": quiet_ms, "kernel_ms": ms, "pool_recycling_under_load": recycle, "mismatching_queries": len(bad), "detail": bad[:12]})
 
 
 if __name__ == "__main__":
