@@ -95,7 +95,8 @@ static int plpa_ensure(mplx_plpa *l, int control) {
   const uint64_t nch = std::max<uint64_t>(1, (l->cap_nodes + (1u << NODE_CH_LOG) - 1) >> NODE_CH_LOG);
   const uint64_t ech = std::max<uint64_t>(1, (l->cap_edges + (1u << EDGE_CH_LOG) - 1) >> EDGE_CH_LOG);
   const uint64_t och = std::max<uint64_t>(1, (l->cap_log + (1u << OPEN_CH_LOG) - 1) >> OPEN_CH_LOG);
-  if (nch > 0xFFFFull || ech > 0xFFFFull || och > 0xFFFFull) return lf(l, MPLX_ERR_ARG, "capacity too large (more than 65535 chunks in a pool)");
+  if (nch > (uint64_t)MAX_NODE_CH || ech > (uint64_t)MAX_EDGE_CH || och > (uint64_t)MAX_OPEN_CH)
+    return lf(l, MPLX_ERR_ARG, "capacity too large (at most %d node / %d predecessor / %d OPEN-log chunks)", MAX_NODE_CH, MAX_EDGE_CH, MAX_OPEN_CH);
   l->table_slots = np2(4ull * (nch << NODE_CH_LOG));
   LH(l, hipMalloc((void **)&l->node_pool, (size_t)(nch << NODE_CH_LOG) * rec_bytes(control)));
   LH(l, hipMalloc((void **)&l->edge_pool, (size_t)(ech << EDGE_CH_LOG) * EDGE_BYTES));

@@ -64,6 +64,9 @@ for a in range(0, NQ, PER_LAUNCH):
     for k in sample:
         if a <= k < a + len(part):
             traj[k] = pl.getTraj(k - a).actions.copy()
+    for k, r in enumerate(rr):  # a query that reports POOL_FULL: which of its three resources is at a limit
+        if r.status == 4:
+            print(f"  query {a + k} POOL_FULL: expansions {r.n_expanded} states {r.n_nodes} predecessor records {r.n_edges} OPEN-log entries {r.n_push}", file=sys.stderr, flush=True)
     R += rr
     print(f"launch {len(launches)}: {launches[-1]}", file=sys.stderr, flush=True)
 gpu_s = time.perf_counter() - t0
