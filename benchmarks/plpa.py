@@ -39,12 +39,14 @@ def run(args):
             t2 = time.perf_counter()
             r = l.result
             lpa_ms = l.last_kernel_ms()
+            cyc = l.cycles()
             ra = team.plan_batch([0], [start], [goal], max_expand=-1)[0]
             t3 = time.perf_counter()
             rows.append({"t": t, "lpa_expansions": int(r.n_expanded), "fresh_expansions": int(ra.n_expanded), "entries_blocked": nb, "entries_cleared": nc,
                          "update_wall_ms": 1e3 * (t1 - t0), "lpa_wall_ms": 1e3 * (t2 - t1), "lpa_kernel_ms": lpa_ms, "fresh_wall_ms": 1e3 * (t3 - t2),
                          "fresh_kernel_ms": team.last_kernel_ms(), "cost": float(r.cost), "status": int(r.status), "n_states": int(r.n_nodes),
                          "same_cost_as_fresh": bool(ra.status == r.status and ra.cost == r.cost),
+                         "cycles_per_expansion": {k: round(v / max(int(r.n_expanded), 1)) for k, v in cyc.items()},
                          "_bytes": int(r.n_expanded) * 64 + int(r.n_succ) * obs_bytes + int(r.n_succ_finite) * 128})
             act, ids, st = l.traj()
             if not ok or len(act) <= 2:

@@ -464,6 +464,9 @@ int mplx_plpa_sub_state_space(mplx_plpa *l, int32_t world, int32_t time_step);
 int mplx_plpa_traj_len(const mplx_plpa *l);
 int mplx_plpa_result_traj(mplx_plpa *l, int32_t *actions, int32_t *node_ids, double *states);
 int mplx_plpa_last_kernel_ms(const mplx_plpa *l, float *ms);
+/* shader cycles of the last plan's launch by section of an iteration (thread 0's clock): 0 pop, 1 stop test + settling the expanded
+ * state, 2 primitives / keys / look-ups / heuristics, 3 isFree of the primitives, 4 link, 5 updateNode of the children (look-ahead values, flags, pushes), 6 goal test + barrier */
+int mplx_plpa_result_cycles(const mplx_plpa *l, uint64_t cyc[10]);
 int mplx_plpa_counts(const mplx_plpa *l, uint64_t *n_nodes, uint64_t *n_entries);
 int mplx_plpa_result_expanded(mplx_plpa *l, uint32_t cap, int32_t *ids, uint32_t *n);
 /* state-space dumps (parity tests): per state pos2 vel2 acc2 jrk2 t, g, rhs, h, closed / opened / built flags; per entry, in creation

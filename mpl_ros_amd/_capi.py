@@ -67,7 +67,7 @@ EXPORTS = [
     "mplx_poly_create", "mplx_poly_destroy", "mplx_poly_last_error", "mplx_poly_config", "mplx_poly_begin", "mplx_poly_set_world",
     "mplx_poly_add_static", "mplx_poly_add_linear", "mplx_poly_add_nonlinear", "mplx_poly_commit", "mplx_poly_get_succ_batch", "mplx_poly_set_capacity", "mplx_poly_plan_batch", "mplx_poly_result_traj",
     "mplx_poly_set_record", "mplx_poly_result_expanded", "mplx_poly_last_kernel_ms", "mplx_poly_result_cycles", "mplx_poly_set_helpers", "mplx_poly_last_helpers", "mplx_poly_set_deadline", "mplx_plpa_create", "mplx_plpa_destroy", "mplx_plpa_last_error", "mplx_plpa_set_capacity", "mplx_plpa_initialized", "mplx_plpa_reset",
-    "mplx_plpa_plan", "mplx_plpa_update_nodes", "mplx_plpa_changed", "mplx_plpa_sub_state_space", "mplx_plpa_traj_len", "mplx_plpa_result_traj", "mplx_plpa_last_kernel_ms",
+    "mplx_plpa_plan", "mplx_plpa_update_nodes", "mplx_plpa_changed", "mplx_plpa_sub_state_space", "mplx_plpa_traj_len", "mplx_plpa_result_traj", "mplx_plpa_last_kernel_ms", "mplx_plpa_result_cycles",
     "mplx_plpa_counts", "mplx_plpa_result_expanded", "mplx_plpa_result_nodes", "mplx_plpa_result_entries",
     "mplx_traj_solve", "mplx_traj_sample", "mplx_traj_effort",
     "mplx_plan_batch_submit", "mplx_plan_batch_wait", "mplx_plan_batch_done", "mplx_set_helper_limit", "mplx_release_pools",
@@ -230,6 +230,7 @@ def load():
     L.mplx_plpa_traj_len.argtypes = [P]
     L.mplx_plpa_result_traj.argtypes = [P, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mplx_plpa_last_kernel_ms.argtypes = [P, C.POINTER(C.c_float)]
+    L.mplx_plpa_result_cycles.argtypes = [P, C.POINTER(C.c_uint64)]
     L.mplx_plpa_counts.argtypes = [P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mplx_plpa_result_expanded.argtypes = [P, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32)]
     L.mplx_plpa_result_nodes.argtypes = [P, C.c_uint64] + [C.c_void_p] * 7

@@ -24,6 +24,11 @@
 
 namespace mplx {
 
+// thread 0's clock per section of an iteration of plpa_plan_kernel -> QueryOut::cyc (mplx_plpa_result_cycles):
+// 0 pop, 1 stop test + settling the expanded state, 2 primitives / keys / look-ups / heuristics (lanes), 3 isFree of the primitives
+// (poly_collide_all), 4 link (lanes), 5 updateNode of the children: look-ahead values, flags, pushes (lanes), 6 goal test of the expanded state, barrier
+#define PLPA_T(k) do { if (tid == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); S.cyc[k] += now_ - t_sec; t_sec = now_; } } while (0)
+
 struct PlpaArgs {
   LpaState *st;
   int32_t fresh;        // start a new state space (the host cleared the table)
@@ -116,10 +121,12 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
   __shared__ uint32_t su_id[POLY_MAX_U];             // the successor's state if the table holds it (looked up by its own lane)
   __shared__ unsigned long long su_epos[POLY_MAX_U]; // else the empty slot its probe ended at
   __shared__ uint32_t s_kids[POLY_MAX_U];            // states whose look-ahead value this expansion may have changed, in order
-  __shared__ double s_kid_rhs[POLY_MAX_U], su_h[POLY_MAX_U];
-  __shared__ double s_kid_g[POLY_MAX_U], s_kid_oldr[POLY_MAX_U];
-  __shared__ uint32_t s_kid_fl[POLY_MAX_U], su_pred[POLY_MAX_U], s_fid[POLY_MAX_U], s_feidx[POLY_MAX_U];
-  __shared__ int32_t s_nkids, s_created;
+  __shared__ double su_h[POLY_MAX_U];
+  __shared__ uint32_t su_pred[POLY_MAX_U], s_fid[POLY_MAX_U], s_feidx[POLY_MAX_U];
+  __shared__ int32_t s_nkids;
+  __shared__ int32_t s_new[POLY_MAX_U];                   // this input created its successor's state in this expansion ...
+  __shared__ unsigned long long s_epos_used[POLY_MAX_U];  // ... in this table slot
+  __shared__ unsigned long long plevel[2];                // the time level pprep[] holds (poly_collide_all re-uses it for the next state of that level)
   // isFree(pr, t) of the nine primitives against all obstacles, spread over the lanes below the pair level (poly_collide_all)
   __shared__ double pcs[POLY_MAX_U][2][6];
   __shared__ int32_t phit[POLY_MAX_U], pstart_hit, punsupported, php_max;
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
   const PolyDev &D = P.poly;
   const PolyWorld W = D.worlds[A.world];
   lpa_smem_init<BLOCK>(P, S, tid);
+  if (tid == 0) { plevel[0] = 0ull; plevel[1] = 0ull; }
   __syncthreads();
   const unsigned long long t_begin = wall_clock64();
   if (tid == 0) {
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
     __syncthreads();
     // ---- main loop
     uint32_t guard_it = 0;
+    unsigned long long t_sec = __builtin_readcyclecounter();
     while (S.status < 0) {
       if ((++guard_it & 63u) == 0u) {
         if (tid == 0) {
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         __syncthreads();
       }
       const bool popped = lpa_pop<BLOCK, CONTROL, false>(Q, tid, P.eps, R);
+      PLPA_T(0);
       if (tid == 0) {
         double kgoal = INFINITY;
         int gcons = 1, gfin = 0;
@@ -283,6 +293,7 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         }
         V::flags(rec) = fl | FLAG_BUILT;
       }
+      PLPA_T(1);
       // ---- env_poly_map::get_succ(u): lane = control input
       const double T = P.dt, cur_t = S.cur[0][12], t_rel = cur_t - W.start_t;
       if (tid < P.n_u) {
@@ -316,43 +327,122 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
       }
       if (tid == 0) { pstart_hit = 0; punsupported = 0; }
       __syncthreads();
+      PLPA_T(2);
       // PolyMapUtil::isFree(pr, t) of every valid primitive: the start point against every obstacle, then collide() per obstacle -- the same
       // routine the batched A* of this environment runs (pinned against the compiled reference there), all 64 lanes
-      poly_collide_all<BLOCK, PolyNoHook, GEN>(D, W, pcs, su_valid, P.n_u, T, t_rel, pprep, phit_idx, puns_idx, &php_max, phit, &punsupported, &pstart_hit, tid, 0, PolyNoHook());
+      poly_collide_all<BLOCK, PolyNoHook, GEN>(D, W, pcs, su_valid, P.n_u, T, t_rel, pprep, phit_idx, puns_idx, &php_max, phit, &punsupported, &pstart_hit, tid, 1, PolyNoHook(), nullptr,
+                                               plevel);
       __syncthreads();
       if (tid < P.n_u) su_blocked[tid] = (su_valid[tid] && (pstart_hit || phit[tid])) ? 1 : 0;
       if (tid == 0 && punsupported) S.status = 5;  // (a hyperplane equation of a degree this build does not solve)
       __syncthreads();
+      PLPA_T(3);
       if (S.status >= 0) break;
-      // ---- link (first expansion) and updateNode of the successors, by one lane, in the order get_succ emits them
-      if (tid == 0) {
+      // ---- link (first expansion) and the list of children to update.  The lanes do it side by side -- ids of new states and entry
+      // numbers from prefix counts in input order, i.e. what a loop over the inputs hands out -- unless two inputs of this expansion meet
+      // in one state or in one empty table slot (equal key hashes / equal slots: rare); then one lane does it in the order get_succ emits.
+      static_assert(BLOCK == 64, "one wavefront: ballots and lane reads span the workgroup");
+      bool lanes_linked = false;
+      {
+        const bool first = s_first != 0;
+        const bool mv = tid < P.n_u && su_valid[tid < POLY_MAX_U ? tid : 0] != 0;
+        const int ti = tid < POLY_MAX_U ? tid : 0;
+        uint32_t my_id = mv ? su_id[ti] : NIL;
+        const unsigned long long my_epos = mv ? su_epos[ti] : 0ull;
+        const unsigned long long my_h64 = mv ? key_hash64(su_key[ti], NK) : 0ull;
+        bool clash = false;
+        for (int j = 0; j < P.n_u; j++) {  // (uniform)
+          const unsigned long long hj = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_h64 >> 32), j) << 32) |
+                                        (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_h64, j);
+          const unsigned long long ej = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_epos >> 32), j) << 32) |
+                                        (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_epos, j);
+          const bool vj = __builtin_amdgcn_readlane(mv ? 1 : 0, j) != 0;
+          const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j);
+          if (mv && vj && tid > j && (hj == my_h64 || (my_id == NIL && idj == NIL && ej == my_epos))) clash = true;
+        }
+        const unsigned long long below = (1ull << tid) - 1ull;
+        const unsigned long long m_val = __ballot(mv), m_new = __ballot(mv && first && my_id == NIL);
+        const uint32_t n_val = (uint32_t)__popcll(m_val), n_new = (uint32_t)__popcll(m_new);
+        const bool full = first && (__ballot(mv && my_id == NIL && my_epos == ~0ull) != 0ull ||
+                                    (unsigned long long)S.n_nodes + n_new > ((unsigned long long)P.node_chunks << NODE_CH_LOG) ||
+                                    (unsigned long long)S.n_edges + n_val > ((unsigned long long)P.edge_chunks << EDGE_CH_LOG));
+        if (__ballot(clash) == 0ull && !full) {  // (uniform)
+          lanes_linked = true;
+          const uint32_t base_n = S.n_nodes, base_e = S.n_edges;
+          if (first && mv) {
+            const bool is_new = my_id == NIL;
+            if (is_new) {
+              my_id = base_n + (uint32_t)__popcll(m_new & below);
+              char *rec = Q.node(my_id);
+              for (int k = 0; k < NK; k++) V::key(rec)[k] = su_key[ti][k];
+              double *st = V::state(rec);
+              st[0] = su_state[ti][0]; st[1] = su_state[ti][1]; st[2] = 0.0;
+              st[3] = su_state[ti][2]; st[4] = su_state[ti][3]; st[5] = 0.0;
+              if constexpr (ns > 6) { st[6] = su_state[ti][4]; st[7] = su_state[ti][5]; st[8] = 0.0; }
+              st[ns] = cur_t + P.dt;
+              V::h(rec) = su_h[ti];
+              V::g(rec) = INFINITY;
+              V::rhs(rec) = INFINITY;
+              V::flags(rec) = 0;
+              st_u64(&P.table[(size_t)my_epos], ((my_h64 >> 48) << 48) | (unsigned long long)my_id);
+            }
+            const uint32_t eidx = base_e + (uint32_t)__popcll(m_val & below);
+            EdgeRec *e = Q.edge(eidx);
+            e->parent = u;
+            e->next = is_new ? NIL : su_pred[ti];
+            e->action = (uint32_t)tid | (su_blocked[ti] ? EDGE_BLOCKED : 0u);
+            A.edge_cost[eidx] = su_cost[ti];
+            V::pred(Q.node(my_id)) = eidx;
+          }
+          const bool kid = mv && my_id != NIL && !su_blocked[ti];
+          const unsigned long long m_kid = __ballot(kid);
+          if (kid) s_kids[__popcll(m_kid & below)] = my_id;
+          if (tid == 0) {
+            if (first) { S.n_nodes = base_n + n_new; S.n_edges = base_e + n_val; }
+            S.c_prims += (unsigned long long)P.n_u;
+            S.c_succ += n_val;
+            S.c_succ_finite += (uint32_t)__popcll(m_kid);
+            s_nkids = (int32_t)__popcll(m_kid);
+          }
+        }
+      }
+      if (!lanes_linked && tid == 0) {
         const bool first = s_first != 0;
         uint32_t *kids = s_kids;
         int nk_ = 0;
         uint32_t n_valid = 0, n_fin = 0;
-        s_created = 0;
+        for (int i = 0; i < P.n_u; i++) s_new[i] = 0;
         for (int i = 0; i < P.n_u && S.status < 0; i++) {
           if (!su_valid[i]) continue;
           n_valid++;
           const unsigned long long h64 = key_hash64(su_key[i], NK);
           size_t epos = (size_t)su_epos[i];
           uint32_t id = su_id[i];
-          // (a state created a moment ago by an earlier input of this expansion: the lane's look-up could not see it, and the empty
-          //  slot it found may be taken by now)
-          if (id == NIL && s_created) id = plpa_find<CONTROL, NK>(P, su_key[i], h64, &epos);
+          if (id == NIL) {
+            // the lane's look-up saw the table as it was before this expansion: an earlier input may have created this very state since
+            // (same key: compared here), or taken the empty slot the lane's probe ended at (then, and only then, the probe is repeated)
+            bool again = false;
+            for (int j = 0; j < i; j++) {
+              if (!s_new[j]) continue;
+              bool same = true;
+              for (int k = 0; k < NK; k++) same = same && su_key[j][k] == su_key[i][k];
+              if (same) id = s_fid[j];
+              else if (s_epos_used[j] == (unsigned long long)epos) again = true;
+            }
+            if (id == NIL && again) id = plpa_find<CONTROL, NK>(P, su_key[i], h64, &epos);
+          }
           if (first) {
             if (id == NIL) {
               if (epos == (size_t)~0ull || (unsigned long long)S.n_nodes + 1ull > ((unsigned long long)P.node_chunks << NODE_CH_LOG)) { S.status = 4; break; }
               id = S.n_nodes++;
               char *rec = Q.node(id);
               for (int k = 0; k < NK; k++) V::key(rec)[k] = su_key[i][k];
+              // (the record's state: pos3 vel3 [acc3], then t -- written field by field: a State object addressed through a pointer would live
+              //  in scratch memory, and every read of it would wait for all the stores in flight)
               double *st = V::state(rec);
-              State tn;
-              tn.p[0] = su_state[i][0]; tn.p[1] = su_state[i][1]; tn.p[2] = 0.0; tn.v[0] = su_state[i][2]; tn.v[1] = su_state[i][3]; tn.v[2] = 0.0;
-              tn.a[0] = su_state[i][4]; tn.a[1] = su_state[i][5]; tn.a[2] = 0.0;
-              for (int k = 0; k < 3; k++) tn.j[k] = 0.0;
-              const double *src = (const double *)&tn;
-              for (int k = 0; k < ns; k++) st[k] = src[k];
+              st[0] = su_state[i][0]; st[1] = su_state[i][1]; st[2] = 0.0;
+              st[3] = su_state[i][2]; st[4] = su_state[i][3]; st[5] = 0.0;
+              if constexpr (ns > 6) { st[6] = su_state[i][4]; st[7] = su_state[i][5]; st[8] = 0.0; }
               st[ns] = cur_t + P.dt;
               V::h(rec) = su_h[i];
               V::g(rec) = INFINITY;
@@ -360,7 +450,8 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
               V::flags(rec) = 0;
               V::pred(rec) = NIL;
               st_u64(&P.table[epos], ((h64 >> 48) << 48) | (unsigned long long)id);
-              s_created = 1;
+              s_new[i] = 1;
+              s_epos_used[i] = (unsigned long long)epos;
             }
             if ((unsigned long long)S.n_edges + 1ull > ((unsigned long long)P.edge_chunks << EDGE_CH_LOG)) { S.status = 4; break; }
             const uint32_t eidx = S.n_edges++;
@@ -391,41 +482,51 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         s_nkids = S.status < 0 ? nk_ : 0;
       }
       __syncthreads();
-      // the look-ahead value of every child, one lane each (entries and g values are final for this expansion)
-      if (tid < s_nkids) {
-        const uint32_t id = s_kids[tid];
-        char *rec = Q.node(id);
-        s_kid_rhs[tid] = id != root ? plpa_rhs_of<CONTROL, V>(Q, A.edge_cost, rec) : V::rhs(rec);
-        s_kid_g[tid] = V::g(rec); s_kid_oldr[tid] = V::rhs(rec); s_kid_fl[tid] = V::flags(rec);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        const int nk_ = s_nkids;
-        const uint32_t *kids = s_kids;
-        for (int j = 0; j < nk_ && S.status < 0; j++) {  // updateNode(child)
-          const uint32_t id = kids[j];
-          char *rec = Q.node(id);
-          const double g = s_kid_g[j], old_r = s_kid_oldr[j];
-          const double nr = s_kid_rhs[j];
-          uint32_t fl = s_kid_fl[j];
-          V::rhs(rec) = nr;
+      PLPA_T(4);
+      // updateNode of every child, one lane each (entries and g values are final for this expansion; the children are distinct states):
+      // look-ahead value, flags, and -- where its key changed or it has no entry -- a new OPEN entry, whose place in the log is its rank
+      // among the pushing children in input order
+      {
+        const int nk_ = s_nkids;  // (uniform)
+        const bool mine = tid < nk_;
+        const uint32_t id = mine ? s_kids[tid] : NIL;
+        char *rec = mine ? Q.node(id) : nullptr;
+        double g = 0.0, nr = 0.0, h = 0.0;
+        uint32_t fl = 0u;
+        bool need = false;
+        if (mine) {
+          const double old_r = V::rhs(rec);
+          g = V::g(rec); fl = V::flags(rec); h = V::h(rec);
+          nr = id != root ? plpa_rhs_of<CONTROL, V>(Q, A.edge_cost, rec) : old_r;
           if (!f64_same(g, nr)) {
             const bool had_entry = (fl & FLAG_OPENED) && !(fl & FLAG_CLOSED) && f64_same(nr, old_r);
             fl = (fl | FLAG_OPENED) & ~FLAG_CLOSED;
-            if (!had_entry) {
-              if ((unsigned long long)S.n_log + 1ull > ((unsigned long long)P.open_chunks << OPEN_CH_LOG)) { S.status = 4; break; }
-              const double m = lpa_min(g, nr);
-              open_push(Q, S.n_log, m + P.eps * V::h(rec), m, id);
-              S.n_log++;
-              S.c_push++;
-            }
+            need = !had_entry;
           } else if ((fl & FLAG_OPENED) && !(fl & FLAG_CLOSED)) {
             fl |= FLAG_CLOSED;
           }
-          V::flags(rec) = fl;
         }
-        State s;
-        for (int i = 0; i < 12; i++) ((double *)&s)[i] = S.cur[0][i];
+        const unsigned long long m_push = __ballot(need);
+        const uint32_t n_push = (uint32_t)__popcll(m_push), base_log = S.n_log;
+        if ((unsigned long long)base_log + n_push > ((unsigned long long)P.open_chunks << OPEN_CH_LOG)) {  // (uniform)
+          if (tid == 0) S.status = 4;
+        } else {
+          if (mine) {
+            V::rhs(rec) = nr;
+            V::flags(rec) = fl;
+            if (need) {
+              const double m = lpa_min(g, nr);
+              open_push(Q, base_log + (uint32_t)__popcll(m_push & ((1ull << tid) - 1ull)), m + P.eps * h, m, id);
+            }
+          }
+          if (tid == 0) { S.n_log = base_log + n_push; S.c_push += n_push; }
+        }
+      }
+      PLPA_T(5);
+      if (tid == 0) {
+        State s;  // (field by field: a State addressed through a pointer would live in scratch memory)
+        s.p[0] = S.cur[0][0]; s.p[1] = S.cur[0][1]; s.p[2] = S.cur[0][2]; s.v[0] = S.cur[0][3]; s.v[1] = S.cur[0][4]; s.v[2] = S.cur[0][5];
+        s.a[0] = S.cur[0][6]; s.a[1] = S.cur[0][7]; s.a[2] = S.cur[0][8]; s.j[0] = S.cur[0][9]; s.j[1] = S.cur[0][10]; s.j[2] = S.cur[0][11];
         if (S.cur_g < INFINITY && (S.cur[0][12] >= P.t_max || is_goal_state(s, in.goal, in.goal_control, P.tol_pos, P.tol_vel, P.tol_acc))) s_gid = u;
         if (S.status < 0) {
           if (P.max_expand > 0 && S.c_expanded >= (unsigned long long)P.max_expand) S.status = 3;
@@ -433,6 +534,7 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         }
       }
       __syncthreads();
+      PLPA_T(6);
     }
     clear_buckets(Q, tid);
   }
@@ -512,7 +614,7 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
     o.spec[0] = o.spec[1] = o.spec[2] = o.spec[3] = 0;
     o.t_begin = t_begin;
     o.t_end = wall_clock64();
-    for (int i = 0; i < 10; i++) o.cyc[i] = 0;
+    for (int i = 0; i < 10; i++) o.cyc[i] = S.cyc[i];
   }
 }
 

@@ -392,6 +392,13 @@ extern "C" int mplx_plpa_last_kernel_ms(const mplx_plpa *l, float *ms) {
   *ms = l->last_ms;
   return MPLX_OK;
 }
+// thread 0's clock per section of the last plan's iterations (shader cycles): 0 pop, 1 stop test + settling, 2 primitives / look-ups /
+// heuristics, 3 isFree of the primitives, 4 link, 5 updateNode of the children (look-ahead values, flags, pushes), 6 goal test + barrier
+extern "C" int mplx_plpa_result_cycles(const mplx_plpa *l, uint64_t cyc[10]) {
+  if (!l || !cyc) return MPLX_ERR_ARG;
+  for (int i = 0; i < 10; i++) cyc[i] = l->last_out.cyc[i];
+  return MPLX_OK;
+}
 extern "C" int mplx_plpa_counts(const mplx_plpa *l, uint64_t *n_nodes, uint64_t *n_entries) {
   if (!l) return MPLX_ERR_ARG;
   if (n_nodes) *n_nodes = l->valid ? l->st.n_nodes : 0;

@@ -433,6 +433,13 @@ class PolyLpa:
         self.check(self.lib.mplx_plpa_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
 
+    def cycles(self):
+        """shader cycles of the last plan by section of an iteration (thread 0's clock)"""
+        cyc = (C.c_uint64 * 10)()
+        self.check(self.lib.mplx_plpa_result_cycles(self.h, cyc))
+        names = ("pop", "stop_test_settle", "primitives_lookups_heuristics", "is_free", "link", "update_children", "goal_test_barrier")
+        return {n: int(cyc[i]) for i, n in enumerate(names)}
+
     def state_space(self):
         nn, ne = C.c_uint64(), C.c_uint64()
         self.check(self.lib.mplx_plpa_counts(self.h, C.byref(nn), C.byref(ne)))
