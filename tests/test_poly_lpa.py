@@ -119,3 +119,47 @@ def test_hip_poly_lpastar_replays_the_replanner_flow_bit_exact(control, turn):
     assert changes > 0 and repairs[0][0] == repairs[0][1]
     assert sum(x[0] for x in repairs[1:]) < sum(x[1] for x in repairs[1:])
     print("poly LPA* (control=%s turn=%s): (LPA* expansions, fresh A* expansions, LPA* kernel ms, fresh kernel ms) per tick" % (control, turn), repairs)
+
+
+@pytest.mark.gpu
+def test_hip_poly_lpastar_when_the_space_is_kept_and_when_it_is_not():
+    """The rules around the search (L6 of the LPA* restatement; the host side of mplx_plpa_plan): a capped plan leaves a space the next
+    call goes on repairing; another goal, or a start that is not the current root, starts a new space; eps 2.  Every step against the
+    LPA* over the compiled reference environment, state for state."""
+    control, turn = pm.ACC, True
+    Lo = refpoly.RefWorld(world(0.0, turn), control, pm.U9, **KW[control])
+    Lo.lpa_reset()
+    team = pm.PolyTeam()
+    team.configure(control, pm.U9, **KW[control])
+    team.set_worlds([world(0.0, turn)])
+    team.set_capacity(1, 1 << 18, 1 << 21, 1 << 20)
+    l = team.lpa()
+    start, goal = endpoints()
+
+    def both(s, g, **kw):
+        ro = Lo.lpa_plan(s, g, **kw)
+        ok = l.plan(s, g, **kw)
+        compare(Lo, l, ro, ok, control)
+        return ro
+
+    n0 = len(both(start, goal)["expanded"])
+    assert n0 > 50
+    goal2 = goal.copy()
+    goal2[1] = 4.0
+    ro = both(start, goal2, max_expand=20)          # another goal: a new space; capped after 20 expansions
+    assert ro["status"] == 3 and len(ro["expanded"]) == 20
+    ro = both(start, goal2)                         # the same call without the cap goes on where the capped one stopped
+    assert ro["status"] == 0 and 0 < len(ro["expanded"])
+    act, ids, st = l.traj()
+    s2 = st[1].copy()
+    W = world(1.0, turn)
+    Lo.reload(W)
+    team.set_worlds([W])
+    assert Lo.lpa_update_nodes() == l.update_nodes()
+    ro = both(s2, goal2)                            # a start that is not the root (no getSubStateSpace before): a new space
+    assert ro["status"] == 0 and l.state_space()["states"][0][8] == 1.0
+    both(s2, goal)                                  # back to the first goal: a new space again
+    Lo.lpa_reset()
+    l.reset()
+    ro = both(s2, goal, eps=2.0)                    # inflated heuristic, from scratch
+    assert ro["status"] == 0
