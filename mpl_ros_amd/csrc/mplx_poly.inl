@@ -31,6 +31,7 @@ struct mplx_poly {
   std::vector<int> obs_world;
   std::vector<mplx::PolyWorld> worlds;
   bool committed = false;
+  uint64_t commit_epoch = 0;  // counts mplx_poly_commit calls: what a state space's stored collision outcomes are synchronised with (mplx_plpa_*)
   // device copies
   mplx::PolyHP *d_hps = nullptr;
   mplx::PolySeg *d_segs = nullptr;
@@ -234,6 +235,7 @@ extern "C" int mplx_poly_commit(mplx_poly *p) {
   PCHK(p, up(&p->d_worlds, p->worlds));
   PCHK(p, hipStreamSynchronize(p->stream));
   p->committed = true;
+  p->commit_epoch++;
   return MPLX_OK;
 }
 // hyperplane equations above degree two can occur: JRK / SNP primitives, or an obstacle trajectory with such segments
@@ -261,7 +263,7 @@ extern "C" int mplx_poly_internal_view(mplx_poly *p, mplx_poly_view *out) {
   out->stream = p->ctx->stream;
   out->guard = p->ctx->guard;
   out->deadline_s = p->ctx->deadline_s;
-  out->tbl_unused = 0.0;
+  out->commit_epoch = p->commit_epoch;
   return MPLX_OK;
 }
 

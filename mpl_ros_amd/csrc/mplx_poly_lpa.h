@@ -37,6 +37,10 @@ struct PlpaArgs {
   uint32_t changed_cap;
   uint32_t *counters;   // (update) [0] entries that became blocked, [1] became free, [2] appended to `changed`, [3] unsupported degree met
   double *edge_cost;    // per predecessor entry: calculate_intrinsic_cost of its primitive, written when the entry is (the parent state never changes)
+  // per built state and control input: the successor state and the entry it got when the state was first expanded (NIL: no valid successor)
+  uint32_t *succ_child, *succ_entry;
+  int32_t trust_entries;  // the entries' blocked bits are those of the world as committed now (a fresh space, or updateNodes ran after the last commit):
+                          // a state that is expanded AGAIN reads its successors' outcomes from its entries instead of running get_succ once more
 };
 
 // isFree(pr, t) of PolyMapUtil (poly_map_util.h:92-109) for the primitive `cs` that starts at time t_rel (relative to the world's start
@@ -294,8 +298,30 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         V::flags(rec) = fl | FLAG_BUILT;
       }
       PLPA_T(1);
-      // ---- env_poly_map::get_succ(u): lane = control input
+      // ---- a state that is expanded AGAIN (it was built before) and whose entries are in step with the world: its successors and
+      // whether their primitives are blocked stand in the entries it made when it was first expanded -- nothing of get_succ is run again
       const double T = P.dt, cur_t = S.cur[0][12], t_rel = cur_t - W.start_t;
+      const bool again = s_first == 0 && A.trust_entries != 0 && A.succ_child != nullptr;  // (uniform)
+      if (again) {
+        uint32_t child = NIL;
+        bool blocked = false;
+        if (tid < P.n_u) {
+          const size_t at = (size_t)u * (size_t)P.n_u + (size_t)tid;
+          child = A.succ_child[at];
+          if (child != NIL) blocked = (Q.edge(A.succ_entry[at])->action & EDGE_BLOCKED) != 0u;
+        }
+        const bool kid = child != NIL && !blocked;
+        const unsigned long long m_val = __ballot(child != NIL), m_kid = __ballot(kid);
+        if (kid) s_kids[__popcll(m_kid & ((1ull << tid) - 1ull))] = child;
+        if (tid == 0) {
+          S.c_prims += (unsigned long long)P.n_u;
+          S.c_succ += (uint32_t)__popcll(m_val);
+          S.c_succ_finite += (uint32_t)__popcll(m_kid);
+          s_nkids = (int32_t)__popcll(m_kid);
+        }
+        PLPA_T(2);
+      } else {
+      // ---- env_poly_map::get_succ(u): lane = control input
       if (tid < P.n_u) {
         const double pos[2] = {S.cur[0][0], S.cur[0][1]}, vel[2] = {S.cur[0][3], S.cur[0][4]}, acc[2] = {S.cur[0][6], S.cur[0][7]};
         const double uu[2] = {D.U[2 * tid], D.U[2 * tid + 1]};
@@ -369,6 +395,7 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         if (__ballot(clash) == 0ull && !full) {  // (uniform)
           lanes_linked = true;
           const uint32_t base_n = S.n_nodes, base_e = S.n_edges;
+          uint32_t my_eidx = NIL;
           if (first && mv) {
             const bool is_new = my_id == NIL;
             if (is_new) {
@@ -387,12 +414,18 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
               st_u64(&P.table[(size_t)my_epos], ((my_h64 >> 48) << 48) | (unsigned long long)my_id);
             }
             const uint32_t eidx = base_e + (uint32_t)__popcll(m_val & below);
+            my_eidx = eidx;
             EdgeRec *e = Q.edge(eidx);
             e->parent = u;
             e->next = is_new ? NIL : su_pred[ti];
             e->action = (uint32_t)tid | (su_blocked[ti] ? EDGE_BLOCKED : 0u);
             A.edge_cost[eidx] = su_cost[ti];
             V::pred(Q.node(my_id)) = eidx;
+          }
+          if (first && A.succ_child && tid < P.n_u) {  // (what a later expansion of u reads instead of running get_succ again)
+            const size_t at = (size_t)u * (size_t)P.n_u + (size_t)tid;
+            A.succ_child[at] = mv ? my_id : NIL;
+            A.succ_entry[at] = my_eidx;
           }
           const bool kid = mv && my_id != NIL && !su_blocked[ti];
           const unsigned long long m_kid = __ballot(kid);
@@ -412,6 +445,8 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         int nk_ = 0;
         uint32_t n_valid = 0, n_fin = 0;
         for (int i = 0; i < P.n_u; i++) s_new[i] = 0;
+        if (first && A.succ_child)
+          for (int i = 0; i < P.n_u; i++) A.succ_child[(size_t)u * (size_t)P.n_u + (size_t)i] = NIL;
         for (int i = 0; i < P.n_u && S.status < 0; i++) {
           if (!su_valid[i]) continue;
           n_valid++;
@@ -467,6 +502,10 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
             e->action = (uint32_t)i | (su_blocked[i] ? EDGE_BLOCKED : 0u);
             A.edge_cost[eidx] = su_cost[i];
             V::pred(rec) = eidx;
+            if (A.succ_child) {
+              A.succ_child[(size_t)u * (size_t)P.n_u + (size_t)i] = id;
+              A.succ_entry[(size_t)u * (size_t)P.n_u + (size_t)i] = eidx;
+            }
           } else if (id == NIL) {
             continue;
           }
@@ -480,6 +519,7 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
         S.c_succ += n_valid;
         S.c_succ_finite += n_fin;
         s_nkids = S.status < 0 ? nk_ : 0;
+      }
       }
       __syncthreads();
       PLPA_T(4);

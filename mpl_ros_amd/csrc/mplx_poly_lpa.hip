@@ -42,6 +42,9 @@ struct mplx_plpa {
   double *d_traj_states = nullptr;
   uint32_t *d_changed = nullptr, *d_counters = nullptr;
   double *d_edge_cost = nullptr;
+  uint32_t *d_succ_child = nullptr, *d_succ_entry = nullptr;  // per state x control input (null when that would be too large)
+  int succ_n_u = 0;
+  uint64_t synced_epoch = ~0ull;  // mplx_poly commit count the entries' blocked bits were last brought in step with
   uint32_t cap_rec = 0;
   // host copies
   LpaState st{};
@@ -81,15 +84,15 @@ static uint64_t np2(uint64_t v) {
 static void plpa_free(mplx_plpa *l) {
   (void)hipFree(l->node_pool); (void)hipFree(l->edge_pool); (void)hipFree(l->open_pool); (void)hipFree(l->table); (void)hipFree(l->bkt_head);
   (void)hipFree(l->d_st); (void)hipFree(l->d_in); (void)hipFree(l->d_out); (void)hipFree(l->d_traj_nodes); (void)hipFree(l->d_traj_actions);
-  (void)hipFree(l->d_traj_states); (void)hipFree(l->d_changed); (void)hipFree(l->d_counters); (void)hipFree(l->d_rec); (void)hipFree(l->d_edge_cost);
-  l->d_edge_cost = nullptr;
+  (void)hipFree(l->d_traj_states); (void)hipFree(l->d_changed); (void)hipFree(l->d_counters); (void)hipFree(l->d_rec); (void)hipFree(l->d_edge_cost); (void)hipFree(l->d_succ_child); (void)hipFree(l->d_succ_entry);
+  l->d_edge_cost = nullptr; l->d_succ_child = l->d_succ_entry = nullptr;
   l->node_pool = l->edge_pool = l->open_pool = nullptr;
   l->table = nullptr; l->bkt_head = nullptr; l->d_st = nullptr; l->d_in = nullptr; l->d_out = nullptr;
   l->d_traj_nodes = l->d_traj_actions = l->d_rec = nullptr; l->d_traj_states = nullptr; l->d_changed = l->d_counters = nullptr;
   l->pools_valid = false;
 }
-static int plpa_ensure(mplx_plpa *l, int control) {
-  if (l->pools_valid && l->pool_control == control) return MPLX_OK;
+static int plpa_ensure(mplx_plpa *l, int control, int n_u) {
+  if (l->pools_valid && l->pool_control == control && l->succ_n_u == n_u) return MPLX_OK;
   plpa_free(l);
   l->valid = false;
   const uint64_t nch = std::max<uint64_t>(1, (l->cap_nodes + (1u << NODE_CH_LOG) - 1) >> NODE_CH_LOG);
@@ -113,6 +116,11 @@ static int plpa_ensure(mplx_plpa *l, int control) {
   LH(l, hipMalloc((void **)&l->d_changed, sizeof(uint32_t) * (size_t)(ech << EDGE_CH_LOG)));
   LH(l, hipMalloc((void **)&l->d_counters, sizeof(uint32_t) * 4));
   LH(l, hipMalloc((void **)&l->d_edge_cost, sizeof(double) * (size_t)(ech << EDGE_CH_LOG)));
+  l->succ_n_u = n_u;
+  if ((nch << NODE_CH_LOG) * (uint64_t)n_u * 8ull <= (4ull << 30)) {  // (beyond 4 GB the re-expansion shortcut is off: get_succ runs again)
+    LH(l, hipMalloc((void **)&l->d_succ_child, sizeof(uint32_t) * (size_t)(nch << NODE_CH_LOG) * (size_t)n_u));
+    LH(l, hipMalloc((void **)&l->d_succ_entry, sizeof(uint32_t) * (size_t)(nch << NODE_CH_LOG) * (size_t)n_u));
+  }
   l->cap_rec = (uint32_t)std::min<uint64_t>(l->cap_nodes, 1u << 24);
   LH(l, hipMalloc((void **)&l->d_rec, sizeof(int32_t) * (size_t)l->cap_rec));
   l->pool_control = control;
@@ -232,7 +240,7 @@ static int plpa_plan_impl(mplx_plpa *l, int32_t world, const double *start, cons
   if (r) return r;
   LH(l, hipSetDevice(v.device));
   const int control = v.dev.control;
-  if ((r = plpa_ensure(l, control)) != MPLX_OK) return r;
+  if ((r = plpa_ensure(l, control, v.dev.n_u)) != MPLX_OK) return r;
   if (!l->ev0) { LH(l, hipEventCreate(&l->ev0)); LH(l, hipEventCreate(&l->ev1)); }
   QueryIn in{};
   in.start.p[0] = start[0]; in.start.p[1] = start[1]; in.start.v[0] = start[2]; in.start.v[1] = start[3];
@@ -249,6 +257,10 @@ static int plpa_plan_impl(mplx_plpa *l, int32_t world, const double *start, cons
   plpa_params(l, v, P);
   PlpaArgs A{};
   A.st = l->d_st; A.fresh = fresh ? 1 : 0; A.world = world; A.edge_cost = l->d_edge_cost;
+  A.succ_child = l->d_succ_child; A.succ_entry = l->d_succ_entry;
+  // the entries are in step with the committed world when the space is new, or when updateNodes ran after the last commit
+  if (fresh) l->synced_epoch = v.commit_epoch;
+  A.trust_entries = (l->synced_epoch == v.commit_epoch && getenv("MPLX_PLPA_NO_REUSE") == nullptr) ? 1 : 0;
   hipStream_t s = v.stream;
   LH(l, hipMemcpyAsync(l->d_in, &in, sizeof(QueryIn), hipMemcpyHostToDevice, s));
   if (fresh) {
@@ -326,6 +338,7 @@ extern "C" int mplx_plpa_update_nodes(mplx_plpa *l, int32_t world, uint64_t *n_b
   plpa_params(l, v, P);
   PlpaArgs A{};
   A.st = l->d_st; A.world = world; A.changed = l->d_changed; A.counters = l->d_counters; A.edge_cost = l->d_edge_cost;
+  A.succ_child = l->d_succ_child; A.succ_entry = l->d_succ_entry;
   A.changed_cap = (uint32_t)std::min<uint64_t>((uint64_t)P.edge_chunks << EDGE_CH_LOG, 0xFFFFFFF0ull);
   hipStream_t s = v.stream;
   LH(l, hipMemsetAsync(l->d_counters, 0, sizeof(uint32_t) * 4, s));
@@ -336,6 +349,7 @@ extern "C" int mplx_plpa_update_nodes(mplx_plpa *l, int32_t world, uint64_t *n_b
   LH(l, hipMemcpyAsync(ctr, l->d_counters, sizeof(ctr), hipMemcpyDeviceToHost, s));
   LH(l, hipStreamSynchronize(s));
   if (ctr[3]) { l->valid = false; return lf(l, MPLX_ERR_ARG, "internal: a hyperplane equation of unsupported degree was met"); }
+  l->synced_epoch = v.commit_epoch;  // every entry has just been re-tested against the world as committed now
   const uint32_t n = std::min(ctr[2], A.changed_cap);
   l->changed.resize(n);
   if (n) LH(l, hipMemcpy(l->changed.data(), l->d_changed, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));

@@ -13,7 +13,7 @@ struct mplx_poly_view {
   hipStream_t stream;
   mplx::GuardBlock *guard;  // host-coherent launch-guard block of the handle's planner context
   double deadline_s;        // <= 0: none
-  double tbl_unused;
+  uint64_t commit_epoch;    // number of mplx_poly_commit calls so far (the worlds a kernel sees are those of the last one)
 };
 // MPLX_OK, or MPLX_ERR_ARG when the handle is not configured / committed (the text is in mplx_poly_last_error)
 extern "C" int mplx_poly_internal_view(mplx_poly *p, mplx_poly_view *out);

@@ -159,6 +159,14 @@ def test_hip_poly_lpastar_when_the_space_is_kept_and_when_it_is_not():
     ro = both(s2, goal2)                            # a start that is not the root (no getSubStateSpace before): a new space
     assert ro["status"] == 0 and l.state_space()["states"][0][8] == 1.0
     both(s2, goal)                                  # back to the first goal: a new space again
+    # the world moves on and updateNodes is NOT called (not what the node does, but nothing forbids it): the stored entries are out of
+    # step with the obstacles, so a state that is expanded again has to run get_succ again -- as the CPU's loop always does
+    W = world(3.0, turn)
+    Lo.reload(W)
+    team.set_worlds([W])
+    both(s2, goal)
+    assert Lo.lpa_update_nodes() == l.update_nodes()    # ... and now in step again
+    both(s2, goal)
     Lo.lpa_reset()
     l.reset()
     ro = both(s2, goal, eps=2.0)                    # inflated heuristic, from scratch
