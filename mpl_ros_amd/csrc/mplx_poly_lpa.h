@@ -310,13 +310,21 @@ __global__ __launch_bounds__(64) void plpa_plan_kernel(SearchParams P, PlpaArgs 
           child = A.succ_child[at];
           if (child != NIL) blocked = (Q.edge(A.succ_entry[at])->action & EDGE_BLOCKED) != 0u;
         }
-        const bool kid = child != NIL && !blocked;
-        const unsigned long long m_val = __ballot(child != NIL), m_kid = __ballot(kid);
+        bool kid = child != NIL && !blocked;
+        {  // (two inputs that lead to one state: the child is updated once -- the first of them that is not blocked, as a loop over the inputs finds it)
+          const bool kid0 = kid;
+          for (int j = 0; j < P.n_u; j++) {  // (uniform)
+            const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)child, j);
+            const bool kj = __builtin_amdgcn_readlane(kid0 ? 1 : 0, j) != 0;
+            if (tid > j && kj && cj == child) kid = false;
+          }
+        }
+        const unsigned long long m_val = __ballot(child != NIL), m_kid = __ballot(kid), m_fin = __ballot(child != NIL && !blocked);
         if (kid) s_kids[__popcll(m_kid & ((1ull << tid) - 1ull))] = child;
         if (tid == 0) {
           S.c_prims += (unsigned long long)P.n_u;
           S.c_succ += (uint32_t)__popcll(m_val);
-          S.c_succ_finite += (uint32_t)__popcll(m_kid);
+          S.c_succ_finite += (uint32_t)__popcll(m_fin);
           s_nkids = (int32_t)__popcll(m_kid);
         }
         PLPA_T(2);
