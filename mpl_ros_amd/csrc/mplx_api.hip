@@ -801,7 +801,7 @@ extern "C" int mplx_set_record(mplx_ctx *c, uint32_t cap) {
   return MPLX_OK;
 }
 
-static void fill_params(const mplx_ctx *c, SearchParams &P) {
+static void fill_params(const mplx_ctx *c, SearchParams &P, bool spec_kernels = false) {
   const mplx_config &g = c->cfg;
   P.control = g.control;
   P.n_u = g.n_u;
@@ -824,8 +824,15 @@ static void fill_params(const mplx_ctx *c, SearchParams &P) {
     double sn;
     det_sincos(P.yaw_max, &sn, &P.yaw_cos);
   }
-  // width of a coarse OPEN bucket in units of f: BUCKET_FACTOR edge costs of w dt (measurement: MPLX_BUCKET_FACTOR)
-  static const double bucket_factor = [] { const char *e = getenv("MPLX_BUCKET_FACTOR"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 8.0; }();
+  // width of a coarse OPEN bucket in units of f: BUCKET_FACTOR edge costs of w dt (measurement: MPLX_BUCKET_FACTOR).  Deep searches
+  // want narrow buckets (small near sets, no evictions), sparse OPEN lists wide ones (a pull per batch otherwise).  The kernels of
+  // >= 256 threads pull a run of sparse buckets in one walk (mplx_kernels.h pull_fine_run), so the searches on the speculative
+  // kernels take the narrow ones: 3 edge costs for the lattices of at most 64 inputs, 2 for the larger ones (125-input JRK: the OPEN
+  // list grows with the branching factor).  profiles/r06ae_merged_refill_sweep.txt: C4-ACC blocking step -4.9 %, its bulk phase
+  // -3.2 %, C2 -16 %; profiles/r06m_bucket_width_sweep.txt: C3 -9 %.  The one-node kernels (64 / 128 lanes: no run pulls) keep 8.
+  // The pop order does not depend on it.
+  static const double bucket_factor_env = [] { const char *e = getenv("MPLX_BUCKET_FACTOR"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 0.0; }();
+  const double bucket_factor = bucket_factor_env > 0 ? bucket_factor_env : (!spec_kernels ? 8.0 : g.n_u > 64 ? 2.0 : 3.0);
   P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt * bucket_factor : 1.0);
   P.guard = c->guard;
 }
@@ -1269,7 +1276,8 @@ static int plan_batch_launch(mplx_ctx *c, int nq, const mplx_waypoint *starts, c
     for (int i = 0; i < nq; i++) order[i] = key[i].second;
   }
   SearchParams P = c->pools;
-  fill_params(c, P);
+  // (the speculative kernels run ACC / JRK lattices of at most 128 inputs unless speculation is switched off: mplx_launch_spec*)
+  fill_params(c, P, (c->speculation < 0 || c->speculation > 1) && (c->cfg.control == CTRL_ACC || c->cfg.control == CTRL_JRK) && c->cfg.n_u <= 128);
   if (c->wedged) return fail(c, MPLX_ERR_TIMEOUT, "this context was lost to a launch that never ended (destroy it)");
   const int xflags = getenv("MPLX_X_FLAGS") ? atoi(getenv("MPLX_X_FLAGS")) : 0;  // (diagnostics; read per launch so that a probe can switch between runs)
   P.xflags = xflags | (c->debug_hang ? 8 : 0);

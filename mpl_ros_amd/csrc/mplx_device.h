@@ -18,6 +18,19 @@ namespace mplx {
 
 constexpr int NB = 1024;          // OPEN buckets per level (coarse level 1, fine level 0)
 constexpr int NSUB = 256;         // sub-lists per bucket (walked in parallel, one per thread, when a bucket is pulled)
+// a refill of a sparse OPEN list pulls a run of fine buckets in one walk (mplx_kernels.h pull_fine_run)
+#ifndef MPLX_X_MERGE_PULL
+#define MPLX_X_MERGE_PULL 1
+#endif
+#ifndef MPLX_MERGE_TARGET
+#define MPLX_MERGE_TARGET 512
+#endif
+#ifndef MPLX_MERGE_CUR
+#define MPLX_MERGE_CUR 4
+#endif
+constexpr int MERGE_CUR = MPLX_MERGE_CUR;  // sub-list cursors per thread (8: the search kernels' register allocation suffers, tail +10 %)
+constexpr int MERGE_MAXB_ALL = 16;  // buckets per run at most (512 threads x 8 cursors / NSUB)
+constexpr int MERGE_TARGET = MPLX_MERGE_TARGET;  // entries per run at most (a bucket that holds more is pulled alone)
 constexpr int NC = 512;           // near OPEN capacity (LDS)
 constexpr int OWN = 2048;         // LDS (primitive, sample) owner map; larger expansions fall back to a search
 constexpr uint32_t NIL = 0xFFFFFFFFu;

@@ -257,6 +257,7 @@ struct Smem {
   uint32_t reserve;  // near-set slots one iteration may need (successors pushed + candidates returned)
   uint32_t node_chunks, edge_chunks, open_chunks;  // chunks owned
   int32_t cur1, cur0;  // active coarse bucket, active fine bucket inside it
+  int32_t pull_n, pull_list[MERGE_MAXB_ALL];  // the run of fine buckets one refill pulls together (refill / pull_fine_run)
   double lo1;          // f of the lower edge of coarse bucket cur1
   double ts_f, ts_g;
   uint32_t ts_id;      // split threshold inside fine bucket cur0
@@ -1105,14 +1106,107 @@ __device__ __forceinline__ void pull_bucket(const QView<BLOCK, CONTROL, SM> &Q, 
   __syncthreads();
 }
 
+// Pull the run of fine buckets S.pull_list[0 .. S.pull_n) in ONE walk (round 6).  A sparse OPEN list -- the first thousands of
+// expansions of a search, a short search altogether -- leaves a handful of entries per fine bucket, and a pull costs the same two
+// dependent memory trips and half a dozen barriers whether it brings 5 entries or 500: with one bucket per pull nearly every batch
+// of such a phase paid for one (C2: 36.4 ms; 31.0 ms with buckets four times as wide, which cost the deep searches 15 %; 30.6 ms with run pulls).  The
+// near / far boundary is any (bucket, threshold) pair, so a refill may as well move it to the END of the last bucket of a run of
+// non-empty buckets and take them all: every thread walks up to MERGE_CUR sub-lists side by side (a bucket has NSUB of them; the
+// loads of a round are issued together).  The run is chosen so that it holds at most MERGE_TARGET entries and fits the near set
+// next to what an iteration reserves (per-bucket counts are exact): the near set cannot overflow inside the walk, and a dense
+// bucket is pulled alone, as before.  The pop order does not
+// depend on any of this.
+template <int BLOCK, int CONTROL, class SM>
+__device__ __forceinline__ void pull_fine_run(const QView<BLOCK, CONTROL, SM> &Q, int tid) {
+  SM &S = Q.S;
+  const double w1 = Q.P.bucket_width;
+  constexpr int MAXC = MERGE_CUR;
+  const int n = S.pull_n;
+  uint32_t cur[MAXC], pulled[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; c++) {
+    const int li = tid + c * BLOCK, j = li / NSUB;
+    pulled[c] = 0;
+    cur[c] = j < n ? atomicExch(&Q.bkt_head[(size_t)S.pull_list[j] * NSUB + (li & (NSUB - 1))], NIL) : NIL;
+  }
+  __syncthreads();
+  const uint32_t max_rounds = S.n_log + 2u;
+  for (uint32_t rounds = 0;; rounds++) {
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) any |= cur[c] != NIL;
+    if (!block_any<BLOCK>(any, S, tid)) break;
+    if (rounds > max_rounds) {  // (uniform) a list that closes on itself: see pull_bucket
+      if (tid == 0) {
+        if (S.status < 0) S.status = 5;
+        guard_mark(Q.P, GUARD_PULL, 0u, S.c_expanded, (unsigned long long)rounds);
+      }
+      __syncthreads();
+      break;
+    }
+    OpenRec r[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++)
+      if (cur[c] != NIL) r[c] = *Q.open(cur[c]);
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+      if (cur[c] != NIL) {
+        const int code = classify(S, w1, r[c].f, r[c].g, r[c].id);
+        if (code < 0) {
+          uint32_t pos = atomicAdd(&S.n_near, 1u);
+          S.near_f[pos] = r[c].f; S.near_g[pos] = r[c].g; S.near_id[pos] = r[c].id; S.near_idx[pos] = cur[c];
+        } else {
+          far_link(Q, code, cur[c]);
+        }
+        pulled[c]++;
+        cur[c] = r[c].next;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int c = 0; c < MAXC; c++)
+    if (pulled[c]) atomicSub(&S.cnt[0][S.pull_list[(tid + c * BLOCK) / NSUB]], pulled[c]);
+  __syncthreads();
+}
+
 // near set empty: bring in the lowest far entries.  false when OPEN is empty.
 template <int BLOCK, int CONTROL, class SM>
 __device__ __forceinline__ bool refill(const QView<BLOCK, CONTROL, SM> &Q, int tid) {
   SM &S = Q.S;
+  // buckets one pull may take together: MERGE_CUR sub-list cursors per thread (none for the narrow one-node kernels)
+  constexpr int MAXB = MPLX_X_MERGE_PULL && BLOCK >= NSUB ? MERGE_CUR * BLOCK / NSUB : 1;
+  static_assert(MAXB <= MERGE_MAXB_ALL, "S.pull_list");
   for (int guard = 0; guard < 4 * NB; guard++) {
     const int b0 = lowest_bucket<BLOCK>(S, 0, tid);
     if (b0 < NB) {
       MPLX_TIC(t0);
+      if constexpr (MAXB > 1) {
+        if (tid < 64) {  // the run: non-empty buckets among the 64 from b0 on, while they hold <= target entries together
+          const int b = b0 + tid;
+          const uint32_t c = b < NB ? S.cnt[0][b] : 0u;
+          const unsigned long long m = __ballot(c > 0u);
+          const uint32_t pre = wave_incl_sum<64>(c);
+          const int rank = __popcll(m & ((1ull << tid) - 1ull));
+          // (what the near set can take without an eviction at the head of the next iteration: n_near + reserve <= NCAP there)
+          const uint32_t used = S.n_near + S.reserve, cap = used < (uint32_t)SM::NCAP ? (uint32_t)SM::NCAP - used : 0u;
+          const uint32_t target = cap < (uint32_t)MERGE_TARGET ? cap : (uint32_t)MERGE_TARGET;
+          const bool take = c > 0u && (tid == 0 || (rank < MAXB && pre <= target));
+          const unsigned long long tm = __ballot(take);  // (a prefix of the non-empty ones: rank and pre only grow)
+          if (take) S.pull_list[rank] = b;
+          if (tid == 0) {
+            S.pull_n = __popcll(tm);
+            S.cur0 = b0 + 63 - __clzll((long long)tm);
+            S.ts_f = INFINITY;
+            S.ts_g = INFINITY;
+            S.ts_id = 0xFFFFFFFFu;
+            S.c_refill++;
+          }
+        }
+        __syncthreads();
+        if (S.pull_n > 1) pull_fine_run(Q, tid);
+        else pull_bucket(Q, b0, tid);
+      } else {
       if (tid == 0) {
         S.cur0 = b0;
         S.ts_f = INFINITY;
@@ -1122,6 +1216,7 @@ __device__ __forceinline__ bool refill(const QView<BLOCK, CONTROL, SM> &Q, int t
       }
       __syncthreads();
       pull_bucket(Q, b0, tid);
+      }
       MPLX_TOC(S, 4, t0);
       if (S.n_near > 0) return true;
       __syncthreads();

@@ -14,7 +14,8 @@ OBJS=""
 for u in api spec help yaw lpa poly filter; do
   src=mplx_${u}_launch; [ $u = api ] && src=mplx_api
   if [[ " $UNITS " == *" $u "* ]]; then
-    /opt/rocm/bin/hipcc $F -c -o $O/kv_${N}_$u.o $S/$src.hip &
+    OPT=""; case $u in spec|help|yaw|filter) OPT="-O2";; esac  # (the Makefile's FLAGS_SPEC: the speculative kernel's units at -O2; a -O of $DEF still wins)
+    /opt/rocm/bin/hipcc ${F/ $DEF/} $OPT $DEF -c -o $O/kv_${N}_$u.o $S/$src.hip &
     OBJS="$OBJS $O/kv_${N}_$u.o"
   else
     OBJS="$OBJS $S/$src.o"
