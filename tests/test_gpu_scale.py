@@ -39,6 +39,27 @@ def test_c2_full_query_acc_256():
     print(f"C2: expanded {r.n_expanded} states {r.n_nodes} edges {r.n_edges} cost {r.cost} kernel {pl.lastKernelMs():.1f} ms")
 
 
+def test_c2_query_does_not_depend_on_the_open_bucket_width():
+    """The OPEN structure's bucket width is a speed knob only: the C2 query at 1 / 30 of the default width (sparse fine buckets: every
+    refill pulls a run of them in one walk -- mplx_kernels.h pull_fine_run --, 64-bucket windows with gaps, a coarse bucket activated every
+    few batches), at the default, and at 30 times the default (dense buckets pulled alone, near-set evictions) returns the same words,
+    expansion order included; one of them is compared with the oracle in full by the test above."""
+    grid, origin, res, start, goal, _ = mapgen.benchmark_map(256)
+    U = mapgen.control_lattice(1.0, 1, True)
+    kw = dict(v_max=2.0, a_max=1.0, tol_pos=0.5)
+    mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=1 << 22, max_edges=1 << 24, max_log=1 << 23, **kw)
+    words, refills = [], []
+    for width in (1.0, 0.0, 30.0, 900.0):  # (w dt = 10: a tenth of an edge cost, the default of 3 edge costs, 3, 90)
+        pl.setBucketWidth(width)
+        assert pl.plan(util.gpu_wp(start), util.gpu_wp(goal))
+        r = pl.getResult()
+        words.append((r.status, r.traj_len, r.cost, r.n_expanded, r.n_nodes, r.n_edges, r.n_succ_finite, r.voxel_reads, r.n_push, r.expand_hash))
+        refills.append((width, r.n_refill, r.n_evict, round(pl.lastKernelMs(), 1)))
+    print("C2 (width, refills, evictions, kernel ms):", refills)
+    assert all(w == words[0] for w in words), words
+    assert words[0][3] > 10000
+
+
 @pytest.mark.parametrize("cap", [250_000])
 def test_c3_single_query_jrk_512_equal_cap(map512, cap):
     grid, origin, res, start, goal = map512
