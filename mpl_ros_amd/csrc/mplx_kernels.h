@@ -1207,15 +1207,15 @@ __device__ __forceinline__ bool refill(const QView<BLOCK, CONTROL, SM> &Q, int t
         if (S.pull_n > 1) pull_fine_run(Q, tid);
         else pull_bucket(Q, b0, tid);
       } else {
-      if (tid == 0) {
-        S.cur0 = b0;
-        S.ts_f = INFINITY;
-        S.ts_g = INFINITY;
-        S.ts_id = 0xFFFFFFFFu;
-        S.c_refill++;
-      }
-      __syncthreads();
-      pull_bucket(Q, b0, tid);
+        if (tid == 0) {
+          S.cur0 = b0;
+          S.ts_f = INFINITY;
+          S.ts_g = INFINITY;
+          S.ts_id = 0xFFFFFFFFu;
+          S.c_refill++;
+        }
+        __syncthreads();
+        pull_bucket(Q, b0, tid);
       }
       MPLX_TOC(S, 4, t0);
       if (S.n_near > 0) return true;
