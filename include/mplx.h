@@ -224,7 +224,7 @@ int mplx_set_helpers(mplx_ctx *ctx, int32_t per_leader, int32_t reserved, uint64
  * completed no batch for ~1 s of polling (0 in a healthy run), [3] helpers that left because every running leader was served */
 int mplx_helper_stats(const mplx_ctx *ctx, uint32_t stats[4]);
 /* f-width of one coarse OPEN bucket; the fine level divides it by 1024.  0 = default: 3*w*dt for searches on the speculative kernels with
- * lattices of at most 64 inputs, 1*w*dt for their larger lattices, 8*w*dt on the one-node kernels, 64*w*dt for LPA*.  A speed knob only: the
+ * lattices of at most 64 inputs, 0.5*w*dt for their larger lattices, 8*w*dt on the one-node kernels, 64*w*dt for LPA*.  A speed knob only: the
  * pop order -- and with it every result -- does not depend on it (tests/test_gpu_scale.py). */
 int mplx_set_bucket_width(mplx_ctx *ctx, double width);
 

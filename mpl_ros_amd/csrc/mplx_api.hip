@@ -827,12 +827,13 @@ static void fill_params(const mplx_ctx *c, SearchParams &P, bool spec_kernels = 
   // width of a coarse OPEN bucket in units of f: BUCKET_FACTOR edge costs of w dt (measurement: MPLX_BUCKET_FACTOR).  Deep searches
   // want narrow buckets (small near sets, no evictions), sparse OPEN lists wide ones (a pull per batch otherwise).  The kernels of
   // >= 256 threads pull a run of sparse buckets in one walk (mplx_kernels.h pull_fine_run), so the searches on the speculative
-  // kernels take the narrow ones: 3 edge costs for the lattices of at most 64 inputs, 1 for the larger ones (125-input JRK: the OPEN
-  // list grows with the branching factor; C3 at 1 / 2 / 3: 7.08 / 7.35 / 7.41 s, the capped C4-JRK batch 654 / 656 / 656 ms).  profiles/r06ae_merged_refill_sweep.txt: C4-ACC blocking step -4.9 %, its bulk phase
+  // kernels take the narrow ones: 3 edge costs for the lattices of at most 64 inputs, half an edge cost for the larger ones (125-input
+  // JRK: the OPEN list grows with the branching factor; C3 at 0.25 / 0.5 / 1 / 2 / 3: 7.06 / 7.00 / 7.24 | 7.08 / 7.35 / 7.41 s on two
+  // boxes, the capped C4-JRK batch 654 / 656 / 656 ms at 1 / 2 / 3).  profiles/r06ae_merged_refill_sweep.txt: C4-ACC blocking step -4.9 %, its bulk phase
   // -3.2 %, C2 -16 %; profiles/r06m_bucket_width_sweep.txt: C3 -9 %.  The one-node kernels (64 / 128 lanes: no run pulls) keep 8.
   // The pop order does not depend on it.
   static const double bucket_factor_env = [] { const char *e = getenv("MPLX_BUCKET_FACTOR"); const double v = e ? atof(e) : 0.0; return v > 0 ? v : 0.0; }();
-  const double bucket_factor = bucket_factor_env > 0 ? bucket_factor_env : (!spec_kernels ? 8.0 : g.n_u > 64 ? 1.0 : 3.0);
+  const double bucket_factor = bucket_factor_env > 0 ? bucket_factor_env : (!spec_kernels ? 8.0 : g.n_u > 64 ? 0.5 : 3.0);
   P.bucket_width = c->bucket_width > 0 ? c->bucket_width : (g.w * g.dt > 0 ? g.w * g.dt * bucket_factor : 1.0);
   P.guard = c->guard;
 }
