@@ -1,6 +1,7 @@
 #!/bin/bash
-# A/B of the merged refill (pull_fine_run): variant libraries m_off / m_<target> (tools/build_kernel_variant.sh m_<t> "-DMPLX_ONLY_ACC -DMPLX_MERGE_TARGET=<t>" "help spec")
-# crossed with the coarse bucket width (MPLX_BUCKET_FACTOR x w dt), on one box
+# A/B of variant libraries of the 27-input ACC kernels -- the merged refill (pull_fine_run): m_off / m_<target> (tools/build_kernel_variant.sh m_<t>
+# "-DMPLX_ONLY_ACC -DMPLX_MERGE_TARGET=<t>" "help spec"), compiler options: f_<name> (... f_o2 "-DMPLX_ONLY_ACC -O2" "help spec") -- crossed with the coarse
+# bucket width (MPLX_BUCKET_FACTOR x w dt), on one box.  VARIANTS / FACTORS / MODES / BLOCKS select; C2 knob runs: VARIANTS= with AB_BUCKET_WIDTH in the environment
 set -u
 TAG=${1:-r06ac}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # validation of a new library on one box: the -m gpu suite in the driver's form, smoke, the default bench line, then the C3 query and the capped C4-JRK
-# batch against the coarse bucket width (MPLX_BUCKET_FACTOR), then optimisation-level variants of the ACC kernel units
+# batch against the coarse bucket width (MPLX_BUCKET_FACTOR), then variant libraries of the ACC kernel units named in VARIANTS (tools/build_kernel_variant.sh)
 set -u
 TAG=${1:-r06af}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
@@ -31,4 +31,4 @@ except Exception as e: print("$name failed", e)
 PY
 }
 one product "tail bulk c2 block" A=1
-for v in m_512o2 o_os o_o1 o_o2nu; do one $v "tail bulk c2" MPLX_LIB=$PWD/build_tmp/libmplx_$v.so MPLX_BUCKET_FACTOR=3; done
+for v in ${VARIANTS:-}; do one $v "tail bulk c2" MPLX_LIB=$PWD/build_tmp/libmplx_$v.so MPLX_BUCKET_FACTOR=3; done  # (r06af: VARIANTS="m_512o2 o_os o_o1 o_o2nu")
