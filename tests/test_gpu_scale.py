@@ -73,6 +73,26 @@ def test_c3_single_query_jrk_512_equal_cap(map512, cap):
     print(f"C3: expanded {r.n_expanded} states {r.n_nodes} edges {r.n_edges} voxel reads {r.voxel_reads} kernel {pl.lastKernelMs():.1f} ms")
 
 
+def test_c3_prefix_does_not_depend_on_the_open_bucket_width(map512):
+    """The same for the 125-input jerk lattice (four 128-lane units; its near set has room for runs of about 500 entries next to the
+    504 an iteration reserves): the first 60 000 expansions of the C3 query at a tenth of the default width, the default (half an edge
+    cost), 10 and 200 edge costs -- the same words, expansion order included."""
+    grid, origin, res, start, goal = map512
+    U = mapgen.control_lattice(1.0, 2, True)
+    kw = dict(v_max=2.0, a_max=1.0, j_max=1.0, tol_pos=0.5, max_expand=60_000)
+    mu, pl = util.make_gpu(grid, origin, res, U, max_nodes=1 << 22, max_edges=1 << 25, max_log=1 << 23, **kw)
+    words, refills = [], []
+    for width in (0.5, 0.0, 100.0, 2000.0):  # (w dt = 10)
+        pl.setBucketWidth(width)
+        pl.plan(util.gpu_wp(start, control=orc.JRK), util.gpu_wp(goal, control=orc.JRK))
+        r = pl.getResult()
+        words.append((r.status, r.traj_len, r.cost, r.n_expanded, r.n_nodes, r.n_edges, r.n_succ_finite, r.voxel_reads, r.n_push, r.expand_hash))
+        refills.append((width, r.n_refill, r.n_evict, round(pl.lastKernelMs(), 1)))
+    print("C3 prefix (width, refills, evictions, kernel ms):", refills)
+    assert all(w == words[0] for w in words), words
+    assert words[0][0] == 3 and words[0][3] == 60_000
+
+
 def test_c3_single_query_jrk_512_full_cap(map512):
     """BASELINE config 3 at its stated size: the 125-input jerk lattice on the 512^3 map, capped at 2 000 000
     expansions on both sides (deep OPEN lists, far-bucket pulls, the helper cache of the JRK kernel -- the part of
